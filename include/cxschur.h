@@ -1,0 +1,282 @@
+/*
+ * cxschur.h -- C ABI of libcxschur: the MI355X (gfx950) implementation of the
+ * Levenberg-Marquardt inner linear solve of Ceres Solver (block-sparse
+ * Jacobian evaluation, J products, Schur elimination, reduced camera solve,
+ * back substitution, CGNR).
+ *
+ * Every entry point names the reference interface it stands in for
+ * (file:line relative to the Ceres source tree).  Signatures use only plain
+ * pointers and sizes; nothing here depends on torch, Eigen or abseil.  All
+ * functions return 0 on success and a negative cx_status on error; the text of
+ * the last error of the calling thread is available from cx_last_error().
+ *
+ * Conventions shared with the reference:
+ *   - all small dense blocks are ROW-major (block_random_access_matrix.h:66-68)
+ *   - the solver minimises |A x - b|^2 + |D x|^2; D may be NULL
+ *     (linear_solver.h:148-354)
+ *   - termination types carry the numeric order of linear_solver.h:57-74
+ */
+#ifndef CXSCHUR_H_
+#define CXSCHUR_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ------------------------------------------------------------------ types */
+
+/* == ceres::internal::Block (block_structure.h:54-60) */
+typedef struct { int32_t size; int32_t position; } cx_block;
+/* == ceres::internal::Cell (block_structure.h:66-75) */
+typedef struct { int32_t block_id; int32_t position; } cx_cell;
+
+/* Flattened ceres::internal::CompressedRowBlockStructure
+ * (block_structure.h:84-182).  The reference keeps one std::vector<Cell> per
+ * row; here row i owns cells[row_cell_begin[i] .. row_cell_begin[i+1]).  This is
+ * the flattening the reference itself performs for its device code
+ * (cuda_block_structure.cc:50-236). */
+typedef struct {
+  int32_t num_row_blocks;
+  int32_t num_col_blocks;
+  const cx_block* row_blocks;      /* [num_row_blocks] size/position of each row block */
+  const cx_block* col_blocks;      /* [num_col_blocks] */
+  const int32_t* row_cell_begin;   /* [num_row_blocks + 1] */
+  const cx_cell* cells;            /* [row_cell_begin[num_row_blocks]] */
+} cx_block_structure;
+
+typedef enum {
+  CX_OK = 0,
+  CX_ERR_INVALID_ARGUMENT = -1,
+  CX_ERR_HIP = -2,            /* a HIP runtime call failed            */
+  CX_ERR_NO_DEVICE = -3,      /* no gfx950 device / code object       */
+  CX_ERR_COMM = -4,           /* RCCL failure                          */
+  CX_ERR_UNSUPPORTED = -5,
+  CX_ERR_OUT_OF_MEMORY = -6
+} cx_status;
+
+/* linear_solver.h:57-74, same numeric order */
+typedef enum {
+  CX_SUCCESS = 0,
+  CX_NO_CONVERGENCE = 1,
+  CX_FAILURE = 2,
+  CX_FATAL_ERROR = 3
+} cx_termination;
+
+/* include/ceres/types.h:57-91 (LinearSolverType); only the Schur / CGNR
+ * members exist here. */
+typedef enum {
+  CX_DENSE_SCHUR = 0,      /* explicit S, dense storage, dense Cholesky          */
+  CX_SPARSE_SCHUR = 1,     /* explicit S; stored dense on device while 9C fits   */
+  CX_ITERATIVE_SCHUR = 2,  /* implicit S + PCG                                   */
+  CX_CGNR = 3              /* PCG on J'J + D'D                                   */
+} cx_linear_solver_type;
+
+/* include/ceres/types.h:93-141 (PreconditionerType) */
+typedef enum {
+  CX_IDENTITY = 0,
+  CX_JACOBI = 1,
+  CX_SCHUR_JACOBI = 2,
+  CX_SCHUR_POWER_SERIES_EXPANSION = 3
+} cx_preconditioner_type;
+
+/* Where b, D, x, state ... pointers of a call live. */
+typedef enum { CX_HOST = 0, CX_DEVICE = 1 } cx_memspace;
+
+/* LinearSolver::Options (linear_solver.h:150-230), the fields this path reads. */
+typedef struct {
+  int32_t type;                       /* cx_linear_solver_type */
+  int32_t preconditioner_type;        /* cx_preconditioner_type */
+  int32_t min_num_iterations;         /* default 0   */
+  int32_t max_num_iterations;         /* default 500 (solver.h max_linear_solver_iterations) */
+  int32_t residual_reset_period;      /* default 10  */
+  int32_t num_eliminate_blocks;       /* == elimination_groups[0]; 0 for CGNR */
+  int32_t use_mixed_precision_solves; /* dense Cholesky: fp32 factor + fp64 refinement */
+  int32_t max_num_refinement_iterations;
+  int32_t max_num_spse_iterations;    /* default 5 */
+  int32_t use_spse_initialization;    /* default 0 */
+  double spse_tolerance;              /* default 0.1 */
+  int32_t deterministic;              /* 1: camera-space sums in fixed order (bitwise reproducible) */
+  int32_t reserved;
+} cx_solver_options;
+
+/* LinearSolver::PerSolveOptions (linear_solver.h:232-318) */
+typedef struct {
+  const double* D;       /* [num_cols] or NULL */
+  double r_tolerance;    /* default -1 */
+  double q_tolerance;    /* default 0  */
+  int32_t memspace;      /* cx_memspace of b, D and x */
+  int32_t reserved;
+} cx_per_solve_options;
+
+/* LinearSolver::Summary (linear_solver.h:320-326) */
+typedef struct {
+  double residual_norm;
+  int32_t num_iterations;
+  int32_t termination_type;  /* cx_termination */
+  char message[256];
+} cx_summary;
+
+/* Phase timings of the last solve in milliseconds (device time, HIP events);
+ * the phases are the reference's EventLogger events
+ * (schur_complement_solver.cc:106-155, iterative_schur_complement_solver.cc:64-157). */
+typedef struct {
+  double setup_ms;
+  double eliminate_ms;        /* Eliminate, or implicit-Schur Init */
+  double reduced_solve_ms;    /* Cholesky, or the CG loop          */
+  double back_substitute_ms;
+  double total_ms;
+  double allreduce_ms;        /* host-side estimate of time in RCCL calls */
+} cx_solve_timing;
+
+typedef struct cx_context cx_context;
+typedef struct cx_matrix cx_matrix;
+typedef struct cx_solver cx_solver;
+typedef struct cx_evaluator cx_evaluator;
+
+/* ---------------------------------------------------------------- context */
+
+/* One context per process and GPU: a HIP stream plus, after cx_context_set_comm,
+ * an RCCL communicator.  Stands in for ContextImpl (context_impl.h:60-150),
+ * whose CUDA half owns the stream and library handles. */
+int cx_context_create(int device_id, cx_context** out);
+void cx_context_destroy(cx_context* ctx);
+
+/* Multi-GPU (new; the reference is single-device, context_impl.h:74-83).
+ * cx_comm_unique_id fills a 128-byte id on one rank; the caller distributes it
+ * (any out-of-band channel) and every rank calls cx_context_set_comm.  From then
+ * on solvers and evaluators on this context treat their matrix as one shard of
+ * a point-partitioned Jacobian and all-reduce camera-space sums. */
+int cx_comm_unique_id(void* out_128_bytes);
+int cx_context_set_comm(cx_context* ctx, int rank, int nranks, const void* unique_id_128_bytes);
+int cx_context_rank(const cx_context* ctx);
+int cx_context_num_ranks(const cx_context* ctx);
+/* sum-all-reduce of n doubles in place on the context's stream (exposed for tests) */
+int cx_allreduce_sum(cx_context* ctx, double* device_ptr, int64_t n);
+
+int cx_malloc(cx_context* ctx, size_t bytes, void** device_ptr);
+int cx_free(cx_context* ctx, void* device_ptr);
+int cx_memcpy_h2d(cx_context* ctx, void* dst_device, const void* src_host, size_t bytes);
+int cx_memcpy_d2h(cx_context* ctx, void* dst_host, const void* src_device, size_t bytes);
+int cx_memset_zero(cx_context* ctx, void* device_ptr, size_t bytes);
+int cx_synchronize(cx_context* ctx);
+/* the hipStream_t all work of this context is enqueued on */
+void* cx_context_stream(cx_context* ctx);
+const char* cx_last_error(void);
+/* "gfx950 ..." description of the device the context is bound to */
+int cx_device_name(cx_context* ctx, char* out, size_t n);
+
+/* ----------------------------------------------------------------- matrix */
+
+/* Device-resident BlockSparseMatrix (block_sparse_matrix.h:60-176).  The value
+ * array has exactly the reference layout (cells row-major at Cell::position), so
+ * a host BlockSparseMatrix::values() array can be uploaded verbatim.
+ * num_eliminate_blocks > 0 declares the [E F] partition of
+ * PartitionedMatrixView (partitioned_matrix_view.h:60-140). */
+int cx_matrix_create(cx_context* ctx, const cx_block_structure* bs,
+                     int32_t num_eliminate_blocks, cx_matrix** out);
+void cx_matrix_destroy(cx_matrix* A);
+int64_t cx_matrix_num_rows(const cx_matrix* A);
+int64_t cx_matrix_num_cols(const cx_matrix* A);
+int64_t cx_matrix_num_nonzeros(const cx_matrix* A);
+/* 1 when the <2,3,9> bundle-adjustment kernels are in use (detect_structure.cc:39-120) */
+int cx_matrix_is_static_239(const cx_matrix* A);
+/* BlockSparseMatrix::mutable_values(): device pointer to num_nonzeros doubles */
+double* cx_matrix_device_values(cx_matrix* A);
+/* copy values in (memspace says where src lives) */
+int cx_matrix_set_values(cx_matrix* A, const double* src, int32_t memspace);
+int cx_matrix_get_values(const cx_matrix* A, double* dst_host);
+/* call after writing through cx_matrix_device_values(): drops cached copies */
+int cx_matrix_values_changed(cx_matrix* A);
+/* BlockSparseMatrix::SetZero (block_sparse_matrix.cc:220-225) */
+int cx_matrix_set_zero(cx_matrix* A);
+/* y += A x   BlockSparseMatrix::RightMultiplyAndAccumulate (block_sparse_matrix.cc:239-274) */
+int cx_matrix_right_multiply(cx_matrix* A, const double* x, double* y, int32_t memspace);
+/* y += A' x  BlockSparseMatrix::LeftMultiplyAndAccumulate (block_sparse_matrix.cc:278-349) */
+int cx_matrix_left_multiply(cx_matrix* A, const double* x, double* y, int32_t memspace);
+/* x = diag(A'A)  BlockSparseMatrix::SquaredColumnNorm (block_sparse_matrix.cc:351-401) */
+int cx_matrix_squared_column_norm(cx_matrix* A, double* x, int32_t memspace);
+/* A <- A diag(scale)  BlockSparseMatrix::ScaleColumns (block_sparse_matrix.cc:403-450) */
+int cx_matrix_scale_columns(cx_matrix* A, const double* scale, int32_t memspace);
+/* device time of the last cx_matrix_* product in ms (HIP events on the context stream) */
+double cx_matrix_last_kernel_ms(const cx_matrix* A);
+
+/* ----------------------------------------------------------------- solver */
+
+/* LinearSolver::Create (linear_solver.cc:75-128) for the Schur / CGNR members. */
+int cx_solver_create(cx_context* ctx, const cx_solver_options* options, cx_solver** out);
+void cx_solver_destroy(cx_solver* s);
+void cx_solver_default_options(cx_solver_options* options);
+/* TypedLinearSolver<BlockSparseMatrix>::Solve (linear_solver.h:363-390):
+ * b has num_rows entries, x num_cols; x is fully overwritten. */
+int cx_solver_solve(cx_solver* s, cx_matrix* A, const double* b,
+                    const cx_per_solve_options* per_solve, double* x, cx_summary* summary);
+int cx_solver_last_timing(const cx_solver* s, cx_solve_timing* out);
+
+/* The Schur pieces on their own, for parity tests against
+ * schur_eliminator_test.cc / implicit_schur_complement_test.cc.
+ * SchurEliminator::Eliminate (schur_eliminator_impl.h:177-304) into a dense
+ * row-major lhs of order num_cols_f (upper block triangle, as the reference) */
+int cx_schur_eliminate_dense(cx_context* ctx, cx_matrix* A, const double* b, const double* D,
+                             double* lhs, double* rhs, int32_t memspace);
+/* SchurEliminator::BackSubstitute (schur_eliminator_impl.h:307-373): z has
+ * num_cols_f entries, x num_cols; only the e-part of x is written. */
+int cx_schur_back_substitute(cx_context* ctx, cx_matrix* A, const double* b, const double* D,
+                             const double* z, double* x, int32_t memspace);
+/* ImplicitSchurComplement: Init + RightMultiplyAndAccumulate
+ * (implicit_schur_complement.cc:49-144); y = S x (overwrites y), and rhs of the
+ * reduced system (UpdateRhs, :251-276) when rhs != NULL. */
+int cx_implicit_schur_multiply(cx_context* ctx, cx_matrix* A, const double* D, const double* b,
+                               const double* x, double* y, double* rhs, int32_t memspace);
+/* DenseCholesky::FactorAndSolve (dense_cholesky.cc:139-151): lhs is n x n
+ * row-major, only its upper triangle is read; solves lhs x = rhs. */
+int cx_dense_cholesky_solve(cx_context* ctx, int32_t n, double* lhs, const double* rhs,
+                            double* x, int32_t memspace, cx_summary* summary);
+
+/* -------------------------------------------------------------- evaluator */
+
+/* Bundle-adjustment Evaluator: ProgramEvaluator<BlockEvaluatePreparer,
+ * BlockJacobianWriter> (program_evaluator.h:137-304) specialised to
+ * SnavelyReprojectionError (examples/snavely_reprojection_error.h:53-104).
+ * Parameter blocks: column block j < num_points is point j, column block
+ * num_points + i is camera i (the order ApplyOrdering produces for
+ * bundle_adjuster's user ordering, reorder_program.cc:216-254).  Observations
+ * are given in INPUT order; the evaluator orders residual blocks as
+ * LexicographicallyOrderResidualBlocks does (reorder_program.cc:256-338) and
+ * lays out J as BlockJacobianWriter::BuildJacobianLayout
+ * (block_jacobian_writer.cc:68-167).  row_of_observation (may be NULL) receives
+ * for each input observation its row block in J. */
+int cx_evaluator_create_bal(cx_context* ctx, int32_t num_cameras, int32_t num_points,
+                            int64_t num_observations, const int32_t* camera_index,
+                            const int32_t* point_index, const double* observations_xy,
+                            cx_evaluator** out);
+void cx_evaluator_destroy(cx_evaluator* e);
+/* Evaluator::CreateJacobian (evaluator.h:105): matrix owned by the evaluator */
+cx_matrix* cx_evaluator_jacobian(cx_evaluator* e);
+int cx_evaluator_row_of_observation(const cx_evaluator* e, int64_t* out_host);
+/* Evaluator::Evaluate (evaluator.h:120-150).  state = [points (3 each) |
+ * cameras (9 each)] in column order; cost/residuals/gradient may be NULL;
+ * evaluate_jacobian != 0 writes the evaluator's matrix. */
+int cx_evaluator_evaluate(cx_evaluator* e, const double* state, double* cost,
+                          double* residuals, double* gradient, int32_t evaluate_jacobian,
+                          int32_t memspace);
+double cx_evaluator_last_kernel_ms(const cx_evaluator* e);
+
+/* ------------------------------------------------------ host-side helpers */
+
+/* DetectStructure (detect_structure.cc:39-120); -1 stands for Eigen::Dynamic */
+int cx_detect_structure(const cx_block_structure* bs, int32_t num_eliminate_blocks,
+                        int32_t* row_block_size, int32_t* e_block_size, int32_t* f_block_size);
+/* Partition the first num_eliminate_blocks column blocks (points) into nranks
+ * contiguous ranges holding about equal numbers of non-zeros -- the balancing
+ * PartitionRangeForParallelFor does on cumulative_nnz
+ * (partition_range_for_parallel_for.h:60-150).  bounds has nranks+1 entries. */
+int cx_partition_points(const cx_block_structure* bs, int32_t num_eliminate_blocks,
+                        int32_t nranks, int32_t* bounds);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CXSCHUR_H_ */

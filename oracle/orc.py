@@ -1,0 +1,281 @@
+"""ORACLE -- TEST INFRASTRUCTURE ONLY.
+
+ctypes binding of oracle/liborc.so (the CPU restatement of the reference
+algorithms, see oracle/orc_common.h).  Imported only by tests/,
+__graft_entry__.smoke() and bench.py's cpu_baseline leg.
+"""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+c_double_p = ctypes.POINTER(ctypes.c_double)
+
+
+class cx_solver_options(ctypes.Structure):
+    _fields_ = [
+        ("type", ctypes.c_int32),
+        ("preconditioner_type", ctypes.c_int32),
+        ("min_num_iterations", ctypes.c_int32),
+        ("max_num_iterations", ctypes.c_int32),
+        ("residual_reset_period", ctypes.c_int32),
+        ("num_eliminate_blocks", ctypes.c_int32),
+        ("use_mixed_precision_solves", ctypes.c_int32),
+        ("max_num_refinement_iterations", ctypes.c_int32),
+        ("max_num_spse_iterations", ctypes.c_int32),
+        ("use_spse_initialization", ctypes.c_int32),
+        ("spse_tolerance", ctypes.c_double),
+        ("deterministic", ctypes.c_int32),
+        ("reserved", ctypes.c_int32),
+    ]
+
+
+class cx_summary(ctypes.Structure):
+    _fields_ = [
+        ("residual_norm", ctypes.c_double),
+        ("num_iterations", ctypes.c_int32),
+        ("termination_type", ctypes.c_int32),
+        ("message", ctypes.c_char * 256),
+    ]
+
+
+DENSE_SCHUR, SPARSE_SCHUR, ITERATIVE_SCHUR, CGNR = 0, 1, 2, 3
+IDENTITY, JACOBI, SCHUR_JACOBI, SCHUR_POWER_SERIES_EXPANSION = 0, 1, 2, 3
+SUCCESS, NO_CONVERGENCE, FAILURE, FATAL_ERROR = 0, 1, 2, 3
+
+ALLREDUCE_FN = ctypes.CFUNCTYPE(None, c_double_p, ctypes.c_int64, ctypes.c_void_p)
+
+
+def build():
+    subprocess.check_call(["make", "-s", "-C", _HERE, "liborc.so"])
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        path = os.path.join(_HERE, "liborc.so")
+        if not os.path.exists(path):
+            build()
+        _LIB = ctypes.CDLL(path)
+        _LIB.orc_to_crs.restype = ctypes.c_int64
+        _LIB.orc_stable_schur_ordering.restype = ctypes.c_int
+    return _LIB
+
+
+def _p(a):
+    if a is None:
+        return None
+    assert a.flags["C_CONTIGUOUS"]
+    return ctypes.c_void_p(a.ctypes.data)
+
+
+def _f64(a):
+    return None if a is None else np.ascontiguousarray(a, dtype=np.float64)
+
+
+def set_num_threads(n):
+    lib().orc_set_num_threads(int(n))
+
+
+def make_options(type=ITERATIVE_SCHUR, preconditioner_type=JACOBI, num_eliminate_blocks=0,
+                 min_num_iterations=0, max_num_iterations=500, residual_reset_period=10,
+                 max_num_spse_iterations=5, use_spse_initialization=0, spse_tolerance=0.1):
+    o = cx_solver_options()
+    o.type = type
+    o.preconditioner_type = preconditioner_type
+    o.min_num_iterations = min_num_iterations
+    o.max_num_iterations = max_num_iterations
+    o.residual_reset_period = residual_reset_period
+    o.num_eliminate_blocks = num_eliminate_blocks
+    o.max_num_spse_iterations = max_num_spse_iterations
+    o.use_spse_initialization = use_spse_initialization
+    o.spse_tolerance = spse_tolerance
+    return o
+
+
+def right_multiply(bs, values, x, y=None):
+    values, x = _f64(values), _f64(x)
+    y = np.zeros(bs.num_rows) if y is None else _f64(y).copy()
+    lib().orc_right_multiply(bs.c, _p(values), _p(x), _p(y))
+    return y
+
+
+def left_multiply(bs, values, x, y=None):
+    values, x = _f64(values), _f64(x)
+    y = np.zeros(bs.num_cols) if y is None else _f64(y).copy()
+    lib().orc_left_multiply(bs.c, _p(values), _p(x), _p(y))
+    return y
+
+
+def squared_column_norm(bs, values):
+    values = _f64(values)
+    x = np.zeros(bs.num_cols)
+    lib().orc_squared_column_norm(bs.c, _p(values), _p(x))
+    return x
+
+
+def scale_columns(bs, values, scale):
+    v = _f64(values).copy()
+    lib().orc_scale_columns(bs.c, _p(v), _p(_f64(scale)))
+    return v
+
+
+def to_crs(bs, values, transpose=False):
+    values = _f64(values)
+    n = bs.num_cols if transpose else bs.num_rows
+    nnz = bs.num_nonzeros
+    rows = np.zeros(n + 1, dtype=np.int32)
+    cols = np.zeros(nnz, dtype=np.int32)
+    vals = np.zeros(nnz)
+    got = lib().orc_to_crs(bs.c, _p(values), int(transpose), _p(rows), _p(cols), _p(vals))
+    assert got == nnz
+    return rows, cols, vals
+
+
+def detect_structure(bs, num_eliminate_blocks):
+    r, e, f = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+    lib().orc_detect_structure(bs.c, int(num_eliminate_blocks), ctypes.byref(r), ctypes.byref(e), ctypes.byref(f))
+    return r.value, e.value, f.value
+
+
+def _num_cols_f(bs, nelim):
+    return int(bs.col_blocks["size"][nelim:].sum())
+
+
+def schur_eliminate_dense(bs, values, b, D, nelim):
+    n = _num_cols_f(bs, nelim)
+    lhs = np.zeros((n, n))
+    rhs = np.zeros(n) if b is not None else None
+    lib().orc_schur_eliminate_dense(bs.c, _p(_f64(values)), _p(_f64(b)), _p(_f64(D)), int(nelim), _p(lhs), _p(rhs))
+    return lhs, rhs
+
+
+def schur_eliminate_diagonal(bs, values, D, nelim):
+    sizes = bs.col_blocks["size"][nelim:].astype(np.int64)
+    blocks = np.zeros(int((sizes * sizes).sum()))
+    lib().orc_schur_eliminate_diagonal(bs.c, _p(_f64(values)), _p(_f64(D)), int(nelim), _p(blocks))
+    return blocks
+
+
+def schur_back_substitute(bs, values, b, D, nelim, z):
+    x = np.zeros(bs.num_cols)
+    lib().orc_schur_back_substitute(bs.c, _p(_f64(values)), _p(_f64(b)), _p(_f64(D)), int(nelim), _p(_f64(z)), _p(x))
+    return x
+
+
+def dense_cholesky_solve(lhs, rhs):
+    a = _f64(lhs).copy()
+    n = a.shape[0]
+    x = np.zeros(n)
+    t = lib().orc_dense_cholesky_solve(n, _p(a), _p(_f64(rhs)), _p(x))
+    return x, t
+
+
+def implicit_schur_multiply(bs, values, D, b, nelim, x):
+    n = _num_cols_f(bs, nelim)
+    y = np.zeros(n)
+    rhs = np.zeros(n) if b is not None else None
+    lib().orc_implicit_schur_multiply(bs.c, _p(_f64(values)), _p(_f64(D)), _p(_f64(b)), int(nelim), _p(_f64(x)), _p(y), _p(rhs))
+    return y, rhs
+
+
+def block_diagonal_inverses(bs, values, D, nelim, want_ftf=True):
+    es = bs.col_blocks["size"][:nelim].astype(np.int64)
+    fs = bs.col_blocks["size"][nelim:].astype(np.int64)
+    ete = np.zeros(int((es * es).sum()))
+    ftf = np.zeros(int((fs * fs).sum())) if want_ftf else None
+    lib().orc_block_diagonal_inverses(bs.c, _p(_f64(values)), _p(_f64(D)), int(nelim), _p(ete), _p(ftf))
+    return ete, ftf
+
+
+def solve(bs, values, b, D, options, r_tolerance=-1.0, q_tolerance=0.0, allreduce=None):
+    x = np.zeros(bs.num_cols)
+    s = cx_summary()
+    args = [bs.c, _p(_f64(values)), _p(_f64(b)), _p(_f64(D)), ctypes.byref(options),
+            ctypes.c_double(r_tolerance), ctypes.c_double(q_tolerance), _p(x), ctypes.byref(s)]
+    if allreduce is None:
+        rc = lib().orc_solve(*args)
+    else:
+        def _cb(buf, n, _user):
+            a = np.ctypeslib.as_array(buf, shape=(n,))
+            allreduce(a)
+        cb = ALLREDUCE_FN(_cb)
+        rc = lib().orc_solve_sharded(*args, cb, None)
+    assert rc == 0
+    return x, s
+
+
+def cg_dense(A, b, x0, max_num_iterations, r_tolerance=-1.0, q_tolerance=0.0, min_num_iterations=0,
+             residual_reset_period=10):
+    A = _f64(A)
+    x = _f64(x0).copy()
+    s = cx_summary()
+    lib().orc_cg_dense(A.shape[0], _p(A), _p(_f64(b)), _p(x), int(min_num_iterations),
+                       int(max_num_iterations), int(residual_reset_period), ctypes.c_double(r_tolerance), ctypes.c_double(q_tolerance), ctypes.byref(s))
+    return x, s
+
+
+def snavely(camera, point, obs, jacobians=True):
+    r = np.zeros(2)
+    jc = np.zeros((2, 9)) if jacobians else None
+    jp = np.zeros((2, 3)) if jacobians else None
+    lib().orc_snavely(_p(_f64(camera)), _p(_f64(point)), _p(_f64(obs)), _p(r), _p(jc), _p(jp))
+    return r, jc, jp
+
+
+def angle_axis_rotate_point(aa, pt):
+    out = np.zeros(3)
+    lib().orc_angle_axis_rotate_point(_p(_f64(aa)), _p(_f64(pt)), _p(out))
+    return out
+
+
+def bal_residual_order(num_points, point_index):
+    point_index = np.ascontiguousarray(point_index, dtype=np.int32)
+    order = np.zeros(point_index.shape[0], dtype=np.int64)
+    lib().orc_bal_residual_order(int(num_points), ctypes.c_int64(point_index.shape[0]), _p(point_index), _p(order))
+    return order
+
+
+def stable_schur_ordering(num_cameras, num_points, camera_index, point_index):
+    camera_index = np.ascontiguousarray(camera_index, dtype=np.int32)
+    point_index = np.ascontiguousarray(point_index, dtype=np.int32)
+    ordering = np.zeros(num_cameras + num_points, dtype=np.int32)
+    k = lib().orc_stable_schur_ordering(int(num_cameras), int(num_points), ctypes.c_int64(camera_index.shape[0]),
+                                        _p(camera_index), _p(point_index), _p(ordering))
+    return ordering, k
+
+
+def bal_structure_arrays(num_cameras, num_points, camera_index, point_index, order):
+    """Returns (row_blocks, col_blocks, row_cell_begin, cells) numpy arrays."""
+    from numpy import zeros
+    O = int(camera_index.shape[0])
+    blk = np.dtype([("size", np.int32), ("position", np.int32)])
+    cel = np.dtype([("block_id", np.int32), ("position", np.int32)])
+    rb = zeros(O, dtype=blk)
+    cb = zeros(num_points + num_cameras, dtype=blk)
+    rcb = zeros(O + 1, dtype=np.int32)
+    cells = zeros(2 * O, dtype=cel)
+    lib().orc_bal_structure(int(num_cameras), int(num_points), ctypes.c_int64(O),
+                            _p(np.ascontiguousarray(camera_index, dtype=np.int32)),
+                            _p(np.ascontiguousarray(point_index, dtype=np.int32)),
+                            _p(np.ascontiguousarray(order, dtype=np.int64)), _p(rb), _p(cb), _p(rcb), _p(cells))
+    return rb, cb, rcb, cells
+
+
+def bal_evaluate(bs, num_cameras, num_points, camera_index, point_index, observations, order, state,
+                 want_residuals=True, want_gradient=True, want_jacobian=True):
+    O = int(camera_index.shape[0])
+    cost = ctypes.c_double()
+    res = np.zeros(2 * O) if want_residuals else None
+    grad = np.zeros(3 * num_points + 9 * num_cameras) if want_gradient else None
+    vals = np.zeros(24 * O) if want_jacobian else None
+    lib().orc_bal_evaluate(bs.c, int(num_cameras), int(num_points), ctypes.c_int64(O),
+                           _p(np.ascontiguousarray(camera_index, dtype=np.int32)),
+                           _p(np.ascontiguousarray(point_index, dtype=np.int32)),
+                           _p(_f64(observations)), _p(np.ascontiguousarray(order, dtype=np.int64)),
+                           _p(_f64(state)), ctypes.byref(cost), _p(res), _p(grad), _p(vals))
+    return cost.value, res, grad, vals

@@ -1,0 +1,107 @@
+// ORACLE -- TEST INFRASTRUCTURE ONLY (see orc_common.h).
+// extern "C" surface of liborc.so, consumed through ctypes by tests/ and by
+// bench.py's cpu_baseline leg.
+#ifndef ORC_API_H_
+#define ORC_API_H_
+
+#include "../include/cxschur.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+void orc_set_num_threads(int n);
+int orc_get_num_threads(void);
+
+/* BlockSparseMatrix (block_sparse_matrix.cc) */
+void orc_right_multiply(const cx_block_structure* bs, const double* values, const double* x, double* y);
+void orc_left_multiply(const cx_block_structure* bs, const double* values, const double* x, double* y);
+void orc_squared_column_norm(const cx_block_structure* bs, const double* values, double* x);
+void orc_scale_columns(const cx_block_structure* bs, double* values, const double* scale);
+/* ToCompressedRowSparseMatrix / ...Transpose (block_sparse_matrix.cc:451-492);
+ * rows has num_rows+1 (or num_cols+1) entries; returns nnz */
+int64_t orc_to_crs(const cx_block_structure* bs, const double* values, int transpose,
+                   int32_t* rows, int32_t* cols, double* vals);
+
+void orc_detect_structure(const cx_block_structure* bs, int num_eliminate_blocks,
+                          int* row_block_size, int* e_block_size, int* f_block_size);
+
+/* SchurEliminator (schur_eliminator_impl.h).  lhs: dense row-major n x n with
+ * n = sum of f block sizes, upper block triangle written (BlockRandomAccessDenseMatrix);
+ * b / rhs / D may be NULL as in the reference. */
+int orc_schur_eliminate_dense(const cx_block_structure* bs, const double* values, const double* b,
+                              const double* D, int num_eliminate_blocks, double* lhs, double* rhs);
+/* same with a BlockRandomAccessDiagonalMatrix lhs (SchurJacobiPreconditioner):
+ * blocks = concatenated f_i x f_i row-major diagonal blocks of S (not inverted) */
+int orc_schur_eliminate_diagonal(const cx_block_structure* bs, const double* values,
+                                 const double* D, int num_eliminate_blocks, double* blocks);
+int orc_schur_back_substitute(const cx_block_structure* bs, const double* values, const double* b,
+                              const double* D, int num_eliminate_blocks, const double* z, double* x);
+/* DenseCholesky::FactorAndSolve on the upper triangle of row-major lhs (lhs is
+ * overwritten by the factor).  Returns cx_termination. */
+int orc_dense_cholesky_solve(int n, double* lhs, const double* rhs, double* x);
+
+/* ImplicitSchurComplement (implicit_schur_complement.cc): y = S x; rhs optional */
+int orc_implicit_schur_multiply(const cx_block_structure* bs, const double* values, const double* D,
+                                const double* b, int num_eliminate_blocks, const double* x,
+                                double* y, double* rhs);
+/* block diagonal of E'E (+D^2) inverse and F'F (+D^2) inverse
+ * (partitioned_matrix_view_impl.h:420-658 + AddDiagonalAndInvert) */
+int orc_block_diagonal_inverses(const cx_block_structure* bs, const double* values, const double* D,
+                                int num_eliminate_blocks, double* ete_inv, double* ftf_inv);
+
+/* LinearSolver::Solve for DENSE_SCHUR / SPARSE_SCHUR(dense S) / ITERATIVE_SCHUR / CGNR */
+int orc_solve(const cx_block_structure* bs, const double* values, const double* b, const double* D,
+              const cx_solver_options* options, double r_tolerance, double q_tolerance, double* x,
+              cx_summary* summary);
+
+/* The same solve on one shard of a point-partitioned J; camera-space sums go
+ * through the callback (sum-all-reduce in place).  Used by the gloo tests. */
+typedef void (*orc_allreduce_fn)(double* buf, int64_t n, void* user);
+int orc_solve_sharded(const cx_block_structure* bs, const double* values, const double* b,
+                      const double* D, const cx_solver_options* options, double r_tolerance,
+                      double q_tolerance, double* x, cx_summary* summary, orc_allreduce_fn fn,
+                      void* user);
+
+/* ConjugateGradientsSolver on a small dense SPD system with identity
+ * preconditioner (conjugate_gradients_solver_test.cc:46-153) */
+int orc_cg_dense(int n, const double* A, const double* b, double* x, int min_num_iterations,
+                 int max_num_iterations, int residual_reset_period, double r_tolerance,
+                 double q_tolerance, cx_summary* summary);
+
+/* ---- bundle adjustment ---- */
+/* SnavelyReprojectionError via forward-mode duals (Jet<double,12>):
+ * residual[2], jac_cam[2x9 row-major], jac_pt[2x3]; jacobians may be NULL */
+void orc_snavely(const double* camera9, const double* point3, const double* obs2,
+                 double* residual, double* jac_cam, double* jac_pt);
+void orc_angle_axis_rotate_point(const double* aa, const double* pt, double* out);
+
+/* LexicographicallyOrderResidualBlocks (reorder_program.cc:256-338) for BAL:
+ * order[k] = input observation index placed at row block k. */
+void orc_bal_residual_order(int num_points, int64_t num_obs, const int32_t* point_index,
+                            int64_t* order);
+/* ComputeStableSchurOrdering (parameter_block_ordering.cc:50-83) on the BAL
+ * Hessian graph with parameter blocks in program order cameras 0..C-1, points
+ * 0..P-1 (bal_problem / bundle_adjuster.cc:253-267): vertex ids camera i -> i,
+ * point j -> C + j.  Returns the independent set size. */
+int orc_stable_schur_ordering(int num_cameras, int num_points, int64_t num_obs,
+                              const int32_t* camera_index, const int32_t* point_index,
+                              int32_t* ordering);
+/* Fill a block structure for BAL in the layout BuildJacobianLayout gives
+ * (block_jacobian_writer.cc:68-167): caller allocates row_blocks[O],
+ * col_blocks[P+C], row_cell_begin[O+1], cells[2O]. */
+void orc_bal_structure(int num_cameras, int num_points, int64_t num_obs,
+                       const int32_t* camera_index, const int32_t* point_index,
+                       const int64_t* order, cx_block* row_blocks, cx_block* col_blocks,
+                       int32_t* row_cell_begin, cx_cell* cells);
+/* ProgramEvaluator::Evaluate for BAL (program_evaluator.h:137-304): state =
+ * [points | cameras]; any of cost/residuals/gradient/values may be NULL */
+void orc_bal_evaluate(const cx_block_structure* bs, int num_cameras, int num_points,
+                      int64_t num_obs, const int32_t* camera_index, const int32_t* point_index,
+                      const double* observations, const int64_t* order, const double* state,
+                      double* cost, double* residuals, double* gradient, double* values);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

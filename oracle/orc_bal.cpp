@@ -1,0 +1,257 @@
+// ORACLE -- TEST INFRASTRUCTURE ONLY (see orc_common.h).
+// Bundle-adjustment evaluation and ordering: SnavelyReprojectionError through
+// forward-mode duals (include/ceres/jet.h, internal/autodiff.h),
+// AngleAxisRotatePoint (include/ceres/rotation.h:792-857),
+// LexicographicallyOrderResidualBlocks (reorder_program.cc:256-338),
+// ComputeStableSchurOrdering (parameter_block_ordering.cc:50-83,
+// graph_algorithms.h:165-227), BuildJacobianLayout
+// (block_jacobian_writer.cc:68-167) and ProgramEvaluator::Evaluate
+// (program_evaluator.h:137-304) for the BAL program.
+//
+// PARITY UNPINNED for the Snavely arithmetic: the reference holds no numeric
+// fixture for it (data/problem-16-22106-pre.txt is a stripped blob); tests pin
+// it by central differences and scipy's rotation instead.
+#include <omp.h>
+
+#include <algorithm>
+#include <numeric>
+
+#include "orc_api.h"
+#include "orc_common.h"
+
+namespace orc {
+
+// include/ceres/jet.h restated for T = double.
+template <int N>
+struct Jet {
+  double a;
+  double v[N];
+  Jet() : a(0.0) { for (int i = 0; i < N; ++i) v[i] = 0.0; }
+  explicit Jet(double s) : a(s) { for (int i = 0; i < N; ++i) v[i] = 0.0; }
+  Jet(double s, int k) : a(s) { for (int i = 0; i < N; ++i) v[i] = 0.0; v[k] = 1.0; }
+};
+template <int N> inline Jet<N> operator-(const Jet<N>& f) { Jet<N> r; r.a = -f.a; for (int i = 0; i < N; ++i) r.v[i] = -f.v[i]; return r; }
+template <int N> inline Jet<N> operator+(const Jet<N>& f, const Jet<N>& g) { Jet<N> r; r.a = f.a + g.a; for (int i = 0; i < N; ++i) r.v[i] = f.v[i] + g.v[i]; return r; }
+template <int N> inline Jet<N> operator-(const Jet<N>& f, const Jet<N>& g) { Jet<N> r; r.a = f.a - g.a; for (int i = 0; i < N; ++i) r.v[i] = f.v[i] - g.v[i]; return r; }
+template <int N> inline Jet<N> operator+(double s, const Jet<N>& f) { Jet<N> r = f; r.a = f.a + s; return r; }
+template <int N> inline Jet<N> operator-(const Jet<N>& f, double s) { Jet<N> r = f; r.a = f.a - s; return r; }
+template <int N> inline Jet<N> operator-(double s, const Jet<N>& f) { Jet<N> r; r.a = s - f.a; for (int i = 0; i < N; ++i) r.v[i] = -f.v[i]; return r; }
+// jet.h:349-352
+template <int N> inline Jet<N> operator*(const Jet<N>& f, const Jet<N>& g) { Jet<N> r; r.a = f.a * g.a; for (int i = 0; i < N; ++i) r.v[i] = f.a * g.v[i] + f.v[i] * g.a; return r; }
+template <int N> inline Jet<N> operator*(const Jet<N>& f, double s) { Jet<N> r; r.a = f.a * s; for (int i = 0; i < N; ++i) r.v[i] = f.v[i] * s; return r; }
+// jet.h:367-379
+template <int N> inline Jet<N> operator/(const Jet<N>& f, const Jet<N>& g) {
+  const double g_a_inverse = 1.0 / g.a;
+  const double f_a_by_g_a = f.a * g_a_inverse;
+  Jet<N> r; r.a = f_a_by_g_a;
+  for (int i = 0; i < N; ++i) r.v[i] = (f.v[i] - f_a_by_g_a * g.v[i]) * g_a_inverse;
+  return r;
+}
+// jet.h:382-386
+template <int N> inline Jet<N> operator/(double s, const Jet<N>& g) {
+  const double m = -s / (g.a * g.a);
+  Jet<N> r; r.a = s / g.a; for (int i = 0; i < N; ++i) r.v[i] = g.v[i] * m; return r;
+}
+// jet.h:614-629
+template <int N> inline Jet<N> cos(const Jet<N>& f) { Jet<N> r; r.a = std::cos(f.a); const double m = -std::sin(f.a); for (int i = 0; i < N; ++i) r.v[i] = m * f.v[i]; return r; }
+template <int N> inline Jet<N> sin(const Jet<N>& f) { Jet<N> r; r.a = std::sin(f.a); const double m = std::cos(f.a); for (int i = 0; i < N; ++i) r.v[i] = m * f.v[i]; return r; }
+// jet.h:733-748
+template <int N> inline Jet<N> hypot3(const Jet<N>& x, const Jet<N>& y, const Jet<N>& z) {
+  const double tmp = std::hypot(x.a, y.a, z.a);
+  Jet<N> r; r.a = tmp;
+  const double cx = x.a / tmp, cy = y.a / tmp, cz = z.a / tmp;
+  for (int i = 0; i < N; ++i) r.v[i] = cx * x.v[i] + cy * y.v[i] + cz * z.v[i];
+  return r;
+}
+inline double hypot3(double x, double y, double z) { return std::hypot(x, y, z); }
+inline double value_of(double x) { return x; }
+template <int N> inline double value_of(const Jet<N>& x) { return x.a; }
+inline double make(double, double s) { return s; }
+template <int N> inline Jet<N> make(const Jet<N>&, double s) { return Jet<N>(s); }
+
+// rotation.h:792-857
+template <typename T>
+inline void AngleAxisRotatePoint(const T aa[3], const T pt[3], T result[3]) {
+  using std::cos;
+  using std::sin;
+  const T theta = hypot3(aa[0], aa[1], aa[2]);
+  if (std::fpclassify(value_of(theta)) != FP_ZERO) {
+    const T costheta = cos(theta);
+    const T sintheta = sin(theta);
+    const T theta_inverse = 1.0 / theta;
+    const T w[3] = {aa[0] * theta_inverse, aa[1] * theta_inverse, aa[2] * theta_inverse};
+    const T w_cross_pt[3] = {w[1] * pt[2] - w[2] * pt[1], w[2] * pt[0] - w[0] * pt[2], w[0] * pt[1] - w[1] * pt[0]};
+    const T tmp = (w[0] * pt[0] + w[1] * pt[1] + w[2] * pt[2]) * (1.0 - costheta);
+    result[0] = pt[0] * costheta + w_cross_pt[0] * sintheta + w[0] * tmp;
+    result[1] = pt[1] * costheta + w_cross_pt[1] * sintheta + w[1] * tmp;
+    result[2] = pt[2] * costheta + w_cross_pt[2] * sintheta + w[2] * tmp;
+  } else {
+    const T w_cross_pt[3] = {aa[1] * pt[2] - aa[2] * pt[1], aa[2] * pt[0] - aa[0] * pt[2], aa[0] * pt[1] - aa[1] * pt[0]};
+    result[0] = pt[0] + w_cross_pt[0];
+    result[1] = pt[1] + w_cross_pt[1];
+    result[2] = pt[2] + w_cross_pt[2];
+  }
+}
+
+// examples/snavely_reprojection_error.h:57-92
+template <typename T>
+inline void Snavely(const T* camera, const T* point, double ox, double oy, T* residuals) {
+  T p[3];
+  AngleAxisRotatePoint(camera, point, p);
+  p[0] = p[0] + camera[3];
+  p[1] = p[1] + camera[4];
+  p[2] = p[2] + camera[5];
+  const T xp = -p[0] / p[2];
+  const T yp = -p[1] / p[2];
+  const T& l1 = camera[7];
+  const T& l2 = camera[8];
+  const T r2 = xp * xp + yp * yp;
+  const T distortion = 1.0 + r2 * (l1 + l2 * r2);
+  const T& focal = camera[6];
+  const T predicted_x = focal * distortion * xp;
+  const T predicted_y = focal * distortion * yp;
+  residuals[0] = predicted_x - ox;
+  residuals[1] = predicted_y - oy;
+}
+
+// AutoDiffCostFunction<Snavely,2,9,3>::Evaluate (internal/autodiff.h:296-360):
+// one pass with Jet<double,12>, camera parameters in dual slots 0..8, point in 9..11.
+static void SnavelyAutoDiff(const double* cam, const double* pt, const double* obs, double* res,
+                            double* jc, double* jp) {
+  if (!jc && !jp) {
+    Snavely<double>(cam, pt, obs[0], obs[1], res);
+    return;
+  }
+  using J = Jet<12>;
+  J c[9], p[3], r[2];
+  for (int i = 0; i < 9; ++i) c[i] = J(cam[i], i);
+  for (int i = 0; i < 3; ++i) p[i] = J(pt[i], 9 + i);
+  Snavely<J>(c, p, obs[0], obs[1], r);
+  for (int k = 0; k < 2; ++k) {
+    res[k] = r[k].a;
+    if (jc) for (int i = 0; i < 9; ++i) jc[k * 9 + i] = r[k].v[i];
+    if (jp) for (int i = 0; i < 3; ++i) jp[k * 3 + i] = r[k].v[9 + i];
+  }
+}
+
+}  // namespace orc
+
+using namespace orc;
+
+extern "C" {
+
+void orc_snavely(const double* cam, const double* pt, const double* obs, double* res, double* jc, double* jp) {
+  SnavelyAutoDiff(cam, pt, obs, res, jc, jp);
+}
+
+void orc_angle_axis_rotate_point(const double* aa, const double* pt, double* out) {
+  AngleAxisRotatePoint<double>(aa, pt, out);
+}
+
+// reorder_program.cc:256-338 with MinParameterBlock == point index (the only
+// parameter block of a BAL residual that lies in the first elimination group)
+void orc_bal_residual_order(int num_points, int64_t num_obs, const int32_t* point_index, int64_t* order) {
+  std::vector<int64_t> offsets(num_points + 1, 0);
+  for (int64_t i = 0; i < num_obs; ++i) offsets[point_index[i]]++;
+  std::partial_sum(offsets.begin(), offsets.end(), offsets.begin());
+  // each bucket is filled from its back to its front
+  for (int64_t i = 0; i < num_obs; ++i) {
+    const int bucket = point_index[i];
+    offsets[bucket]--;
+    order[offsets[bucket]] = i;
+  }
+}
+
+// parameter_block_ordering.cc:50-83 + graph_algorithms.h:165-227.
+// Hessian graph (parameter_block_ordering.cc:120-160): vertices = parameter
+// blocks, an edge between every pair of blocks sharing a residual.  For BAL that
+// is the bipartite camera-point graph.  Degree = number of distinct neighbours.
+int orc_stable_schur_ordering(int C, int P, int64_t O, const int32_t* cam, const int32_t* pt, int32_t* ordering) {
+  const int n = C + P;
+  std::vector<std::vector<int32_t>> nbr(n);
+  for (int64_t i = 0; i < O; ++i) {
+    nbr[cam[i]].push_back(C + pt[i]);
+    nbr[C + pt[i]].push_back(cam[i]);
+  }
+  for (auto& v : nbr) { std::sort(v.begin(), v.end()); v.erase(std::unique(v.begin(), v.end()), v.end()); }
+  // CreateHessianGraph adds every non-constant parameter block as a vertex
+  // (parameter_block_ordering.cc:126-135), so isolated blocks are kept; the
+  // queue starts in program order (cameras, then points).
+  std::vector<int32_t> queue(n);
+  std::iota(queue.begin(), queue.end(), 0);
+  std::stable_sort(queue.begin(), queue.end(), [&](int32_t a, int32_t b) { return nbr[a].size() < nbr[b].size(); });
+  std::vector<char> color(n, 0);  // 0 white, 1 grey, 2 black
+  int k = 0;
+  for (int32_t v : queue) {
+    if (color[v] != 0) continue;
+    ordering[k++] = v;
+    color[v] = 2;
+    for (int32_t u : nbr[v]) color[u] = 1;
+  }
+  const int independent_set_size = k;
+  for (int32_t v : queue) if (color[v] != 2) ordering[k++] = v;
+  return independent_set_size;
+}
+
+// block_jacobian_writer.cc:68-263 for residual blocks {point (e), camera (f)}:
+// E cells packed first in row order, then F cells.
+void orc_bal_structure(int C, int P, int64_t O, const int32_t* cam, const int32_t* pt,
+                       const int64_t* order, cx_block* row_blocks, cx_block* col_blocks,
+                       int32_t* row_cell_begin, cx_cell* cells) {
+  for (int j = 0; j < P; ++j) { col_blocks[j].size = 3; col_blocks[j].position = 3 * j; }
+  for (int i = 0; i < C; ++i) { col_blocks[P + i].size = 9; col_blocks[P + i].position = 3 * P + 9 * i; }
+  const int64_t f_block_pos = 6 * O;
+  for (int64_t k = 0; k < O; ++k) {
+    const int64_t i = order[k];
+    row_blocks[k].size = 2;
+    row_blocks[k].position = int32_t(2 * k);
+    row_cell_begin[k] = int32_t(2 * k);
+    cells[2 * k].block_id = pt[i];
+    cells[2 * k].position = int32_t(6 * k);
+    cells[2 * k + 1].block_id = P + cam[i];
+    cells[2 * k + 1].position = int32_t(f_block_pos + 18 * k);
+  }
+  row_cell_begin[O] = int32_t(2 * O);
+}
+
+// program_evaluator.h:137-304 (no loss function, no manifolds: bundle_adjuster
+// defaults, bundle_adjuster.cc:112,327-328)
+void orc_bal_evaluate(const cx_block_structure* s, int C, int P, int64_t O, const int32_t* cam,
+                      const int32_t* pt, const double* observations, const int64_t* order,
+                      const double* state, double* cost, double* residuals, double* gradient,
+                      double* values) {
+  BS bs(s);
+  const int threads = orc_get_num_threads();
+  double total = 0.0;
+  const int num_cols = 3 * P + 9 * C;
+  std::vector<std::vector<double>> grads;
+  if (gradient) grads.assign(threads, std::vector<double>(num_cols, 0.0));
+  (void)bs;
+#pragma omp parallel for schedule(static) num_threads(threads) reduction(+ : total)
+  for (int64_t k = 0; k < O; ++k) {
+    const int64_t i = order[k];
+    const double* camera = state + 3 * P + 9 * cam[i];
+    const double* point = state + 3 * pt[i];
+    double r[2], jc[18], jp[6];
+    const bool need_j = values || gradient;
+    SnavelyAutoDiff(camera, point, observations + 2 * i, r, need_j ? jc : nullptr, need_j ? jp : nullptr);
+    total += 0.5 * (r[0] * r[0] + r[1] * r[1]);
+    if (residuals) { residuals[2 * k] = r[0]; residuals[2 * k + 1] = r[1]; }
+    if (values) {
+      std::copy(jp, jp + 6, values + 6 * k);
+      std::copy(jc, jc + 18, values + 6 * O + 18 * k);
+    }
+    if (gradient) {
+      double* g = grads[omp_get_thread_num()].data();
+      MatTVec(jp, 2, 3, r, g + 3 * pt[i], 1);
+      MatTVec(jc, 2, 9, r, g + 3 * P + 9 * cam[i], 1);
+    }
+  }
+  if (cost) *cost = total;
+  if (gradient) {
+    std::fill(gradient, gradient + num_cols, 0.0);
+    for (auto& g : grads) for (int i = 0; i < num_cols; ++i) gradient[i] += g[i];
+  }
+}
+
+}  // extern "C"
