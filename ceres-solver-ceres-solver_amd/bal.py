@@ -1,0 +1,209 @@
+"""Synthetic BAL-shaped bundle-adjustment problems (host side, numpy).
+
+No BAL file exists in the build image (the reference's
+data/problem-16-22106-pre.txt is a stripped blob), so benchmarks and parity tests
+run on deterministic problems with the public BAL header sizes: C cameras with 9
+parameters (angle-axis, translation, focal, k1, k2 -- the camera model of
+examples/snavely_reprojection_error.h:53-104), P points, O observations listed
+point-major like BAL files (examples/bal_problem.cc:73-130).
+"""
+from dataclasses import dataclass
+
+import numpy as np
+
+from .structure import BLOCK_DTYPE, CELL_DTYPE, BlockStructure
+
+# name -> (cameras, points, observations, seed); sizes are the public BAL headers
+PRESETS = {
+    "ladybug16": (16, 22106, 83718, 16),
+    "ladybug49": (49, 7776, 31843, 49),
+    "dubrovnik356": (356, 226730, 1255268, 356),
+    "final13682": (13682, 4456117, 28987644, 13682),
+    "synthetic10M": (5000, 1500000, 10000000, 10),
+}
+
+
+@dataclass
+class BalProblem:
+    num_cameras: int
+    num_points: int
+    camera_index: np.ndarray   # [O] int32, input (file) order
+    point_index: np.ndarray    # [O] int32
+    observations: np.ndarray   # [O, 2] float64
+    cameras: np.ndarray        # [C, 9]
+    points: np.ndarray         # [P, 3]
+
+    @property
+    def num_observations(self):
+        return int(self.camera_index.shape[0])
+
+    def state(self):
+        """Parameter vector in column order: points then cameras (the order
+        ApplyOrdering gives bundle_adjuster's user ordering, reorder_program.cc:216-254)."""
+        return np.concatenate([self.points.ravel(), self.cameras.ravel()])
+
+
+def _rodrigues(aa, X):
+    theta = np.linalg.norm(aa, axis=1, keepdims=True)
+    theta = np.where(theta == 0.0, 1.0, theta)
+    w = aa / theta
+    c, s = np.cos(theta), np.sin(theta)
+    return X * c + np.cross(w, X) * s + w * (np.sum(w * X, axis=1, keepdims=True) * (1.0 - c))
+
+
+def project(cameras, points, camera_index, point_index):
+    """Snavely projection of the listed (camera, point) pairs; [O, 2]."""
+    cam = cameras[camera_index]
+    p = _rodrigues(cam[:, 0:3], points[point_index]) + cam[:, 3:6]
+    xp = -p[:, 0] / p[:, 2]
+    yp = -p[:, 1] / p[:, 2]
+    r2 = xp * xp + yp * yp
+    d = 1.0 + r2 * (cam[:, 7] + cam[:, 8] * r2)
+    return np.stack([cam[:, 6] * d * xp, cam[:, 6] * d * yp], axis=1)
+
+
+def _track_lengths(rng, C, P, O):
+    """k_j >= 2 observations per point, sum = O, k_j <= C."""
+    assert 2 * P <= O <= C * P, "need 2P <= O <= C*P"
+    extra = O - 2 * P
+    mean_extra = extra / P
+    kmax = C - 2
+    if mean_extra <= 0:
+        k = np.zeros(P, dtype=np.int64)
+    else:
+        p = 1.0 / (1.0 + mean_extra)
+        k = np.minimum(rng.geometric(p, size=P) - 1, kmax).astype(np.int64)
+    diff = int(extra - k.sum())
+    # fix the total deterministically by single increments / decrements
+    while diff != 0:
+        if diff > 0:
+            cand = np.flatnonzero(k < kmax)
+            take = cand[rng.permutation(cand.size)[:min(diff, cand.size)]]
+            k[take] += 1
+            diff -= take.size
+        else:
+            cand = np.flatnonzero(k > 0)
+            take = cand[rng.permutation(cand.size)[:min(-diff, cand.size)]]
+            k[take] -= 1
+            diff += take.size
+    return k + 2
+
+
+def make_bal_like(C, P, O, seed, noise_px=0.5, perturb=True):
+    """Cameras on a noisy ring looking at a point cloud; each point is seen from a
+    window of neighbouring cameras, so the reduced camera matrix is banded like
+    real SfM data.  Deterministic in (C, P, O, seed)."""
+    rng = np.random.default_rng(seed)
+    # ---- scene
+    ang = 2.0 * np.pi * np.arange(C) / C
+    radius = 300.0 * (1.0 + 0.05 * rng.standard_normal(C))
+    centers = np.stack([radius * np.cos(ang), radius * np.sin(ang), 20.0 * rng.standard_normal(C)], axis=1)
+    z = centers / np.linalg.norm(centers, axis=1, keepdims=True)      # camera looks down -z at the origin
+    up = np.array([0.0, 0.0, 1.0])
+    x = np.cross(up, z)
+    x /= np.linalg.norm(x, axis=1, keepdims=True)
+    y = np.cross(z, x)
+    R = np.stack([x, y, z], axis=1)                                   # world -> camera
+    from scipy.spatial.transform import Rotation
+    aa = Rotation.from_matrix(R).as_rotvec()
+    t = -np.einsum("cij,cj->ci", R, centers)
+    cameras = np.zeros((C, 9))
+    cameras[:, 0:3] = aa
+    cameras[:, 3:6] = t
+    cameras[:, 6] = 1000.0 * (1.0 + 0.1 * rng.standard_normal(C))
+    cameras[:, 7] = -0.05 + 0.01 * rng.standard_normal(C)
+    cameras[:, 8] = 0.01 + 0.002 * rng.standard_normal(C)
+    points = 30.0 * rng.standard_normal((P, 3))
+    # ---- visibility: point j is seen by k_j distinct cameras around a home camera
+    k = _track_lengths(rng, C, P, O)
+    home = (np.arange(P, dtype=np.int64) * C) // max(P, 1)
+    home = (home + rng.integers(0, max(1, C // 8) + 1, size=P)) % C
+    max_stride = np.maximum(1, np.minimum(3, C // np.maximum(k, 1)))
+    stride = 1 + (rng.integers(0, 3, size=P) % max_stride)
+    point_index = np.repeat(np.arange(P, dtype=np.int64), k)
+    first = np.concatenate([[0], np.cumsum(k)[:-1]])
+    within = np.arange(O, dtype=np.int64) - np.repeat(first, k)
+    camera_index = (np.repeat(home, k) + within * np.repeat(stride, k)) % C
+    # BAL lists observations point-major with ascending camera index
+    key = point_index * C + camera_index
+    order = np.argsort(key, kind="stable")
+    camera_index = camera_index[order].astype(np.int32)
+    point_index = point_index[order].astype(np.int32)
+    obs = project(cameras, points, camera_index, point_index)
+    obs += noise_px * rng.standard_normal(obs.shape)
+    if perturb:  # BALProblem::Perturb (bal_problem.cc:294-333)
+        cameras[:, 0:3] += 1e-4 * rng.standard_normal((C, 3))
+        cameras[:, 3:6] += 1e-2 * rng.standard_normal((C, 3))
+        points += 5e-2 * rng.standard_normal((P, 3))
+    return BalProblem(C, P, camera_index, point_index, obs, cameras, points)
+
+
+def make_preset(name, **kw):
+    C, P, O, seed = PRESETS[name]
+    return make_bal_like(C, P, O, seed, **kw)
+
+
+def residual_order(point_index, num_points):
+    """order[k] = input observation at row block k: residual blocks bucketed by
+    point, each bucket filled back to front, i.e. REVERSE input order inside a
+    chunk (LexicographicallyOrderResidualBlocks, reorder_program.cc:256-338)."""
+    O = point_index.shape[0]
+    rev = point_index[::-1]
+    return (O - 1 - np.argsort(rev, kind="stable")).astype(np.int64)
+
+
+def build_structure(problem, order=None):
+    """Block structure of J in the BuildJacobianLayout layout
+    (block_jacobian_writer.cc:68-167): E cells (2x3) packed first in row order,
+    then F cells (2x9); column blocks = points then cameras.  Returns
+    (BlockStructure, order)."""
+    C, P, O = problem.num_cameras, problem.num_points, problem.num_observations
+    assert 24 * O < 2 ** 31, "cell positions are int32 (block_jacobian_writer.cc:95-99)"
+    if order is None:
+        order = residual_order(problem.point_index, P)
+    cols = np.zeros(P + C, dtype=BLOCK_DTYPE)
+    cols["size"][:P] = 3
+    cols["size"][P:] = 9
+    cols["position"][:P] = 3 * np.arange(P)
+    cols["position"][P:] = 3 * P + 9 * np.arange(C)
+    rows = np.zeros(O, dtype=BLOCK_DTYPE)
+    rows["size"] = 2
+    rows["position"] = 2 * np.arange(O)
+    rcb = (2 * np.arange(O + 1)).astype(np.int32)
+    cells = np.zeros(2 * O, dtype=CELL_DTYPE)
+    cells["block_id"][0::2] = problem.point_index[order]
+    cells["position"][0::2] = 6 * np.arange(O)
+    cells["block_id"][1::2] = P + problem.camera_index[order]
+    cells["position"][1::2] = 6 * O + 18 * np.arange(O)
+    return BlockStructure(rows, cols, rcb, cells), order
+
+
+def random_jacobian_values(num_observations, seed):
+    """J values ~ N(0,1) on the BAL structure, as the reference's kernel
+    benchmarks do (evaluation_benchmark.cc:147-153)."""
+    return np.random.default_rng(seed).standard_normal(24 * num_observations)
+
+
+def partition_points(problem_or_counts, nranks, num_points=None):
+    """Contiguous point ranges with about equal observation counts (host mirror
+    of cx_partition_points); bounds[nranks + 1]."""
+    if isinstance(problem_or_counts, BalProblem):
+        counts = np.bincount(problem_or_counts.point_index, minlength=problem_or_counts.num_points)
+    else:
+        counts = np.asarray(problem_or_counts)
+    cum = np.concatenate([[0], np.cumsum(counts)])
+    total = cum[-1]
+    bounds = [0]
+    for r in range(1, nranks):
+        bounds.append(int(np.searchsorted(cum, total * r / nranks, side="left")))
+    bounds.append(len(counts))
+    return np.maximum.accumulate(np.array(bounds, dtype=np.int64))
+
+
+def shard(problem, lo, hi):
+    """The sub-problem holding points [lo, hi) and every camera (cameras stay
+    replicated; point indices are renumbered from 0)."""
+    sel = (problem.point_index >= lo) & (problem.point_index < hi)
+    return BalProblem(problem.num_cameras, hi - lo, problem.camera_index[sel],
+                      (problem.point_index[sel] - lo).astype(np.int32), problem.observations[sel],
+                      problem.cameras, problem.points[lo:hi])

@@ -1,0 +1,456 @@
+"""ctypes binding of csrc/libcxschur.so (C ABI: include/cxschur.h).
+
+Thin object wrappers used by tests/ and bench.py.  Nothing here computes: every
+call goes to the HIP library and raises CxError when it reports a failure (there
+is no CPU fallback).
+"""
+import ctypes
+import os
+
+import numpy as np
+
+from .structure import BlockStructure, cx_block_structure
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libcxschur.so")
+_lib = None
+
+HOST, DEVICE = 0, 1
+DENSE_SCHUR, SPARSE_SCHUR, ITERATIVE_SCHUR, CGNR = 0, 1, 2, 3
+IDENTITY, JACOBI, SCHUR_JACOBI, SCHUR_POWER_SERIES_EXPANSION = 0, 1, 2, 3
+SUCCESS, NO_CONVERGENCE, FAILURE, FATAL_ERROR = 0, 1, 2, 3
+
+# every symbol include/cxschur.h declares (tests check that the library exports them all)
+EXPORTED_SYMBOLS = [
+    "cx_context_create", "cx_context_destroy", "cx_comm_unique_id", "cx_context_set_comm", "cx_context_rank",
+    "cx_context_num_ranks", "cx_allreduce_sum", "cx_malloc", "cx_free", "cx_memcpy_h2d", "cx_memcpy_d2h",
+    "cx_memset_zero", "cx_synchronize", "cx_context_stream", "cx_last_error", "cx_device_name",
+    "cx_matrix_create", "cx_matrix_destroy", "cx_matrix_num_rows", "cx_matrix_num_cols",
+    "cx_matrix_num_nonzeros", "cx_matrix_is_static_239", "cx_matrix_device_values", "cx_matrix_set_values",
+    "cx_matrix_get_values", "cx_matrix_values_changed", "cx_matrix_set_zero", "cx_matrix_right_multiply",
+    "cx_matrix_left_multiply", "cx_matrix_squared_column_norm", "cx_matrix_scale_columns",
+    "cx_matrix_last_kernel_ms", "cx_solver_create", "cx_solver_destroy", "cx_solver_default_options",
+    "cx_solver_solve", "cx_solver_last_timing", "cx_schur_eliminate_dense", "cx_schur_back_substitute",
+    "cx_implicit_schur_multiply", "cx_dense_cholesky_solve", "cx_evaluator_create_bal", "cx_evaluator_destroy",
+    "cx_evaluator_jacobian", "cx_evaluator_row_of_observation", "cx_evaluator_evaluate",
+    "cx_evaluator_last_kernel_ms", "cx_detect_structure", "cx_partition_points",
+]
+
+
+class CxError(RuntimeError):
+    pass
+
+
+class cx_solver_options(ctypes.Structure):
+    _fields_ = [
+        ("type", ctypes.c_int32),
+        ("preconditioner_type", ctypes.c_int32),
+        ("min_num_iterations", ctypes.c_int32),
+        ("max_num_iterations", ctypes.c_int32),
+        ("residual_reset_period", ctypes.c_int32),
+        ("num_eliminate_blocks", ctypes.c_int32),
+        ("use_mixed_precision_solves", ctypes.c_int32),
+        ("max_num_refinement_iterations", ctypes.c_int32),
+        ("max_num_spse_iterations", ctypes.c_int32),
+        ("use_spse_initialization", ctypes.c_int32),
+        ("spse_tolerance", ctypes.c_double),
+        ("deterministic", ctypes.c_int32),
+        ("reserved", ctypes.c_int32),
+    ]
+
+
+class cx_per_solve_options(ctypes.Structure):
+    _fields_ = [
+        ("D", ctypes.c_void_p),
+        ("r_tolerance", ctypes.c_double),
+        ("q_tolerance", ctypes.c_double),
+        ("memspace", ctypes.c_int32),
+        ("reserved", ctypes.c_int32),
+    ]
+
+
+class cx_summary(ctypes.Structure):
+    _fields_ = [
+        ("residual_norm", ctypes.c_double),
+        ("num_iterations", ctypes.c_int32),
+        ("termination_type", ctypes.c_int32),
+        ("message", ctypes.c_char * 256),
+    ]
+
+
+class cx_solve_timing(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_double) for n in
+                ("setup_ms", "eliminate_ms", "reduced_solve_ms", "back_substitute_ms", "total_ms", "allreduce_ms")]
+
+
+def library_path():
+    return LIB_PATH
+
+
+def load_library():
+    """Load libcxschur.so; raises CxError when it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise CxError("libcxschur.so is missing: run __graft_entry__.build() "
+                      "(python ceres-solver-ceres-solver_amd/build.py); there is no CPU fallback")
+    lib = ctypes.CDLL(LIB_PATH, mode=ctypes.RTLD_GLOBAL)
+    lib.cx_last_error.restype = ctypes.c_char_p
+    lib.cx_matrix_num_rows.restype = ctypes.c_int64
+    lib.cx_matrix_num_cols.restype = ctypes.c_int64
+    lib.cx_matrix_num_nonzeros.restype = ctypes.c_int64
+    lib.cx_matrix_device_values.restype = ctypes.c_void_p
+    lib.cx_matrix_last_kernel_ms.restype = ctypes.c_double
+    lib.cx_evaluator_last_kernel_ms.restype = ctypes.c_double
+    lib.cx_evaluator_jacobian.restype = ctypes.c_void_p
+    lib.cx_context_stream.restype = ctypes.c_void_p
+    for name in ("cx_matrix_destroy", "cx_solver_destroy", "cx_evaluator_destroy", "cx_context_destroy",
+                 "cx_matrix_num_rows", "cx_matrix_num_cols", "cx_matrix_num_nonzeros", "cx_matrix_is_static_239",
+                 "cx_matrix_device_values", "cx_matrix_last_kernel_ms", "cx_evaluator_jacobian",
+                 "cx_evaluator_last_kernel_ms", "cx_context_stream", "cx_context_rank", "cx_context_num_ranks"):
+        getattr(lib, name).argtypes = [ctypes.c_void_p]
+    _lib = lib
+    return lib
+
+
+def _check(rc):
+    if rc != 0:
+        raise CxError("cxschur error %d: %s" % (rc, load_library().cx_last_error().decode()))
+
+
+def _ptr(a):
+    """Host numpy array (float64, contiguous) or DeviceArray or None -> void*"""
+    if a is None:
+        return None
+    if isinstance(a, DeviceArray):
+        return ctypes.c_void_p(a.ptr)
+    assert isinstance(a, np.ndarray) and a.flags["C_CONTIGUOUS"]
+    return ctypes.c_void_p(a.ctypes.data)
+
+
+def _space(*arrays):
+    spaces = {DEVICE if isinstance(a, DeviceArray) else HOST for a in arrays if a is not None}
+    assert len(spaces) <= 1, "mixing host and device arrays in one call"
+    return spaces.pop() if spaces else HOST
+
+
+def _f64(a):
+    if a is None or isinstance(a, DeviceArray):
+        return a
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+class Context:
+    def __init__(self, device=0):
+        lib = load_library()
+        self._h = ctypes.c_void_p()
+        _check(lib.cx_context_create(int(device), ctypes.byref(self._h)))
+        self.lib = lib
+
+    def close(self):
+        if self._h:
+            self.lib.cx_context_destroy(self._h)
+            self._h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def name(self):
+        buf = ctypes.create_string_buffer(256)
+        _check(self.lib.cx_device_name(self._h, buf, 256))
+        return buf.value.decode()
+
+    @staticmethod
+    def unique_id():
+        buf = ctypes.create_string_buffer(128)
+        _check(load_library().cx_comm_unique_id(buf))
+        return buf.raw
+
+    def set_comm(self, rank, nranks, unique_id):
+        _check(self.lib.cx_context_set_comm(self._h, int(rank), int(nranks), unique_id))
+
+    @property
+    def rank(self):
+        return self.lib.cx_context_rank(self._h)
+
+    @property
+    def num_ranks(self):
+        return self.lib.cx_context_num_ranks(self._h)
+
+    def synchronize(self):
+        _check(self.lib.cx_synchronize(self._h))
+
+    def allreduce_sum(self, dev):
+        _check(self.lib.cx_allreduce_sum(self._h, ctypes.c_void_p(dev.ptr), ctypes.c_int64(dev.size)))
+
+    def empty(self, n, dtype=np.float64):
+        return DeviceArray(self, int(n), np.dtype(dtype))
+
+    def zeros(self, n, dtype=np.float64):
+        d = self.empty(n, dtype)
+        _check(self.lib.cx_memset_zero(self._h, ctypes.c_void_p(d.ptr), ctypes.c_size_t(d.nbytes)))
+        return d
+
+    def to_device(self, host):
+        host = np.ascontiguousarray(host)
+        d = self.empty(host.size, host.dtype)
+        _check(self.lib.cx_memcpy_h2d(self._h, ctypes.c_void_p(d.ptr), _ptr(host), ctypes.c_size_t(host.nbytes)))
+        return d
+
+
+class DeviceArray:
+    """A device allocation owned by a Context (cx_malloc / cx_free)."""
+
+    def __init__(self, ctx, n, dtype):
+        self.ctx, self.size, self.dtype = ctx, n, dtype
+        self.nbytes = n * dtype.itemsize
+        p = ctypes.c_void_p()
+        _check(ctx.lib.cx_malloc(ctx._h, ctypes.c_size_t(max(self.nbytes, 1)), ctypes.byref(p)))
+        self.ptr = p.value
+
+    def to_host(self):
+        out = np.empty(self.size, dtype=self.dtype)
+        _check(self.ctx.lib.cx_memcpy_d2h(self.ctx._h, _ptr(out), ctypes.c_void_p(self.ptr), ctypes.c_size_t(self.nbytes)))
+        return out
+
+    def copy_from_host(self, host):
+        host = np.ascontiguousarray(host, dtype=self.dtype)
+        assert host.size == self.size
+        _check(self.ctx.lib.cx_memcpy_h2d(self.ctx._h, ctypes.c_void_p(self.ptr), _ptr(host), ctypes.c_size_t(self.nbytes)))
+
+    def free(self):
+        if self.ptr and self.ctx._h:
+            self.ctx.lib.cx_free(self.ctx._h, ctypes.c_void_p(self.ptr))
+        self.ptr = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class Matrix:
+    """Device BlockSparseMatrix (cx_matrix)."""
+
+    def __init__(self, ctx, bs, num_eliminate_blocks=0, _handle=None):
+        self.ctx, self.bs, self.lib = ctx, bs, ctx.lib
+        self._owned = _handle is None
+        if _handle is None:
+            self._h = ctypes.c_void_p()
+            _check(self.lib.cx_matrix_create(ctx._h, bs.c, int(num_eliminate_blocks), ctypes.byref(self._h)))
+        else:
+            self._h = ctypes.c_void_p(_handle)
+
+    def close(self):
+        if self._h and self._owned and self.ctx._h:
+            self.lib.cx_matrix_destroy(self._h)
+        self._h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    num_rows = property(lambda s: s.lib.cx_matrix_num_rows(s._h))
+    num_cols = property(lambda s: s.lib.cx_matrix_num_cols(s._h))
+    num_nonzeros = property(lambda s: s.lib.cx_matrix_num_nonzeros(s._h))
+    is_static_239 = property(lambda s: bool(s.lib.cx_matrix_is_static_239(s._h)))
+    last_kernel_ms = property(lambda s: s.lib.cx_matrix_last_kernel_ms(s._h))
+
+    def set_values(self, values):
+        values = _f64(values)
+        _check(self.lib.cx_matrix_set_values(self._h, _ptr(values), _space(values)))
+
+    def get_values(self):
+        out = np.empty(self.num_nonzeros)
+        _check(self.lib.cx_matrix_get_values(self._h, _ptr(out)))
+        return out
+
+    def _vec(self, a, n):
+        a = _f64(a)
+        assert a.size == n
+        return a
+
+    def right_multiply(self, x, y=None):
+        """y += A x ; host arrays return a new array, device arrays are updated in place."""
+        x = self._vec(x, self.num_cols)
+        if isinstance(x, DeviceArray):
+            _check(self.lib.cx_matrix_right_multiply(self._h, _ptr(x), _ptr(y), DEVICE))
+            return y
+        y = np.zeros(self.num_rows) if y is None else np.array(y, dtype=np.float64)
+        _check(self.lib.cx_matrix_right_multiply(self._h, _ptr(x), _ptr(y), HOST))
+        return y
+
+    def left_multiply(self, x, y=None):
+        x = self._vec(x, self.num_rows)
+        if isinstance(x, DeviceArray):
+            _check(self.lib.cx_matrix_left_multiply(self._h, _ptr(x), _ptr(y), DEVICE))
+            return y
+        y = np.zeros(self.num_cols) if y is None else np.array(y, dtype=np.float64)
+        _check(self.lib.cx_matrix_left_multiply(self._h, _ptr(x), _ptr(y), HOST))
+        return y
+
+    def squared_column_norm(self, out=None):
+        if isinstance(out, DeviceArray):
+            _check(self.lib.cx_matrix_squared_column_norm(self._h, _ptr(out), DEVICE))
+            return out
+        out = np.zeros(self.num_cols)
+        _check(self.lib.cx_matrix_squared_column_norm(self._h, _ptr(out), HOST))
+        return out
+
+    def scale_columns(self, scale):
+        scale = self._vec(scale, self.num_cols)
+        _check(self.lib.cx_matrix_scale_columns(self._h, _ptr(scale), _space(scale)))
+
+
+def default_options(**kw):
+    o = cx_solver_options()
+    load_library().cx_solver_default_options(ctypes.byref(o))
+    for k, v in kw.items():
+        assert hasattr(o, k), k
+        setattr(o, k, v)
+    return o
+
+
+class Solver:
+    """LinearSolver (cx_solver)."""
+
+    def __init__(self, ctx, **options):
+        self.ctx, self.lib = ctx, ctx.lib
+        self.options = default_options(**options)
+        self._h = ctypes.c_void_p()
+        _check(self.lib.cx_solver_create(ctx._h, ctypes.byref(self.options), ctypes.byref(self._h)))
+
+    def close(self):
+        if self._h and self.ctx._h:
+            self.lib.cx_solver_destroy(self._h)
+        self._h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def solve(self, A, b, D=None, r_tolerance=-1.0, q_tolerance=0.0, x=None):
+        """Returns (x, summary).  Host in -> host out; device in -> device x (must be passed)."""
+        b, D = _f64(b), _f64(D)
+        space = _space(b, D, x)
+        if space == HOST:
+            x = np.full(A.num_cols, np.nan)
+        else:
+            assert x is not None
+        ps = cx_per_solve_options()
+        ps.D = _ptr(D).value if D is not None else None
+        ps.r_tolerance, ps.q_tolerance, ps.memspace = r_tolerance, q_tolerance, space
+        s = cx_summary()
+        _check(self.lib.cx_solver_solve(self._h, A._h, _ptr(b), ctypes.byref(ps), _ptr(x), ctypes.byref(s)))
+        return x, s
+
+    def timing(self):
+        t = cx_solve_timing()
+        _check(self.lib.cx_solver_last_timing(self._h, ctypes.byref(t)))
+        return {n: getattr(t, n) for n, _ in cx_solve_timing._fields_}
+
+
+def eliminate_dense(ctx, A, b, D, num_cols_f):
+    lhs = np.zeros((num_cols_f, num_cols_f))
+    rhs = np.zeros(num_cols_f)
+    _check(ctx.lib.cx_schur_eliminate_dense(ctx._h, A._h, _ptr(_f64(b)), _ptr(_f64(D)), _ptr(lhs),
+                                            _ptr(rhs) if b is not None else None, HOST))
+    return lhs, (rhs if b is not None else None)
+
+
+def back_substitute(ctx, A, b, D, z):
+    x = np.zeros(A.num_cols)
+    _check(ctx.lib.cx_schur_back_substitute(ctx._h, A._h, _ptr(_f64(b)), _ptr(_f64(D)), _ptr(_f64(z)), _ptr(x), HOST))
+    return x
+
+
+def implicit_schur_multiply(ctx, A, D, b, x, num_cols_f):
+    y = np.zeros(num_cols_f)
+    rhs = np.zeros(num_cols_f) if b is not None else None
+    _check(ctx.lib.cx_implicit_schur_multiply(ctx._h, A._h, _ptr(_f64(D)), _ptr(_f64(b)), _ptr(_f64(x)), _ptr(y),
+                                              _ptr(rhs), HOST))
+    return y, rhs
+
+
+def dense_cholesky_solve(ctx, lhs, rhs):
+    a = np.array(lhs, dtype=np.float64)
+    n = a.shape[0]
+    x = np.zeros(n)
+    s = cx_summary()
+    _check(ctx.lib.cx_dense_cholesky_solve(ctx._h, n, _ptr(a), _ptr(_f64(rhs)), _ptr(x), HOST, ctypes.byref(s)))
+    return x, s
+
+
+class Evaluator:
+    """Bundle-adjustment Evaluator (cx_evaluator)."""
+
+    def __init__(self, ctx, problem):
+        self.ctx, self.lib, self.problem = ctx, ctx.lib, problem
+        self._h = ctypes.c_void_p()
+        cam = np.ascontiguousarray(problem.camera_index, dtype=np.int32)
+        pt = np.ascontiguousarray(problem.point_index, dtype=np.int32)
+        obs = np.ascontiguousarray(problem.observations, dtype=np.float64)
+        _check(self.lib.cx_evaluator_create_bal(ctx._h, int(problem.num_cameras), int(problem.num_points),
+                                                ctypes.c_int64(problem.num_observations), _ptr(cam), _ptr(pt),
+                                                _ptr(obs), ctypes.byref(self._h)))
+        self.num_cols = 3 * problem.num_points + 9 * problem.num_cameras
+        self.num_rows = 2 * problem.num_observations
+
+    def close(self):
+        if self._h and self.ctx._h:
+            self.lib.cx_evaluator_destroy(self._h)
+        self._h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def jacobian(self, bs=None):
+        return Matrix(self.ctx, bs, _handle=self.lib.cx_evaluator_jacobian(self._h))
+
+    def row_of_observation(self):
+        out = np.zeros(self.problem.num_observations, dtype=np.int64)
+        _check(self.lib.cx_evaluator_row_of_observation(self._h, _ptr(out)))
+        return out
+
+    last_kernel_ms = property(lambda s: s.lib.cx_evaluator_last_kernel_ms(s._h))
+
+    def evaluate(self, state, want_residuals=True, want_gradient=True, want_jacobian=True, residuals=None,
+                 gradient=None):
+        """Returns (cost, residuals, gradient); the Jacobian lands in self.jacobian()."""
+        state = _f64(state)
+        cost = ctypes.c_double()
+        if isinstance(state, DeviceArray):
+            _check(self.lib.cx_evaluator_evaluate(self._h, _ptr(state), ctypes.byref(cost), _ptr(residuals),
+                                                  _ptr(gradient), int(want_jacobian), DEVICE))
+            return cost.value, residuals, gradient
+        res = np.zeros(self.num_rows) if want_residuals else None
+        grad = np.zeros(self.num_cols) if want_gradient else None
+        _check(self.lib.cx_evaluator_evaluate(self._h, _ptr(state), ctypes.byref(cost), _ptr(res), _ptr(grad),
+                                              int(want_jacobian), HOST))
+        return cost.value, res, grad
+
+
+def detect_structure(bs, num_eliminate_blocks):
+    r, e, f = ctypes.c_int32(), ctypes.c_int32(), ctypes.c_int32()
+    _check(load_library().cx_detect_structure(bs.c, int(num_eliminate_blocks), ctypes.byref(r), ctypes.byref(e),
+                                              ctypes.byref(f)))
+    return r.value, e.value, f.value
+
+
+def partition_points(bs, num_eliminate_blocks, nranks):
+    bounds = np.zeros(nranks + 1, dtype=np.int32)
+    _check(load_library().cx_partition_points(bs.c, int(num_eliminate_blocks), int(nranks), _ptr(bounds)))
+    return bounds

@@ -1,0 +1,233 @@
+// Context, memory and communicator entry points of libcxschur
+// (ContextImpl of the reference: context_impl.h:60-150, context_impl.cc:125-203).
+#include <dlfcn.h>
+
+#include <chrono>
+
+#include "cx_internal.h"
+
+static thread_local char g_error[512] = "";
+
+void cx_set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_error, sizeof(g_error), fmt, ap);
+  va_end(ap);
+}
+
+// ------------------------------------------------------------------ RCCL
+// librccl is resolved at run time so that a process that already carries a copy
+// (torch's) keeps exactly one instance: dlopen by soname returns the loaded one.
+namespace {
+struct UniqueId { char internal[128]; };
+using GetUniqueIdFn = int (*)(UniqueId*);
+using CommInitRankFn = int (*)(void**, int, UniqueId, int);
+using AllReduceFn = int (*)(const void*, void*, size_t, int, int, void*, hipStream_t);
+using CommDestroyFn = int (*)(void*);
+using GetErrorStringFn = const char* (*)(int);
+struct Rccl {
+  void* handle = nullptr;
+  GetUniqueIdFn get_unique_id = nullptr;
+  CommInitRankFn comm_init_rank = nullptr;
+  AllReduceFn all_reduce = nullptr;
+  CommDestroyFn comm_destroy = nullptr;
+  GetErrorStringFn error_string = nullptr;
+} g_rccl;
+constexpr int kNcclFloat64 = 8;  // rccl.h:467
+constexpr int kNcclSum = 0;      // rccl.h:448
+
+int LoadRccl() {
+  if (g_rccl.handle) return CX_OK;
+  const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+  void* h = nullptr;
+  for (const char* n : names) {
+    h = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+    if (h) break;
+  }
+  if (!h) {
+    cx_set_error("cannot load librccl: %s", dlerror());
+    return CX_ERR_COMM;
+  }
+  g_rccl.get_unique_id = reinterpret_cast<GetUniqueIdFn>(dlsym(h, "ncclGetUniqueId"));
+  g_rccl.comm_init_rank = reinterpret_cast<CommInitRankFn>(dlsym(h, "ncclCommInitRank"));
+  g_rccl.all_reduce = reinterpret_cast<AllReduceFn>(dlsym(h, "ncclAllReduce"));
+  g_rccl.comm_destroy = reinterpret_cast<CommDestroyFn>(dlsym(h, "ncclCommDestroy"));
+  g_rccl.error_string = reinterpret_cast<GetErrorStringFn>(dlsym(h, "ncclGetErrorString"));
+  if (!g_rccl.get_unique_id || !g_rccl.comm_init_rank || !g_rccl.all_reduce || !g_rccl.comm_destroy) {
+    cx_set_error("librccl lacks a required symbol");
+    return CX_ERR_COMM;
+  }
+  g_rccl.handle = h;
+  return CX_OK;
+}
+int RcclCheck(int rc, const char* what) {
+  if (rc == 0) return CX_OK;
+  cx_set_error("%s failed: %s", what, g_rccl.error_string ? g_rccl.error_string(rc) : "rccl error");
+  return CX_ERR_COMM;
+}
+}  // namespace
+
+int cx_allreduce_device(cx_context* ctx, double* p, int64_t n) {
+  if (ctx->nranks <= 1 || n == 0) return CX_OK;
+  if (!ctx->comm) {
+    cx_set_error("context has %d ranks but no communicator", ctx->nranks);
+    return CX_ERR_COMM;
+  }
+  auto t0 = std::chrono::steady_clock::now();
+  int rc = g_rccl.all_reduce(p, p, size_t(n), kNcclFloat64, kNcclSum, ctx->comm, ctx->stream);
+  ctx->allreduce_host_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+  return RcclCheck(rc, "ncclAllReduce");
+}
+
+extern "C" {
+
+const char* cx_last_error(void) { return g_error; }
+
+int cx_context_create(int device_id, cx_context** out) {
+  CX_CHECK_ARG(out != nullptr);
+  int count = 0;
+  hipError_t e = hipGetDeviceCount(&count);
+  if (e != hipSuccess || count == 0) {
+    cx_set_error("no HIP device available (%s); libcxschur has no CPU path", hipGetErrorString(e));
+    return CX_ERR_NO_DEVICE;
+  }
+  CX_CHECK_ARG(device_id >= 0 && device_id < count);
+  CX_HIP(hipSetDevice(device_id));
+  hipDeviceProp_t prop;
+  CX_HIP(hipGetDeviceProperties(&prop, device_id));
+  if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+    cx_set_error("device %d is %s; libcxschur carries gfx950 code objects only", device_id, prop.gcnArchName);
+    return CX_ERR_NO_DEVICE;
+  }
+  auto* ctx = new cx_context;
+  ctx->device = device_id;
+  ctx->num_cus = prop.multiProcessorCount;
+  std::snprintf(ctx->name, sizeof(ctx->name), "%s %s (%d CUs, %.0f GiB)", prop.gcnArchName, prop.name,
+                prop.multiProcessorCount, double(prop.totalGlobalMem) / (1 << 30));
+  CX_HIP(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+  for (auto& ev : ctx->ev) CX_HIP(hipEventCreate(&ev));
+  *out = ctx;
+  return CX_OK;
+}
+
+void cx_context_destroy(cx_context* ctx) {
+  if (!ctx) return;
+  (void)hipSetDevice(ctx->device);
+  (void)hipStreamSynchronize(ctx->stream);
+  if (ctx->comm && g_rccl.comm_destroy) g_rccl.comm_destroy(ctx->comm);
+  for (auto& ev : ctx->ev)
+    if (ev) (void)hipEventDestroy(ev);
+  if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+  delete ctx;
+}
+
+int cx_comm_unique_id(void* out) {
+  CX_CHECK_ARG(out != nullptr);
+  CX_TRY(LoadRccl());
+  UniqueId id;
+  CX_TRY(RcclCheck(g_rccl.get_unique_id(&id), "ncclGetUniqueId"));
+  std::memcpy(out, &id, sizeof(id));
+  return CX_OK;
+}
+
+int cx_context_set_comm(cx_context* ctx, int rank, int nranks, const void* unique_id) {
+  CX_CHECK_ARG(ctx != nullptr && nranks >= 1 && rank >= 0 && rank < nranks);
+  if (nranks == 1 && unique_id == nullptr) {
+    ctx->rank = 0;
+    ctx->nranks = 1;
+    return CX_OK;
+  }
+  CX_CHECK_ARG(unique_id != nullptr);
+  CX_TRY(LoadRccl());
+  CX_HIP(hipSetDevice(ctx->device));
+  UniqueId id;
+  std::memcpy(&id, unique_id, sizeof(id));
+  void* comm = nullptr;
+  CX_TRY(RcclCheck(g_rccl.comm_init_rank(&comm, nranks, id, rank), "ncclCommInitRank"));
+  ctx->comm = comm;
+  ctx->rank = rank;
+  ctx->nranks = nranks;
+  return CX_OK;
+}
+
+int cx_context_rank(const cx_context* ctx) { return ctx ? ctx->rank : 0; }
+int cx_context_num_ranks(const cx_context* ctx) { return ctx ? ctx->nranks : 1; }
+
+int cx_allreduce_sum(cx_context* ctx, double* device_ptr, int64_t n) {
+  CX_CHECK_ARG(ctx != nullptr && (device_ptr != nullptr || n == 0));
+  return cx_allreduce_device(ctx, device_ptr, n);
+}
+
+int cx_malloc(cx_context* ctx, size_t bytes, void** device_ptr) {
+  CX_CHECK_ARG(ctx != nullptr && device_ptr != nullptr);
+  CX_HIP(hipMalloc(device_ptr, bytes ? bytes : 1));
+  return CX_OK;
+}
+int cx_free(cx_context* ctx, void* device_ptr) {
+  CX_CHECK_ARG(ctx != nullptr);
+  if (device_ptr) CX_HIP(hipFree(device_ptr));
+  return CX_OK;
+}
+int cx_memcpy_h2d(cx_context* ctx, void* dst, const void* src, size_t bytes) {
+  CX_CHECK_ARG(ctx != nullptr);
+  if (bytes == 0) return CX_OK;
+  CX_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ctx->stream));
+  CX_HIP(hipStreamSynchronize(ctx->stream));
+  return CX_OK;
+}
+int cx_memcpy_d2h(cx_context* ctx, void* dst, const void* src, size_t bytes) {
+  CX_CHECK_ARG(ctx != nullptr);
+  if (bytes == 0) return CX_OK;
+  CX_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+  CX_HIP(hipStreamSynchronize(ctx->stream));
+  return CX_OK;
+}
+int cx_memset_zero(cx_context* ctx, void* p, size_t bytes) {
+  CX_CHECK_ARG(ctx != nullptr);
+  if (bytes) CX_HIP(hipMemsetAsync(p, 0, bytes, ctx->stream));
+  return CX_OK;
+}
+int cx_synchronize(cx_context* ctx) {
+  CX_CHECK_ARG(ctx != nullptr);
+  CX_HIP(hipStreamSynchronize(ctx->stream));
+  return CX_OK;
+}
+void* cx_context_stream(cx_context* ctx) { return ctx ? ctx->stream : nullptr; }
+
+int cx_device_name(cx_context* ctx, char* out, size_t n) {
+  CX_CHECK_ARG(ctx != nullptr && out != nullptr && n > 0);
+  std::snprintf(out, n, "%s", ctx->name);
+  return CX_OK;
+}
+
+}  // extern "C"
+
+// ---------------------------------------------------------- HostOrDevice
+int HostOrDevice::in(const double* u, size_t count, int memspace) {
+  user = const_cast<double*>(u);
+  n = count;
+  is_host = (memspace == CX_HOST);
+  if (!u) { dptr = nullptr; return CX_OK; }
+  if (!is_host) { dptr = user; return CX_OK; }
+  CX_TRY(tmp.alloc(count));
+  CX_HIP(hipMemcpyAsync(tmp.p, u, count * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+  dptr = tmp.p;
+  return CX_OK;
+}
+int HostOrDevice::inout(double* u, size_t count, int memspace, bool copy_in) {
+  user = u;
+  n = count;
+  is_host = (memspace == CX_HOST);
+  if (!u) { dptr = nullptr; return CX_OK; }
+  if (!is_host) { dptr = user; return CX_OK; }
+  CX_TRY(tmp.alloc(count));
+  if (copy_in) CX_HIP(hipMemcpyAsync(tmp.p, u, count * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+  dptr = tmp.p;
+  return CX_OK;
+}
+int HostOrDevice::out() {
+  if (!user || !is_host) return CX_OK;
+  CX_HIP(hipMemcpyAsync(user, dptr, n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  CX_HIP(hipStreamSynchronize(ctx->stream));
+  return CX_OK;
+}

@@ -1,0 +1,344 @@
+// Bundle-adjustment Evaluator on gfx950: residuals, cost, gradient and the block
+// sparse Jacobian of SnavelyReprojectionError written straight into the device
+// matrix (ProgramEvaluator::Evaluate, program_evaluator.h:137-304;
+// BlockEvaluatePreparer::Prepare, block_evaluate_preparer.cc:50-78;
+// examples/snavely_reprojection_error.h:53-104; rotation.h:792-857).
+//
+// One thread per residual block runs the reference's forward-mode arithmetic
+// (Jet<double,12>: camera in dual slots 0..8, point in 9..11, jet.h formulas), the
+// 2x3 and 2x9 cells are transposed through LDS and stored with coalesced 16-byte
+// writes into the reference cell layout.  Algorithmic traffic: 208 B written and
+// 24 B read per residual block plus the parameter gathers (L2 resident).
+#include <algorithm>
+#include <numeric>
+
+#include "cx_internal.h"
+#include "cx_kernels.h"
+
+struct cx_evaluator {
+  cx_context* ctx = nullptr;
+  cx_matrix* J = nullptr;
+  int32_t C = 0, P = 0;
+  int64_t O = 0;
+  std::vector<int64_t> row_of_obs;   // input observation -> row block
+  DevBuf<double> d_obs;              // [2O] in row order
+  DevBuf<double> d_partial, d_state, d_res;
+  float last_ms = 0.f;
+};
+
+namespace {
+
+template <int N>
+struct Jet {
+  double a;
+  double v[N];
+};
+template <int N> __device__ __forceinline__ Jet<N> jconst(double s) { Jet<N> r; r.a = s;
+#pragma unroll
+  for (int i = 0; i < N; ++i) r.v[i] = 0.0; return r; }
+template <int N> __device__ __forceinline__ Jet<N> jvar(double s, int k) { Jet<N> r = jconst<N>(s); r.v[k] = 1.0; return r; }
+template <int N> __device__ __forceinline__ Jet<N> operator+(const Jet<N>& f, const Jet<N>& g) { Jet<N> r; r.a = f.a + g.a;
+#pragma unroll
+  for (int i = 0; i < N; ++i) r.v[i] = f.v[i] + g.v[i]; return r; }
+template <int N> __device__ __forceinline__ Jet<N> operator-(const Jet<N>& f, const Jet<N>& g) { Jet<N> r; r.a = f.a - g.a;
+#pragma unroll
+  for (int i = 0; i < N; ++i) r.v[i] = f.v[i] - g.v[i]; return r; }
+template <int N> __device__ __forceinline__ Jet<N> operator-(const Jet<N>& f) { Jet<N> r; r.a = -f.a;
+#pragma unroll
+  for (int i = 0; i < N; ++i) r.v[i] = -f.v[i]; return r; }
+template <int N> __device__ __forceinline__ Jet<N> operator+(double s, const Jet<N>& f) { Jet<N> r = f; r.a = f.a + s; return r; }
+template <int N> __device__ __forceinline__ Jet<N> operator-(const Jet<N>& f, double s) { Jet<N> r = f; r.a = f.a - s; return r; }
+template <int N> __device__ __forceinline__ Jet<N> operator-(double s, const Jet<N>& f) { Jet<N> r; r.a = s - f.a;
+#pragma unroll
+  for (int i = 0; i < N; ++i) r.v[i] = -f.v[i]; return r; }
+// jet.h:349-352
+template <int N> __device__ __forceinline__ Jet<N> operator*(const Jet<N>& f, const Jet<N>& g) { Jet<N> r; r.a = f.a * g.a;
+#pragma unroll
+  for (int i = 0; i < N; ++i) r.v[i] = f.a * g.v[i] + f.v[i] * g.a; return r; }
+// jet.h:367-379
+template <int N> __device__ __forceinline__ Jet<N> operator/(const Jet<N>& f, const Jet<N>& g) {
+  const double gi = 1.0 / g.a, q = f.a * gi;
+  Jet<N> r; r.a = q;
+#pragma unroll
+  for (int i = 0; i < N; ++i) r.v[i] = (f.v[i] - q * g.v[i]) * gi;
+  return r;
+}
+// jet.h:382-386
+template <int N> __device__ __forceinline__ Jet<N> operator/(double s, const Jet<N>& g) {
+  const double m = -s / (g.a * g.a);
+  Jet<N> r; r.a = s / g.a;
+#pragma unroll
+  for (int i = 0; i < N; ++i) r.v[i] = g.v[i] * m;
+  return r;
+}
+template <int N> __device__ __forceinline__ Jet<N> jcos(const Jet<N>& f) { Jet<N> r; r.a = cos(f.a); const double m = -sin(f.a);
+#pragma unroll
+  for (int i = 0; i < N; ++i) r.v[i] = m * f.v[i]; return r; }
+template <int N> __device__ __forceinline__ Jet<N> jsin(const Jet<N>& f) { Jet<N> r; r.a = sin(f.a); const double m = cos(f.a);
+#pragma unroll
+  for (int i = 0; i < N; ++i) r.v[i] = m * f.v[i]; return r; }
+// jet.h:733-748
+template <int N> __device__ __forceinline__ Jet<N> jhypot3(const Jet<N>& x, const Jet<N>& y, const Jet<N>& z) {
+  const double t = norm3d(x.a, y.a, z.a);
+  const double cx_ = x.a / t, cy_ = y.a / t, cz_ = z.a / t;
+  Jet<N> r; r.a = t;
+#pragma unroll
+  for (int i = 0; i < N; ++i) r.v[i] = cx_ * x.v[i] + cy_ * y.v[i] + cz_ * z.v[i];
+  return r;
+}
+
+// value-only path (plain doubles, true divisions) used when no Jacobian is asked for
+__device__ __forceinline__ void snavely_value(const double* cam, const double* pt, double ox, double oy, double& r0, double& r1) {
+  const double theta = norm3d(cam[0], cam[1], cam[2]);
+  double p[3];
+  if (theta != 0.0) {
+    const double ct = cos(theta), st = sin(theta), ti = 1.0 / theta;
+    const double w[3] = {cam[0] * ti, cam[1] * ti, cam[2] * ti};
+    const double wx[3] = {w[1] * pt[2] - w[2] * pt[1], w[2] * pt[0] - w[0] * pt[2], w[0] * pt[1] - w[1] * pt[0]};
+    const double tmp = (w[0] * pt[0] + w[1] * pt[1] + w[2] * pt[2]) * (1.0 - ct);
+    p[0] = pt[0] * ct + wx[0] * st + w[0] * tmp;
+    p[1] = pt[1] * ct + wx[1] * st + w[1] * tmp;
+    p[2] = pt[2] * ct + wx[2] * st + w[2] * tmp;
+  } else {
+    p[0] = pt[0] + (cam[1] * pt[2] - cam[2] * pt[1]);
+    p[1] = pt[1] + (cam[2] * pt[0] - cam[0] * pt[2]);
+    p[2] = pt[2] + (cam[0] * pt[1] - cam[1] * pt[0]);
+  }
+  p[0] += cam[3]; p[1] += cam[4]; p[2] += cam[5];
+  const double xp = -p[0] / p[2], yp = -p[1] / p[2];
+  const double r2 = xp * xp + yp * yp;
+  const double dist = 1.0 + r2 * (cam[7] + cam[8] * r2);
+  r0 = cam[6] * dist * xp - ox;
+  r1 = cam[6] * dist * yp - oy;
+}
+
+// dual-number path: residual and the 2x9 / 2x3 Jacobian cells
+__device__ __forceinline__ void snavely_jet(const double* camv, const double* ptv, double ox, double oy, double& r0, double& r1,
+                                            double (&jc)[18], double (&jp)[6]) {
+  using J = Jet<12>;
+  J c[9], x[3];
+#pragma unroll
+  for (int i = 0; i < 9; ++i) c[i] = jvar<12>(camv[i], i);
+#pragma unroll
+  for (int i = 0; i < 3; ++i) x[i] = jvar<12>(ptv[i], 9 + i);
+  J p[3];
+  const J theta = jhypot3(c[0], c[1], c[2]);
+  if (theta.a != 0.0) {
+    const J ct = jcos(theta), st = jsin(theta), ti = 1.0 / theta;
+    const J w[3] = {c[0] * ti, c[1] * ti, c[2] * ti};
+    const J wx[3] = {w[1] * x[2] - w[2] * x[1], w[2] * x[0] - w[0] * x[2], w[0] * x[1] - w[1] * x[0]};
+    const J tmp = (w[0] * x[0] + w[1] * x[1] + w[2] * x[2]) * (1.0 - ct);
+    p[0] = x[0] * ct + wx[0] * st + w[0] * tmp;
+    p[1] = x[1] * ct + wx[1] * st + w[1] * tmp;
+    p[2] = x[2] * ct + wx[2] * st + w[2] * tmp;
+  } else {
+    p[0] = x[0] + (c[1] * x[2] - c[2] * x[1]);
+    p[1] = x[1] + (c[2] * x[0] - c[0] * x[2]);
+    p[2] = x[2] + (c[0] * x[1] - c[1] * x[0]);
+  }
+  p[0] = p[0] + c[3]; p[1] = p[1] + c[4]; p[2] = p[2] + c[5];
+  const J xp = -p[0] / p[2], yp = -p[1] / p[2];
+  const J r2 = xp * xp + yp * yp;
+  const J dist = 1.0 + r2 * (c[7] + c[8] * r2);
+  const J px = c[6] * dist * xp, py = c[6] * dist * yp;
+  r0 = px.a - ox;
+  r1 = py.a - oy;
+#pragma unroll
+  for (int i = 0; i < 9; ++i) { jc[i] = px.v[i]; jc[9 + i] = py.v[i]; }
+#pragma unroll
+  for (int i = 0; i < 3; ++i) { jp[i] = px.v[9 + i]; jp[3 + i] = py.v[9 + i]; }
+}
+
+// reverse of stage_cells: every thread hands in its own cell, the workgroup stores
+// the nvalid cells as one contiguous run of 16-byte pieces
+template <int DPR>
+__device__ __forceinline__ void unstage_cells(double* __restrict__ base, int nvalid, double* __restrict__ lds,
+                                              const double (&in)[DPR]) {
+  constexpr int kPieces = DPR / 2;
+  const int tid = threadIdx.x;
+  double2* l2 = reinterpret_cast<double2*>(lds);
+#pragma unroll
+  for (int i = 0; i < kPieces; ++i) l2[tid * kPieces + i] = make_double2(in[2 * i], in[2 * i + 1]);
+  __syncthreads();
+  double2* dst = reinterpret_cast<double2*>(base);
+  const int total = nvalid * kPieces;
+#pragma unroll
+  for (int i = 0; i < kPieces; ++i) {
+    const int idx = i * kBlock + tid;
+    if (idx < total) dst[idx] = l2[idx];
+  }
+  __syncthreads();
+}
+
+template <bool WITH_J>
+__global__ __launch_bounds__(kBlock) void k_bal_evaluate(const double* __restrict__ state,
+                                                         const double* __restrict__ obs,
+                                                         const int32_t* __restrict__ row_pt,
+                                                         const int32_t* __restrict__ row_cam, int64_t O,
+                                                         int64_t cam_off, double* __restrict__ residuals,
+                                                         double* __restrict__ E, double* __restrict__ F,
+                                                         double* __restrict__ cost_partial) {
+  __shared__ double lds[kBlock * 18];
+  __shared__ double red[4];
+  const int64_t r0i = int64_t(blockIdx.x) * kBlock;
+  const int nvalid = int(min(int64_t(kBlock), O - r0i));
+  const int tid = threadIdx.x;
+  const int64_t r = r0i + tid;
+  double res0 = 0.0, res1 = 0.0;
+  double jc[18], jp[6];
+  if (tid < nvalid) {
+    double cam[9], pt[3];
+    const double* cp = state + cam_off + 9 * int64_t(row_cam[r]);
+    const double* pp = state + 3 * int64_t(row_pt[r]);
+#pragma unroll
+    for (int i = 0; i < 9; ++i) cam[i] = cp[i];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) pt[i] = pp[i];
+    const double2 o = reinterpret_cast<const double2*>(obs)[r];
+    if (WITH_J) snavely_jet(cam, pt, o.x, o.y, res0, res1, jc, jp);
+    else snavely_value(cam, pt, o.x, o.y, res0, res1);
+    if (residuals) reinterpret_cast<double2*>(residuals)[r] = make_double2(res0, res1);
+  }
+  if (WITH_J) {
+    unstage_cells<18>(F + 18 * r0i, nvalid, lds, jc);
+    unstage_cells<6>(E + 6 * r0i, nvalid, lds, jp);
+  }
+  if (cost_partial) {
+    double c[1] = {(tid < nvalid) ? 0.5 * (res0 * res0 + res1 * res1) : 0.0};
+    block_sum<1>(c, red);
+    if (tid == 0) cost_partial[blockIdx.x] = c[0];
+  }
+}
+
+// deterministic final sum of the per-workgroup cost partials
+__global__ __launch_bounds__(256) void k_sum_partials(const double* __restrict__ partial, int64_t n, double* __restrict__ out) {
+  __shared__ double red[4];
+  double s[1] = {0.0};
+  for (int64_t i = threadIdx.x; i < n; i += 256) s[0] += partial[i];
+  block_sum<1>(s, red);
+  if (threadIdx.x == 0) *out = s[0];
+}
+
+}  // namespace
+
+extern "C" {
+
+int cx_evaluator_create_bal(cx_context* ctx, int32_t C, int32_t P, int64_t O, const int32_t* cam, const int32_t* pt,
+                            const double* obs, cx_evaluator** out) {
+  CX_CHECK_ARG(ctx && out && C > 0 && P > 0 && O > 0 && cam && pt && obs);
+  CX_CHECK_ARG(24 * O < (int64_t(1) << 31));  // int32 cell positions (block_jacobian_writer.cc:95-99,157-161)
+  for (int64_t i = 0; i < O; ++i) CX_CHECK_ARG(cam[i] >= 0 && cam[i] < C && pt[i] >= 0 && pt[i] < P);
+  // LexicographicallyOrderResidualBlocks (reorder_program.cc:256-338): bucket by point,
+  // every bucket filled from its back, so a chunk lists its residuals in reverse input order
+  std::vector<int64_t> offsets(size_t(P) + 1, 0), order(O);
+  for (int64_t i = 0; i < O; ++i) offsets[pt[i]]++;
+  std::partial_sum(offsets.begin(), offsets.end(), offsets.begin());
+  for (int64_t i = 0; i < O; ++i) order[--offsets[pt[i]]] = i;
+  // BuildJacobianLayout (block_jacobian_writer.cc:68-167)
+  std::vector<cx_block> rows(O), cols(size_t(P) + C);
+  std::vector<int32_t> rcb(O + 1);
+  std::vector<cx_cell> cells(2 * O);
+  for (int j = 0; j < P; ++j) cols[j] = cx_block{3, 3 * j};
+  for (int i = 0; i < C; ++i) cols[P + i] = cx_block{9, 3 * P + 9 * i};
+  auto e = new cx_evaluator;
+  e->ctx = ctx;
+  e->C = C; e->P = P; e->O = O;
+  e->row_of_obs.resize(O);
+  std::vector<double> obs_rows(2 * O);
+  for (int64_t k = 0; k < O; ++k) {
+    const int64_t i = order[k];
+    rows[k] = cx_block{2, int32_t(2 * k)};
+    rcb[k] = int32_t(2 * k);
+    cells[2 * k] = cx_cell{pt[i], int32_t(6 * k)};
+    cells[2 * k + 1] = cx_cell{P + cam[i], int32_t(6 * O + 18 * k)};
+    e->row_of_obs[i] = k;
+    obs_rows[2 * k] = obs[2 * i];
+    obs_rows[2 * k + 1] = obs[2 * i + 1];
+  }
+  rcb[O] = int32_t(2 * O);
+  cx_block_structure bs{int32_t(O), P + C, rows.data(), cols.data(), rcb.data(), cells.data()};
+  int rc = cx_matrix_create(ctx, &bs, P, &e->J);
+  if (rc == CX_OK && !e->J->is239) {
+    cx_set_error("BAL problem does not map onto the static <2,3,9> layout (duplicate observation of a point by a camera?)");
+    rc = CX_ERR_UNSUPPORTED;
+  }
+  if (rc == CX_OK) rc = e->d_obs.upload(obs_rows, ctx->stream);
+  if (rc == CX_OK) rc = e->d_partial.alloc(size_t((O + kBlock - 1) / kBlock) + 1);
+  if (rc != CX_OK) {
+    if (e->J) cx_matrix_destroy(e->J);
+    delete e;
+    return rc;
+  }
+  *out = e;
+  return CX_OK;
+}
+
+void cx_evaluator_destroy(cx_evaluator* e) {
+  if (!e) return;
+  cx_matrix_destroy(e->J);
+  delete e;
+}
+
+cx_matrix* cx_evaluator_jacobian(cx_evaluator* e) { return e ? e->J : nullptr; }
+
+int cx_evaluator_row_of_observation(const cx_evaluator* e, int64_t* out) {
+  CX_CHECK_ARG(e && out);
+  std::copy(e->row_of_obs.begin(), e->row_of_obs.end(), out);
+  return CX_OK;
+}
+
+int cx_evaluator_evaluate(cx_evaluator* e, const double* state, double* cost, double* residuals, double* gradient,
+                          int32_t evaluate_jacobian, int32_t memspace) {
+  CX_CHECK_ARG(e && state);
+  cx_context* ctx = e->ctx;
+  cx_matrix* A = e->J;
+  hipStream_t st = ctx->stream;
+  CX_HIP(hipSetDevice(ctx->device));
+  const int64_t ncols = A->num_cols, nrows = A->num_rows;
+  HostOrDevice hs(ctx), hr(ctx), hg(ctx);
+  CX_TRY(hs.in(state, size_t(ncols), memspace));
+  CX_TRY(hr.inout(residuals, size_t(nrows), memspace, false));
+  CX_TRY(hg.inout(gradient, size_t(ncols), memspace, false));
+  const bool with_j = evaluate_jacobian != 0 || gradient != nullptr;
+  double* res_dev = hr.dptr;
+  if (gradient && !res_dev) {
+    CX_TRY(e->d_res.alloc(size_t(nrows)));
+    res_dev = e->d_res.p;
+  }
+  const int grid = int((e->O + kBlock - 1) / kBlock);
+  double* E = A->d_values.p;
+  double* F = A->d_values.p + 6 * e->O;
+  CX_HIP(hipEventRecord(ctx->ev[6], st));
+  if (with_j)
+    hipLaunchKernelGGL(k_bal_evaluate<true>, dim3(grid), dim3(kBlock), 0, st, (const double*)hs.dptr, (const double*)e->d_obs.p,
+                       (const int32_t*)A->d_row_pt.p, (const int32_t*)A->d_row_cam.p, e->O, 3 * int64_t(e->P), res_dev, E, F,
+                       cost ? e->d_partial.p : nullptr);
+  else
+    hipLaunchKernelGGL(k_bal_evaluate<false>, dim3(grid), dim3(kBlock), 0, st, (const double*)hs.dptr, (const double*)e->d_obs.p,
+                       (const int32_t*)A->d_row_pt.p, (const int32_t*)A->d_row_cam.p, e->O, 3 * int64_t(e->P), res_dev, E, F,
+                       cost ? e->d_partial.p : nullptr);
+  if (cost) hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(256), 0, st, (const double*)e->d_partial.p, int64_t(grid), e->d_partial.p + grid);
+  CX_HIP(hipGetLastError());
+  CX_HIP(hipEventRecord(ctx->ev[7], st));
+  if (with_j) A->ft_valid = false;
+  if (gradient) {
+    // g = J' r (program_evaluator.h:242-258)
+    CX_HIP(hipMemsetAsync(hg.dptr, 0, size_t(ncols) * sizeof(double), st));
+    CX_TRY(cxk_left_multiply(A, res_dev, hg.dptr));
+    if (ctx->nranks > 1) CX_TRY(cx_allreduce_device(ctx, hg.dptr + 3 * int64_t(e->P), 9 * int64_t(e->C)));
+  }
+  if (cost) {
+    if (ctx->nranks > 1) CX_TRY(cx_allreduce_device(ctx, e->d_partial.p + grid, 1));  // shards sum their costs
+    CX_HIP(hipMemcpyAsync(cost, e->d_partial.p + grid, sizeof(double), hipMemcpyDeviceToHost, st));
+  }
+  CX_HIP(hipEventSynchronize(ctx->ev[7]));
+  CX_HIP(hipEventElapsedTime(&e->last_ms, ctx->ev[6], ctx->ev[7]));
+  CX_TRY(hr.out());
+  CX_TRY(hg.out());
+  CX_HIP(hipStreamSynchronize(st));
+  return CX_OK;
+}
+
+double cx_evaluator_last_kernel_ms(const cx_evaluator* e) { return e ? double(e->last_ms) : 0.0; }
+
+}  // extern "C"

@@ -1,0 +1,167 @@
+// Internal declarations of libcxschur (not part of the C ABI).
+#ifndef CX_INTERNAL_H_
+#define CX_INTERNAL_H_
+
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/cxschur.h"
+
+// ------------------------------------------------------------------ errors
+void cx_set_error(const char* fmt, ...);
+
+#define CX_HIP(expr)                                                                         \
+  do {                                                                                       \
+    hipError_t _e = (expr);                                                                  \
+    if (_e != hipSuccess) {                                                                  \
+      cx_set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+      return (_e == hipErrorOutOfMemory) ? CX_ERR_OUT_OF_MEMORY : CX_ERR_HIP;                \
+    }                                                                                        \
+  } while (0)
+
+#define CX_CHECK_ARG(cond)                                                        \
+  do {                                                                            \
+    if (!(cond)) {                                                                \
+      cx_set_error("invalid argument: %s (%s:%d)", #cond, __FILE__, __LINE__);    \
+      return CX_ERR_INVALID_ARGUMENT;                                             \
+    }                                                                             \
+  } while (0)
+
+#define CX_TRY(expr)            \
+  do {                          \
+    int _rc = (expr);           \
+    if (_rc != CX_OK) return _rc; \
+  } while (0)
+
+// ---------------------------------------------------------------- context
+struct cx_context {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  hipEvent_t ev[8] = {};
+  // RCCL (resolved at run time from librccl.so.1; see cx_context.cpp)
+  void* comm = nullptr;
+  int rank = 0;
+  int nranks = 1;
+  double allreduce_host_ms = 0.0;
+  int num_cus = 256;
+  char name[128] = {};
+};
+
+// RAII device array
+template <typename T>
+struct DevBuf {
+  T* p = nullptr;
+  size_t n = 0;
+  DevBuf() = default;
+  DevBuf(const DevBuf&) = delete;
+  DevBuf& operator=(const DevBuf&) = delete;
+  ~DevBuf() { release(); }
+  void release() {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    n = 0;
+  }
+  int alloc(size_t count) {
+    if (count <= n && p) return CX_OK;
+    release();
+    if (count == 0) count = 1;
+    CX_HIP(hipMalloc(reinterpret_cast<void**>(&p), count * sizeof(T)));
+    n = count;
+    return CX_OK;
+  }
+  int upload(const std::vector<T>& h, hipStream_t s) {
+    CX_TRY(alloc(h.size()));
+    if (!h.empty()) CX_HIP(hipMemcpyAsync(p, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice, s));
+    CX_HIP(hipStreamSynchronize(s));
+    return CX_OK;
+  }
+};
+
+// ----------------------------------------------------------------- matrix
+// Tile of the point-major ("chunk") kernels: whole chunks, at most kTileRows rows,
+// unless a single chunk is larger than that (then the tile is that one chunk).
+constexpr int kTileRows = 256;
+// Segment of the camera-major kernels: a run of rows of ONE camera.
+constexpr int kSegRows = 512;
+
+struct cx_matrix {
+  cx_context* ctx = nullptr;
+  // host copy of the structure (flat)
+  int32_t R = 0, Cb = 0;  // row blocks / column blocks
+  int32_t nelim = 0;
+  std::vector<cx_block> rows, cols;
+  std::vector<int32_t> rcb;
+  std::vector<cx_cell> cells;
+  int64_t num_rows = 0, num_cols = 0, nnz = 0;
+  int64_t num_cols_e = 0, num_cols_f = 0;
+  int32_t num_row_blocks_e = 0;  // rows whose first cell is an e block (partitioned_matrix_view_impl.h:60-90)
+  int32_t row_size = 0, e_size = 0, f_size = 0;  // DetectStructure result (-1 dynamic)
+
+  // generic device structure
+  DevBuf<cx_block> d_rows, d_cols;
+  DevBuf<int32_t> d_rcb;
+  DevBuf<cx_cell> d_cells;
+  DevBuf<int32_t> d_chunk_start;  // generic eliminator chunks (row ranges), [num_chunks+1]
+  int32_t num_chunks = 0;
+
+  // values
+  DevBuf<double> d_values;
+
+  // ---- static <2,3,9> bundle-adjustment layout
+  bool is239 = false;
+  int64_t O = 0;  // row blocks
+  int32_t P = 0, C = 0;
+  DevBuf<int32_t> d_row_pt, d_row_cam;   // [O]
+  DevBuf<int32_t> d_pt_start;            // [P+1] first row of each point's chunk
+  DevBuf<int32_t> d_tile_row, d_tile_pt; // [T+1] chunk-aligned tiles
+  int32_t num_tiles = 0;
+  bool has_big_tiles = false;            // some chunk is longer than kTileRows
+  DevBuf<int32_t> d_cam_rows;            // [O] rows in camera-major order
+  DevBuf<int32_t> d_seg_begin, d_seg_cam;  // [S+1], [S] camera-major segments (positions in d_cam_rows)
+  DevBuf<int32_t> d_cam_seg_start;       // [C+1] segments of each camera
+  int32_t num_segs = 0;
+  DevBuf<double> d_Ft;                   // camera-major copy of the F cells [O][18]
+  bool ft_valid = false;
+  DevBuf<double> d_partials;             // camera-major partial sums [S][81]
+
+  // scratch for host-pointer calls
+  DevBuf<double> d_x, d_y;
+  float last_ms = 0.f;
+};
+
+// upload/download helpers for the (memspace) convention
+struct HostOrDevice {
+  // wraps a user pointer: if host, stages through a device buffer
+  cx_context* ctx;
+  DevBuf<double> tmp;
+  double* dptr = nullptr;
+  double* user = nullptr;
+  size_t n = 0;
+  bool is_host = false;
+  explicit HostOrDevice(cx_context* c) : ctx(c) {}
+  int in(const double* u, size_t count, int memspace);   // read-only input (u may be NULL -> dptr NULL)
+  int inout(double* u, size_t count, int memspace, bool copy_in);
+  int out();  // copy back if host
+};
+
+// ------------------------------------------------ kernels (cx_matrix.hip etc.)
+int cx_matrix_ensure_ft(cx_matrix* A);
+
+// all of these enqueue on ctx->stream and work on device pointers
+int cxk_right_multiply(cx_matrix* A, const double* x, double* y);
+int cxk_left_multiply(cx_matrix* A, const double* x, double* y);
+int cxk_squared_column_norm(cx_matrix* A, double* x);
+int cxk_scale_columns(cx_matrix* A, const double* scale);
+
+// y_f (+)= F' t  for the static path; t is row-sized
+int cxk_ft_multiply(cx_matrix* A, const double* t, double* y_f, bool accumulate);
+
+int cx_allreduce_device(cx_context* ctx, double* p, int64_t n);
+
+#endif

@@ -1,0 +1,115 @@
+// Device-side helpers shared by the gfx950 kernels of libcxschur.
+//
+// Data layout (static <2,3,9> bundle-adjustment path).  The value array is the
+// reference's BlockSparseMatrix::values_ verbatim: E cells (2x3 row-major, 48 B)
+// of all row blocks first, then the F cells (2x9 row-major, 144 B).  A wavefront
+// reads 64 consecutive cells as one contiguous run with 16-byte loads per lane
+// (coalesced), parks them in LDS and every lane then picks up its own row's cell
+// with ds_read_b128 (row stride 144 B / 48 B: conflict free).
+#ifndef CX_KERNELS_H_
+#define CX_KERNELS_H_
+
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+constexpr int kBlock = 256;  // threads per workgroup = rows per tile (4 wavefronts of 64)
+
+// Stage `nvalid` (<= kBlock) consecutive cells of DPR doubles each, starting at
+// `base`, through `lds` (kBlock*DPR doubles) and return the calling thread's own
+// cell in out[].  base must be 16-byte aligned.  Contains two block barriers.
+template <int DPR>
+__device__ __forceinline__ void stage_cells(const double* __restrict__ base, int nvalid,
+                                            double* __restrict__ lds, double (&out)[DPR]) {
+  static_assert(DPR % 2 == 0, "cells are moved as 16-byte pieces");
+  constexpr int kPieces = DPR / 2;  // double2 pieces per row
+  const int tid = threadIdx.x;
+  const double2* __restrict__ src = reinterpret_cast<const double2*>(base);
+  double2* l2 = reinterpret_cast<double2*>(lds);
+  double2 v[kPieces];
+  const int total = nvalid * kPieces;
+#pragma unroll
+  for (int i = 0; i < kPieces; ++i) {
+    const int idx = i * kBlock + tid;
+    v[i] = (idx < total) ? src[idx] : make_double2(0.0, 0.0);
+  }
+#pragma unroll
+  for (int i = 0; i < kPieces; ++i) l2[i * kBlock + tid] = v[i];
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < kPieces; ++i) {
+    const double2 t = l2[tid * kPieces + i];
+    out[2 * i] = t.x;
+    out[2 * i + 1] = t.y;
+  }
+  __syncthreads();
+}
+
+// Sum of v over the 64 lanes of a wavefront, returned in every lane.
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+
+// Deterministic block sum of N values per thread: wave butterflies, then the 4
+// wave results are added in wave order.  scratch: N*4 doubles of LDS.  Result in
+// every thread.  Contains two block barriers.
+template <int N>
+__device__ __forceinline__ void block_sum(double (&v)[N], double* scratch) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int i = 0; i < N; ++i) {
+    const double s = wave_sum(v[i]);
+    if (lane == 0) scratch[i * 4 + wave] = s;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < N; ++i) v[i] = ((scratch[i * 4] + scratch[i * 4 + 1]) + scratch[i * 4 + 2]) + scratch[i * 4 + 3];
+  __syncthreads();
+}
+
+// Inverse of a symmetric positive definite 3x3 (row-major, upper triangle read)
+// through LLT, the arithmetic of selfadjointView<Upper>().llt().solve(I)
+// (implicit_schur_complement.cc:201-202).  ok = false if not PD.
+__device__ __forceinline__ void inv3_llt(const double (&m)[9], double (&inv)[9], bool& ok) {
+  // A = U'U, U upper
+  const double a00 = m[0], a01 = m[1], a02 = m[2], a11 = m[4], a12 = m[5], a22 = m[8];
+  ok = a00 > 0.0;
+  const double u00 = sqrt(a00);
+  const double u01 = a01 / u00, u02 = a02 / u00;
+  const double d1 = a11 - u01 * u01;
+  ok = ok && d1 > 0.0;
+  const double u11 = sqrt(d1);
+  const double u12 = (a12 - u01 * u02) / u11;
+  const double d2 = a22 - u02 * u02 - u12 * u12;
+  ok = ok && d2 > 0.0;
+  const double u22 = sqrt(d2);
+  // X = U^-1 (upper): solve U X = I
+  const double x00 = 1.0 / u00, x11 = 1.0 / u11, x22 = 1.0 / u22;
+  const double x01 = -u01 * x11 / u00;
+  const double x12 = -u12 * x22 / u11;
+  const double x02 = -(u01 * x12 + u02 * x22) / u00;
+  // A^-1 = X X'
+  inv[0] = x00 * x00 + x01 * x01 + x02 * x02;
+  inv[1] = x01 * x11 + x02 * x12;
+  inv[2] = x02 * x22;
+  inv[4] = x11 * x11 + x12 * x12;
+  inv[5] = x12 * x22;
+  inv[8] = x22 * x22;
+  inv[3] = inv[1];
+  inv[6] = inv[2];
+  inv[7] = inv[5];
+}
+
+// Closed-form (cofactor) inverse of a general 3x3 -- Eigen's fixed-size
+// inverse() that InvertPSDMatrix<3> uses (invert_psd_matrix.h:60-63).
+__device__ __forceinline__ void inv3_cofactor(const double (&m)[9], double (&inv)[9]) {
+  const double c00 = m[4] * m[8] - m[5] * m[7], c01 = m[5] * m[6] - m[3] * m[8], c02 = m[3] * m[7] - m[4] * m[6];
+  const double invdet = 1.0 / (m[0] * c00 + m[1] * c01 + m[2] * c02);
+  inv[0] = c00 * invdet; inv[1] = (m[2] * m[7] - m[1] * m[8]) * invdet; inv[2] = (m[1] * m[5] - m[2] * m[4]) * invdet;
+  inv[3] = c01 * invdet; inv[4] = (m[0] * m[8] - m[2] * m[6]) * invdet; inv[5] = (m[2] * m[3] - m[0] * m[5]) * invdet;
+  inv[6] = c02 * invdet; inv[7] = (m[1] * m[6] - m[0] * m[7]) * invdet; inv[8] = (m[0] * m[4] - m[1] * m[3]) * invdet;
+}
+
+#endif

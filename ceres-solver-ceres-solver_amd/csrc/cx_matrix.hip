@@ -1,0 +1,718 @@
+// Device-resident BlockSparseMatrix: structure analysis (host) and the J product
+// kernels (gfx950).  Reference: block_sparse_matrix.cc:220-450,
+// partitioned_matrix_view_impl.h, detect_structure.cc.
+//
+// Kernels and the roofline that bounds them (all HBM-bound, fp64, 2 flop / 8 B):
+//   k_right_239      y += J x        240 B/row block read+write (24 values, 2 ids, y rmw)
+//   k_left_e_239     y_e += E' x     64 B/row block
+//   k_cam_ft         y_f  = F' x     164 B/row block from the camera-major copy (+ 16 B gather)
+//   k_permute_ft     Ft <- F         288 B/row block, once per value update
+#include <algorithm>
+#include <numeric>
+
+#include "cx_internal.h"
+#include "cx_kernels.h"
+
+// ============================================================ static 239 kernels
+
+// y[2r..2r+1] += E_r x_pt + F_r x_cam        (block_sparse_matrix.cc:239-274)
+__global__ __launch_bounds__(kBlock) void k_right_239(const double* __restrict__ E,
+                                                      const double* __restrict__ F,
+                                                      const int32_t* __restrict__ row_pt,
+                                                      const int32_t* __restrict__ row_cam,
+                                                      const double* __restrict__ xe,
+                                                      const double* __restrict__ xf,
+                                                      double* __restrict__ y, int64_t O, int use_e,
+                                                      int use_f, int accumulate) {
+  __shared__ double lds[kBlock * 18];
+  const int64_t r0 = int64_t(blockIdx.x) * kBlock;
+  const int nvalid = int(min(int64_t(kBlock), O - r0));
+  const int tid = threadIdx.x;
+  const int64_t r = r0 + tid;
+  double acc0 = 0.0, acc1 = 0.0;
+  if (use_f) {
+    double f[18];
+    stage_cells<18>(F + 18 * r0, nvalid, lds, f);
+    if (tid < nvalid) {
+      const double* xc = xf + 9 * int64_t(row_cam[r]);
+#pragma unroll
+      for (int k = 0; k < 9; ++k) {
+        const double xv = xc[k];
+        acc0 += f[k] * xv;
+        acc1 += f[9 + k] * xv;
+      }
+    }
+  }
+  if (use_e) {
+    double e[6];
+    stage_cells<6>(E + 6 * r0, nvalid, lds, e);
+    if (tid < nvalid) {
+      const double* xp = xe + 3 * int64_t(row_pt[r]);
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        const double xv = xp[k];
+        acc0 += e[k] * xv;
+        acc1 += e[3 + k] * xv;
+      }
+    }
+  }
+  if (tid < nvalid) {
+    double2* yp = reinterpret_cast<double2*>(y) + r;
+    double2 v = accumulate ? *yp : make_double2(0.0, 0.0);
+    v.x += acc0;
+    v.y += acc1;
+    *yp = v;
+  }
+}
+
+// y_pt (+)= sum over the rows of the point of E_r' x_r   (chunk-aligned tiles)
+__global__ __launch_bounds__(kBlock) void k_left_e_239(const double* __restrict__ E,
+                                                       const int32_t* __restrict__ tile_row,
+                                                       const int32_t* __restrict__ tile_pt,
+                                                       const int32_t* __restrict__ pt_start,
+                                                       const double* __restrict__ x,
+                                                       double* __restrict__ ye, int accumulate) {
+  __shared__ double lds[kBlock * 6];
+  __shared__ double w[kBlock * 3];
+  __shared__ double red[3 * 4];
+  const int t = blockIdx.x, tid = threadIdx.x;
+  const int r0 = tile_row[t], r1 = tile_row[t + 1];
+  const int p0 = tile_pt[t], p1 = tile_pt[t + 1];
+  if (r1 - r0 <= kBlock) {
+    const int nvalid = r1 - r0;
+    double e[6];
+    stage_cells<6>(E + 6 * int64_t(r0), nvalid, lds, e);
+    if (tid < nvalid) {
+      const double2 xv = reinterpret_cast<const double2*>(x)[r0 + tid];
+      w[tid * 3 + 0] = e[0] * xv.x + e[3] * xv.y;
+      w[tid * 3 + 1] = e[1] * xv.x + e[4] * xv.y;
+      w[tid * 3 + 2] = e[2] * xv.x + e[5] * xv.y;
+    }
+    __syncthreads();
+    if (tid < p1 - p0) {
+      const int p = p0 + tid;
+      double s0 = 0.0, s1 = 0.0, s2 = 0.0;
+      for (int j = pt_start[p] - r0; j < pt_start[p + 1] - r0; ++j) {
+        s0 += w[j * 3];
+        s1 += w[j * 3 + 1];
+        s2 += w[j * 3 + 2];
+      }
+      double* yp = ye + 3 * int64_t(p);
+      if (accumulate) { yp[0] += s0; yp[1] += s1; yp[2] += s2; }
+      else { yp[0] = s0; yp[1] = s1; yp[2] = s2; }
+    }
+  } else {
+    // one point whose chunk is longer than a tile: strided loop + block reduction
+    double s[3] = {0.0, 0.0, 0.0};
+    for (int r = r0 + tid; r < r1; r += kBlock) {
+      const double* e = E + 6 * int64_t(r);
+      const double2 xv = reinterpret_cast<const double2*>(x)[r];
+      s[0] += e[0] * xv.x + e[3] * xv.y;
+      s[1] += e[1] * xv.x + e[4] * xv.y;
+      s[2] += e[2] * xv.x + e[5] * xv.y;
+    }
+    block_sum<3>(s, red);
+    if (tid == 0) {
+      double* yp = ye + 3 * int64_t(p0);
+      if (accumulate) { yp[0] += s[0]; yp[1] += s[1]; yp[2] += s[2]; }
+      else { yp[0] = s[0]; yp[1] = s[1]; yp[2] = s[2]; }
+    }
+  }
+}
+
+// Ft[k] = F[cam_rows[k]]: camera-major copy of the F cells.  One wavefront moves
+// 64 cells: gathered 144-byte reads, contiguous writes.
+__global__ __launch_bounds__(kBlock) void k_permute_ft(const double* __restrict__ F,
+                                                       const int32_t* __restrict__ cam_rows,
+                                                       double* __restrict__ Ft, int64_t O) {
+  // 9 lanes per cell (16 B each): 256 threads move 28 cells per pass; simpler: thread per 16-byte piece
+  const int64_t piece = int64_t(blockIdx.x) * kBlock + threadIdx.x;
+  if (piece >= O * 9) return;
+  const int64_t k = piece / 9;
+  const int part = int(piece - k * 9);
+  const int64_t r = cam_rows[k];
+  reinterpret_cast<double2*>(Ft)[piece] = reinterpret_cast<const double2*>(F)[r * 9 + part];
+}
+
+// Camera-major pass: one workgroup per segment (<= kSegRows rows of ONE camera),
+// partial[seg][0..8] = sum over the segment of Ft_r' t_row(r).
+__global__ __launch_bounds__(kBlock) void k_cam_ft(const double* __restrict__ Ft,
+                                                   const int32_t* __restrict__ cam_rows,
+                                                   const int32_t* __restrict__ seg_begin,
+                                                   const double* __restrict__ t,
+                                                   double* __restrict__ partial) {
+  __shared__ double lds[kBlock * 18];
+  __shared__ double red[9 * 4];
+  const int s = blockIdx.x, tid = threadIdx.x;
+  const int b = seg_begin[s], e = seg_begin[s + 1];
+  double acc[9];
+#pragma unroll
+  for (int k = 0; k < 9; ++k) acc[k] = 0.0;
+  for (int k0 = b; k0 < e; k0 += kBlock) {
+    const int nvalid = min(kBlock, e - k0);
+    double f[18];
+    stage_cells<18>(Ft + 18 * int64_t(k0), nvalid, lds, f);
+    if (tid < nvalid) {
+      const double2 tv = reinterpret_cast<const double2*>(t)[cam_rows[k0 + tid]];
+#pragma unroll
+      for (int k = 0; k < 9; ++k) acc[k] += f[k] * tv.x + f[9 + k] * tv.y;
+    }
+  }
+  block_sum<9>(acc, red);
+  if (tid < 9) partial[int64_t(s) * 9 + tid] = acc[tid];
+}
+
+// y_f[9c + k] (+)= sum of the camera's segment partials, in segment order (deterministic),
+// optionally + d[9c+k]^2 * x[9c+k]
+__global__ void k_cam_reduce9(const double* __restrict__ partial, const int32_t* __restrict__ cam_seg_start,
+                              double* __restrict__ yf, int C, int accumulate,
+                              const double* __restrict__ d, const double* __restrict__ x) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= C * 9) return;
+  const int c = i / 9, k = i - c * 9;
+  double s = 0.0;
+  for (int sg = cam_seg_start[c]; sg < cam_seg_start[c + 1]; ++sg) s += partial[int64_t(sg) * 9 + k];
+  if (d) s += d[i] * d[i] * x[i];
+  yf[i] = accumulate ? yf[i] + s : s;
+}
+
+// x_e[3p+k] = sum over the chunk of E(:,k)^2 ; x_f via the camera-major copy
+__global__ __launch_bounds__(kBlock) void k_sqnorm_e_239(const double* __restrict__ E,
+                                                         const int32_t* __restrict__ pt_start,
+                                                         double* __restrict__ xe, int P) {
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= P) return;
+  double s0 = 0.0, s1 = 0.0, s2 = 0.0;
+  for (int r = pt_start[p]; r < pt_start[p + 1]; ++r) {
+    const double* e = E + 6 * int64_t(r);
+    s0 += e[0] * e[0] + e[3] * e[3];
+    s1 += e[1] * e[1] + e[4] * e[4];
+    s2 += e[2] * e[2] + e[5] * e[5];
+  }
+  xe[3 * int64_t(p)] = s0;
+  xe[3 * int64_t(p) + 1] = s1;
+  xe[3 * int64_t(p) + 2] = s2;
+}
+
+__global__ __launch_bounds__(kBlock) void k_cam_sqnorm(const double* __restrict__ Ft,
+                                                       const int32_t* __restrict__ seg_begin,
+                                                       double* __restrict__ partial) {
+  __shared__ double lds[kBlock * 18];
+  __shared__ double red[9 * 4];
+  const int s = blockIdx.x, tid = threadIdx.x;
+  const int b = seg_begin[s], e = seg_begin[s + 1];
+  double acc[9];
+#pragma unroll
+  for (int k = 0; k < 9; ++k) acc[k] = 0.0;
+  for (int k0 = b; k0 < e; k0 += kBlock) {
+    const int nvalid = min(kBlock, e - k0);
+    double f[18];
+    stage_cells<18>(Ft + 18 * int64_t(k0), nvalid, lds, f);
+    if (tid < nvalid) {
+#pragma unroll
+      for (int k = 0; k < 9; ++k) acc[k] += f[k] * f[k] + f[9 + k] * f[9 + k];
+    }
+  }
+  block_sum<9>(acc, red);
+  if (tid < 9) partial[int64_t(s) * 9 + tid] = acc[tid];
+}
+
+// J <- J diag(scale)   (block_sparse_matrix.cc:403-450): thread per 16-byte piece
+__global__ __launch_bounds__(kBlock) void k_scale_239(double* __restrict__ E, double* __restrict__ F,
+                                                      const int32_t* __restrict__ row_pt,
+                                                      const int32_t* __restrict__ row_cam,
+                                                      const double* __restrict__ scale, int64_t O,
+                                                      int64_t xf_off) {
+  const int64_t r = int64_t(blockIdx.x) * kBlock + threadIdx.x;
+  if (r >= O) return;
+  const double* sp = scale + 3 * int64_t(row_pt[r]);
+  const double* sc = scale + xf_off + 9 * int64_t(row_cam[r]);
+  double* e = E + 6 * r;
+  double* f = F + 18 * r;
+#pragma unroll
+  for (int k = 0; k < 3; ++k) { e[k] *= sp[k]; e[3 + k] *= sp[k]; }
+#pragma unroll
+  for (int k = 0; k < 9; ++k) { f[k] *= sc[k]; f[9 + k] *= sc[k]; }
+}
+
+// ============================================================== generic kernels
+// Dynamic block sizes: one thread per row block, atomics for transposed products.
+// This is the fallback the reference's Eigen::Dynamic template instantiations are.
+
+__global__ void kg_right(const cx_block* __restrict__ rows, const cx_block* __restrict__ cols,
+                         const int32_t* __restrict__ rcb, const cx_cell* __restrict__ cells,
+                         const double* __restrict__ values, const double* __restrict__ x,
+                         double* __restrict__ y, int R) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= R) return;
+  const int rs = rows[r].size, rp = rows[r].position;
+  for (int c = rcb[r]; c < rcb[r + 1]; ++c) {
+    const cx_cell cell = cells[c];
+    const int cs = cols[cell.block_id].size, cp = cols[cell.block_id].position;
+    const double* m = values + cell.position;
+    for (int i = 0; i < rs; ++i) {
+      double s = 0.0;
+      for (int j = 0; j < cs; ++j) s += m[i * cs + j] * x[cp + j];
+      y[rp + i] += s;
+    }
+  }
+}
+
+__global__ void kg_left(const cx_block* __restrict__ rows, const cx_block* __restrict__ cols,
+                        const int32_t* __restrict__ rcb, const cx_cell* __restrict__ cells,
+                        const double* __restrict__ values, const double* __restrict__ x,
+                        double* __restrict__ y, int R) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= R) return;
+  const int rs = rows[r].size, rp = rows[r].position;
+  for (int c = rcb[r]; c < rcb[r + 1]; ++c) {
+    const cx_cell cell = cells[c];
+    const int cs = cols[cell.block_id].size, cp = cols[cell.block_id].position;
+    const double* m = values + cell.position;
+    for (int j = 0; j < cs; ++j) {
+      double s = 0.0;
+      for (int i = 0; i < rs; ++i) s += m[i * cs + j] * x[rp + i];
+      atomicAdd(&y[cp + j], s);
+    }
+  }
+}
+
+__global__ void kg_sqnorm(const cx_block* __restrict__ rows, const cx_block* __restrict__ cols,
+                          const int32_t* __restrict__ rcb, const cx_cell* __restrict__ cells,
+                          const double* __restrict__ values, double* __restrict__ x, int R) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= R) return;
+  const int rs = rows[r].size;
+  for (int c = rcb[r]; c < rcb[r + 1]; ++c) {
+    const cx_cell cell = cells[c];
+    const int cs = cols[cell.block_id].size, cp = cols[cell.block_id].position;
+    const double* m = values + cell.position;
+    for (int j = 0; j < cs; ++j) {
+      double s = 0.0;
+      for (int i = 0; i < rs; ++i) s += m[i * cs + j] * m[i * cs + j];
+      atomicAdd(&x[cp + j], s);
+    }
+  }
+}
+
+__global__ void kg_scale(const cx_block* __restrict__ rows, const cx_block* __restrict__ cols,
+                         const int32_t* __restrict__ rcb, const cx_cell* __restrict__ cells,
+                         double* __restrict__ values, const double* __restrict__ scale, int R) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= R) return;
+  const int rs = rows[r].size;
+  for (int c = rcb[r]; c < rcb[r + 1]; ++c) {
+    const cx_cell cell = cells[c];
+    const int cs = cols[cell.block_id].size, cp = cols[cell.block_id].position;
+    double* m = values + cell.position;
+    for (int i = 0; i < rs; ++i)
+      for (int j = 0; j < cs; ++j) m[i * cs + j] *= scale[cp + j];
+  }
+}
+
+// ============================================================= host: structure
+
+static int grid_for(int64_t n, int block) { return int((n + block - 1) / block); }
+
+// DetectStructure (detect_structure.cc:39-120); -1 == Eigen::Dynamic
+static void DetectStructureHost(const cx_block_structure* bs, int nelim, int32_t* rsz, int32_t* esz, int32_t* fsz) {
+  *rsz = *esz = *fsz = 0;
+  for (int r = 0; r < bs->num_row_blocks; ++r) {
+    const int nc = bs->row_cell_begin[r + 1] - bs->row_cell_begin[r];
+    if (nc == 0) continue;
+    const cx_cell* cells = bs->cells + bs->row_cell_begin[r];
+    if (cells[0].block_id >= nelim) break;
+    if (*rsz == 0) *rsz = bs->row_blocks[r].size;
+    else if (*rsz != -1 && *rsz != bs->row_blocks[r].size) *rsz = -1;
+    const int e = bs->col_blocks[cells[0].block_id].size;
+    if (*esz == 0) *esz = e;
+    else if (*esz != -1 && *esz != e) *esz = -1;
+    if (nc > 1) {
+      if (*fsz == 0) *fsz = bs->col_blocks[cells[1].block_id].size;
+      for (int c = 1; c < nc && *fsz != -1; ++c)
+        if (*fsz != bs->col_blocks[cells[c].block_id].size) *fsz = -1;
+    }
+    if (*rsz == -1 && *esz == -1 && *fsz == -1) break;
+  }
+}
+
+// Is this exactly the bundle-adjustment layout the <2,3,9> kernels assume?
+static bool Detect239(const cx_matrix* A, int32_t* P_out, int32_t* C_out) {
+  const int R = A->R, Cb = A->Cb;
+  if (R == 0 || Cb < 2) return false;
+  int P = 0;
+  while (P < Cb && A->cols[P].size == 3) ++P;
+  const int C = Cb - P;
+  if (P == 0 || C == 0) return false;
+  if (A->nelim != 0 && A->nelim != P) return false;
+  for (int j = 0; j < P; ++j) if (A->cols[j].position != 3 * j) return false;
+  for (int i = 0; i < C; ++i) if (A->cols[P + i].size != 9 || int64_t(A->cols[P + i].position) != 3ll * P + 9ll * i) return false;
+  const int64_t O = R;
+  if (24 * O >= (int64_t(1) << 31)) return false;
+  std::vector<int32_t> last_pt(C, -1);
+  int prev_pt = 0;
+  for (int r = 0; r < R; ++r) {
+    if (A->rows[r].size != 2 || A->rows[r].position != 2 * r) return false;
+    if (A->rcb[r] != 2 * r || A->rcb[r + 1] != 2 * r + 2) return false;
+    const cx_cell& ce = A->cells[2 * r];
+    const cx_cell& cf = A->cells[2 * r + 1];
+    if (ce.block_id < 0 || ce.block_id >= P || cf.block_id < P || cf.block_id >= Cb) return false;
+    if (int64_t(ce.position) != 6ll * r || int64_t(cf.position) != 6 * O + 18ll * r) return false;
+    if (ce.block_id < prev_pt) return false;  // chunks must be contiguous and ascending
+    prev_pt = ce.block_id;
+    const int cam = cf.block_id - P;
+    if (last_pt[cam] == ce.block_id) return false;  // a camera seeing a point twice: generic path
+    last_pt[cam] = ce.block_id;
+  }
+  *P_out = P;
+  *C_out = C;
+  return true;
+}
+
+static int Build239(cx_matrix* A) {
+  const int64_t O = A->R;
+  const int P = A->P, C = A->C;
+  hipStream_t st = A->ctx->stream;
+  std::vector<int32_t> row_pt(O), row_cam(O), pt_start(P + 1, 0);
+  for (int64_t r = 0; r < O; ++r) {
+    row_pt[r] = A->cells[2 * r].block_id;
+    row_cam[r] = A->cells[2 * r + 1].block_id - P;
+    pt_start[row_pt[r] + 1]++;
+  }
+  std::partial_sum(pt_start.begin(), pt_start.end(), pt_start.begin());
+  // chunk-aligned tiles
+  std::vector<int32_t> tile_row{0}, tile_pt{0};
+  {
+    int p = 0;
+    while (p < P) {
+      const int p_begin = p;
+      const int r_begin = pt_start[p];
+      int rows = pt_start[p + 1] - pt_start[p];
+      ++p;
+      if (rows <= kTileRows) {
+        while (p < P && p - p_begin < kTileRows && (pt_start[p + 1] - r_begin) <= kTileRows) ++p;
+      }
+      tile_row.push_back(pt_start[p]);
+      tile_pt.push_back(p);
+      if (rows > kTileRows) A->has_big_tiles = true;
+    }
+  }
+  A->num_tiles = int(tile_row.size()) - 1;
+  // camera-major order: stable counting sort by camera (ascending row inside a camera,
+  // the order of the reference's transpose block structure, block_sparse_matrix.cc:784-808)
+  std::vector<int32_t> cam_start(C + 1, 0), cam_rows(O);
+  for (int64_t r = 0; r < O; ++r) cam_start[row_cam[r] + 1]++;
+  std::partial_sum(cam_start.begin(), cam_start.end(), cam_start.begin());
+  {
+    std::vector<int32_t> cur(cam_start.begin(), cam_start.end() - 1);
+    for (int64_t r = 0; r < O; ++r) cam_rows[cur[row_cam[r]]++] = int32_t(r);
+  }
+  std::vector<int32_t> seg_begin, seg_cam, cam_seg_start(C + 1, 0);
+  for (int c = 0; c < C; ++c) {
+    cam_seg_start[c] = int32_t(seg_cam.size());
+    for (int b = cam_start[c]; b < cam_start[c + 1]; b += kSegRows) {
+      seg_begin.push_back(b);
+      seg_cam.push_back(c);
+    }
+  }
+  cam_seg_start[C] = int32_t(seg_cam.size());
+  seg_begin.push_back(int32_t(O));
+  A->num_segs = int(seg_cam.size());
+  CX_TRY(A->d_row_pt.upload(row_pt, st));
+  CX_TRY(A->d_row_cam.upload(row_cam, st));
+  CX_TRY(A->d_pt_start.upload(pt_start, st));
+  CX_TRY(A->d_tile_row.upload(tile_row, st));
+  CX_TRY(A->d_tile_pt.upload(tile_pt, st));
+  CX_TRY(A->d_cam_rows.upload(cam_rows, st));
+  CX_TRY(A->d_seg_begin.upload(seg_begin, st));
+  CX_TRY(A->d_seg_cam.upload(seg_cam, st));
+  CX_TRY(A->d_cam_seg_start.upload(cam_seg_start, st));
+  CX_TRY(A->d_partials.alloc(size_t(std::max(1, A->num_segs)) * 81));
+  return CX_OK;
+}
+
+int cx_matrix_ensure_ft(cx_matrix* A) {
+  if (!A->is239 || A->ft_valid) return CX_OK;
+  CX_TRY(A->d_Ft.alloc(size_t(A->O) * 18));
+  const int64_t pieces = A->O * 9;
+  hipLaunchKernelGGL(k_permute_ft, dim3(grid_for(pieces, kBlock)), dim3(kBlock), 0, A->ctx->stream,
+                     A->d_values.p + 6 * A->O, A->d_cam_rows.p, A->d_Ft.p, A->O);
+  CX_HIP(hipGetLastError());
+  A->ft_valid = true;
+  return CX_OK;
+}
+
+// ------------------------------------------------------------ product drivers
+int cxk_ft_multiply(cx_matrix* A, const double* t, double* yf, bool accumulate) {
+  CX_TRY(cx_matrix_ensure_ft(A));
+  hipStream_t st = A->ctx->stream;
+  if (A->num_segs > 0)
+    hipLaunchKernelGGL(k_cam_ft, dim3(A->num_segs), dim3(kBlock), 0, st, A->d_Ft.p, A->d_cam_rows.p,
+                       A->d_seg_begin.p, t, A->d_partials.p);
+  hipLaunchKernelGGL(k_cam_reduce9, dim3(grid_for(int64_t(A->C) * 9, 256)), dim3(256), 0, st,
+                     A->d_partials.p, A->d_cam_seg_start.p, yf, A->C, accumulate ? 1 : 0,
+                     (const double*)nullptr, (const double*)nullptr);
+  CX_HIP(hipGetLastError());
+  return CX_OK;
+}
+
+int cxk_right_multiply(cx_matrix* A, const double* x, double* y) {
+  hipStream_t st = A->ctx->stream;
+  if (A->is239) {
+    hipLaunchKernelGGL(k_right_239, dim3(grid_for(A->O, kBlock)), dim3(kBlock), 0, st, A->d_values.p,
+                       A->d_values.p + 6 * A->O, A->d_row_pt.p, A->d_row_cam.p, x, x + 3 * int64_t(A->P), y,
+                       A->O, 1, 1, 1);
+  } else if (A->R > 0) {
+    hipLaunchKernelGGL(kg_right, dim3(grid_for(A->R, 128)), dim3(128), 0, st, A->d_rows.p, A->d_cols.p,
+                       A->d_rcb.p, A->d_cells.p, A->d_values.p, x, y, A->R);
+  }
+  CX_HIP(hipGetLastError());
+  return CX_OK;
+}
+
+int cxk_left_multiply(cx_matrix* A, const double* x, double* y) {
+  hipStream_t st = A->ctx->stream;
+  if (A->is239) {
+    hipLaunchKernelGGL(k_left_e_239, dim3(A->num_tiles), dim3(kBlock), 0, st, A->d_values.p, A->d_tile_row.p,
+                       A->d_tile_pt.p, A->d_pt_start.p, x, y, 1);
+    CX_TRY(cxk_ft_multiply(A, x, y + 3 * int64_t(A->P), true));
+  } else if (A->R > 0) {
+    hipLaunchKernelGGL(kg_left, dim3(grid_for(A->R, 128)), dim3(128), 0, st, A->d_rows.p, A->d_cols.p,
+                       A->d_rcb.p, A->d_cells.p, A->d_values.p, x, y, A->R);
+  }
+  CX_HIP(hipGetLastError());
+  return CX_OK;
+}
+
+int cxk_squared_column_norm(cx_matrix* A, double* x) {
+  hipStream_t st = A->ctx->stream;
+  if (A->is239) {
+    CX_TRY(cx_matrix_ensure_ft(A));
+    hipLaunchKernelGGL(k_sqnorm_e_239, dim3(grid_for(A->P, kBlock)), dim3(kBlock), 0, st, A->d_values.p,
+                       A->d_pt_start.p, x, A->P);
+    if (A->num_segs > 0)
+      hipLaunchKernelGGL(k_cam_sqnorm, dim3(A->num_segs), dim3(kBlock), 0, st, A->d_Ft.p, A->d_seg_begin.p,
+                         A->d_partials.p);
+    hipLaunchKernelGGL(k_cam_reduce9, dim3(grid_for(int64_t(A->C) * 9, 256)), dim3(256), 0, st,
+                       A->d_partials.p, A->d_cam_seg_start.p, x + 3 * int64_t(A->P), A->C, 0,
+                       (const double*)nullptr, (const double*)nullptr);
+  } else {
+    CX_HIP(hipMemsetAsync(x, 0, size_t(A->num_cols) * sizeof(double), st));
+    if (A->R > 0)
+      hipLaunchKernelGGL(kg_sqnorm, dim3(grid_for(A->R, 128)), dim3(128), 0, st, A->d_rows.p, A->d_cols.p,
+                         A->d_rcb.p, A->d_cells.p, A->d_values.p, x, A->R);
+  }
+  CX_HIP(hipGetLastError());
+  return CX_OK;
+}
+
+int cxk_scale_columns(cx_matrix* A, const double* scale) {
+  hipStream_t st = A->ctx->stream;
+  if (A->is239) {
+    hipLaunchKernelGGL(k_scale_239, dim3(grid_for(A->O, kBlock)), dim3(kBlock), 0, st, A->d_values.p,
+                       A->d_values.p + 6 * A->O, A->d_row_pt.p, A->d_row_cam.p, scale, A->O,
+                       3 * int64_t(A->P));
+  } else if (A->R > 0) {
+    hipLaunchKernelGGL(kg_scale, dim3(grid_for(A->R, 128)), dim3(128), 0, st, A->d_rows.p, A->d_cols.p,
+                       A->d_rcb.p, A->d_cells.p, A->d_values.p, scale, A->R);
+  }
+  A->ft_valid = false;
+  CX_HIP(hipGetLastError());
+  return CX_OK;
+}
+
+// run `body` between two events and keep the device time
+template <typename Fn>
+static int Timed(cx_matrix* A, Fn body) {
+  cx_context* ctx = A->ctx;
+  CX_HIP(hipEventRecord(ctx->ev[0], ctx->stream));
+  CX_TRY(body());
+  CX_HIP(hipEventRecord(ctx->ev[1], ctx->stream));
+  CX_HIP(hipEventSynchronize(ctx->ev[1]));
+  CX_HIP(hipEventElapsedTime(&A->last_ms, ctx->ev[0], ctx->ev[1]));
+  return CX_OK;
+}
+
+// =================================================================== C ABI
+extern "C" {
+
+int cx_detect_structure(const cx_block_structure* bs, int32_t nelim, int32_t* r, int32_t* e, int32_t* f) {
+  CX_CHECK_ARG(bs && r && e && f);
+  DetectStructureHost(bs, nelim, r, e, f);
+  return CX_OK;
+}
+
+int cx_partition_points(const cx_block_structure* bs, int32_t nelim, int32_t nranks, int32_t* bounds) {
+  CX_CHECK_ARG(bs && bounds && nranks >= 1 && nelim >= 0 && nelim <= bs->num_col_blocks);
+  // non-zeros of each eliminated column block
+  std::vector<int64_t> nnz(nelim + 1, 0);
+  for (int r = 0; r < bs->num_row_blocks; ++r) {
+    const int b = bs->row_cell_begin[r], e = bs->row_cell_begin[r + 1];
+    if (b == e) continue;
+    const int first = bs->cells[b].block_id;
+    if (first >= nelim) continue;
+    int64_t n = 0;
+    for (int c = b; c < e; ++c) n += int64_t(bs->row_blocks[r].size) * bs->col_blocks[bs->cells[c].block_id].size;
+    nnz[first + 1] += n;
+  }
+  std::partial_sum(nnz.begin(), nnz.end(), nnz.begin());
+  const int64_t total = nnz[nelim];
+  bounds[0] = 0;
+  for (int k = 1; k < nranks; ++k) {
+    const int64_t target = total * k / nranks;
+    int32_t j = int32_t(std::lower_bound(nnz.begin(), nnz.end(), target) - nnz.begin());
+    bounds[k] = std::max(bounds[k - 1], std::min(j, nelim));
+  }
+  bounds[nranks] = nelim;
+  return CX_OK;
+}
+
+int cx_matrix_create(cx_context* ctx, const cx_block_structure* bs, int32_t nelim, cx_matrix** out) {
+  CX_CHECK_ARG(ctx && bs && out);
+  CX_CHECK_ARG(bs->num_row_blocks >= 0 && bs->num_col_blocks >= 0);
+  CX_CHECK_ARG(nelim >= 0 && nelim <= bs->num_col_blocks);
+  CX_HIP(hipSetDevice(ctx->device));
+  auto A = new cx_matrix;
+  A->ctx = ctx;
+  A->R = bs->num_row_blocks;
+  A->Cb = bs->num_col_blocks;
+  A->nelim = nelim;
+  A->rows.assign(bs->row_blocks, bs->row_blocks + A->R);
+  A->cols.assign(bs->col_blocks, bs->col_blocks + A->Cb);
+  A->rcb.assign(bs->row_cell_begin, bs->row_cell_begin + A->R + 1);
+  A->cells.assign(bs->cells, bs->cells + A->rcb[A->R]);
+  A->num_rows = A->R ? int64_t(A->rows.back().position) + A->rows.back().size : 0;
+  A->num_cols = A->Cb ? int64_t(A->cols.back().position) + A->cols.back().size : 0;
+  // validate + count
+  int64_t nnz = 0, max_end = 0;
+  for (int r = 0; r < A->R; ++r) {
+    for (int c = A->rcb[r]; c < A->rcb[r + 1]; ++c) {
+      const cx_cell& cell = A->cells[c];
+      if (cell.block_id < 0 || cell.block_id >= A->Cb || cell.position < 0) {
+        delete A;
+        cx_set_error("cell %d of row block %d is out of range", c, r);
+        return CX_ERR_INVALID_ARGUMENT;
+      }
+      const int64_t sz = int64_t(A->rows[r].size) * A->cols[cell.block_id].size;
+      nnz += sz;
+      max_end = std::max(max_end, int64_t(cell.position) + sz);
+    }
+  }
+  A->nnz = nnz;
+  if (max_end > nnz) {  // the reference allocates exactly num_nonzeros values
+    delete A;
+    cx_set_error("cell positions reach %lld but the matrix has only %lld non-zeros", (long long)max_end, (long long)nnz);
+    return CX_ERR_INVALID_ARGUMENT;
+  }
+  for (int c = 0; c < A->Cb; ++c) (c < nelim ? A->num_cols_e : A->num_cols_f) += A->cols[c].size;
+  for (int r = 0; r < A->R; ++r)
+    if (A->rcb[r + 1] > A->rcb[r] && A->cells[A->rcb[r]].block_id < nelim) A->num_row_blocks_e = r + 1;
+  DetectStructureHost(bs, nelim, &A->row_size, &A->e_size, &A->f_size);
+
+  int rc = A->d_values.alloc(size_t(std::max<int64_t>(nnz, 1)));
+  if (rc == CX_OK) rc = (hipMemsetAsync(A->d_values.p, 0, size_t(std::max<int64_t>(nnz, 1)) * sizeof(double), ctx->stream) == hipSuccess) ? CX_OK : CX_ERR_HIP;
+  int32_t P = 0, C = 0;
+  if (rc == CX_OK && Detect239(A, &P, &C)) {
+    A->is239 = true;
+    A->O = A->R;
+    A->P = P;
+    A->C = C;
+    rc = Build239(A);
+  }
+  if (rc == CX_OK && !A->is239) {
+    hipStream_t st = ctx->stream;
+    rc = A->d_rows.upload(A->rows, st);
+    if (rc == CX_OK) rc = A->d_cols.upload(A->cols, st);
+    if (rc == CX_OK) rc = A->d_rcb.upload(A->rcb, st);
+    if (rc == CX_OK) rc = A->d_cells.upload(A->cells, st);
+  }
+  if (rc != CX_OK) {
+    delete A;
+    return rc;
+  }
+  *out = A;
+  return CX_OK;
+}
+
+void cx_matrix_destroy(cx_matrix* A) {
+  if (!A) return;
+  (void)hipSetDevice(A->ctx->device);
+  (void)hipStreamSynchronize(A->ctx->stream);
+  delete A;
+}
+
+int64_t cx_matrix_num_rows(const cx_matrix* A) { return A ? A->num_rows : 0; }
+int64_t cx_matrix_num_cols(const cx_matrix* A) { return A ? A->num_cols : 0; }
+int64_t cx_matrix_num_nonzeros(const cx_matrix* A) { return A ? A->nnz : 0; }
+int cx_matrix_is_static_239(const cx_matrix* A) { return A && A->is239 ? 1 : 0; }
+double* cx_matrix_device_values(cx_matrix* A) { return A ? A->d_values.p : nullptr; }
+
+int cx_matrix_values_changed(cx_matrix* A) {
+  CX_CHECK_ARG(A);
+  A->ft_valid = false;
+  return CX_OK;
+}
+
+int cx_matrix_set_values(cx_matrix* A, const double* src, int32_t memspace) {
+  CX_CHECK_ARG(A && (src || A->nnz == 0));
+  if (A->nnz)
+    CX_HIP(hipMemcpyAsync(A->d_values.p, src, size_t(A->nnz) * sizeof(double),
+                          memspace == CX_HOST ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice, A->ctx->stream));
+  CX_HIP(hipStreamSynchronize(A->ctx->stream));
+  A->ft_valid = false;
+  return CX_OK;
+}
+
+int cx_matrix_get_values(const cx_matrix* A, double* dst) {
+  CX_CHECK_ARG(A && (dst || A->nnz == 0));
+  if (A->nnz) CX_HIP(hipMemcpyAsync(dst, A->d_values.p, size_t(A->nnz) * sizeof(double), hipMemcpyDeviceToHost, A->ctx->stream));
+  CX_HIP(hipStreamSynchronize(A->ctx->stream));
+  return CX_OK;
+}
+
+int cx_matrix_set_zero(cx_matrix* A) {
+  CX_CHECK_ARG(A);
+  if (A->nnz) CX_HIP(hipMemsetAsync(A->d_values.p, 0, size_t(A->nnz) * sizeof(double), A->ctx->stream));
+  A->ft_valid = false;
+  return CX_OK;
+}
+
+int cx_matrix_right_multiply(cx_matrix* A, const double* x, double* y, int32_t memspace) {
+  CX_CHECK_ARG(A && x && y);
+  HostOrDevice hx(A->ctx), hy(A->ctx);
+  CX_TRY(hx.in(x, size_t(A->num_cols), memspace));
+  CX_TRY(hy.inout(y, size_t(A->num_rows), memspace, true));
+  CX_TRY(Timed(A, [&] { return cxk_right_multiply(A, hx.dptr, hy.dptr); }));
+  return hy.out();
+}
+
+int cx_matrix_left_multiply(cx_matrix* A, const double* x, double* y, int32_t memspace) {
+  CX_CHECK_ARG(A && x && y);
+  HostOrDevice hx(A->ctx), hy(A->ctx);
+  CX_TRY(hx.in(x, size_t(A->num_rows), memspace));
+  CX_TRY(hy.inout(y, size_t(A->num_cols), memspace, true));
+  CX_TRY(cx_matrix_ensure_ft(A));  // the camera-major copy is part of the matrix, not of the product
+  CX_TRY(Timed(A, [&] { return cxk_left_multiply(A, hx.dptr, hy.dptr); }));
+  return hy.out();
+}
+
+int cx_matrix_squared_column_norm(cx_matrix* A, double* x, int32_t memspace) {
+  CX_CHECK_ARG(A && x);
+  HostOrDevice hx(A->ctx);
+  CX_TRY(hx.inout(x, size_t(A->num_cols), memspace, false));
+  CX_TRY(cx_matrix_ensure_ft(A));
+  CX_TRY(Timed(A, [&] { return cxk_squared_column_norm(A, hx.dptr); }));
+  return hx.out();
+}
+
+int cx_matrix_scale_columns(cx_matrix* A, const double* scale, int32_t memspace) {
+  CX_CHECK_ARG(A && scale);
+  HostOrDevice hs(A->ctx);
+  CX_TRY(hs.in(scale, size_t(A->num_cols), memspace));
+  CX_TRY(Timed(A, [&] { return cxk_scale_columns(A, hs.dptr); }));
+  return CX_OK;
+}
+
+double cx_matrix_last_kernel_ms(const cx_matrix* A) { return A ? double(A->last_ms) : 0.0; }
+
+}  // extern "C"

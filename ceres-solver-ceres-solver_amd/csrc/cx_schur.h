@@ -1,0 +1,22 @@
+// Host drivers of the Schur kernels (cx_schur.hip); device pointers throughout.
+#ifndef CX_SCHUR_H_
+#define CX_SCHUR_H_
+#include "cx_internal.h"
+
+// ete_inv[9P] = (E'E + D_e^2)^-1 per point; g[3P] = E'b (optional).  llt selects
+// the LLT inverse (ImplicitSchurComplement) or the cofactor inverse (SchurEliminator).
+int cxs_compute_ete_inverse(cx_matrix* A, const double* D, const double* b, double* ete_inv, double* g,
+                            bool llt, int* d_flag);
+// mode 0: out[2O] = (I - E (E'E)^-1 E') F xf ; 1: out[2O] = (I - E (E'E)^-1 E') b ;
+// 2: out[3P] = (E'E)^-1 E' (b - F xf)
+int cxs_chunk_pass(cx_matrix* A, int mode, const double* ete_inv, const double* xf, const double* b, double* out);
+// blocks[81C] = block diagonal of F'F (with_schur = false) or of S without D_f^2 (true)
+int cxs_camera_block_diagonal(cx_matrix* A, bool with_schur, const double* ete_inv, double* blocks);
+int cxs_block9_add_diag_invert(cx_context* ctx, double* blocks, const double* Df, int C, int* d_flag);
+// dense lhs (9C x 9C row-major, upper block triangle) and rhs of the reduced system
+int cxs_eliminate_dense(cx_matrix* A, const double* b, const double* D, bool add_df, double* lhs, double* rhs);
+
+// dense Cholesky (cx_cholesky.hip): factor the upper triangle of row-major a (n x n) in
+// place (a = U'U) and solve a x = rhs.  *d_flag set to 1 when not positive definite.
+int cxd_cholesky_solve(cx_context* ctx, int n, double* a, const double* rhs, double* x, int* d_flag);
+#endif

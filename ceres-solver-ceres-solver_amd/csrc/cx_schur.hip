@@ -1,0 +1,708 @@
+// Schur-complement kernels for the static <2,3,9> bundle-adjustment layout (gfx950).
+//
+// Reference functions replaced:
+//   ImplicitSchurComplement::{Init,RightMultiplyAndAccumulate,UpdateRhs,BackSubstitute,
+//     AddDiagonalAndInvert}                      implicit_schur_complement.cc:49-276
+//   PartitionedMatrixView::UpdateBlockDiagonal{EtE,FtF}   partitioned_matrix_view_impl.h:420-658
+//   SchurEliminator<2,3,9>::{Eliminate,BackSubstitute}    schur_eliminator_impl.h:177-561
+//   SchurJacobiPreconditioner::UpdateImpl        schur_jacobi_preconditioner.cc:88-98
+//
+// Work decomposition.  Point-major ("chunk") kernels run one workgroup per tile of
+// whole chunks (<= 256 row blocks): E / F cells are streamed once through LDS into
+// registers (coalesced 16-byte loads), per-row partial results go to LDS, one
+// thread per point folds the rows of its chunk in row order (deterministic), and
+// the rows read the per-point result back.  Camera-space sums run camera-major over
+// a second copy of the F cells (cx_matrix.hip) in fixed-size segments whose partial
+// sums are added in segment order, so every result is bitwise reproducible.
+#include "cx_internal.h"
+#include "cx_kernels.h"
+#include "cx_schur.h"
+
+static int grid_for(int64_t n, int block) { return int((n + block - 1) / block); }
+
+// (i, j), i <= j < k, of the q-th pair in row-major order of the upper triangle
+__device__ __forceinline__ void tri_decode(int64_t q, int k, int& i, int& j) {
+  const double kk = 2.0 * k + 1.0;
+  int ii = int((kk - sqrt(kk * kk - 8.0 * double(q))) * 0.5);
+  if (ii < 0) ii = 0;
+  if (ii > k - 1) ii = k - 1;
+  // first pair index of row ii is ii*k - ii*(ii-1)/2
+  while (ii > 0 && int64_t(ii) * k - int64_t(ii) * (ii - 1) / 2 > q) --ii;
+  while (int64_t(ii + 1) * k - int64_t(ii + 1) * ii / 2 <= q) ++ii;
+  i = ii;
+  j = ii + int(q - (int64_t(ii) * k - int64_t(ii) * (ii - 1) / 2));
+}
+
+// ------------------------------------------------------------ (E'E + D^2)^-1, E'b
+// USE_LLT = true : LLT inverse, as AddDiagonalAndInvert (implicit_schur_complement.cc:179-204)
+// USE_LLT = false: cofactor inverse, as InvertPSDMatrix<3> (invert_psd_matrix.h:60-63)
+template <bool USE_LLT>
+__global__ __launch_bounds__(kBlock) void k_chunk_ete(const double* __restrict__ E,
+                                                      const int32_t* __restrict__ tile_row,
+                                                      const int32_t* __restrict__ tile_pt,
+                                                      const int32_t* __restrict__ pt_start,
+                                                      const double* __restrict__ De,   // [3P] or null
+                                                      const double* __restrict__ b,    // [2O] or null
+                                                      double* __restrict__ ete_inv,    // [9P]
+                                                      double* __restrict__ g,          // [3P] or null: E'b
+                                                      int* __restrict__ not_pd) {
+  __shared__ double lds[kBlock * 6];
+  __shared__ double w[kBlock * 9];
+  __shared__ double red[9 * 4];
+  const int t = blockIdx.x, tid = threadIdx.x;
+  const int r0 = tile_row[t], r1 = tile_row[t + 1];
+  const int p0 = tile_pt[t], p1 = tile_pt[t + 1];
+  double m[9], gg[3] = {0.0, 0.0, 0.0};
+  bool have = false;
+  int p = -1;
+  if (r1 - r0 <= kBlock) {
+    const int nvalid = r1 - r0;
+    double e[6];
+    stage_cells<6>(E + 6 * int64_t(r0), nvalid, lds, e);
+    if (tid < nvalid) {
+      double2 bv = make_double2(0.0, 0.0);
+      if (b) bv = reinterpret_cast<const double2*>(b)[r0 + tid];
+      double* wr = w + tid * 9;
+      wr[0] = e[0] * e[0] + e[3] * e[3];
+      wr[1] = e[0] * e[1] + e[3] * e[4];
+      wr[2] = e[0] * e[2] + e[3] * e[5];
+      wr[3] = e[1] * e[1] + e[4] * e[4];
+      wr[4] = e[1] * e[2] + e[4] * e[5];
+      wr[5] = e[2] * e[2] + e[5] * e[5];
+      wr[6] = e[0] * bv.x + e[3] * bv.y;
+      wr[7] = e[1] * bv.x + e[4] * bv.y;
+      wr[8] = e[2] * bv.x + e[5] * bv.y;
+    }
+    __syncthreads();
+    if (tid < p1 - p0) {
+      p = p0 + tid;
+      have = true;
+      double s[9];
+#pragma unroll
+      for (int k = 0; k < 9; ++k) s[k] = 0.0;
+      for (int j = pt_start[p] - r0; j < pt_start[p + 1] - r0; ++j) {
+#pragma unroll
+        for (int k = 0; k < 9; ++k) s[k] += w[j * 9 + k];
+      }
+      m[0] = s[0]; m[1] = s[1]; m[2] = s[2]; m[4] = s[3]; m[5] = s[4]; m[8] = s[5];
+      gg[0] = s[6]; gg[1] = s[7]; gg[2] = s[8];
+    }
+  } else {
+    double s[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) s[k] = 0.0;
+    for (int r = r0 + tid; r < r1; r += kBlock) {
+      const double* e = E + 6 * int64_t(r);
+      double2 bv = make_double2(0.0, 0.0);
+      if (b) bv = reinterpret_cast<const double2*>(b)[r];
+      s[0] += e[0] * e[0] + e[3] * e[3];
+      s[1] += e[0] * e[1] + e[3] * e[4];
+      s[2] += e[0] * e[2] + e[3] * e[5];
+      s[3] += e[1] * e[1] + e[4] * e[4];
+      s[4] += e[1] * e[2] + e[4] * e[5];
+      s[5] += e[2] * e[2] + e[5] * e[5];
+      s[6] += e[0] * bv.x + e[3] * bv.y;
+      s[7] += e[1] * bv.x + e[4] * bv.y;
+      s[8] += e[2] * bv.x + e[5] * bv.y;
+    }
+    block_sum<9>(s, red);
+    if (tid == 0) {
+      p = p0;
+      have = true;
+      m[0] = s[0]; m[1] = s[1]; m[2] = s[2]; m[4] = s[3]; m[5] = s[4]; m[8] = s[5];
+      gg[0] = s[6]; gg[1] = s[7]; gg[2] = s[8];
+    }
+  }
+  if (have) {
+    if (De) {
+      const double* d = De + 3 * int64_t(p);
+      m[0] += d[0] * d[0];
+      m[4] += d[1] * d[1];
+      m[8] += d[2] * d[2];
+    }
+    m[3] = m[1]; m[6] = m[2]; m[7] = m[5];
+    double inv[9];
+    if (USE_LLT) {
+      bool ok;
+      inv3_llt(m, inv, ok);
+      if (!ok) *not_pd = 1;
+    } else {
+      inv3_cofactor(m, inv);
+    }
+    double* o = ete_inv + 9 * int64_t(p);
+#pragma unroll
+    for (int k = 0; k < 9; ++k) o[k] = inv[k];
+    if (g) { g[3 * int64_t(p)] = gg[0]; g[3 * int64_t(p) + 1] = gg[1]; g[3 * int64_t(p) + 2] = gg[2]; }
+  }
+}
+
+// ------------------------------------------------- chunk pass of the implicit S
+// MODE 0 (SX)     : t = F x_f ;  t' = t - E (E'E)^-1 E' t ; write t'        (S x, first half)
+// MODE 1 (RHS)    : t = b     ;  t' = t - E (E'E)^-1 E' t ; write t'        (UpdateRhs)
+// MODE 2 (BACKSUB): s = b - F z;  x_pt = (E'E)^-1 E' s                       (BackSubstitute)
+template <int MODE>
+__global__ __launch_bounds__(kBlock) void k_chunk_pass(const double* __restrict__ E,
+                                                       const double* __restrict__ F,
+                                                       const int32_t* __restrict__ tile_row,
+                                                       const int32_t* __restrict__ tile_pt,
+                                                       const int32_t* __restrict__ pt_start,
+                                                       const int32_t* __restrict__ row_cam,
+                                                       const double* __restrict__ ete_inv,
+                                                       const double* __restrict__ xf,   // camera vector (SX: x, BACKSUB: z)
+                                                       const double* __restrict__ b,    // row vector (RHS, BACKSUB)
+                                                       double* __restrict__ out) {      // t' [2O]  or x_e [3P]
+  __shared__ double lds[kBlock * 18];
+  __shared__ double w[kBlock * 3];
+  __shared__ double u[kBlock * 3];
+  __shared__ double red[3 * 4];
+  const int tl = blockIdx.x, tid = threadIdx.x;
+  const int r0 = tile_row[tl], r1 = tile_row[tl + 1];
+  const int p0 = tile_pt[tl], p1 = tile_pt[tl + 1];
+  if (r1 - r0 <= kBlock) {
+    const int nvalid = r1 - r0;
+    const int r = r0 + tid;
+    double e[6];
+    double t0 = 0.0, t1 = 0.0;
+    if (MODE != 1) {
+      double f[18];
+      stage_cells<18>(F + 18 * int64_t(r0), nvalid, lds, f);
+      if (tid < nvalid) {
+        const double* xc = xf + 9 * int64_t(row_cam[r]);
+#pragma unroll
+        for (int k = 0; k < 9; ++k) {
+          const double xv = xc[k];
+          t0 += f[k] * xv;
+          t1 += f[9 + k] * xv;
+        }
+      }
+    }
+    stage_cells<6>(E + 6 * int64_t(r0), nvalid, lds, e);
+    if (tid < nvalid) {
+      if (MODE != 0) {
+        const double2 bv = reinterpret_cast<const double2*>(b)[r];
+        if (MODE == 1) { t0 = bv.x; t1 = bv.y; }
+        else { t0 = bv.x - t0; t1 = bv.y - t1; }
+      }
+      w[tid * 3 + 0] = e[0] * t0 + e[3] * t1;
+      w[tid * 3 + 1] = e[1] * t0 + e[4] * t1;
+      w[tid * 3 + 2] = e[2] * t0 + e[5] * t1;
+    }
+    __syncthreads();
+    if (tid < p1 - p0) {
+      const int p = p0 + tid;
+      double s0 = 0.0, s1 = 0.0, s2 = 0.0;
+      for (int j = pt_start[p] - r0; j < pt_start[p + 1] - r0; ++j) {
+        s0 += w[j * 3];
+        s1 += w[j * 3 + 1];
+        s2 += w[j * 3 + 2];
+      }
+      const double* m = ete_inv + 9 * int64_t(p);
+      const double u0 = m[0] * s0 + m[1] * s1 + m[2] * s2;
+      const double u1 = m[3] * s0 + m[4] * s1 + m[5] * s2;
+      const double u2 = m[6] * s0 + m[7] * s1 + m[8] * s2;
+      if (MODE == 2) {
+        double* o = out + 3 * int64_t(p);
+        o[0] = u0; o[1] = u1; o[2] = u2;
+      } else {
+        u[tid * 3] = u0; u[tid * 3 + 1] = u1; u[tid * 3 + 2] = u2;
+      }
+    }
+    if (MODE != 2) {
+      __syncthreads();
+      if (tid < nvalid) {
+        // point of this row, local to the tile: rows are grouped by point, find by search
+        int lo = 0, hi = p1 - p0 - 1;
+        while (lo < hi) {
+          const int mid = (lo + hi + 1) >> 1;
+          if (pt_start[p0 + mid] <= r) lo = mid; else hi = mid - 1;
+        }
+        const double u0 = u[lo * 3], u1 = u[lo * 3 + 1], u2 = u[lo * 3 + 2];
+        t0 -= e[0] * u0 + e[1] * u1 + e[2] * u2;
+        t1 -= e[3] * u0 + e[4] * u1 + e[5] * u2;
+        reinterpret_cast<double2*>(out)[r] = make_double2(t0, t1);
+      }
+    }
+  } else {
+    // a single point with more than kBlock rows: strided loops and a block reduction
+    const int p = p0;
+    double s[3] = {0.0, 0.0, 0.0};
+    for (int r = r0 + tid; r < r1; r += kBlock) {
+      const double* e = E + 6 * int64_t(r);
+      double t0 = 0.0, t1 = 0.0;
+      if (MODE != 1) {
+        const double* f = F + 18 * int64_t(r);
+        const double* xc = xf + 9 * int64_t(row_cam[r]);
+        for (int k = 0; k < 9; ++k) { t0 += f[k] * xc[k]; t1 += f[9 + k] * xc[k]; }
+      }
+      if (MODE != 0) {
+        const double2 bv = reinterpret_cast<const double2*>(b)[r];
+        if (MODE == 1) { t0 = bv.x; t1 = bv.y; }
+        else { t0 = bv.x - t0; t1 = bv.y - t1; }
+      }
+      s[0] += e[0] * t0 + e[3] * t1;
+      s[1] += e[1] * t0 + e[4] * t1;
+      s[2] += e[2] * t0 + e[5] * t1;
+    }
+    block_sum<3>(s, red);
+    const double* m = ete_inv + 9 * int64_t(p);
+    const double u0 = m[0] * s[0] + m[1] * s[1] + m[2] * s[2];
+    const double u1 = m[3] * s[0] + m[4] * s[1] + m[5] * s[2];
+    const double u2 = m[6] * s[0] + m[7] * s[1] + m[8] * s[2];
+    if (MODE == 2) {
+      if (tid == 0) { double* o = out + 3 * int64_t(p); o[0] = u0; o[1] = u1; o[2] = u2; }
+    } else {
+      for (int r = r0 + tid; r < r1; r += kBlock) {
+        const double* e = E + 6 * int64_t(r);
+        double t0 = 0.0, t1 = 0.0;
+        if (MODE == 0) {
+          const double* f = F + 18 * int64_t(r);
+          const double* xc = xf + 9 * int64_t(row_cam[r]);
+          for (int k = 0; k < 9; ++k) { t0 += f[k] * xc[k]; t1 += f[9 + k] * xc[k]; }
+        } else {
+          const double2 bv = reinterpret_cast<const double2*>(b)[r];
+          t0 = bv.x; t1 = bv.y;
+        }
+        t0 -= e[0] * u0 + e[1] * u1 + e[2] * u2;
+        t1 -= e[3] * u0 + e[4] * u1 + e[5] * u2;
+        reinterpret_cast<double2*>(out)[r] = make_double2(t0, t1);
+      }
+    }
+  }
+}
+
+// ---------------------------------------------- camera-major 9x9 block diagonals
+// WITH_SCHUR = false: partial[seg] = sum F_r' F_r                      (block diagonal of F'F)
+// WITH_SCHUR = true : partial[seg] = sum F_r'F_r - (E_r'F_r)'(E'E)^-1(E_r'F_r)   (block diagonal of S)
+// 45 upper-triangle entries per segment, packed row-major (a <= b).
+template <bool WITH_SCHUR>
+__global__ __launch_bounds__(kBlock) void k_cam_diag(const double* __restrict__ Ft,
+                                                     const double* __restrict__ E,
+                                                     const int32_t* __restrict__ cam_rows,
+                                                     const int32_t* __restrict__ row_pt,
+                                                     const int32_t* __restrict__ seg_begin,
+                                                     const double* __restrict__ ete_inv,
+                                                     double* __restrict__ partial) {  // [S][45]
+  __shared__ double lds[kBlock * 18];
+  __shared__ double red[45 * 4];
+  const int s = blockIdx.x, tid = threadIdx.x;
+  const int b = seg_begin[s], e_ = seg_begin[s + 1];
+  double acc[45];
+#pragma unroll
+  for (int k = 0; k < 45; ++k) acc[k] = 0.0;
+  for (int k0 = b; k0 < e_; k0 += kBlock) {
+    const int nvalid = min(kBlock, e_ - k0);
+    double f[18];
+    stage_cells<18>(Ft + 18 * int64_t(k0), nvalid, lds, f);
+    if (tid < nvalid) {
+      int idx = 0;
+#pragma unroll
+      for (int a = 0; a < 9; ++a)
+#pragma unroll
+        for (int c = a; c < 9; ++c) acc[idx++] += f[a] * f[c] + f[9 + a] * f[9 + c];
+      if (WITH_SCHUR) {
+        const int r = cam_rows[k0 + tid];
+        const double* e = E + 6 * int64_t(r);
+        const double* m = ete_inv + 9 * int64_t(row_pt[r]);
+        double e6[6], mi[9];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) e6[k] = e[k];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) mi[k] = m[k];
+        // B = E'F (3x9), G = inv B (3x9)
+        double B[27], G[27];
+#pragma unroll
+        for (int q = 0; q < 3; ++q)
+#pragma unroll
+          for (int a = 0; a < 9; ++a) B[q * 9 + a] = e6[q] * f[a] + e6[3 + q] * f[9 + a];
+#pragma unroll
+        for (int q = 0; q < 3; ++q)
+#pragma unroll
+          for (int a = 0; a < 9; ++a) G[q * 9 + a] = mi[q * 3] * B[a] + mi[q * 3 + 1] * B[9 + a] + mi[q * 3 + 2] * B[18 + a];
+        idx = 0;
+#pragma unroll
+        for (int a = 0; a < 9; ++a)
+#pragma unroll
+          for (int c = a; c < 9; ++c) acc[idx++] -= B[a] * G[c] + B[9 + a] * G[9 + c] + B[18 + a] * G[18 + c];
+      }
+    }
+  }
+  block_sum<45>(acc, red);
+  if (tid < 45) partial[int64_t(s) * 45 + tid] = acc[tid];
+}
+
+// blocks[c] (81, row-major, full) = sum of the camera's packed segment partials
+__global__ void k_cam_diag_reduce(const double* __restrict__ partial, const int32_t* __restrict__ cam_seg_start,
+                                  double* __restrict__ blocks, int C) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= C * 45) return;
+  const int c = i / 45, k = i - c * 45;
+  double s = 0.0;
+  for (int sg = cam_seg_start[c]; sg < cam_seg_start[c + 1]; ++sg) s += partial[int64_t(sg) * 45 + k];
+  // unpack k -> (a, b), a <= b
+  int a = 0, rem = k;
+  while (rem >= 9 - a) { rem -= 9 - a; ++a; }
+  const int bcol = a + rem;
+  blocks[int64_t(c) * 81 + a * 9 + bcol] = s;
+  blocks[int64_t(c) * 81 + bcol * 9 + a] = s;
+}
+
+// blocks[i] <- (blocks[i] + diag(D_i^2))^-1 through LLT on the upper triangle
+// (BlockRandomAccessDiagonalMatrix::Invert, block_random_access_diagonal_matrix.cc:90-100;
+// AddDiagonalAndInvert).  One thread per 9x9 block, working in its LDS slab.
+__global__ __launch_bounds__(64) void k_block9_add_diag_invert(double* __restrict__ blocks,
+                                                               const double* __restrict__ Df, int C,
+                                                               int* __restrict__ not_pd) {
+  __shared__ double slab[64 * 82];  // stride 82: the Cholesky factor U; +1 pad
+  const int c = blockIdx.x * 64 + threadIdx.x;
+  if (c >= C) return;
+  double* A = blocks + int64_t(c) * 81;
+  double* U = slab + threadIdx.x * 82;
+  bool ok = true;
+  for (int j = 0; j < 9; ++j) {
+    for (int i = 0; i <= j; ++i) {
+      double s = A[i * 9 + j];
+      if (i == j && Df) s += Df[9 * int64_t(c) + j] * Df[9 * int64_t(c) + j];
+      for (int k = 0; k < i; ++k) s -= U[k * 9 + i] * U[k * 9 + j];
+      if (i == j) {
+        if (!(s > 0.0)) ok = false;
+        U[i * 9 + i] = sqrt(s);
+      } else {
+        U[i * 9 + j] = s / U[i * 9 + i];
+      }
+    }
+  }
+  if (!ok) *not_pd = 1;
+  // solve U'U X = I column by column, X written into A
+  for (int col = 0; col < 9; ++col) {
+    double y[9];
+    for (int i = 0; i < 9; ++i) {
+      double s = (i == col) ? 1.0 : 0.0;
+      for (int k = 0; k < i; ++k) s -= U[k * 9 + i] * y[k];
+      y[i] = s / U[i * 9 + i];
+    }
+    for (int i = 8; i >= 0; --i) {
+      double s = y[i];
+      for (int k = i + 1; k < 9; ++k) s -= U[i * 9 + k] * A[k * 9 + col];
+      A[i * 9 + col] = s / U[i * 9 + i];
+    }
+  }
+}
+
+// ------------------------------------------------------- explicit S (dense lhs)
+// SchurEliminator<2,3,9>::Eliminate into a dense row-major lhs of order 9C
+// (BlockRandomAccessDenseMatrix): upper block triangle, full diagonal blocks.
+// Contributions of different chunks to one S cell are combined with fp64 atomics
+// (the reference serialises them with a mutex per cell, schur_eliminator_impl.h:550),
+// so like the reference with num_threads > 1 the sum order is not fixed.
+constexpr int kMaxPtsPerTile = kBlock;
+__global__ __launch_bounds__(kBlock) void k_chunk_eliminate(const double* __restrict__ E,
+                                                            const double* __restrict__ F,
+                                                            const int32_t* __restrict__ tile_row,
+                                                            const int32_t* __restrict__ tile_pt,
+                                                            const int32_t* __restrict__ pt_start,
+                                                            const int32_t* __restrict__ row_cam,
+                                                            const double* __restrict__ De,
+                                                            const double* __restrict__ b,  // may be null
+                                                            double* __restrict__ lhs, int64_t n,
+                                                            double* __restrict__ rhs) {    // may be null
+  __shared__ double Bs[kBlock * 27];     // staging first, then B_r = E_r' F_r (3x9) per row
+  __shared__ double w[kBlock * 9];       // per row: E'E (6), E'b (3)
+  __shared__ double inv_s[kMaxPtsPerTile * 9];
+  __shared__ double invg_s[kMaxPtsPerTile * 3];
+  __shared__ int cam_s[kBlock];
+  __shared__ int pair_start[kMaxPtsPerTile + 1];
+  const int tl = blockIdx.x, tid = threadIdx.x;
+  const int r0 = tile_row[tl], r1 = tile_row[tl + 1];
+  const int p0 = tile_pt[tl], p1 = tile_pt[tl + 1];
+  const int npts = p1 - p0;
+  if (r1 - r0 > kBlock) return;  // long chunks are handled by k_big_chunk_eliminate
+  const int nvalid = r1 - r0;
+  const int r = r0 + tid;
+  double f[18], e[6];
+  stage_cells<18>(F + 18 * int64_t(r0), nvalid, Bs, f);
+  stage_cells<6>(E + 6 * int64_t(r0), nvalid, Bs, e);
+  double2 bv = make_double2(0.0, 0.0);
+  int cam = 0;
+  if (tid < nvalid) {
+    cam = row_cam[r];
+    cam_s[tid] = cam;
+    if (b) bv = reinterpret_cast<const double2*>(b)[r];
+    double* wr = w + tid * 9;
+    wr[0] = e[0] * e[0] + e[3] * e[3];
+    wr[1] = e[0] * e[1] + e[3] * e[4];
+    wr[2] = e[0] * e[2] + e[3] * e[5];
+    wr[3] = e[1] * e[1] + e[4] * e[4];
+    wr[4] = e[1] * e[2] + e[4] * e[5];
+    wr[5] = e[2] * e[2] + e[5] * e[5];
+    wr[6] = e[0] * bv.x + e[3] * bv.y;
+    wr[7] = e[1] * bv.x + e[4] * bv.y;
+    wr[8] = e[2] * bv.x + e[5] * bv.y;
+    double* Br = Bs + tid * 27;
+#pragma unroll
+    for (int q = 0; q < 3; ++q)
+#pragma unroll
+      for (int a = 0; a < 9; ++a) Br[q * 9 + a] = e[q] * f[a] + e[3 + q] * f[9 + a];
+    // S(c,c) += F'F  (EBlockRowOuterProduct, schur_eliminator_impl.h:665-714)
+    double* Scc = lhs + (9 * int64_t(cam)) * n + 9 * int64_t(cam);
+#pragma unroll
+    for (int a = 0; a < 9; ++a)
+#pragma unroll
+      for (int c = 0; c < 9; ++c) atomicAdd(&Scc[a * n + c], f[a] * f[c] + f[9 + a] * f[9 + c]);
+  }
+  __syncthreads();
+  if (tid < npts) {
+    const int p = p0 + tid;
+    double s[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) s[k] = 0.0;
+    for (int j = pt_start[p] - r0; j < pt_start[p + 1] - r0; ++j) {
+#pragma unroll
+      for (int k = 0; k < 9; ++k) s[k] += w[j * 9 + k];
+    }
+    double m[9], inv[9];
+    m[0] = s[0]; m[1] = s[1]; m[2] = s[2]; m[4] = s[3]; m[5] = s[4]; m[8] = s[5];
+    if (De) {
+      const double* d = De + 3 * int64_t(p);
+      m[0] += d[0] * d[0]; m[4] += d[1] * d[1]; m[8] += d[2] * d[2];
+    }
+    m[3] = m[1]; m[6] = m[2]; m[7] = m[5];
+    inv3_cofactor(m, inv);
+#pragma unroll
+    for (int k = 0; k < 9; ++k) inv_s[tid * 9 + k] = inv[k];
+    invg_s[tid * 3 + 0] = inv[0] * s[6] + inv[1] * s[7] + inv[2] * s[8];
+    invg_s[tid * 3 + 1] = inv[3] * s[6] + inv[4] * s[7] + inv[5] * s[8];
+    invg_s[tid * 3 + 2] = inv[6] * s[6] + inv[7] * s[7] + inv[8] * s[8];
+  }
+  if (tid == 0) {
+    int acc = 0;
+    for (int i = 0; i < npts; ++i) {
+      pair_start[i] = acc;
+      const int k = pt_start[p0 + i + 1] - pt_start[p0 + i];
+      acc += k * (k + 1) / 2;
+    }
+    pair_start[npts] = acc;
+  }
+  __syncthreads();
+  // UpdateRhs (schur_eliminator_impl.h:379-420): rhs_c += F_r' (b_r - E_r inv g)
+  if (rhs && tid < nvalid) {
+    int lo = 0, hi = npts - 1;
+    while (lo < hi) {
+      const int mid = (lo + hi + 1) >> 1;
+      if (pt_start[p0 + mid] <= r) lo = mid; else hi = mid - 1;
+    }
+    const double g0 = invg_s[lo * 3], g1 = invg_s[lo * 3 + 1], g2 = invg_s[lo * 3 + 2];
+    const double s0 = bv.x - (e[0] * g0 + e[1] * g1 + e[2] * g2);
+    const double s1 = bv.y - (e[3] * g0 + e[4] * g1 + e[5] * g2);
+    double* rc = rhs + 9 * int64_t(cam);
+#pragma unroll
+    for (int a = 0; a < 9; ++a) atomicAdd(&rc[a], f[a] * s0 + f[9 + a] * s1);
+  }
+  // ChunkOuterProduct (schur_eliminator_impl.h:512-561): S(c1,c2) -= B1' inv B2, c1 <= c2
+  const int total = pair_start[npts] * 81;
+  for (int item = tid; item < total; item += kBlock) {
+    const int pair = item / 81, el = item - pair * 81;
+    int lo = 0, hi = npts - 1;
+    while (lo < hi) {
+      const int mid = (lo + hi + 1) >> 1;
+      if (pair_start[mid] <= pair) lo = mid; else hi = mid - 1;
+    }
+    const int base = pt_start[p0 + lo] - r0;
+    const int k = pt_start[p0 + lo + 1] - pt_start[p0 + lo];
+    int i, j;
+    tri_decode(pair - pair_start[lo], k, i, j);
+    int ri = base + i, rj = base + j;
+    int c1 = cam_s[ri], c2 = cam_s[rj];
+    if (c1 > c2) { const int tq = c1; c1 = c2; c2 = tq; const int tr = ri; ri = rj; rj = tr; }
+    const int a = el / 9, c = el - a * 9;
+    const double* B1 = Bs + ri * 27;
+    const double* B2 = Bs + rj * 27;
+    const double* iv = inv_s + lo * 9;
+    double sum = 0.0;
+#pragma unroll
+    for (int pp = 0; pp < 3; ++pp) {
+      const double g = iv[pp * 3] * B2[c] + iv[pp * 3 + 1] * B2[9 + c] + iv[pp * 3 + 2] * B2[18 + c];
+      sum += B1[pp * 9 + a] * g;
+    }
+    atomicAdd(&lhs[(9 * int64_t(c1) + a) * n + 9 * int64_t(c2) + c], -sum);
+  }
+}
+
+// Long chunks (> kBlock rows): one workgroup per such chunk, same algebra with
+// strided loops over global memory (rare; correctness path).
+__global__ __launch_bounds__(kBlock) void k_big_chunk_eliminate(const double* __restrict__ E,
+                                                                const double* __restrict__ F,
+                                                                const int32_t* __restrict__ tile_row,
+                                                                const int32_t* __restrict__ tile_pt,
+                                                                const int32_t* __restrict__ row_cam,
+                                                                const double* __restrict__ De,
+                                                                const double* __restrict__ b,
+                                                                double* __restrict__ lhs, int64_t n,
+                                                                double* __restrict__ rhs) {
+  __shared__ double red[9 * 4];
+  __shared__ double inv_s[9], invg_s[3];
+  const int tl = blockIdx.x, tid = threadIdx.x;
+  const int r0 = tile_row[tl], r1 = tile_row[tl + 1];
+  if (r1 - r0 <= kBlock) return;
+  const int p = tile_pt[tl];
+  double s[9];
+  for (int k = 0; k < 9; ++k) s[k] = 0.0;
+  for (int r = r0 + tid; r < r1; r += kBlock) {
+    const double* e = E + 6 * int64_t(r);
+    const double* f = F + 18 * int64_t(r);
+    double2 bv = make_double2(0.0, 0.0);
+    if (b) bv = reinterpret_cast<const double2*>(b)[r];
+    s[0] += e[0] * e[0] + e[3] * e[3];
+    s[1] += e[0] * e[1] + e[3] * e[4];
+    s[2] += e[0] * e[2] + e[3] * e[5];
+    s[3] += e[1] * e[1] + e[4] * e[4];
+    s[4] += e[1] * e[2] + e[4] * e[5];
+    s[5] += e[2] * e[2] + e[5] * e[5];
+    s[6] += e[0] * bv.x + e[3] * bv.y;
+    s[7] += e[1] * bv.x + e[4] * bv.y;
+    s[8] += e[2] * bv.x + e[5] * bv.y;
+    const int cam = row_cam[r];
+    double* Scc = lhs + (9 * int64_t(cam)) * n + 9 * int64_t(cam);
+    for (int a = 0; a < 9; ++a)
+      for (int c = 0; c < 9; ++c) atomicAdd(&Scc[a * n + c], f[a] * f[c] + f[9 + a] * f[9 + c]);
+  }
+  block_sum<9>(s, red);
+  if (tid == 0) {
+    double m[9], inv[9];
+    m[0] = s[0]; m[1] = s[1]; m[2] = s[2]; m[4] = s[3]; m[5] = s[4]; m[8] = s[5];
+    if (De) {
+      const double* d = De + 3 * int64_t(p);
+      m[0] += d[0] * d[0]; m[4] += d[1] * d[1]; m[8] += d[2] * d[2];
+    }
+    m[3] = m[1]; m[6] = m[2]; m[7] = m[5];
+    inv3_cofactor(m, inv);
+    for (int k = 0; k < 9; ++k) inv_s[k] = inv[k];
+    invg_s[0] = inv[0] * s[6] + inv[1] * s[7] + inv[2] * s[8];
+    invg_s[1] = inv[3] * s[6] + inv[4] * s[7] + inv[5] * s[8];
+    invg_s[2] = inv[6] * s[6] + inv[7] * s[7] + inv[8] * s[8];
+  }
+  __syncthreads();
+  if (rhs) {
+    for (int r = r0 + tid; r < r1; r += kBlock) {
+      const double* e = E + 6 * int64_t(r);
+      const double* f = F + 18 * int64_t(r);
+      const double2 bv = reinterpret_cast<const double2*>(b)[r];
+      const double s0 = bv.x - (e[0] * invg_s[0] + e[1] * invg_s[1] + e[2] * invg_s[2]);
+      const double s1 = bv.y - (e[3] * invg_s[0] + e[4] * invg_s[1] + e[5] * invg_s[2]);
+      double* rc = rhs + 9 * int64_t(row_cam[r]);
+      for (int a = 0; a < 9; ++a) atomicAdd(&rc[a], f[a] * s0 + f[9 + a] * s1);
+    }
+  }
+  const int k = r1 - r0;
+  const int64_t total = int64_t(k) * (k + 1) / 2;
+  for (int64_t pair = tid; pair < total; pair += kBlock) {
+    int i, j;
+    tri_decode(pair, k, i, j);
+    int ri = r0 + i, rj = r0 + j;
+    int c1 = row_cam[ri], c2 = row_cam[rj];
+    if (c1 > c2) { const int tq = c1; c1 = c2; c2 = tq; const int tr = ri; ri = rj; rj = tr; }
+    double B1[27], G2[27];
+    {
+      const double* e = E + 6 * int64_t(ri);
+      const double* f = F + 18 * int64_t(ri);
+      for (int qq = 0; qq < 3; ++qq)
+        for (int a = 0; a < 9; ++a) B1[qq * 9 + a] = e[qq] * f[a] + e[3 + qq] * f[9 + a];
+    }
+    {
+      const double* e = E + 6 * int64_t(rj);
+      const double* f = F + 18 * int64_t(rj);
+      double B2[27];
+      for (int qq = 0; qq < 3; ++qq)
+        for (int a = 0; a < 9; ++a) B2[qq * 9 + a] = e[qq] * f[a] + e[3 + qq] * f[9 + a];
+      for (int qq = 0; qq < 3; ++qq)
+        for (int a = 0; a < 9; ++a)
+          G2[qq * 9 + a] = inv_s[qq * 3] * B2[a] + inv_s[qq * 3 + 1] * B2[9 + a] + inv_s[qq * 3 + 2] * B2[18 + a];
+    }
+    for (int a = 0; a < 9; ++a)
+      for (int c = 0; c < 9; ++c) {
+        const double sum = B1[a] * G2[c] + B1[9 + a] * G2[9 + c] + B1[18 + a] * G2[18 + c];
+        atomicAdd(&lhs[(9 * int64_t(c1) + a) * n + 9 * int64_t(c2) + c], -sum);
+      }
+  }
+}
+
+// lhs(i,i) += D_f(i)^2      (schur_eliminator_impl.h:194-213)
+__global__ void k_add_diag_sq(double* __restrict__ lhs, int64_t n, const double* __restrict__ Df) {
+  const int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i < n) lhs[i * n + i] += Df[i] * Df[i];
+}
+
+// ================================================================ host drivers
+
+int cxs_compute_ete_inverse(cx_matrix* A, const double* D, const double* b, double* ete_inv, double* g,
+                            bool llt, int* d_flag) {
+  hipStream_t st = A->ctx->stream;
+  if (A->num_tiles == 0) return CX_OK;
+  if (llt)
+    hipLaunchKernelGGL(k_chunk_ete<true>, dim3(A->num_tiles), dim3(kBlock), 0, st, A->d_values.p, A->d_tile_row.p,
+                       A->d_tile_pt.p, A->d_pt_start.p, D, b, ete_inv, g, d_flag);
+  else
+    hipLaunchKernelGGL(k_chunk_ete<false>, dim3(A->num_tiles), dim3(kBlock), 0, st, A->d_values.p, A->d_tile_row.p,
+                       A->d_tile_pt.p, A->d_pt_start.p, D, b, ete_inv, g, d_flag);
+  CX_HIP(hipGetLastError());
+  return CX_OK;
+}
+
+int cxs_chunk_pass(cx_matrix* A, int mode, const double* ete_inv, const double* xf, const double* b, double* out) {
+  hipStream_t st = A->ctx->stream;
+  if (A->num_tiles == 0) return CX_OK;
+  const double* E = A->d_values.p;
+  const double* F = A->d_values.p + 6 * A->O;
+#define CX_LAUNCH_PASS(M)                                                                                   \
+  hipLaunchKernelGGL(k_chunk_pass<M>, dim3(A->num_tiles), dim3(kBlock), 0, st, E, F, A->d_tile_row.p,       \
+                     A->d_tile_pt.p, A->d_pt_start.p, A->d_row_cam.p, ete_inv, xf, b, out)
+  if (mode == 0) CX_LAUNCH_PASS(0);
+  else if (mode == 1) CX_LAUNCH_PASS(1);
+  else CX_LAUNCH_PASS(2);
+#undef CX_LAUNCH_PASS
+  CX_HIP(hipGetLastError());
+  return CX_OK;
+}
+
+int cxs_camera_block_diagonal(cx_matrix* A, bool with_schur, const double* ete_inv, double* blocks) {
+  hipStream_t st = A->ctx->stream;
+  CX_TRY(cx_matrix_ensure_ft(A));
+  if (A->num_segs > 0) {
+    if (with_schur)
+      hipLaunchKernelGGL(k_cam_diag<true>, dim3(A->num_segs), dim3(kBlock), 0, st, A->d_Ft.p, A->d_values.p,
+                         A->d_cam_rows.p, A->d_row_pt.p, A->d_seg_begin.p, ete_inv, A->d_partials.p);
+    else
+      hipLaunchKernelGGL(k_cam_diag<false>, dim3(A->num_segs), dim3(kBlock), 0, st, A->d_Ft.p, A->d_values.p,
+                         A->d_cam_rows.p, A->d_row_pt.p, A->d_seg_begin.p, ete_inv, A->d_partials.p);
+  }
+  hipLaunchKernelGGL(k_cam_diag_reduce, dim3(grid_for(int64_t(A->C) * 45, 256)), dim3(256), 0, st,
+                     A->d_partials.p, A->d_cam_seg_start.p, blocks, A->C);
+  CX_HIP(hipGetLastError());
+  return CX_OK;
+}
+
+int cxs_block9_add_diag_invert(cx_context* ctx, double* blocks, const double* Df, int C, int* d_flag) {
+  if (C == 0) return CX_OK;
+  hipLaunchKernelGGL(k_block9_add_diag_invert, dim3(grid_for(C, 64)), dim3(64), 0, ctx->stream, blocks, Df, C, d_flag);
+  CX_HIP(hipGetLastError());
+  return CX_OK;
+}
+
+int cxs_eliminate_dense(cx_matrix* A, const double* b, const double* D, bool add_df, double* lhs, double* rhs) {
+  hipStream_t st = A->ctx->stream;
+  const int64_t n = 9 * int64_t(A->C);
+  CX_HIP(hipMemsetAsync(lhs, 0, size_t(n) * n * sizeof(double), st));
+  if (rhs) CX_HIP(hipMemsetAsync(rhs, 0, size_t(n) * sizeof(double), st));
+  if (D && add_df && n > 0)
+    hipLaunchKernelGGL(k_add_diag_sq, dim3(grid_for(n, 256)), dim3(256), 0, st, lhs, n, D + 3 * int64_t(A->P));
+  if (A->num_tiles > 0) {
+    const double* E = A->d_values.p;
+    const double* F = A->d_values.p + 6 * A->O;
+    hipLaunchKernelGGL(k_chunk_eliminate, dim3(A->num_tiles), dim3(kBlock), 0, st, E, F, A->d_tile_row.p,
+                       A->d_tile_pt.p, A->d_pt_start.p, A->d_row_cam.p, D, b, lhs, n, rhs);
+    if (A->has_big_tiles)
+      hipLaunchKernelGGL(k_big_chunk_eliminate, dim3(A->num_tiles), dim3(kBlock), 0, st, E, F, A->d_tile_row.p,
+                       A->d_tile_pt.p, A->d_row_cam.p, D, b, lhs, n, rhs);
+  }
+  CX_HIP(hipGetLastError());
+  return CX_OK;
+}

@@ -1,0 +1,800 @@
+// LinearSolver implementations on the device: preconditioned conjugate gradients
+// (ConjugateGradientsSolver, conjugate_gradients_solver.h:107-305), CgnrSolver
+// (cgnr_solver.cc:85-207), IterativeSchurComplementSolver
+// (iterative_schur_complement_solver.cc:64-199), Dense/SparseSchurComplementSolver
+// (schur_complement_solver.cc:101-203).
+//
+// All CG scalars (rho, beta, p'q, alpha, Q, |r|) live in one device struct; every
+// kernel of an iteration reads its coefficients from it and does nothing once a
+// termination flag is set, so the host only polls that struct.  The reference's
+// cuBLAS path synchronises on every dot product (cuda_vector.cc:95-182).
+#include <chrono>
+#include <cmath>
+#include <memory>
+
+#include "cx_internal.h"
+#include "cx_kernels.h"
+#include "cx_schur.h"
+
+static int grid_for(int64_t n, int block) { return int((n + block - 1) / block); }
+
+// ------------------------------------------------------------- CG device state
+enum CgFlag : int {
+  CG_RUNNING = 0,
+  CG_CONVERGED_Q = 1,
+  CG_CONVERGED_R = 2,
+  CG_MAX_ITER = 3,
+  CG_FAIL_RHO = 4,
+  CG_FAIL_BETA = 5,
+  CG_INDEFINITE = 6,
+  CG_FAIL_ALPHA = 7
+};
+
+struct CgState {
+  double rho, last_rho, beta, pq, alpha, Q0, Q1, norm_r, zeta;
+  double tol_r, q_tol;
+  double s0, s1;  // reduction results
+  int flag, iter, min_iter, max_iter;
+};
+
+constexpr int kRedBlocks = 512;  // fixed grid of the two-stage reductions (deterministic)
+
+// partial[blockIdx] = sum a.b ; partial[kRedBlocks + blockIdx] = sum c.d  (second pair optional)
+__global__ __launch_bounds__(256) void k_dot2_partial(const double* __restrict__ a, const double* __restrict__ b,
+                                                      const double* __restrict__ c, const double* __restrict__ d,
+                                                      int64_t n, double* __restrict__ partial,
+                                                      const CgState* __restrict__ st) {
+  __shared__ double red[2 * 4];
+  if (st && st->flag) return;
+  double s[2] = {0.0, 0.0};
+  for (int64_t i = int64_t(blockIdx.x) * 256 + threadIdx.x; i < n; i += int64_t(gridDim.x) * 256) {
+    s[0] += a[i] * b[i];
+    if (c) s[1] += c[i] * d[i];
+  }
+  block_sum<2>(s, red);
+  if (threadIdx.x == 0) {
+    partial[blockIdx.x] = s[0];
+    partial[kRedBlocks + blockIdx.x] = s[1];
+  }
+}
+
+// what to do with the finished sums
+enum FinOp : int { FIN_STORE = 0, FIN_RHO = 1, FIN_PQ = 2, FIN_Q = 3 };
+
+__global__ __launch_bounds__(256) void k_dot2_final(const double* __restrict__ partial, int nblocks, int op,
+                                                    CgState* __restrict__ st, double extra0, double extra1) {
+  __shared__ double red[2 * 4];
+  if (op != FIN_STORE && st->flag) return;
+  double s[2] = {0.0, 0.0};
+  for (int i = threadIdx.x; i < nblocks; i += 256) {
+    s[0] += partial[i];
+    s[1] += partial[kRedBlocks + i];
+  }
+  block_sum<2>(s, red);
+  if (threadIdx.x != 0) return;
+  // replicated camera part counted once in sharded CGNR: extras are added by the caller
+  s[0] += extra0;
+  s[1] += extra1;
+  st->s0 = s[0];
+  st->s1 = s[1];
+  if (op == FIN_RHO) {
+    st->last_rho = st->rho;
+    st->rho = s[0];
+    if (s[0] == 0.0 || isinf(s[0])) { st->flag = CG_FAIL_RHO; return; }
+    if (st->iter > 1) {
+      st->beta = st->rho / st->last_rho;
+      if (st->beta == 0.0 || isinf(st->beta)) st->flag = CG_FAIL_BETA;
+    }
+  } else if (op == FIN_PQ) {
+    st->pq = s[0];
+    if (s[0] <= 0.0 || isinf(s[0])) { st->flag = CG_INDEFINITE; return; }
+    st->alpha = st->rho / st->pq;
+    if (isinf(st->alpha)) st->flag = CG_FAIL_ALPHA;
+  } else if (op == FIN_Q) {
+    // s0 = x.(rhs + r), s1 = r.r
+    st->Q1 = -s[0];
+    st->norm_r = sqrt(s[1]);
+    st->zeta = st->iter * (st->Q1 - st->Q0) / st->Q1;
+    if (st->zeta < st->q_tol && st->iter >= st->min_iter) { st->flag = CG_CONVERGED_Q; return; }
+    st->Q0 = st->Q1;
+    if (st->norm_r <= st->tol_r && st->iter >= st->min_iter) { st->flag = CG_CONVERGED_R; return; }
+    if (st->iter >= st->max_iter) st->flag = CG_MAX_ITER;
+  }
+}
+
+// p = z (first iteration) or z + beta p
+__global__ void k_update_p(double* __restrict__ p, const double* __restrict__ z, int64_t n,
+                           const CgState* __restrict__ st) {
+  if (st->flag) return;
+  const int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  p[i] = (st->iter == 1) ? z[i] : z[i] + st->beta * p[i];
+}
+
+// x += alpha p ; r -= alpha q (unless the residual is recomputed) ; tmp = rhs + r
+__global__ void k_update_xr(double* __restrict__ x, double* __restrict__ r, const double* __restrict__ p,
+                            const double* __restrict__ q, const double* __restrict__ rhs,
+                            double* __restrict__ tmp, int64_t n, int update_r, const CgState* __restrict__ st) {
+  if (st->flag) return;
+  const int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const double alpha = st->alpha;
+  x[i] = x[i] + alpha * p[i];
+  if (update_r) {
+    const double rv = r[i] - alpha * q[i];
+    r[i] = rv;
+    tmp[i] = rhs[i] + rv;
+  }
+}
+
+// r = rhs - ax ; tmp = rhs + r
+__global__ void k_residual(const double* __restrict__ rhs, const double* __restrict__ ax, double* __restrict__ r,
+                           double* __restrict__ tmp, int64_t n, const CgState* __restrict__ st) {
+  if (st && st->flag) return;
+  const int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const double rv = rhs[i] - ax[i];
+  r[i] = rv;
+  tmp[i] = rhs[i] + rv;
+}
+
+__global__ void k_add_d2x(double* __restrict__ y, const double* __restrict__ d, const double* __restrict__ x, int64_t n) {
+  const int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i < n) y[i] += d[i] * d[i] * x[i];
+}
+
+// z = blockdiag(M) r for dense bs x bs row-major blocks (bs = 3 or 9)
+template <int BS>
+__global__ void k_blockdiag_multiply(const double* __restrict__ blocks, const double* __restrict__ r,
+                                     double* __restrict__ z, int64_t nblocks) {
+  const int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i >= nblocks * BS) return;
+  const int64_t blk = i / BS;
+  const int row = int(i - blk * BS);
+  const double* m = blocks + blk * (BS * BS) + row * BS;
+  const double* rv = r + blk * BS;
+  double s = 0.0;
+#pragma unroll
+  for (int k = 0; k < BS; ++k) s += m[k] * rv[k];
+  z[i] = s;
+}
+
+// CGNR Jacobi: 3x3 point blocks of J'J + D^2, inverted through LLT
+__global__ __launch_bounds__(kBlock) void k_point_jacobi(const double* __restrict__ E,
+                                                         const int32_t* __restrict__ pt_start,
+                                                         const double* __restrict__ D, double* __restrict__ blocks,
+                                                         int P, int* __restrict__ not_pd) {
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= P) return;
+  double m[9];
+#pragma unroll
+  for (int k = 0; k < 9; ++k) m[k] = 0.0;
+  for (int r = pt_start[p]; r < pt_start[p + 1]; ++r) {
+    const double* e = E + 6 * int64_t(r);
+    m[0] += e[0] * e[0] + e[3] * e[3];
+    m[1] += e[0] * e[1] + e[3] * e[4];
+    m[2] += e[0] * e[2] + e[3] * e[5];
+    m[4] += e[1] * e[1] + e[4] * e[4];
+    m[5] += e[1] * e[2] + e[4] * e[5];
+    m[8] += e[2] * e[2] + e[5] * e[5];
+  }
+  if (D) {
+    const double* d = D + 3 * int64_t(p);
+    m[0] += d[0] * d[0]; m[4] += d[1] * d[1]; m[8] += d[2] * d[2];
+  }
+  m[3] = m[1]; m[6] = m[2]; m[7] = m[5];
+  double inv[9];
+  bool ok;
+  inv3_llt(m, inv, ok);
+  if (!ok) *not_pd = 1;
+#pragma unroll
+  for (int k = 0; k < 9; ++k) blocks[9 * int64_t(p) + k] = inv[k];
+}
+
+// ------------------------------------------------------------------ operators
+struct LinOp {
+  virtual ~LinOp() = default;
+  virtual int64_t size() const = 0;
+  virtual int apply(const double* x, double* y) = 0;  // y = A x
+};
+
+struct cx_solver {
+  cx_context* ctx = nullptr;
+  cx_solver_options opt{};
+  cx_solve_timing timing{};
+  // persistent device scratch
+  DevBuf<double> v_p, v_r, v_z, v_tmp, v_x, v_rhs, v_rows, v_rows2, v_cols;
+  DevBuf<double> ete_inv, cam_blocks, pt_blocks, g_e, lhs, partial;
+  DevBuf<CgState> state;
+  DevBuf<int> flag;
+};
+
+namespace {
+
+struct CgDriver {
+  cx_solver* S;
+  cx_context* ctx;
+  hipStream_t st;
+  int64_t n;
+  // sharded CGNR: entries [shared0, n) are replicated over the ranks
+  int64_t shared0;
+
+  int dot2(const double* a, const double* b, const double* c, const double* d, int op, CgState* dst) {
+    const int nb = int(std::min<int64_t>(kRedBlocks, std::max<int64_t>(1, (n + 1023) / 1024)));
+    if (ctx->nranks > 1 && shared0 < n) {
+      // local part summed over the ranks, replicated part added once
+      hipLaunchKernelGGL(k_dot2_partial, dim3(nb), dim3(256), 0, st, a, b, c, d, shared0, S->partial.p, (const CgState*)nullptr);
+      hipLaunchKernelGGL(k_dot2_final, dim3(1), dim3(256), 0, st, S->partial.p, nb, int(FIN_STORE), dst, 0.0, 0.0);
+      CX_TRY(cx_allreduce_device(ctx, &dst->s0, 2));
+      double local[2];
+      CX_HIP(hipMemcpyAsync(local, &dst->s0, 2 * sizeof(double), hipMemcpyDeviceToHost, st));
+      CX_HIP(hipStreamSynchronize(st));
+      hipLaunchKernelGGL(k_dot2_partial, dim3(nb), dim3(256), 0, st, a + shared0, b + shared0,
+                         c ? c + shared0 : nullptr, d ? d + shared0 : nullptr, n - shared0, S->partial.p, (const CgState*)nullptr);
+      hipLaunchKernelGGL(k_dot2_final, dim3(1), dim3(256), 0, st, S->partial.p, nb, op, dst, local[0], local[1]);
+    } else {
+      hipLaunchKernelGGL(k_dot2_partial, dim3(nb), dim3(256), 0, st, a, b, c, d, n, S->partial.p,
+                         op == FIN_STORE ? (const CgState*)nullptr : (const CgState*)dst);
+      hipLaunchKernelGGL(k_dot2_final, dim3(1), dim3(256), 0, st, S->partial.p, nb, op, dst, 0.0, 0.0);
+    }
+    CX_HIP(hipGetLastError());
+    return CX_OK;
+  }
+
+  int read_state(CgState* h) {
+    CX_HIP(hipMemcpyAsync(h, S->state.p, sizeof(CgState), hipMemcpyDeviceToHost, st));
+    CX_HIP(hipStreamSynchronize(st));
+    return CX_OK;
+  }
+
+  // conjugate_gradients_solver.h:107-305.  x holds the initial guess (zero_initial
+  // tells that it is all zeros so that A x can be skipped).
+  int run(LinOp& lhs, LinOp& pre, const double* rhs, double* x, bool zero_initial, double r_tol, double q_tol,
+          cx_summary* summary) {
+    const cx_solver_options& o = S->opt;
+    CX_TRY(S->v_p.alloc(n));
+    CX_TRY(S->v_r.alloc(n));
+    CX_TRY(S->v_z.alloc(n));
+    CX_TRY(S->v_tmp.alloc(n));
+    CX_TRY(S->partial.alloc(2 * kRedBlocks));
+    CX_TRY(S->state.alloc(1));
+    double *p = S->v_p.p, *r = S->v_r.p, *z = S->v_z.p, *tmp = S->v_tmp.p;
+    CgState* ds = S->state.p;
+    const int g = grid_for(n, 256);
+
+    summary->termination_type = CX_NO_CONVERGENCE;
+    std::snprintf(summary->message, sizeof(summary->message), "Maximum number of iterations reached.");
+    summary->num_iterations = 0;
+
+    CgState h{};
+    CX_HIP(hipMemcpyAsync(ds, &h, sizeof(h), hipMemcpyHostToDevice, st));
+    CX_TRY(dot2(rhs, rhs, nullptr, nullptr, FIN_STORE, ds));
+    CX_TRY(read_state(&h));
+    const double norm_rhs = std::sqrt(h.s0);
+    if (norm_rhs == 0.0) {
+      CX_HIP(hipMemsetAsync(x, 0, n * sizeof(double), st));
+      summary->termination_type = CX_SUCCESS;
+      std::snprintf(summary->message, sizeof(summary->message), "Convergence. |b| = 0.");
+      return CX_OK;
+    }
+    const double tol_r = r_tol * norm_rhs;
+    if (zero_initial) {
+      CX_HIP(hipMemsetAsync(tmp, 0, n * sizeof(double), st));
+    } else {
+      CX_TRY(lhs.apply(x, tmp));
+    }
+    hipLaunchKernelGGL(k_residual, dim3(g), dim3(256), 0, st, rhs, tmp, r, tmp, n, (const CgState*)nullptr);
+    // tmp = rhs + r now;  s0 = x.tmp, s1 = r.r
+    CX_TRY(dot2(x, tmp, r, r, FIN_STORE, ds));
+    CX_TRY(read_state(&h));
+    double norm_r = std::sqrt(h.s1);
+    if (o.min_num_iterations == 0 && norm_r <= tol_r) {
+      summary->termination_type = CX_SUCCESS;
+      std::snprintf(summary->message, sizeof(summary->message), "Convergence. |r| = %e <= %e.", norm_r, tol_r);
+      return CX_OK;
+    }
+    // Q0 = -x.(rhs + r)   (conjugate_gradients_solver.h:155-158)
+    const double Q0 = -h.s0;
+    h = CgState{};
+    h.rho = 1.0;
+    h.Q0 = Q0;
+    h.tol_r = tol_r;
+    h.q_tol = q_tol;
+    h.min_iter = o.min_num_iterations;
+    h.max_iter = o.max_num_iterations;
+    h.flag = CG_RUNNING;
+    for (int iter = 1;; ++iter) {
+      summary->num_iterations = iter;
+      if (iter == 1) {
+        h.iter = 1;
+        CX_HIP(hipMemcpyAsync(ds, &h, sizeof(h), hipMemcpyHostToDevice, st));
+      } else {
+        CX_HIP(hipMemcpyAsync(&ds->iter, &iter, sizeof(int), hipMemcpyHostToDevice, st));
+      }
+      // z = M^-1 r ; rho = r.z
+      CX_TRY(pre.apply(r, z));
+      CX_TRY(dot2(r, z, nullptr, nullptr, FIN_RHO, ds));
+      hipLaunchKernelGGL(k_update_p, dim3(g), dim3(256), 0, st, p, z, n, (const CgState*)ds);
+      // q = A p (q aliases z)
+      double* q = z;
+      CX_TRY(lhs.apply(p, q));
+      CX_TRY(dot2(p, q, nullptr, nullptr, FIN_PQ, ds));
+      const bool reset = (iter % o.residual_reset_period) == 0;
+      hipLaunchKernelGGL(k_update_xr, dim3(g), dim3(256), 0, st, x, r, (const double*)p, (const double*)q, rhs, tmp, n,
+                         reset ? 0 : 1, (const CgState*)ds);
+      if (reset) {
+        CX_TRY(lhs.apply(x, tmp));
+        hipLaunchKernelGGL(k_residual, dim3(g), dim3(256), 0, st, rhs, (const double*)tmp, r, tmp, n, (const CgState*)ds);
+      }
+      CX_TRY(dot2(x, tmp, r, r, FIN_Q, ds));
+      CX_TRY(read_state(&h));
+      if (h.flag != CG_RUNNING) break;
+    }
+    switch (h.flag) {
+      case CG_CONVERGED_Q:
+        summary->termination_type = CX_SUCCESS;
+        std::snprintf(summary->message, sizeof(summary->message), "Iteration: %d Convergence: zeta = %e < %e. |r| = %e",
+                      summary->num_iterations, h.zeta, q_tol, h.norm_r);
+        break;
+      case CG_CONVERGED_R:
+        summary->termination_type = CX_SUCCESS;
+        std::snprintf(summary->message, sizeof(summary->message), "Iteration: %d Convergence. |r| = %e <= %e.",
+                      summary->num_iterations, h.norm_r, tol_r);
+        break;
+      case CG_FAIL_RHO:
+        summary->termination_type = CX_FAILURE;
+        std::snprintf(summary->message, sizeof(summary->message), "Numerical failure. rho = r'z = %e.", h.rho);
+        break;
+      case CG_FAIL_BETA:
+        summary->termination_type = CX_FAILURE;
+        std::snprintf(summary->message, sizeof(summary->message),
+                      "Numerical failure. beta = rho_n / rho_{n-1} = %e, rho_n = %e, rho_{n-1} = %e", h.beta, h.rho, h.last_rho);
+        break;
+      case CG_INDEFINITE:
+        summary->termination_type = CX_NO_CONVERGENCE;
+        std::snprintf(summary->message, sizeof(summary->message),
+                      "Matrix is indefinite, no more progress can be made. p'q = %e.", h.pq);
+        break;
+      case CG_FAIL_ALPHA:
+        summary->termination_type = CX_FAILURE;
+        std::snprintf(summary->message, sizeof(summary->message),
+                      "Numerical failure. alpha = rho / pq = %e, rho = %e, pq = %e.", h.alpha, h.rho, h.pq);
+        break;
+      default: break;  // CG_MAX_ITER keeps NO_CONVERGENCE
+    }
+    summary->residual_norm = h.norm_r;
+    return CX_OK;
+  }
+};
+
+// ------------------------------------------------ static <2,3,9> operator pieces
+// S x through the chunk pass and the camera-major pass (ImplicitSchurComplement::
+// RightMultiplyAndAccumulate, implicit_schur_complement.cc:106-144)
+struct ImplicitSchurOp : LinOp {
+  cx_solver* S;
+  cx_matrix* A;
+  const double* D;
+  int64_t size() const override { return 9 * int64_t(A->C); }
+  int apply(const double* x, double* y) override {
+    cx_context* ctx = A->ctx;
+    CX_TRY(cxs_chunk_pass(A, 0, S->ete_inv.p, x, nullptr, S->v_rows.p));
+    CX_TRY(cxk_ft_multiply(A, S->v_rows.p, y, false));
+    if (ctx->nranks > 1) CX_TRY(cx_allreduce_device(ctx, y, size()));
+    if (D)
+      hipLaunchKernelGGL(k_add_d2x, dim3(grid_for(size(), 256)), dim3(256), 0, ctx->stream, y,
+                         D + 3 * int64_t(A->P), x, size());
+    CX_HIP(hipGetLastError());
+    return CX_OK;
+  }
+};
+
+struct BlockDiag9Op : LinOp {
+  cx_context* ctx;
+  const double* blocks;
+  int64_t nblocks;
+  int64_t size() const override { return 9 * nblocks; }
+  int apply(const double* x, double* y) override {
+    if (nblocks)
+      hipLaunchKernelGGL(k_blockdiag_multiply<9>, dim3(grid_for(9 * nblocks, 256)), dim3(256), 0, ctx->stream, blocks, x, y, nblocks);
+    CX_HIP(hipGetLastError());
+    return CX_OK;
+  }
+};
+
+struct IdentityOp : LinOp {
+  cx_context* ctx;
+  int64_t n;
+  int64_t size() const override { return n; }
+  int apply(const double* x, double* y) override {
+    CX_HIP(hipMemcpyAsync(y, x, n * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+    return CX_OK;
+  }
+};
+
+// (J'J + D'D) x   (CgnrLinearOperator, cgnr_solver.cc:98-114)
+struct CgnrOp : LinOp {
+  cx_solver* S;
+  cx_matrix* A;
+  const double* D;
+  int64_t size() const override { return A->num_cols; }
+  int apply(const double* x, double* y) override {
+    cx_context* ctx = A->ctx;
+    hipStream_t st = ctx->stream;
+    CX_HIP(hipMemsetAsync(S->v_rows.p, 0, size_t(A->num_rows) * sizeof(double), st));
+    CX_TRY(cxk_right_multiply(A, x, S->v_rows.p));
+    CX_HIP(hipMemsetAsync(y, 0, size_t(A->num_cols) * sizeof(double), st));
+    CX_TRY(cxk_left_multiply(A, S->v_rows.p, y));
+    if (ctx->nranks > 1 && A->is239) CX_TRY(cx_allreduce_device(ctx, y + 3 * int64_t(A->P), 9 * int64_t(A->C)));
+    if (D) hipLaunchKernelGGL(k_add_d2x, dim3(grid_for(size(), 256)), dim3(256), 0, st, y, D, x, size());
+    CX_HIP(hipGetLastError());
+    return CX_OK;
+  }
+};
+
+// block diagonal (J'J + D'D)^-1: 3x3 point blocks then 9x9 camera blocks
+struct CgnrJacobiOp : LinOp {
+  cx_solver* S;
+  cx_matrix* A;
+  int64_t size() const override { return A->num_cols; }
+  int apply(const double* x, double* y) override {
+    hipStream_t st = A->ctx->stream;
+    if (A->P) hipLaunchKernelGGL(k_blockdiag_multiply<3>, dim3(grid_for(3 * int64_t(A->P), 256)), dim3(256), 0, st, S->pt_blocks.p, x, y, int64_t(A->P));
+    if (A->C) hipLaunchKernelGGL(k_blockdiag_multiply<9>, dim3(grid_for(9 * int64_t(A->C), 256)), dim3(256), 0, st, S->cam_blocks.p, x + 3 * int64_t(A->P), y + 3 * int64_t(A->P), int64_t(A->C));
+    CX_HIP(hipGetLastError());
+    return CX_OK;
+  }
+};
+
+struct Stopwatch {
+  hipStream_t st;
+  hipEvent_t a, b;
+  int start() { return hipEventRecord(a, st) == hipSuccess ? CX_OK : CX_ERR_HIP; }
+  int stop(double* ms) {
+    if (hipEventRecord(b, st) != hipSuccess || hipEventSynchronize(b) != hipSuccess) return CX_ERR_HIP;
+    float f = 0.f;
+    if (hipEventElapsedTime(&f, a, b) != hipSuccess) return CX_ERR_HIP;
+    *ms = f;
+    return CX_OK;
+  }
+};
+
+int CheckFlag(cx_solver* S, const char* what, cx_summary* summary, bool* failed) {
+  int h = 0;
+  CX_HIP(hipMemcpyAsync(&h, S->flag.p, sizeof(int), hipMemcpyDeviceToHost, S->ctx->stream));
+  CX_HIP(hipStreamSynchronize(S->ctx->stream));
+  *failed = (h != 0);
+  if (h != 0) {
+    summary->termination_type = CX_FAILURE;
+    summary->num_iterations = 0;
+    std::snprintf(summary->message, sizeof(summary->message), "%s", what);
+  }
+  return CX_OK;
+}
+
+// ------------------------------------------------------------------- solvers
+int SolveIterativeSchur239(cx_solver* S, cx_matrix* A, const double* b, const double* D, double r_tol,
+                           double q_tol, double* x, cx_summary* summary) {
+  cx_context* ctx = S->ctx;
+  hipStream_t st = ctx->stream;
+  const cx_solver_options& o = S->opt;
+  const int64_t nf = 9 * int64_t(A->C), ne = 3 * int64_t(A->P);
+  Stopwatch sw{st, ctx->ev[2], ctx->ev[3]};
+  CX_TRY(S->ete_inv.alloc(9 * size_t(A->P)));
+  CX_TRY(S->v_rows.alloc(size_t(A->num_rows)));
+  CX_TRY(S->v_rhs.alloc(nf));
+  CX_TRY(S->v_x.alloc(nf));
+  CX_TRY(S->flag.alloc(1));
+  CX_HIP(hipMemsetAsync(S->flag.p, 0, sizeof(int), st));
+  CX_TRY(sw.start());
+  // ImplicitSchurComplement::Init (implicit_schur_complement.cc:49-97)
+  CX_TRY(cx_matrix_ensure_ft(A));
+  CX_TRY(cxs_compute_ete_inverse(A, D, nullptr, S->ete_inv.p, nullptr, true, S->flag.p));
+  const bool need_ftf = o.preconditioner_type == CX_JACOBI;
+  if (need_ftf || o.preconditioner_type == CX_SCHUR_JACOBI) {
+    CX_TRY(S->cam_blocks.alloc(81 * size_t(A->C)));
+    CX_TRY(cxs_camera_block_diagonal(A, o.preconditioner_type == CX_SCHUR_JACOBI, S->ete_inv.p, S->cam_blocks.p));
+    if (ctx->nranks > 1) CX_TRY(cx_allreduce_device(ctx, S->cam_blocks.p, 81 * int64_t(A->C)));
+    CX_TRY(cxs_block9_add_diag_invert(ctx, S->cam_blocks.p, D ? D + ne : nullptr, A->C, S->flag.p));
+  } else if (o.preconditioner_type != CX_IDENTITY) {
+    cx_set_error("preconditioner %d is not available for ITERATIVE_SCHUR on the device", o.preconditioner_type);
+    return CX_ERR_UNSUPPORTED;
+  }
+  // UpdateRhs (:251-276): rhs = F'(b - E (E'E)^-1 E'b)
+  CX_TRY(cxs_chunk_pass(A, 1, S->ete_inv.p, nullptr, b, S->v_rows.p));
+  CX_TRY(cxk_ft_multiply(A, S->v_rows.p, S->v_rhs.p, false));
+  if (ctx->nranks > 1) CX_TRY(cx_allreduce_device(ctx, S->v_rhs.p, nf));
+  CX_TRY(sw.stop(&S->timing.eliminate_ms));
+  bool failed = false;
+  CX_TRY(CheckFlag(S, "Preconditioner update failed.", summary, &failed));
+  if (failed) return CX_OK;
+
+  CX_TRY(sw.start());
+  CX_HIP(hipMemsetAsync(S->v_x.p, 0, nf * sizeof(double), st));
+  ImplicitSchurOp lhs;
+  lhs.S = S; lhs.A = A; lhs.D = D;
+  BlockDiag9Op bd;
+  bd.ctx = ctx; bd.blocks = S->cam_blocks.p; bd.nblocks = A->C;
+  IdentityOp id;
+  id.ctx = ctx; id.n = nf;
+  LinOp& pre = (o.preconditioner_type == CX_IDENTITY) ? static_cast<LinOp&>(id) : static_cast<LinOp&>(bd);
+  CgDriver cg{S, ctx, st, nf, nf};
+  CX_TRY(cg.run(lhs, pre, S->v_rhs.p, S->v_x.p, true, r_tol, q_tol, summary));
+  CX_TRY(sw.stop(&S->timing.reduced_solve_ms));
+
+  CX_TRY(sw.start());
+  if (summary->termination_type != CX_FAILURE && summary->termination_type != CX_FATAL_ERROR) {
+    // BackSubstitute (:208-243)
+    CX_TRY(cxs_chunk_pass(A, 2, S->ete_inv.p, S->v_x.p, b, x));
+    CX_HIP(hipMemcpyAsync(x + ne, S->v_x.p, nf * sizeof(double), hipMemcpyDeviceToDevice, st));
+  }
+  CX_TRY(sw.stop(&S->timing.back_substitute_ms));
+  return CX_OK;
+}
+
+int SolveCgnr239(cx_solver* S, cx_matrix* A, const double* b, const double* D, double r_tol, double q_tol,
+                 double* x, cx_summary* summary) {
+  cx_context* ctx = S->ctx;
+  hipStream_t st = ctx->stream;
+  const cx_solver_options& o = S->opt;
+  const int64_t n = A->num_cols, ne = 3 * int64_t(A->P);
+  Stopwatch sw{st, ctx->ev[2], ctx->ev[3]};
+  CX_TRY(S->v_rows.alloc(size_t(A->num_rows)));
+  CX_TRY(S->v_rhs.alloc(n));
+  CX_TRY(S->flag.alloc(1));
+  CX_HIP(hipMemsetAsync(S->flag.p, 0, sizeof(int), st));
+  CX_TRY(sw.start());
+  CX_TRY(cx_matrix_ensure_ft(A));
+  if (o.preconditioner_type == CX_JACOBI) {
+    // BlockSparseJacobiPreconditioner::UpdateImpl (block_jacobi_preconditioner.cc:59-115)
+    CX_TRY(S->pt_blocks.alloc(9 * size_t(A->P)));
+    CX_TRY(S->cam_blocks.alloc(81 * size_t(A->C)));
+    if (A->P) hipLaunchKernelGGL(k_point_jacobi, dim3(grid_for(A->P, kBlock)), dim3(kBlock), 0, st, A->d_values.p, A->d_pt_start.p, D, S->pt_blocks.p, A->P, S->flag.p);
+    CX_TRY(cxs_camera_block_diagonal(A, false, nullptr, S->cam_blocks.p));
+    if (ctx->nranks > 1) CX_TRY(cx_allreduce_device(ctx, S->cam_blocks.p, 81 * int64_t(A->C)));
+    CX_TRY(cxs_block9_add_diag_invert(ctx, S->cam_blocks.p, D ? D + ne : nullptr, A->C, S->flag.p));
+  } else if (o.preconditioner_type != CX_IDENTITY) {
+    cx_set_error("CGNR supports JACOBI and IDENTITY preconditioners (cgnr_solver.cc:125-133)");
+    return CX_ERR_UNSUPPORTED;
+  }
+  // rhs = J'b
+  CX_HIP(hipMemsetAsync(S->v_rhs.p, 0, n * sizeof(double), st));
+  CX_TRY(cxk_left_multiply(A, b, S->v_rhs.p));
+  if (ctx->nranks > 1) CX_TRY(cx_allreduce_device(ctx, S->v_rhs.p + ne, n - ne));
+  CX_TRY(sw.stop(&S->timing.eliminate_ms));
+  CX_TRY(sw.start());
+  CX_HIP(hipMemsetAsync(x, 0, n * sizeof(double), st));
+  CgnrOp lhs;
+  lhs.S = S; lhs.A = A; lhs.D = D;
+  CgnrJacobiOp jac;
+  jac.S = S; jac.A = A;
+  IdentityOp id;
+  id.ctx = ctx; id.n = n;
+  LinOp& pre = (o.preconditioner_type == CX_IDENTITY) ? static_cast<LinOp&>(id) : static_cast<LinOp&>(jac);
+  CgDriver cg{S, ctx, st, n, ctx->nranks > 1 ? ne : n};
+  CX_TRY(cg.run(lhs, pre, S->v_rhs.p, x, true, r_tol, q_tol, summary));
+  CX_TRY(sw.stop(&S->timing.reduced_solve_ms));
+  return CX_OK;
+}
+
+int SolveDenseSchur239(cx_solver* S, cx_matrix* A, const double* b, const double* D, double* x, cx_summary* summary) {
+  cx_context* ctx = S->ctx;
+  hipStream_t st = ctx->stream;
+  const int64_t nf = 9 * int64_t(A->C), ne = 3 * int64_t(A->P);
+  Stopwatch sw{st, ctx->ev[2], ctx->ev[3]};
+  CX_TRY(S->lhs.alloc(size_t(nf) * nf));
+  CX_TRY(S->v_rhs.alloc(nf));
+  CX_TRY(S->ete_inv.alloc(9 * size_t(A->P)));
+  CX_TRY(S->flag.alloc(1));
+  CX_HIP(hipMemsetAsync(S->flag.p, 0, sizeof(int), st));
+  CX_TRY(sw.start());
+  // Eliminate (schur_eliminator_impl.h:177-304).  Sharded: D_f^2 is added once after the sum.
+  const bool sharded = ctx->nranks > 1;
+  CX_TRY(cxs_eliminate_dense(A, b, D, !sharded || ctx->rank == 0, S->lhs.p, S->v_rhs.p));
+  if (sharded) {
+    CX_TRY(cx_allreduce_device(ctx, S->lhs.p, nf * nf));
+    CX_TRY(cx_allreduce_device(ctx, S->v_rhs.p, nf));
+  }
+  CX_TRY(sw.stop(&S->timing.eliminate_ms));
+  CX_TRY(sw.start());
+  // DenseSchurComplementSolver::SolveReducedLinearSystem (schur_complement_solver.cc:182-203)
+  double* z = x + ne;
+  summary->num_iterations = 0;
+  summary->termination_type = CX_SUCCESS;
+  std::snprintf(summary->message, sizeof(summary->message), "Success.");
+  if (nf > 0) {
+    CX_TRY(cxd_cholesky_solve(ctx, int(nf), S->lhs.p, S->v_rhs.p, z, S->flag.p));
+    summary->num_iterations = 1;
+    bool failed = false;
+    CX_TRY(CheckFlag(S, "Dense Cholesky factorization failed: the reduced camera matrix is not positive definite.", summary, &failed));
+    if (failed) summary->num_iterations = 1;
+  }
+  CX_TRY(sw.stop(&S->timing.reduced_solve_ms));
+  CX_TRY(sw.start());
+  if (summary->termination_type == CX_SUCCESS) {
+    // SchurEliminator::BackSubstitute (schur_eliminator_impl.h:307-373): cofactor inverse of E'E + D^2
+    CX_TRY(cxs_compute_ete_inverse(A, D, nullptr, S->ete_inv.p, nullptr, false, S->flag.p));
+    CX_TRY(cxs_chunk_pass(A, 2, S->ete_inv.p, z, b, x));
+  }
+  CX_TRY(sw.stop(&S->timing.back_substitute_ms));
+  return CX_OK;
+}
+
+}  // namespace
+
+// generic (dynamic block size) solvers live in cx_generic.hip
+int cxg_solve(cx_solver* S, cx_matrix* A, const double* b, const double* D, double r_tol, double q_tol, double* x,
+              cx_summary* summary);
+
+extern "C" {
+
+void cx_solver_default_options(cx_solver_options* o) {
+  if (!o) return;
+  std::memset(o, 0, sizeof(*o));
+  o->type = CX_ITERATIVE_SCHUR;
+  o->preconditioner_type = CX_JACOBI;
+  o->min_num_iterations = 0;
+  o->max_num_iterations = 500;
+  o->residual_reset_period = 10;
+  o->max_num_refinement_iterations = 0;
+  o->max_num_spse_iterations = 5;
+  o->spse_tolerance = 0.1;
+  o->deterministic = 1;
+}
+
+int cx_solver_create(cx_context* ctx, const cx_solver_options* options, cx_solver** out) {
+  CX_CHECK_ARG(ctx && options && out);
+  CX_CHECK_ARG(options->type >= CX_DENSE_SCHUR && options->type <= CX_CGNR);
+  CX_CHECK_ARG(options->residual_reset_period > 0 && options->max_num_iterations >= 0);
+  if (options->type != CX_CGNR) CX_CHECK_ARG(options->num_eliminate_blocks > 0);
+  auto* s = new cx_solver;
+  s->ctx = ctx;
+  s->opt = *options;
+  *out = s;
+  return CX_OK;
+}
+
+void cx_solver_destroy(cx_solver* s) {
+  if (!s) return;
+  (void)hipSetDevice(s->ctx->device);
+  (void)hipStreamSynchronize(s->ctx->stream);
+  delete s;
+}
+
+int cx_solver_last_timing(const cx_solver* s, cx_solve_timing* out) {
+  CX_CHECK_ARG(s && out);
+  *out = s->timing;
+  return CX_OK;
+}
+
+int cx_solver_solve(cx_solver* S, cx_matrix* A, const double* b, const cx_per_solve_options* ps, double* x,
+                    cx_summary* summary) {
+  CX_CHECK_ARG(S && A && b && ps && x && summary);
+  CX_CHECK_ARG(S->ctx == A->ctx);
+  cx_context* ctx = S->ctx;
+  CX_HIP(hipSetDevice(ctx->device));
+  const cx_solver_options& o = S->opt;
+  if (o.type != CX_CGNR) CX_CHECK_ARG(o.num_eliminate_blocks == A->nelim);
+  std::memset(summary, 0, sizeof(*summary));
+  S->timing = cx_solve_timing{};
+  ctx->allreduce_host_ms = 0.0;
+  HostOrDevice hb(ctx), hD(ctx), hx(ctx);
+  CX_TRY(hb.in(b, size_t(A->num_rows), ps->memspace));
+  CX_TRY(hD.in(ps->D, size_t(A->num_cols), ps->memspace));
+  CX_TRY(hx.inout(x, size_t(A->num_cols), ps->memspace, false));
+  CX_HIP(hipEventRecord(ctx->ev[4], ctx->stream));
+  int rc;
+  if (A->is239) {
+    switch (o.type) {
+      case CX_ITERATIVE_SCHUR: rc = SolveIterativeSchur239(S, A, hb.dptr, hD.dptr, ps->r_tolerance, ps->q_tolerance, hx.dptr, summary); break;
+      case CX_CGNR: rc = SolveCgnr239(S, A, hb.dptr, hD.dptr, ps->r_tolerance, ps->q_tolerance, hx.dptr, summary); break;
+      default: rc = SolveDenseSchur239(S, A, hb.dptr, hD.dptr, hx.dptr, summary); break;
+    }
+  } else {
+    rc = cxg_solve(S, A, hb.dptr, hD.dptr, ps->r_tolerance, ps->q_tolerance, hx.dptr, summary);
+  }
+  if (rc != CX_OK) {
+    summary->termination_type = CX_FATAL_ERROR;
+    std::snprintf(summary->message, sizeof(summary->message), "%s", cx_last_error());
+    return rc;
+  }
+  CX_HIP(hipEventRecord(ctx->ev[5], ctx->stream));
+  CX_HIP(hipEventSynchronize(ctx->ev[5]));
+  float ms = 0.f;
+  CX_HIP(hipEventElapsedTime(&ms, ctx->ev[4], ctx->ev[5]));
+  S->timing.total_ms = ms;
+  S->timing.allreduce_ms = ctx->allreduce_host_ms;
+  return hx.out();
+}
+
+// ---- Schur pieces on their own (parity tests)
+int cx_schur_eliminate_dense(cx_context* ctx, cx_matrix* A, const double* b, const double* D, double* lhs,
+                             double* rhs, int32_t memspace) {
+  CX_CHECK_ARG(ctx && A && lhs);
+  if (!A->is239) { cx_set_error("cx_schur_eliminate_dense: matrix is not on the static <2,3,9> path; use cx_solver_solve"); return CX_ERR_UNSUPPORTED; }
+  const int64_t nf = 9 * int64_t(A->C);
+  HostOrDevice hb(ctx), hD(ctx), hl(ctx), hr(ctx);
+  CX_TRY(hb.in(b, size_t(A->num_rows), memspace));
+  CX_TRY(hD.in(D, size_t(A->num_cols), memspace));
+  CX_TRY(hl.inout(lhs, size_t(nf) * nf, memspace, false));
+  CX_TRY(hr.inout(rhs, size_t(nf), memspace, false));
+  CX_TRY(cxs_eliminate_dense(A, hb.dptr, hD.dptr, true, hl.dptr, hb.dptr ? hr.dptr : nullptr));
+  CX_TRY(hl.out());
+  return hr.out();
+}
+
+int cx_schur_back_substitute(cx_context* ctx, cx_matrix* A, const double* b, const double* D, const double* z,
+                             double* x, int32_t memspace) {
+  CX_CHECK_ARG(ctx && A && b && z && x);
+  if (!A->is239) { cx_set_error("cx_schur_back_substitute: matrix is not on the static <2,3,9> path"); return CX_ERR_UNSUPPORTED; }
+  HostOrDevice hb(ctx), hD(ctx), hz(ctx), hx(ctx);
+  DevBuf<double> ete;
+  DevBuf<int> flag;
+  CX_TRY(ete.alloc(9 * size_t(A->P)));
+  CX_TRY(flag.alloc(1));
+  CX_TRY(hb.in(b, size_t(A->num_rows), memspace));
+  CX_TRY(hD.in(D, size_t(A->num_cols), memspace));
+  CX_TRY(hz.in(z, 9 * size_t(A->C), memspace));
+  CX_TRY(hx.inout(x, size_t(A->num_cols), memspace, true));
+  CX_TRY(cxs_compute_ete_inverse(A, hD.dptr, nullptr, ete.p, nullptr, false, flag.p));
+  CX_TRY(cxs_chunk_pass(A, 2, ete.p, hz.dptr, hb.dptr, hx.dptr));
+  return hx.out();
+}
+
+int cx_implicit_schur_multiply(cx_context* ctx, cx_matrix* A, const double* D, const double* b, const double* x,
+                               double* y, double* rhs, int32_t memspace) {
+  CX_CHECK_ARG(ctx && A);
+  if (!A->is239) { cx_set_error("cx_implicit_schur_multiply: matrix is not on the static <2,3,9> path"); return CX_ERR_UNSUPPORTED; }
+  const int64_t nf = 9 * int64_t(A->C);
+  HostOrDevice hb(ctx), hD(ctx), hx(ctx), hy(ctx), hr(ctx);
+  DevBuf<double> ete, rows;
+  DevBuf<int> flag;
+  CX_TRY(ete.alloc(9 * size_t(A->P)));
+  CX_TRY(rows.alloc(size_t(A->num_rows)));
+  CX_TRY(flag.alloc(1));
+  CX_TRY(hb.in(b, size_t(A->num_rows), memspace));
+  CX_TRY(hD.in(D, size_t(A->num_cols), memspace));
+  CX_TRY(hx.in(x, size_t(nf), memspace));
+  CX_TRY(hy.inout(y, size_t(nf), memspace, false));
+  CX_TRY(hr.inout(rhs, size_t(nf), memspace, false));
+  CX_TRY(cxs_compute_ete_inverse(A, hD.dptr, nullptr, ete.p, nullptr, true, flag.p));
+  if (hx.dptr && hy.dptr) {
+    CX_TRY(cxs_chunk_pass(A, 0, ete.p, hx.dptr, nullptr, rows.p));
+    CX_TRY(cxk_ft_multiply(A, rows.p, hy.dptr, false));
+    if (hD.dptr)
+      hipLaunchKernelGGL(k_add_d2x, dim3(grid_for(nf, 256)), dim3(256), 0, ctx->stream, hy.dptr,
+                         hD.dptr + 3 * int64_t(A->P), (const double*)hx.dptr, nf);
+    CX_TRY(hy.out());
+  }
+  if (hr.dptr && hb.dptr) {
+    CX_TRY(cxs_chunk_pass(A, 1, ete.p, nullptr, hb.dptr, rows.p));
+    CX_TRY(cxk_ft_multiply(A, rows.p, hr.dptr, false));
+    CX_TRY(hr.out());
+  }
+  CX_HIP(hipStreamSynchronize(ctx->stream));
+  return CX_OK;
+}
+
+int cx_dense_cholesky_solve(cx_context* ctx, int32_t n, double* lhs, const double* rhs, double* x, int32_t memspace,
+                            cx_summary* summary) {
+  CX_CHECK_ARG(ctx && n >= 0 && (n == 0 || (lhs && rhs && x)));
+  HostOrDevice hl(ctx), hr(ctx), hx(ctx);
+  DevBuf<int> flag;
+  CX_TRY(flag.alloc(1));
+  CX_HIP(hipMemsetAsync(flag.p, 0, sizeof(int), ctx->stream));
+  CX_TRY(hl.inout(lhs, size_t(n) * n, memspace, true));
+  CX_TRY(hr.in(rhs, size_t(n), memspace));
+  CX_TRY(hx.inout(x, size_t(n), memspace, false));
+  if (n > 0) CX_TRY(cxd_cholesky_solve(ctx, n, hl.dptr, hr.dptr, hx.dptr, flag.p));
+  int h = 0;
+  CX_HIP(hipMemcpyAsync(&h, flag.p, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+  CX_HIP(hipStreamSynchronize(ctx->stream));
+  if (summary) {
+    std::memset(summary, 0, sizeof(*summary));
+    summary->num_iterations = 1;
+    summary->termination_type = h ? CX_FAILURE : CX_SUCCESS;
+    std::snprintf(summary->message, sizeof(summary->message), "%s", h ? "Matrix is not positive definite." : "Success.");
+  }
+  return hx.out();
+}
+
+}  // extern "C"

@@ -1,0 +1,262 @@
+"""Parity of the HIP path (libcxschur.so through its C ABI) against the oracle on
+seeded BAL-shaped problems.  fp64 tolerances are stated per test; integer
+structure (ordering, layout) is compared exactly."""
+import numpy as np
+import pytest
+
+from conftest import cx
+
+pytestmark = pytest.mark.gpu
+
+REL = 1e-12   # relative tolerance for single J passes (different summation order only)
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    c = cx.Context(0)
+    yield c
+    c.close()
+
+
+def make(C, P, O, seed, values="eval", oracle=None):
+    prob = cx.bal.make_bal_like(C, P, O, seed)
+    bs, order = cx.bal.build_structure(prob)
+    rng = np.random.default_rng(seed + 1000)
+    if values == "random":
+        vals = cx.bal.random_jacobian_values(O, seed)
+        b = rng.standard_normal(2 * O)
+    else:
+        _, b, _, vals = oracle.bal_evaluate(bs, C, P, prob.camera_index, prob.point_index, prob.observations,
+                                            order, prob.state(), want_gradient=False)
+    D = rng.uniform(0.5, 2.0, bs.num_cols) * (1.0 if values == "random" else 1e-2 * np.sqrt(np.abs(vals).mean()))
+    return prob, bs, order, vals, b, D
+
+
+def relerr(a, b):
+    return np.abs(a - b).max() / max(np.abs(b).max(), 1e-300)
+
+
+PROBLEMS = [(6, 40, 130, 1), (16, 700, 2800, 2), (49, 7776, 31843, 49)]
+
+
+@pytest.mark.parametrize("C,P,O,seed", PROBLEMS)
+def test_products(ctx, oracle, C, P, O, seed):
+    prob, bs, order, vals, b, D = make(C, P, O, seed, "random")
+    A = cx.Matrix(ctx, bs, P)
+    assert A.is_static_239 and A.num_rows == 2 * O and A.num_cols == 3 * P + 9 * C and A.num_nonzeros == 24 * O
+    A.set_values(vals)
+    assert np.array_equal(A.get_values(), vals)
+    rng = np.random.default_rng(seed)
+    x, y0 = rng.standard_normal(A.num_cols), rng.standard_normal(A.num_rows)
+    assert relerr(A.right_multiply(x, y0), oracle.right_multiply(bs, vals, x, y0)) < REL
+    z, c0 = rng.standard_normal(A.num_rows), rng.standard_normal(A.num_cols)
+    assert relerr(A.left_multiply(z, c0), oracle.left_multiply(bs, vals, z, c0)) < REL
+    assert relerr(A.squared_column_norm(), oracle.squared_column_norm(bs, vals)) < REL
+    s = rng.uniform(0.5, 2.0, A.num_cols)
+    A.scale_columns(s)
+    np.testing.assert_array_equal(A.get_values(), oracle.scale_columns(bs, vals, s))   # one rounding each: bit exact
+    # the camera-major copy must follow the new values
+    assert relerr(A.left_multiply(z), oracle.left_multiply(bs, oracle.scale_columns(bs, vals, s), z)) < REL
+    A.close()
+
+
+def test_products_bit_exact_on_integers(ctx, oracle):
+    """cuda_block_sparse_crs_view_test.cc:60-125 style: integer-valued matrix and unit
+    vectors make every product exact, so device == CPU bit for bit."""
+    prob, bs, order, vals, b, D = make(8, 60, 240, 7, "random")
+    vals = np.arange(1, vals.size + 1, dtype=np.float64)
+    A = cx.Matrix(ctx, bs, prob.num_points)
+    A.set_values(vals)
+    for j in (0, 5, 3 * 60, A.num_cols - 1):
+        e = np.zeros(A.num_cols)
+        e[j] = 1.0
+        np.testing.assert_array_equal(A.right_multiply(e), oracle.right_multiply(bs, vals, e))
+    for i in (0, 7, A.num_rows - 1):
+        e = np.zeros(A.num_rows)
+        e[i] = 1.0
+        np.testing.assert_array_equal(A.left_multiply(e), oracle.left_multiply(bs, vals, e))
+    A.close()
+
+
+@pytest.mark.parametrize("C,P,O,seed", PROBLEMS[:2])
+def test_implicit_schur_and_eliminator(ctx, oracle, C, P, O, seed):
+    prob, bs, order, vals, b, D = make(C, P, O, seed, "random")
+    A = cx.Matrix(ctx, bs, P)
+    A.set_values(vals)
+    nf = 9 * C
+    x = np.random.default_rng(3).standard_normal(nf)
+    y_ref, rhs_ref = oracle.implicit_schur_multiply(bs, vals, D, b, P, x)
+    y, rhs = cx.implicit_schur_multiply(ctx, A, D, b, x, nf)
+    assert relerr(y, y_ref) < 1e-11 and relerr(rhs, rhs_ref) < 1e-11
+    # explicit S (schur_eliminator_test.cc:137-177 bound: 1e-14 relative, looser here for longer sums)
+    lhs_ref, r_ref = oracle.schur_eliminate_dense(bs, vals, b, D, P)
+    lhs, r = cx.eliminate_dense(ctx, A, b, D, nf)
+    assert relerr(np.triu(lhs), np.triu(lhs_ref)) < 1e-11 and relerr(r, r_ref) < 1e-11
+    # block structure of lhs: strictly-lower blocks stay zero, like the reference's upper block triangle
+    for i in range(C):
+        assert not lhs[9 * i:9 * i + 9, :9 * i].any()
+    z = np.random.default_rng(4).standard_normal(nf)
+    xb_ref = oracle.schur_back_substitute(bs, vals, b, D, P, z)
+    xb = cx.back_substitute(ctx, A, b, D, z)
+    assert relerr(xb[:3 * P], xb_ref[:3 * P]) < 1e-10
+    A.close()
+
+
+@pytest.mark.parametrize("n", [9, 64, 200, 441])
+def test_dense_cholesky(ctx, oracle, n):
+    rng = np.random.default_rng(n)
+    M = rng.standard_normal((n, n + 5))
+    S = M @ M.T + n * np.eye(n)
+    rhs = rng.standard_normal(n)
+    lhs = np.triu(S) + np.tril(rng.standard_normal((n, n)), -1)   # lower triangle must be ignored
+    x, s = cx.dense_cholesky_solve(ctx, lhs, rhs)
+    assert s.termination_type == cx.SUCCESS
+    ref = np.linalg.solve(S, rhs)
+    assert relerr(x, ref) < 1e-10                                  # dense_cholesky_test.cc: 10 eps * cond
+    xo, t = oracle.dense_cholesky_solve(lhs, rhs)
+    assert relerr(x, xo) < 1e-10
+    # not positive definite -> FAILURE
+    bad = S.copy()
+    bad[n // 2, n // 2] = -1.0
+    x, s = cx.dense_cholesky_solve(ctx, bad, rhs)
+    assert s.termination_type == cx.FAILURE
+
+
+SOLVERS = [("ITERATIVE_SCHUR", "JACOBI"), ("ITERATIVE_SCHUR", "SCHUR_JACOBI"), ("ITERATIVE_SCHUR", "IDENTITY"),
+           ("CGNR", "JACOBI"), ("CGNR", "IDENTITY"), ("DENSE_SCHUR", "IDENTITY")]
+
+
+@pytest.mark.parametrize("stype,pre", SOLVERS)
+@pytest.mark.parametrize("C,P,O,seed", PROBLEMS[:2])
+def test_solvers_match_oracle(ctx, oracle, stype, pre, C, P, O, seed):
+    """Same LM-style call the reference makes (levenberg_marquardt_strategy.cc:97-116):
+    q_tolerance = eta = 0.1, r_tolerance = -1.  The iteration count is an integer
+    outcome and must match; the solution matches to 1e-8 relative (CG amplifies
+    summation-order differences by the condition number)."""
+    prob, bs, order, vals, b, D = make(C, P, O, seed, "eval", oracle)
+    nelim = 0 if stype == "CGNR" else P
+    A = cx.Matrix(ctx, bs, nelim)
+    A.set_values(vals)
+    kw = dict(type=getattr(cx, stype), preconditioner_type=getattr(cx, pre), num_eliminate_blocks=nelim,
+              max_num_iterations=200)
+    S = cx.Solver(ctx, **kw)
+    x, s = S.solve(A, b, D, r_tolerance=-1.0, q_tolerance=0.1)
+    oo = oracle.make_options(type=getattr(oracle, stype), preconditioner_type=getattr(oracle, pre),
+                             num_eliminate_blocks=P, max_num_iterations=200)
+    xr, sr = oracle.solve(bs, vals, b, D, oo, r_tolerance=-1.0, q_tolerance=0.1)
+    assert s.termination_type == sr.termination_type, (s.message, sr.message)
+    assert s.num_iterations == sr.num_iterations, (s.message, sr.message)
+    assert np.all(np.isfinite(x))
+    assert relerr(x, xr) < 1e-8
+    S.close()
+    A.close()
+
+
+@pytest.mark.parametrize("stype,pre", [("ITERATIVE_SCHUR", "JACOBI"), ("CGNR", "JACOBI"), ("DENSE_SCHUR", "IDENTITY")])
+def test_solvers_converged_solution(ctx, oracle, stype, pre):
+    """Run to r_tolerance 1e-12 and compare with the dense normal-equation solution
+    (schur_complement_solver_test.cc / iterative_schur_complement_solver_test.cc bound 1e-10)."""
+    C, P, O = 5, 30, 100
+    prob, bs, order, vals, b, D = make(C, P, O, 21, "random")
+    J = bs.to_dense(vals)
+    ref = np.linalg.solve(J.T @ J + np.diag(D ** 2), J.T @ b)
+    nelim = 0 if stype == "CGNR" else P
+    A = cx.Matrix(ctx, bs, nelim)
+    A.set_values(vals)
+    S = cx.Solver(ctx, type=getattr(cx, stype), preconditioner_type=getattr(cx, pre), num_eliminate_blocks=nelim,
+                  max_num_iterations=A.num_cols * 2)
+    x, s = S.solve(A, b, D, r_tolerance=1e-13, q_tolerance=0.0)
+    assert s.termination_type == cx.SUCCESS, s.message
+    assert np.linalg.norm(x - ref) / A.num_cols < 1e-10
+    S.close()
+    A.close()
+
+
+def test_device_pointer_solve_matches_host_pointer_solve(ctx, oracle):
+    prob, bs, order, vals, b, D = make(16, 700, 2800, 2, "eval", oracle)
+    A = cx.Matrix(ctx, bs, prob.num_points)
+    A.set_values(vals)
+    S = cx.Solver(ctx, type=cx.ITERATIVE_SCHUR, preconditioner_type=cx.JACOBI, num_eliminate_blocks=prob.num_points)
+    xh, sh = S.solve(A, b, D, q_tolerance=0.1)
+    db, dD, dx = ctx.to_device(b), ctx.to_device(D), ctx.empty(A.num_cols)
+    _, sd = S.solve(A, db, dD, q_tolerance=0.1, x=dx)
+    np.testing.assert_array_equal(dx.to_host(), xh)          # deterministic kernels: bit identical
+    assert sd.num_iterations == sh.num_iterations
+    t = S.timing()
+    assert t["total_ms"] > 0 and t["reduced_solve_ms"] > 0
+    S.close()
+    A.close()
+
+
+@pytest.mark.parametrize("C,P,O,seed", PROBLEMS)
+def test_evaluator(ctx, oracle, C, P, O, seed):
+    prob = cx.bal.make_bal_like(C, P, O, seed)
+    bs, order = cx.bal.build_structure(prob)
+    ev = cx.Evaluator(ctx, prob)
+    # integer layout: bit exact
+    row_of_obs = ev.row_of_observation()
+    assert np.array_equal(order[row_of_obs], np.arange(O))
+    state = prob.state()
+    cost, res, grad = ev.evaluate(state)
+    cost_r, res_r, grad_r, vals_r = oracle.bal_evaluate(bs, C, P, prob.camera_index, prob.point_index,
+                                                        prob.observations, order, state)
+    Jm = ev.jacobian(bs)
+    vals = Jm.get_values()
+    # device libm (sin, cos, sqrt) differs from glibc in the last ulps: 1e-11 relative to the largest entry
+    assert relerr(res, res_r) < 1e-11 and relerr(vals, vals_r) < 1e-11
+    assert abs(cost - cost_r) <= 1e-11 * cost_r
+    assert relerr(grad, grad_r) < 1e-10
+    # residual-only evaluation takes the plain-double path
+    cost2, res2, _ = ev.evaluate(state, want_gradient=False, want_jacobian=False)
+    assert relerr(res2, res_r) < 1e-11 and abs(cost2 - cost_r) <= 1e-11 * cost_r
+    ev.close()
+
+
+def test_big_chunk_paths(ctx, oracle):
+    """A point seen by more cameras than a tile has rows exercises the long-chunk code paths."""
+    C, P = 300, 40
+    rng = np.random.default_rng(5)
+    cam, pt = [], []
+    for j in range(P):
+        k = 290 if j in (3, 17) else int(rng.integers(2, 6))
+        cams = np.sort(rng.choice(C, size=k, replace=False))
+        cam.extend(cams.tolist())
+        pt.extend([j] * k)
+    cam, pt = np.array(cam, dtype=np.int32), np.array(pt, dtype=np.int32)
+    O = cam.size
+    prob = cx.bal.BalProblem(C, P, cam, pt, np.zeros((O, 2)), np.zeros((C, 9)), np.zeros((P, 3)))
+    bs, order = cx.bal.build_structure(prob)
+    vals = cx.bal.random_jacobian_values(O, 1)
+    b = rng.standard_normal(2 * O)
+    D = rng.uniform(0.5, 2.0, bs.num_cols)
+    A = cx.Matrix(ctx, bs, P)
+    A.set_values(vals)
+    assert A.is_static_239
+    z = rng.standard_normal(2 * O)
+    assert relerr(A.left_multiply(z), oracle.left_multiply(bs, vals, z)) < REL
+    x = rng.standard_normal(9 * C)
+    y_ref, rhs_ref = oracle.implicit_schur_multiply(bs, vals, D, b, P, x)
+    y, rhs = cx.implicit_schur_multiply(ctx, A, D, b, x, 9 * C)
+    assert relerr(y, y_ref) < 1e-11 and relerr(rhs, rhs_ref) < 1e-11
+    lhs_ref, r_ref = oracle.schur_eliminate_dense(bs, vals, b, D, P)
+    lhs, r = cx.eliminate_dense(ctx, A, b, D, 9 * C)
+    assert relerr(np.triu(lhs), np.triu(lhs_ref)) < 1e-11 and relerr(r, r_ref) < 1e-11
+    xb = cx.back_substitute(ctx, A, b, D, x)
+    assert relerr(xb[:3 * P], oracle.schur_back_substitute(bs, vals, b, D, P, x)[:3 * P]) < 1e-10
+    A.close()
+
+
+def test_generic_layout_products(ctx, oracle):
+    """Matrices outside the static <2,3,9> layout (the reference fixtures) use the dynamic kernels."""
+    from conftest import lls_problem
+    for pid in (2, 4, 5, 6):
+        bs, values, b, D, nelim, raw = lls_problem(pid)
+        A = cx.Matrix(ctx, bs, nelim)
+        assert not A.is_static_239
+        A.set_values(values)
+        rng = np.random.default_rng(pid)
+        x, y = rng.standard_normal(bs.num_cols), rng.standard_normal(bs.num_rows)
+        assert relerr(A.right_multiply(x), oracle.right_multiply(bs, values, x)) < 1e-14
+        assert relerr(A.left_multiply(y), oracle.left_multiply(bs, values, y)) < 1e-14
+        assert relerr(A.squared_column_norm(), oracle.squared_column_norm(bs, values)) < 1e-14
+        A.close()

@@ -1,0 +1,53 @@
+"""CPU-side checks of the C-ABI library: it loads, exports every symbol
+include/cxschur.h declares, fails loudly without a GPU, and the host-side helpers
+(no device needed) agree with the oracle."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, cx, lls_problem
+
+
+def test_header_symbols_are_exported():
+    lib = cx.load_library()
+    header = open(os.path.join(ROOT, "include", "cxschur.h")).read()
+    declared = set(re.findall(r"\b(cx_[a-z0-9_]+)\s*\(", header))
+    declared -= {"cx_block", "cx_cell"}
+    assert declared, "no declarations found"
+    assert declared == set(cx.EXPORTED_SYMBOLS), declared ^ set(cx.EXPORTED_SYMBOLS)
+    for name in sorted(declared):
+        assert hasattr(lib, name), "libcxschur.so does not export %s" % name
+
+
+def test_no_cpu_fallback():
+    """Without a gfx950 device context creation must fail with an error, not fall back."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    with pytest.raises(cx.CxError):
+        cx.Context(0)
+
+
+def test_detect_structure_host(oracle):
+    for pid in (2, 4, 6):
+        bs, values, b, D, nelim, raw = lls_problem(pid)
+        assert cx.detect_structure(bs, nelim) == oracle.detect_structure(bs, nelim)
+    prob = cx.bal.make_bal_like(7, 50, 160, seed=9)
+    bs, order = cx.bal.build_structure(prob)
+    assert cx.detect_structure(bs, prob.num_points) == (2, 3, 9)
+
+
+def test_partition_points_balanced():
+    prob = cx.bal.make_bal_like(12, 500, 2600, seed=4)
+    bs, order = cx.bal.build_structure(prob)
+    for nranks in (1, 2, 3, 8):
+        bounds = cx.partition_points(bs, prob.num_points, nranks)
+        assert bounds[0] == 0 and bounds[-1] == prob.num_points and np.all(np.diff(bounds) >= 0)
+        counts = np.bincount(prob.point_index, minlength=prob.num_points)
+        per = [counts[bounds[i]:bounds[i + 1]].sum() for i in range(nranks)]
+        assert sum(per) == prob.num_observations
+        assert max(per) - min(per) <= counts.max() * 2 + 1
+        assert np.array_equal(bounds, cx.bal.partition_points(prob, nranks))
