@@ -1,0 +1,274 @@
+#!/usr/bin/env python3
+"""Benchmark of the LM inner linear solve on MI355X (BASELINE.json metric:
+linear-solve ms/iter + J SpMV GB/s on BAL final-13682).
+
+One "step" = one LinearSolver::Solve exactly as LevenbergMarquardtStrategy::
+ComputeStep issues it at an LM iteration (levenberg_marquardt_strategy.cc:69-156):
+ITERATIVE_SCHUR + JACOBI, q_tolerance = eta = 0.1, r_tolerance = -1,
+max_num_iterations = 500, on the Jacobi-scaled Jacobian of a synthetic problem with
+the public BAL Final-13682 header sizes (no BAL file exists offline).  Inputs
+(J values, residuals, D) are resident in HBM before the timed region.
+
+N > 1: launched by torch.distributed.run, one rank per GPU.  Points (and with them
+residual blocks) are sharded over the ranks, camera-space sums go through RCCL
+all-reduce inside the library (strong scaling of the fixed problem).
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import importlib.util
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+
+
+def _load(name, path, search=None):
+    if name in sys.modules:
+        return sys.modules[name]
+    spec = importlib.util.spec_from_file_location(name, path, submodule_search_locations=search)
+    mod = importlib.util.module_from_spec(spec)
+    sys.modules[name] = mod
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def load_cx():
+    pkg = os.path.join(ROOT, "ceres-solver-ceres-solver_amd")
+    return _load("cxschur", os.path.join(pkg, "__init__.py"), [pkg])
+
+
+def load_oracle():
+    return _load("orc", os.path.join(ROOT, "oracle", "orc.py"))
+
+
+HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec
+HBM_COPY_GBPS = 6290.0          # measured float4 copy
+MIN_LM_DIAGONAL, MAX_LM_DIAGONAL = 1e-6, 1e32   # solver.h:294-295
+INITIAL_RADIUS = 1e4            # solver.h initial_trust_region_radius
+ETA = 0.1                       # solver.h eta -> q_tolerance
+
+
+def lm_prepare_device(cx, ctx, prob):
+    """What TrustRegionMinimizer / LevenbergMarquardtStrategy do before the first
+    linear solve, all on the device: evaluate r and J, Jacobi-scale J
+    (trust_region_minimizer.cc:263-279), build the LM diagonal D
+    (levenberg_marquardt_strategy.cc:79-95).  Returns (evaluator, A, b, D, cost)."""
+    ev = cx.Evaluator(ctx, prob)
+    A = ev.jacobian()
+    P, C = prob.num_points, prob.num_cameras
+    ncols = 3 * P + 9 * C
+    state = ctx.to_device(prob.state())
+    res = ctx.empty(2 * prob.num_observations)
+    cost, _, _ = ev.evaluate(state, residuals=res, gradient=None, want_jacobian=True)
+    eval_ms = ev.last_kernel_ms
+    sq = ctx.empty(ncols)
+
+    def colnorm():
+        A.squared_column_norm(sq)
+        if ctx.num_ranks > 1:
+            ctx.allreduce_sum(sq, offset=3 * P, count=9 * C)
+        ctx.synchronize()
+        return sq.to_host()
+
+    scale = 1.0 / (1.0 + np.sqrt(colnorm()))
+    dscale = ctx.to_device(scale)
+    A.scale_columns(dscale)
+    diag = np.clip(colnorm(), MIN_LM_DIAGONAL, MAX_LM_DIAGONAL)
+    D = ctx.to_device(np.sqrt(diag / INITIAL_RADIUS))
+    return ev, A, res, D, cost, eval_ms
+
+
+def cpu_baseline(cx, prob, solver_kw, threads):
+    """Oracle (CPU restatement, kind 'port') on a bounded sample: the first quarter of the
+    points (same sharding rule as the multi-GPU path), same LM preparation and solve."""
+    orc = load_oracle()
+    orc.lib()
+    orc.set_num_threads(threads)
+    P = prob.num_points
+    hi = max(1, P // 4)
+    sub = cx.bal.shard(prob, 0, hi)
+    bs, order = cx.bal.build_structure(sub)
+    _, res, _, vals = orc.bal_evaluate(bs, sub.num_cameras, sub.num_points, sub.camera_index, sub.point_index,
+                                       sub.observations, order, sub.state(), want_gradient=False)
+    scale = 1.0 / (1.0 + np.sqrt(orc.squared_column_norm(bs, vals)))
+    vals = orc.scale_columns(bs, vals, scale)
+    diag = np.clip(orc.squared_column_norm(bs, vals), MIN_LM_DIAGONAL, MAX_LM_DIAGONAL)
+    # cameras unseen by the sample keep only the clamp value; the solve stays well posed
+    D = np.sqrt(diag / INITIAL_RADIUS)
+    o = orc.make_options(type=orc.ITERATIVE_SCHUR, preconditioner_type=orc.JACOBI,
+                         num_eliminate_blocks=sub.num_points, max_num_iterations=solver_kw["max_num_iterations"])
+    t0 = time.time()
+    x, s = orc.solve(bs, vals, res, D, o, r_tolerance=-1.0, q_tolerance=ETA)
+    wall = time.time() - t0
+    numeric_s = orc.last_solve_seconds()
+    ratio = prob.num_observations / sub.num_observations
+    return {
+        "value": numeric_s * 1e3 * ratio,
+        "unit": "ms",
+        "cores": threads,
+        "kind": "port",
+        "sample": "oracle ITERATIVE_SCHUR+JACOBI on points [0,%d) of the workload (%d of %d residual blocks, all "
+                  "cameras): %.0f ms for %d CG iterations (%.0f ms incl. structure set-up), scaled by the residual-"
+                  "block ratio %.2f" % (hi, sub.num_observations, prob.num_observations, numeric_s * 1e3,
+                                        s.num_iterations, wall * 1e3, ratio),
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--workload", default="final13682", choices=sorted(load_cx().bal.PRESETS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-threads", type=int, default=0)
+    args = ap.parse_args()
+
+    import torch  # first, so that libcxschur shares torch's HIP runtime instance
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node %d"
+                         % (args.gpus, world, args.gpus))
+    cx = load_cx()
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="gloo", rank=rank, world_size=world)   # control plane only
+    ctx = cx.Context(local_rank)
+    if world > 1:
+        ids = [cx.Context.unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(ids, src=0)
+        ctx.set_comm(rank, world, ids[0])                                     # data plane: RCCL over xGMI
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        ctx.synchronize()
+        torch.cuda.synchronize()
+
+    t_gen = time.time()
+    full = cx.bal.make_preset(args.workload)
+    C, P, O = full.num_cameras, full.num_points, full.num_observations
+    if world > 1:
+        bounds = cx.bal.partition_points(full, world)
+        prob = cx.bal.shard(full, int(bounds[rank]), int(bounds[rank + 1]))
+    else:
+        prob = full
+    t_gen = time.time() - t_gen
+
+    ev, A, b, D, cost, eval_ms = lm_prepare_device(cx, ctx, prob)
+    solver_kw = dict(type=cx.ITERATIVE_SCHUR, preconditioner_type=cx.JACOBI, num_eliminate_blocks=prob.num_points,
+                     max_num_iterations=500, min_num_iterations=0, residual_reset_period=10)
+    S = cx.Solver(ctx, **solver_kw)
+    x = ctx.empty(A.num_cols)
+
+    for _ in range(args.warmup):
+        _, summ = S.solve(A, b, D, r_tolerance=-1.0, q_tolerance=ETA, x=x)
+    barrier()
+    t0 = time.perf_counter()
+    kstats = {}
+    phases = {}
+    for _ in range(args.steps):
+        _, summ = S.solve(A, b, D, r_tolerance=-1.0, q_tolerance=ETA, x=x)
+        for k in S.kernel_stats():
+            e = kstats.setdefault(k["name"], [0.0, 0, 0])
+            e[0] += k["sampled_ms"]
+            e[1] += k["sampled_launches"]
+            e[2] += k["launches"]
+        for n, v in S.timing().items():
+            phases[n] = phases.get(n, 0.0) + v
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt[0])
+    ms_per_step = elapsed * 1e3 / max(1, args.steps)
+
+    # ---- J SpMV GB/s (block_sparse_matrix.cc:239-349 replacement), this rank's shard
+    Ol, Pl = prob.num_observations, prob.num_points
+    n_c, n_r = 3 * Pl + 9 * C, 2 * Ol
+    xv = ctx.to_device(np.random.default_rng(1).standard_normal(n_c))
+    yv = ctx.zeros(n_r)
+    zv = ctx.to_device(np.random.default_rng(2).standard_normal(n_r))
+    cv = ctx.zeros(n_c)
+    right_ms, left_ms = [], []
+    for i in range(12):
+        A.right_multiply(xv, yv)
+        right_ms.append(A.last_kernel_ms)
+        A.left_multiply(zv, cv)
+        left_ms.append(A.last_kernel_ms)
+    right_ms, left_ms = float(np.median(right_ms[2:])), float(np.median(left_ms[2:]))
+    right_bytes = 240.0 * Ol + 8.0 * n_c       # 8 nnz + 16 O + 8 n_c + 16 n_r
+    left_bytes = 224.0 * Ol + 16.0 * n_c       # 8 nnz + 16 O + 8 n_r + 16 n_c
+    spmv = {
+        "right_gbps": right_bytes / right_ms / 1e6, "left_gbps": left_bytes / left_ms / 1e6,
+        "right_ms": right_ms, "left_ms": left_ms,
+        "right_frac_of_8TBps": right_bytes / right_ms / 1e6 / HBM_PEAK_GBPS,
+        "left_frac_of_8TBps": left_bytes / left_ms / 1e6 / HBM_PEAK_GBPS,
+        "scope": "per GPU (this rank's shard)",
+    }
+
+    # ---- roofline of the dominant kernel: the chunk pass of S x
+    dom = "k_chunk_pass<0>"
+    roof = None
+    if dom in kstats and kstats[dom][1] > 0:
+        avg_ms = kstats[dom][0] / kstats[dom][1]
+        # algorithmic bytes per launch: E+F values 192 B, camera id 4 B, t' written 16 B per residual
+        # block; (E'E)^-1 72 B per point; x_f 72 B per camera  (kernel table)
+        abytes = 212.0 * Ol + 72.0 * Pl + 72.0 * C
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tpath):
+            try:
+                traffic = json.load(open(tpath)).get(args.workload, {}).get(dom)
+            except Exception:
+                traffic = None
+        roof = {"bound": "hbm", "kernel": dom, "achieved": abytes / avg_ms / 1e6, "peak": HBM_PEAK_GBPS,
+                "unit": "GB/s", "frac": abytes / avg_ms / 1e6 / HBM_PEAK_GBPS,
+                "frac_of_measured_copy_peak": abytes / avg_ms / 1e6 / HBM_COPY_GBPS,
+                "avg_launch_ms": avg_ms, "launches_sampled": kstats[dom][1], "algorithmic_bytes_per_launch": abytes,
+                "traffic": traffic}
+
+    out = None
+    if rank == 0:
+        cpu = None
+        if world == 1 and not args.no_cpu_baseline:
+            threads = args.cpu_threads or min(16, os.cpu_count() or 1)
+            cpu = cpu_baseline(cx, full, solver_kw, threads)
+        out = {
+            "metric": "linear_solve_ms_per_iter", "value": ms_per_step, "unit": "ms",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
+            "higher_is_better": False, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "%s: ITERATIVE_SCHUR + JACOBI, q_tol=0.1, synthetic BAL-shaped J "
+                                   "(%d cameras, %d points, %d residual blocks)" % (args.workload, C, P, O),
+                       "cameras": C, "points": P, "residual_blocks": O, "cg_iterations": int(summ.num_iterations),
+                       "termination": int(summ.termination_type), "initial_cost": cost,
+                       "sharding": "points over %d rank(s), RCCL all-reduce of camera-space sums" % world},
+            "phases_ms_per_solve": {k: v / max(1, args.steps) for k, v in phases.items()},
+            "jacobian_eval_ms": eval_ms,
+            "spmv": spmv,
+            "kernels": {k: {"avg_ms": v[0] / max(1, v[1]), "launches_per_solve": v[2] / max(1, args.steps)} for k, v in kstats.items()},
+            "roofline": roof,
+            "cpu_baseline": cpu,
+            "device": ctx.name,
+            "problem_generation_s": t_gen,
+        }
+        print(json.dumps(out), flush=True)
+    barrier()
+    if world > 1:
+        dist.destroy_process_group()
+    return out
+
+
+if __name__ == "__main__":
+    main()

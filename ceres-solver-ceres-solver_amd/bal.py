@@ -131,10 +131,17 @@ def make_bal_like(C, P, O, seed, noise_px=0.5, perturb=True):
     point_index = point_index[order].astype(np.int32)
     obs = project(cameras, points, camera_index, point_index)
     obs += noise_px * rng.standard_normal(obs.shape)
-    if perturb:  # BALProblem::Perturb (bal_problem.cc:294-333)
+    if perturb:  # BALProblem::Perturb (bal_problem.cc:294-333): iid noise on every block ...
         cameras[:, 0:3] += 1e-4 * rng.standard_normal((C, 3))
         cameras[:, 3:6] += 1e-2 * rng.standard_normal((C, 3))
         points += 5e-2 * rng.standard_normal((P, 3))
+        # ... plus a smooth drift along the camera ring (the low-frequency error real SfM
+        # reconstructions accumulate); without it CG on the reduced system converges in two
+        # iterations, which no real BAL problem does
+        s = np.arange(C) / C
+        for m in (1, 2, 3, 5, 8):
+            cameras[:, 3:6] += (2.0 / m) * np.sin(2 * np.pi * m * s)[:, None] * rng.standard_normal(3)
+            cameras[:, 0:3] += (2e-3 / m) * np.cos(2 * np.pi * m * s)[:, None] * rng.standard_normal(3)
     return BalProblem(C, P, camera_index, point_index, obs, cameras, points)
 
 

@@ -30,7 +30,7 @@ EXPORTED_SYMBOLS = [
     "cx_matrix_get_values", "cx_matrix_values_changed", "cx_matrix_set_zero", "cx_matrix_right_multiply",
     "cx_matrix_left_multiply", "cx_matrix_squared_column_norm", "cx_matrix_scale_columns",
     "cx_matrix_last_kernel_ms", "cx_solver_create", "cx_solver_destroy", "cx_solver_default_options",
-    "cx_solver_solve", "cx_solver_last_timing", "cx_schur_eliminate_dense", "cx_schur_back_substitute",
+    "cx_solver_solve", "cx_solver_last_timing", "cx_solver_kernel_stats", "cx_schur_eliminate_dense", "cx_schur_back_substitute",
     "cx_implicit_schur_multiply", "cx_dense_cholesky_solve", "cx_evaluator_create_bal", "cx_evaluator_destroy",
     "cx_evaluator_jacobian", "cx_evaluator_row_of_observation", "cx_evaluator_evaluate",
     "cx_evaluator_last_kernel_ms", "cx_detect_structure", "cx_partition_points",
@@ -81,6 +81,11 @@ class cx_summary(ctypes.Structure):
 class cx_solve_timing(ctypes.Structure):
     _fields_ = [(n, ctypes.c_double) for n in
                 ("setup_ms", "eliminate_ms", "reduced_solve_ms", "back_substitute_ms", "total_ms", "allreduce_ms")]
+
+
+class cx_kernel_stat(ctypes.Structure):
+    _fields_ = [("name", ctypes.c_char * 64), ("sampled_ms", ctypes.c_double),
+                ("sampled_launches", ctypes.c_int32), ("launches", ctypes.c_int32)]
 
 
 def library_path():
@@ -185,8 +190,10 @@ class Context:
     def synchronize(self):
         _check(self.lib.cx_synchronize(self._h))
 
-    def allreduce_sum(self, dev):
-        _check(self.lib.cx_allreduce_sum(self._h, ctypes.c_void_p(dev.ptr), ctypes.c_int64(dev.size)))
+    def allreduce_sum(self, dev, offset=0, count=None):
+        """In-place sum over the ranks of dev[offset:offset+count] (float64 device array)."""
+        count = dev.size - offset if count is None else count
+        _check(self.lib.cx_allreduce_sum(self._h, ctypes.c_void_p(dev.ptr + 8 * offset), ctypes.c_int64(count)))
 
     def empty(self, n, dtype=np.float64):
         return DeviceArray(self, int(n), np.dtype(dtype))
@@ -353,6 +360,13 @@ class Solver:
         s = cx_summary()
         _check(self.lib.cx_solver_solve(self._h, A._h, _ptr(b), ctypes.byref(ps), _ptr(x), ctypes.byref(s)))
         return x, s
+
+    def kernel_stats(self):
+        arr = (cx_kernel_stat * 8)()
+        n = ctypes.c_int32()
+        _check(self.lib.cx_solver_kernel_stats(self._h, arr, 8, ctypes.byref(n)))
+        return [dict(name=arr[i].name.decode(), sampled_ms=arr[i].sampled_ms,
+                     sampled_launches=arr[i].sampled_launches, launches=arr[i].launches) for i in range(n.value)]
 
     def timing(self):
         t = cx_solve_timing()

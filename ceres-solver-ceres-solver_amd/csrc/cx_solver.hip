@@ -198,10 +198,51 @@ struct LinOp {
   virtual int apply(const double* x, double* y) = 0;  // y = A x
 };
 
+// Per-kernel device time of the last solve, sampled with HIP event pairs on the
+// context stream (read back after the solve; no synchronisation inside the loop).
+struct KernelTimer {
+  static constexpr int kSlots = 4, kMaxSamples = 64;
+  const char* names[kSlots] = {"k_chunk_pass<0>", "k_cam_ft+k_cam_reduce9", "k_right_239", "k_left_e_239+k_cam_ft"};
+  hipEvent_t ev[kSlots][kMaxSamples][2] = {};
+  int count[kSlots] = {};
+  int launches[kSlots] = {};
+  double total_ms[kSlots] = {};
+  bool created = false;
+  void reset() { for (int i = 0; i < kSlots; ++i) { count[i] = 0; launches[i] = 0; total_ms[i] = 0.0; } }
+  int begin(int slot, hipStream_t st) {
+    if (!created) {
+      for (auto& a : ev) for (auto& b : a) for (auto& e : b) CX_HIP(hipEventCreate(&e));
+      created = true;
+    }
+    ++launches[slot];
+    if (count[slot] < kMaxSamples) CX_HIP(hipEventRecord(ev[slot][count[slot]][0], st));
+    return CX_OK;
+  }
+  int end(int slot, hipStream_t st) {
+    if (count[slot] < kMaxSamples) { CX_HIP(hipEventRecord(ev[slot][count[slot]][1], st)); ++count[slot]; }
+    return CX_OK;
+  }
+  int collect() {  // call after the stream has been synchronised
+    for (int s = 0; s < kSlots; ++s) {
+      total_ms[s] = 0.0;
+      for (int i = 0; i < count[s]; ++i) {
+        float f = 0.f;
+        CX_HIP(hipEventElapsedTime(&f, ev[s][i][0], ev[s][i][1]));
+        total_ms[s] += f;
+      }
+    }
+    return CX_OK;
+  }
+  ~KernelTimer() {
+    if (created) for (auto& a : ev) for (auto& b : a) for (auto& e : b) (void)hipEventDestroy(e);
+  }
+};
+
 struct cx_solver {
   cx_context* ctx = nullptr;
   cx_solver_options opt{};
   cx_solve_timing timing{};
+  KernelTimer ktimer;
   // persistent device scratch
   DevBuf<double> v_p, v_r, v_z, v_tmp, v_x, v_rhs, v_rows, v_rows2, v_cols;
   DevBuf<double> ete_inv, cam_blocks, pt_blocks, g_e, lhs, partial;
@@ -377,8 +418,12 @@ struct ImplicitSchurOp : LinOp {
   int64_t size() const override { return 9 * int64_t(A->C); }
   int apply(const double* x, double* y) override {
     cx_context* ctx = A->ctx;
+    CX_TRY(S->ktimer.begin(0, ctx->stream));
     CX_TRY(cxs_chunk_pass(A, 0, S->ete_inv.p, x, nullptr, S->v_rows.p));
+    CX_TRY(S->ktimer.end(0, ctx->stream));
+    CX_TRY(S->ktimer.begin(1, ctx->stream));
     CX_TRY(cxk_ft_multiply(A, S->v_rows.p, y, false));
+    CX_TRY(S->ktimer.end(1, ctx->stream));
     if (ctx->nranks > 1) CX_TRY(cx_allreduce_device(ctx, y, size()));
     if (D)
       hipLaunchKernelGGL(k_add_d2x, dim3(grid_for(size(), 256)), dim3(256), 0, ctx->stream, y,
@@ -421,9 +466,13 @@ struct CgnrOp : LinOp {
     cx_context* ctx = A->ctx;
     hipStream_t st = ctx->stream;
     CX_HIP(hipMemsetAsync(S->v_rows.p, 0, size_t(A->num_rows) * sizeof(double), st));
+    CX_TRY(S->ktimer.begin(2, st));
     CX_TRY(cxk_right_multiply(A, x, S->v_rows.p));
+    CX_TRY(S->ktimer.end(2, st));
     CX_HIP(hipMemsetAsync(y, 0, size_t(A->num_cols) * sizeof(double), st));
+    CX_TRY(S->ktimer.begin(3, st));
     CX_TRY(cxk_left_multiply(A, S->v_rows.p, y));
+    CX_TRY(S->ktimer.end(3, st));
     if (ctx->nranks > 1 && A->is239) CX_TRY(cx_allreduce_device(ctx, y + 3 * int64_t(A->P), 9 * int64_t(A->C)));
     if (D) hipLaunchKernelGGL(k_add_d2x, dim3(grid_for(size(), 256)), dim3(256), 0, st, y, D, x, size());
     CX_HIP(hipGetLastError());
@@ -660,6 +709,22 @@ void cx_solver_destroy(cx_solver* s) {
   delete s;
 }
 
+int cx_solver_kernel_stats(const cx_solver* s, cx_kernel_stat* out, int32_t capacity, int32_t* count) {
+  CX_CHECK_ARG(s && out && count && capacity >= 0);
+  int n = 0;
+  for (int i = 0; i < KernelTimer::kSlots && n < capacity; ++i) {
+    if (s->ktimer.launches[i] == 0) continue;
+    std::memset(&out[n], 0, sizeof(out[n]));
+    std::snprintf(out[n].name, sizeof(out[n].name), "%s", s->ktimer.names[i]);
+    out[n].sampled_ms = s->ktimer.total_ms[i];
+    out[n].sampled_launches = s->ktimer.count[i];
+    out[n].launches = s->ktimer.launches[i];
+    ++n;
+  }
+  *count = n;
+  return CX_OK;
+}
+
 int cx_solver_last_timing(const cx_solver* s, cx_solve_timing* out) {
   CX_CHECK_ARG(s && out);
   *out = s->timing;
@@ -676,6 +741,7 @@ int cx_solver_solve(cx_solver* S, cx_matrix* A, const double* b, const cx_per_so
   if (o.type != CX_CGNR) CX_CHECK_ARG(o.num_eliminate_blocks == A->nelim);
   std::memset(summary, 0, sizeof(*summary));
   S->timing = cx_solve_timing{};
+  S->ktimer.reset();
   ctx->allreduce_host_ms = 0.0;
   HostOrDevice hb(ctx), hD(ctx), hx(ctx);
   CX_TRY(hb.in(b, size_t(A->num_rows), ps->memspace));
@@ -703,6 +769,7 @@ int cx_solver_solve(cx_solver* S, cx_matrix* A, const double* b, const cx_per_so
   CX_HIP(hipEventElapsedTime(&ms, ctx->ev[4], ctx->ev[5]));
   S->timing.total_ms = ms;
   S->timing.allreduce_ms = ctx->allreduce_host_ms;
+  CX_TRY(S->ktimer.collect());
   return hx.out();
 }
 

@@ -131,6 +131,16 @@ typedef struct {
   double allreduce_ms;        /* host-side estimate of time in RCCL calls */
 } cx_solve_timing;
 
+/* Device time of one kernel (or short kernel sequence) of the hot loop during the
+ * last solve: HIP event pairs on the context's stream around the first
+ * sampled_launches launches (at most 64); launches counts all of them. */
+typedef struct {
+  char name[64];
+  double sampled_ms;
+  int32_t sampled_launches;
+  int32_t launches;
+} cx_kernel_stat;
+
 typedef struct cx_context cx_context;
 typedef struct cx_matrix cx_matrix;
 typedef struct cx_solver cx_solver;
@@ -214,6 +224,9 @@ void cx_solver_default_options(cx_solver_options* options);
 int cx_solver_solve(cx_solver* s, cx_matrix* A, const double* b,
                     const cx_per_solve_options* per_solve, double* x, cx_summary* summary);
 int cx_solver_last_timing(const cx_solver* s, cx_solve_timing* out);
+/* per-kernel device times of the last solve (ExecutionSummary of the reference is host
+ * wall time per phase, execution_summary.h:45-83; this is its device-side counterpart) */
+int cx_solver_kernel_stats(const cx_solver* s, cx_kernel_stat* out, int32_t capacity, int32_t* count);
 
 /* The Schur pieces on their own, for parity tests against
  * schur_eliminator_test.cc / implicit_schur_complement_test.cc.

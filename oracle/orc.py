@@ -63,6 +63,7 @@ def lib():
         _LIB = ctypes.CDLL(path)
         _LIB.orc_to_crs.restype = ctypes.c_int64
         _LIB.orc_stable_schur_ordering.restype = ctypes.c_int
+        _LIB.orc_last_solve_seconds.restype = ctypes.c_double
     return _LIB
 
 
@@ -207,6 +208,10 @@ def solve(bs, values, b, D, options, r_tolerance=-1.0, q_tolerance=0.0, allreduc
         rc = lib().orc_solve_sharded(*args, cb, None)
     assert rc == 0
     return x, s
+
+
+def last_solve_seconds():
+    return lib().orc_last_solve_seconds()
 
 
 def cg_dense(A, b, x0, max_num_iterations, r_tolerance=-1.0, q_tolerance=0.0, min_num_iterations=0,

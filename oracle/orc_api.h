@@ -55,6 +55,9 @@ int orc_solve(const cx_block_structure* bs, const double* values, const double* 
               const cx_solver_options* options, double r_tolerance, double q_tolerance, double* x,
               cx_summary* summary);
 
+/* wall seconds of the numeric part of the last orc_solve (structure set-up excluded) */
+double orc_last_solve_seconds(void);
+
 /* The same solve on one shard of a point-partitioned J; camera-space sums go
  * through the callback (sum-all-reduce in place).  Used by the gloo tests. */
 typedef void (*orc_allreduce_fn)(double* buf, int64_t n, void* user);

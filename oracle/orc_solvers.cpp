@@ -19,6 +19,12 @@ namespace orc {
 
 using Vec = std::vector<double>;
 
+// Wall time of the numeric part of the last solve: the clock starts once the
+// structure-only objects (transpose index, chunks) exist, which the reference
+// builds once per Solver::Solve and reuses across iterations (linear_solver.h:137-142).
+static double g_solve_t0 = 0.0, g_last_solve_seconds = 0.0;
+static void MarkSolveStart() { g_solve_t0 = omp_get_wtime(); }
+
 struct Comm {
   orc_allreduce_fn fn = nullptr;
   void* user = nullptr;
@@ -476,6 +482,7 @@ static cx_summary SolveIterativeSchur(const cx_block_structure* s, const double*
   const bool need_ftf = o.use_spse_initialization || o.preconditioner_type == CX_JACOBI ||
                         o.preconditioner_type == CX_SCHUR_POWER_SERIES_EXPANSION;
   ISC isc(s, values, nelim, threads, need_ftf, comm);
+  MarkSolveStart();
   isc.Init(D, b);
   cx_summary summary;
   std::memset(&summary, 0, sizeof(summary));
@@ -582,6 +589,7 @@ static cx_summary SolveDenseSchur(const cx_block_structure* s, const double* val
   const int num_cols = el.bs.num_cols();
   Vec lhs(size_t(n) * n), rhs(n);
   DenseBRAM m(lhs.data(), sizes);
+  MarkSolveStart();
   std::fill(x, x + num_cols, 0.0);
   if (!comm.active()) {
     el.Eliminate(b, D, &m, rhs.data(), threads);
@@ -618,6 +626,7 @@ static int Solve(const cx_block_structure* bs, const double* values, const doubl
                  const Comm& comm) {
   const int threads = orc_get_num_threads();
   cx_summary s;
+  MarkSolveStart();
   switch (o->type) {
     case CX_CGNR: s = SolveCgnr(bs, values, b, D, *o, r_tol, q_tol, x, comm, threads); break;
     case CX_ITERATIVE_SCHUR: s = SolveIterativeSchur(bs, values, b, D, *o, r_tol, q_tol, x, comm, threads); break;
@@ -625,6 +634,7 @@ static int Solve(const cx_block_structure* bs, const double* values, const doubl
     case CX_SPARSE_SCHUR: s = SolveDenseSchur(bs, values, b, D, *o, x, comm, threads); break;
     default: return -1;
   }
+  g_last_solve_seconds = omp_get_wtime() - g_solve_t0;
   if (out) *out = s;
   return 0;
 }
@@ -634,6 +644,8 @@ static int Solve(const cx_block_structure* bs, const double* values, const doubl
 using namespace orc;
 
 extern "C" {
+
+double orc_last_solve_seconds(void) { return g_last_solve_seconds; }
 
 int orc_solve(const cx_block_structure* bs, const double* values, const double* b, const double* D,
               const cx_solver_options* o, double r_tol, double q_tol, double* x, cx_summary* out) {
