@@ -178,6 +178,9 @@ def main():
     kstats = {}
     phases = {}
     for _ in range(args.steps):
+        # every LM iteration hands the solver a freshly evaluated J: the camera-major copy of
+        # the F cells has to be rebuilt inside the solve, so invalidate it here
+        A.values_changed()
         _, summ = S.solve(A, b, D, r_tolerance=-1.0, q_tolerance=ETA, x=x)
         for k in S.kernel_stats():
             e = kstats.setdefault(k["name"], [0.0, 0, 0])

@@ -275,6 +275,10 @@ class Matrix:
         values = _f64(values)
         _check(self.lib.cx_matrix_set_values(self._h, _ptr(values), _space(values)))
 
+    def values_changed(self):
+        """Tell the matrix its values were rewritten in place (drops the camera-major copy)."""
+        _check(self.lib.cx_matrix_values_changed(self._h))
+
     def get_values(self):
         out = np.empty(self.num_nonzeros)
         _check(self.lib.cx_matrix_get_values(self._h, _ptr(out)))

@@ -69,6 +69,22 @@ __device__ __forceinline__ void block_sum(double (&v)[N], double* scratch) {
   __syncthreads();
 }
 
+// Same reduction, but the N sums are stored to out[0..N) by threads 0..N-1 (no
+// runtime-indexed register array, which would spill to scratch).  N <= kBlock.
+template <int N>
+__device__ __forceinline__ void block_sum_store(const double (&v)[N], double* scratch, double* __restrict__ out) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int i = 0; i < N; ++i) {
+    const double s = wave_sum(v[i]);
+    if (lane == 0) scratch[i * 4 + wave] = s;
+  }
+  __syncthreads();
+  const int t = threadIdx.x;
+  if (t < N) out[t] = ((scratch[t * 4] + scratch[t * 4 + 1]) + scratch[t * 4 + 2]) + scratch[t * 4 + 3];
+  __syncthreads();
+}
+
 // Inverse of a symmetric positive definite 3x3 (row-major, upper triangle read)
 // through LLT, the arithmetic of selfadjointView<Upper>().llt().solve(I)
 // (implicit_schur_complement.cc:201-202).  ok = false if not PD.

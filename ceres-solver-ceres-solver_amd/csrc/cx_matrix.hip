@@ -158,8 +158,7 @@ __global__ __launch_bounds__(kBlock) void k_cam_ft(const double* __restrict__ Ft
       for (int k = 0; k < 9; ++k) acc[k] += f[k] * tv.x + f[9 + k] * tv.y;
     }
   }
-  block_sum<9>(acc, red);
-  if (tid < 9) partial[int64_t(s) * 9 + tid] = acc[tid];
+  block_sum_store<9>(acc, red, partial + int64_t(s) * 9);
 }
 
 // y_f[9c + k] (+)= sum of the camera's segment partials, in segment order (deterministic),
@@ -213,8 +212,7 @@ __global__ __launch_bounds__(kBlock) void k_cam_sqnorm(const double* __restrict_
       for (int k = 0; k < 9; ++k) acc[k] += f[k] * f[k] + f[9 + k] * f[9 + k];
     }
   }
-  block_sum<9>(acc, red);
-  if (tid < 9) partial[int64_t(s) * 9 + tid] = acc[tid];
+  block_sum_store<9>(acc, red, partial + int64_t(s) * 9);
 }
 
 // J <- J diag(scale)   (block_sparse_matrix.cc:403-450): thread per 16-byte piece

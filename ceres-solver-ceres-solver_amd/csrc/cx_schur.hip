@@ -73,17 +73,30 @@ __global__ __launch_bounds__(kBlock) void k_chunk_ete(const double* __restrict__
       wr[7] = e[1] * bv.x + e[4] * bv.y;
       wr[8] = e[2] * bv.x + e[5] * bv.y;
     }
+    int jb = 0, je = 0;
+    if (tid < p1 - p0) {
+      jb = pt_start[p0 + tid] - r0;
+      je = pt_start[p0 + tid + 1] - r0;
+    }
     __syncthreads();
     if (tid < p1 - p0) {
       p = p0 + tid;
       have = true;
-      double s[9];
+      double s[9], s2[9];
 #pragma unroll
-      for (int k = 0; k < 9; ++k) s[k] = 0.0;
-      for (int j = pt_start[p] - r0; j < pt_start[p + 1] - r0; ++j) {
+      for (int k = 0; k < 9; ++k) { s[k] = 0.0; s2[k] = 0.0; }
+      // two independent partial sums over alternating rows, combined at the end
+      int j = jb;
+      for (; j + 2 <= je; j += 2) {
+#pragma unroll
+        for (int k = 0; k < 9; ++k) { s[k] += w[j * 9 + k]; s2[k] += w[j * 9 + 9 + k]; }
+      }
+      if (j < je) {
 #pragma unroll
         for (int k = 0; k < 9; ++k) s[k] += w[j * 9 + k];
       }
+#pragma unroll
+      for (int k = 0; k < 9; ++k) s[k] += s2[k];
       m[0] = s[0]; m[1] = s[1]; m[2] = s[2]; m[4] = s[3]; m[5] = s[4]; m[8] = s[5];
       gg[0] = s[6]; gg[1] = s[7]; gg[2] = s[8];
     }
@@ -147,6 +160,7 @@ __global__ __launch_bounds__(kBlock) void k_chunk_pass(const double* __restrict_
                                                        const int32_t* __restrict__ tile_pt,
                                                        const int32_t* __restrict__ pt_start,
                                                        const int32_t* __restrict__ row_cam,
+                                                       const int32_t* __restrict__ row_pt,
                                                        const double* __restrict__ ete_inv,
                                                        const double* __restrict__ xf,   // camera vector (SX: x, BACKSUB: z)
                                                        const double* __restrict__ b,    // row vector (RHS, BACKSUB)
@@ -161,6 +175,7 @@ __global__ __launch_bounds__(kBlock) void k_chunk_pass(const double* __restrict_
   if (r1 - r0 <= kBlock) {
     const int nvalid = r1 - r0;
     const int r = r0 + tid;
+    const int lp = (MODE != 2 && tid < nvalid) ? row_pt[r] - p0 : 0;
     double e[6];
     double t0 = 0.0, t1 = 0.0;
     if (MODE != 1) {
@@ -187,16 +202,32 @@ __global__ __launch_bounds__(kBlock) void k_chunk_pass(const double* __restrict_
       w[tid * 3 + 1] = e[1] * t0 + e[4] * t1;
       w[tid * 3 + 2] = e[2] * t0 + e[5] * t1;
     }
+    // one thread per point: fetch its (E'E)^-1 and chunk bounds before the barrier so the
+    // loads overlap the row phase of the other wavefronts
+    double m[9];
+    int jb = 0, je = 0;
+    if (tid < p1 - p0) {
+      const double* mp = ete_inv + 9 * int64_t(p0 + tid);
+#pragma unroll
+      for (int k = 0; k < 9; ++k) m[k] = mp[k];
+      jb = pt_start[p0 + tid] - r0;
+      je = pt_start[p0 + tid + 1] - r0;
+    }
     __syncthreads();
     if (tid < p1 - p0) {
       const int p = p0 + tid;
-      double s0 = 0.0, s1 = 0.0, s2 = 0.0;
-      for (int j = pt_start[p] - r0; j < pt_start[p + 1] - r0; ++j) {
-        s0 += w[j * 3];
-        s1 += w[j * 3 + 1];
-        s2 += w[j * 3 + 2];
+      // rows of the chunk, four independent partial sums (fixed combination order)
+      double a0 = 0.0, a1 = 0.0, a2 = 0.0, b0 = 0.0, b1 = 0.0, b2 = 0.0;
+      double c0 = 0.0, c1 = 0.0, c2 = 0.0, d0 = 0.0, d1 = 0.0, d2 = 0.0;
+      int j = jb;
+      for (; j + 4 <= je; j += 4) {
+        a0 += w[j * 3]; a1 += w[j * 3 + 1]; a2 += w[j * 3 + 2];
+        b0 += w[j * 3 + 3]; b1 += w[j * 3 + 4]; b2 += w[j * 3 + 5];
+        c0 += w[j * 3 + 6]; c1 += w[j * 3 + 7]; c2 += w[j * 3 + 8];
+        d0 += w[j * 3 + 9]; d1 += w[j * 3 + 10]; d2 += w[j * 3 + 11];
       }
-      const double* m = ete_inv + 9 * int64_t(p);
+      for (; j < je; ++j) { a0 += w[j * 3]; a1 += w[j * 3 + 1]; a2 += w[j * 3 + 2]; }
+      const double s0 = (a0 + b0) + (c0 + d0), s1 = (a1 + b1) + (c1 + d1), s2 = (a2 + b2) + (c2 + d2);
       const double u0 = m[0] * s0 + m[1] * s1 + m[2] * s2;
       const double u1 = m[3] * s0 + m[4] * s1 + m[5] * s2;
       const double u2 = m[6] * s0 + m[7] * s1 + m[8] * s2;
@@ -210,12 +241,7 @@ __global__ __launch_bounds__(kBlock) void k_chunk_pass(const double* __restrict_
     if (MODE != 2) {
       __syncthreads();
       if (tid < nvalid) {
-        // point of this row, local to the tile: rows are grouped by point, find by search
-        int lo = 0, hi = p1 - p0 - 1;
-        while (lo < hi) {
-          const int mid = (lo + hi + 1) >> 1;
-          if (pt_start[p0 + mid] <= r) lo = mid; else hi = mid - 1;
-        }
+        const int lo = lp;  // point of this row, local to the tile
         const double u0 = u[lo * 3], u1 = u[lo * 3 + 1], u2 = u[lo * 3 + 2];
         t0 -= e[0] * u0 + e[1] * u1 + e[2] * u2;
         t1 -= e[3] * u0 + e[4] * u1 + e[5] * u2;
@@ -294,11 +320,10 @@ __global__ __launch_bounds__(kBlock) void k_cam_diag(const double* __restrict__ 
     double f[18];
     stage_cells<18>(Ft + 18 * int64_t(k0), nvalid, lds, f);
     if (tid < nvalid) {
-      int idx = 0;
 #pragma unroll
       for (int a = 0; a < 9; ++a)
 #pragma unroll
-        for (int c = a; c < 9; ++c) acc[idx++] += f[a] * f[c] + f[9 + a] * f[9 + c];
+        for (int c = a; c < 9; ++c) acc[a * 9 - a * (a - 1) / 2 + c - a] += f[a] * f[c] + f[9 + a] * f[9 + c];
       if (WITH_SCHUR) {
         const int r = cam_rows[k0 + tid];
         const double* e = E + 6 * int64_t(r);
@@ -318,16 +343,15 @@ __global__ __launch_bounds__(kBlock) void k_cam_diag(const double* __restrict__ 
         for (int q = 0; q < 3; ++q)
 #pragma unroll
           for (int a = 0; a < 9; ++a) G[q * 9 + a] = mi[q * 3] * B[a] + mi[q * 3 + 1] * B[9 + a] + mi[q * 3 + 2] * B[18 + a];
-        idx = 0;
 #pragma unroll
         for (int a = 0; a < 9; ++a)
 #pragma unroll
-          for (int c = a; c < 9; ++c) acc[idx++] -= B[a] * G[c] + B[9 + a] * G[9 + c] + B[18 + a] * G[18 + c];
+          for (int c = a; c < 9; ++c)
+            acc[a * 9 - a * (a - 1) / 2 + c - a] -= B[a] * G[c] + B[9 + a] * G[9 + c] + B[18 + a] * G[18 + c];
       }
     }
   }
-  block_sum<45>(acc, red);
-  if (tid < 45) partial[int64_t(s) * 45 + tid] = acc[tid];
+  block_sum_store<45>(acc, red, partial + int64_t(s) * 45);
 }
 
 // blocks[c] (81, row-major, full) = sum of the camera's packed segment partials
@@ -401,6 +425,7 @@ __global__ __launch_bounds__(kBlock) void k_chunk_eliminate(const double* __rest
                                                             const int32_t* __restrict__ tile_pt,
                                                             const int32_t* __restrict__ pt_start,
                                                             const int32_t* __restrict__ row_cam,
+                                                            const int32_t* __restrict__ row_pt,
                                                             const double* __restrict__ De,
                                                             const double* __restrict__ b,  // may be null
                                                             double* __restrict__ lhs, int64_t n,
@@ -485,11 +510,7 @@ __global__ __launch_bounds__(kBlock) void k_chunk_eliminate(const double* __rest
   __syncthreads();
   // UpdateRhs (schur_eliminator_impl.h:379-420): rhs_c += F_r' (b_r - E_r inv g)
   if (rhs && tid < nvalid) {
-    int lo = 0, hi = npts - 1;
-    while (lo < hi) {
-      const int mid = (lo + hi + 1) >> 1;
-      if (pt_start[p0 + mid] <= r) lo = mid; else hi = mid - 1;
-    }
+    const int lo = row_pt[r] - p0;
     const double g0 = invg_s[lo * 3], g1 = invg_s[lo * 3 + 1], g2 = invg_s[lo * 3 + 2];
     const double s0 = bv.x - (e[0] * g0 + e[1] * g1 + e[2] * g2);
     const double s1 = bv.y - (e[3] * g0 + e[4] * g1 + e[5] * g2);
@@ -654,7 +675,7 @@ int cxs_chunk_pass(cx_matrix* A, int mode, const double* ete_inv, const double* 
   const double* F = A->d_values.p + 6 * A->O;
 #define CX_LAUNCH_PASS(M)                                                                                   \
   hipLaunchKernelGGL(k_chunk_pass<M>, dim3(A->num_tiles), dim3(kBlock), 0, st, E, F, A->d_tile_row.p,       \
-                     A->d_tile_pt.p, A->d_pt_start.p, A->d_row_cam.p, ete_inv, xf, b, out)
+                     A->d_tile_pt.p, A->d_pt_start.p, A->d_row_cam.p, A->d_row_pt.p, ete_inv, xf, b, out)
   if (mode == 0) CX_LAUNCH_PASS(0);
   else if (mode == 1) CX_LAUNCH_PASS(1);
   else CX_LAUNCH_PASS(2);
@@ -698,7 +719,7 @@ int cxs_eliminate_dense(cx_matrix* A, const double* b, const double* D, bool add
     const double* E = A->d_values.p;
     const double* F = A->d_values.p + 6 * A->O;
     hipLaunchKernelGGL(k_chunk_eliminate, dim3(A->num_tiles), dim3(kBlock), 0, st, E, F, A->d_tile_row.p,
-                       A->d_tile_pt.p, A->d_pt_start.p, A->d_row_cam.p, D, b, lhs, n, rhs);
+                       A->d_tile_pt.p, A->d_pt_start.p, A->d_row_cam.p, A->d_row_pt.p, D, b, lhs, n, rhs);
     if (A->has_big_tiles)
       hipLaunchKernelGGL(k_big_chunk_eliminate, dim3(A->num_tiles), dim3(kBlock), 0, st, E, F, A->d_tile_row.p,
                        A->d_tile_pt.p, A->d_row_cam.p, D, b, lhs, n, rhs);
