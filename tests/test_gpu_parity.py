@@ -260,3 +260,75 @@ def test_generic_layout_products(ctx, oracle):
         assert relerr(A.left_multiply(y), oracle.left_multiply(bs, values, y)) < 1e-14
         assert relerr(A.squared_column_norm(), oracle.squared_column_norm(bs, values)) < 1e-14
         A.close()
+
+
+def test_host_adapter_cpp():
+    """The C++ adapter behind the mirrored LinearSolver interface (host/cx_linear_solver.h):
+    every solver type against the normal equations, and the LM call sequence."""
+    import os
+    import subprocess
+    from conftest import PKG_DIR
+    host = os.path.join(PKG_DIR, "host")
+    subprocess.check_call(["make", "-s", "-C", host, "test_host_adapter"])
+    out = subprocess.run([os.path.join(host, "test_host_adapter")], capture_output=True, text=True, timeout=300)
+    print(out.stdout)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "ALL OK" in out.stdout
+
+
+def test_rccl_single_rank_communicator(ctx):
+    """librccl is resolved with dlopen and a 1-rank communicator all-reduces in place
+    (the N > 1 data path; more ranks need more GPUs than the test box has)."""
+    c2 = cx.Context(0)
+    uid = cx.Context.unique_id()
+    assert len(uid) == 128
+    c2.set_comm(0, 1, uid)
+    assert c2.rank == 0 and c2.num_ranks == 1
+    v = np.arange(1000, dtype=np.float64)
+    d = c2.to_device(v)
+    c2.allreduce_sum(d)
+    c2.allreduce_sum(d, offset=10, count=100)
+    c2.synchronize()
+    np.testing.assert_array_equal(d.to_host(), v)
+    c2.close()
+
+
+def test_shard_additivity_on_device(ctx, oracle):
+    """What the multi-GPU path relies on: camera-space results of point shards add up to the
+    result of the whole problem (S x, reduced rhs, explicit S), point-space results are local."""
+    prob, bs, order, vals, b, D = make(12, 300, 1400, 11, "random")
+    C, P, O = prob.num_cameras, prob.num_points, prob.num_observations
+    nf = 9 * C
+    A = cx.Matrix(ctx, bs, P)
+    A.set_values(vals)
+    x = np.random.default_rng(1).standard_normal(nf)
+    y_full, rhs_full = cx.implicit_schur_multiply(ctx, A, D, b, x, nf)
+    lhs_full, r_full = cx.eliminate_dense(ctx, A, b, D, nf)
+    z = np.random.default_rng(2).standard_normal(nf)
+    xb_full = cx.back_substitute(ctx, A, b, D, z)
+    Df2x = D[3 * P:] ** 2 * x
+    bounds = cx.partition_points(bs, P, 3)
+    y_sum, rhs_sum, lhs_sum, r_sum = np.zeros(nf), np.zeros(nf), np.zeros((nf, nf)), np.zeros(nf)
+    rows_pt = bs.cells["block_id"][0::2]
+    for k in range(3):
+        lo, hi = int(bounds[k]), int(bounds[k + 1])
+        sub = cx.bal.shard(prob, lo, hi)
+        sbs, sorder = cx.bal.build_structure(sub)
+        rows = np.flatnonzero((rows_pt >= lo) & (rows_pt < hi))
+        svals = np.concatenate([vals[:6 * O].reshape(-1, 6)[rows].ravel(), vals[6 * O:].reshape(-1, 18)[rows].ravel()])
+        sb = b.reshape(-1, 2)[rows].ravel()
+        sD = np.concatenate([D[3 * lo:3 * hi], D[3 * P:]])
+        SA = cx.Matrix(ctx, sbs, sub.num_points)
+        SA.set_values(svals)
+        y, rhs = cx.implicit_schur_multiply(ctx, SA, sD, sb, x, nf)
+        y_sum += y - Df2x
+        rhs_sum += rhs
+        lhs, r = cx.eliminate_dense(ctx, SA, sb, sD, nf)
+        lhs_sum += lhs - np.diag(D[3 * P:] ** 2)
+        r_sum += r
+        xb = cx.back_substitute(ctx, SA, sb, sD, z)
+        assert relerr(xb[:3 * (hi - lo)], xb_full[3 * lo:3 * hi]) < 1e-12
+        SA.close()
+    assert relerr(y_sum + Df2x, y_full) < 1e-12 and relerr(rhs_sum, rhs_full) < 1e-12
+    assert relerr(np.triu(lhs_sum + np.diag(D[3 * P:] ** 2)), np.triu(lhs_full)) < 1e-11 and relerr(r_sum, r_full) < 1e-12
+    A.close()
