@@ -109,6 +109,9 @@ struct cx_matrix {
   DevBuf<cx_cell> d_cells;
   DevBuf<int32_t> d_chunk_start;  // generic eliminator chunks (row ranges), [num_chunks+1]
   int32_t num_chunks = 0;
+  std::vector<int64_t> blk_off;   // packed size^2 offsets of the column blocks, [Cb+1]
+  DevBuf<int64_t> d_blk_off;
+  bool generic_ready = false;
 
   // values
   DevBuf<double> d_values;

@@ -15,29 +15,11 @@
 #include "cx_internal.h"
 #include "cx_kernels.h"
 #include "cx_schur.h"
+#include "cx_solver_internal.h"
 
 static int grid_for(int64_t n, int block) { return int((n + block - 1) / block); }
 
 // ------------------------------------------------------------- CG device state
-enum CgFlag : int {
-  CG_RUNNING = 0,
-  CG_CONVERGED_Q = 1,
-  CG_CONVERGED_R = 2,
-  CG_MAX_ITER = 3,
-  CG_FAIL_RHO = 4,
-  CG_FAIL_BETA = 5,
-  CG_INDEFINITE = 6,
-  CG_FAIL_ALPHA = 7
-};
-
-struct CgState {
-  double rho, last_rho, beta, pq, alpha, Q0, Q1, norm_r, zeta;
-  double tol_r, q_tol;
-  double s0, s1;  // reduction results
-  int flag, iter, min_iter, max_iter;
-};
-
-constexpr int kRedBlocks = 512;  // fixed grid of the two-stage reductions (deterministic)
 
 // partial[blockIdx] = sum a.b ; partial[kRedBlocks + blockIdx] = sum c.d  (second pair optional)
 __global__ __launch_bounds__(256) void k_dot2_partial(const double* __restrict__ a, const double* __restrict__ b,
@@ -192,63 +174,6 @@ __global__ __launch_bounds__(kBlock) void k_point_jacobi(const double* __restric
 }
 
 // ------------------------------------------------------------------ operators
-struct LinOp {
-  virtual ~LinOp() = default;
-  virtual int64_t size() const = 0;
-  virtual int apply(const double* x, double* y) = 0;  // y = A x
-};
-
-// Per-kernel device time of the last solve, sampled with HIP event pairs on the
-// context stream (read back after the solve; no synchronisation inside the loop).
-struct KernelTimer {
-  static constexpr int kSlots = 4, kMaxSamples = 64;
-  const char* names[kSlots] = {"k_chunk_pass<0>", "k_cam_ft+k_cam_reduce9", "k_right_239", "k_left_e_239+k_cam_ft"};
-  hipEvent_t ev[kSlots][kMaxSamples][2] = {};
-  int count[kSlots] = {};
-  int launches[kSlots] = {};
-  double total_ms[kSlots] = {};
-  bool created = false;
-  void reset() { for (int i = 0; i < kSlots; ++i) { count[i] = 0; launches[i] = 0; total_ms[i] = 0.0; } }
-  int begin(int slot, hipStream_t st) {
-    if (!created) {
-      for (auto& a : ev) for (auto& b : a) for (auto& e : b) CX_HIP(hipEventCreate(&e));
-      created = true;
-    }
-    ++launches[slot];
-    if (count[slot] < kMaxSamples) CX_HIP(hipEventRecord(ev[slot][count[slot]][0], st));
-    return CX_OK;
-  }
-  int end(int slot, hipStream_t st) {
-    if (count[slot] < kMaxSamples) { CX_HIP(hipEventRecord(ev[slot][count[slot]][1], st)); ++count[slot]; }
-    return CX_OK;
-  }
-  int collect() {  // call after the stream has been synchronised
-    for (int s = 0; s < kSlots; ++s) {
-      total_ms[s] = 0.0;
-      for (int i = 0; i < count[s]; ++i) {
-        float f = 0.f;
-        CX_HIP(hipEventElapsedTime(&f, ev[s][i][0], ev[s][i][1]));
-        total_ms[s] += f;
-      }
-    }
-    return CX_OK;
-  }
-  ~KernelTimer() {
-    if (created) for (auto& a : ev) for (auto& b : a) for (auto& e : b) (void)hipEventDestroy(e);
-  }
-};
-
-struct cx_solver {
-  cx_context* ctx = nullptr;
-  cx_solver_options opt{};
-  cx_solve_timing timing{};
-  KernelTimer ktimer;
-  // persistent device scratch
-  DevBuf<double> v_p, v_r, v_z, v_tmp, v_x, v_rhs, v_rows, v_rows2, v_cols;
-  DevBuf<double> ete_inv, cam_blocks, pt_blocks, g_e, lhs, partial;
-  DevBuf<CgState> state;
-  DevBuf<int> flag;
-};
 
 namespace {
 
@@ -670,9 +595,23 @@ int SolveDenseSchur239(cx_solver* S, cx_matrix* A, const double* b, const double
 
 }  // namespace
 
+int cx_cg_run(cx_solver* S, int64_t n, int64_t shared0, LinOp& lhs, LinOp& pre, const double* rhs, double* x,
+              bool zero_initial, double r_tol, double q_tol, cx_summary* summary) {
+  CgDriver cg{S, S->ctx, S->ctx->stream, n, shared0};
+  return cg.run(lhs, pre, rhs, x, zero_initial, r_tol, q_tol, summary);
+}
+
+int cx_check_flag(cx_solver* S, const char* what, cx_summary* summary, bool* failed) {
+  return CheckFlag(S, what, summary, failed);
+}
+
 // generic (dynamic block size) solvers live in cx_generic.hip
 int cxg_solve(cx_solver* S, cx_matrix* A, const double* b, const double* D, double r_tol, double q_tol, double* x,
               cx_summary* summary);
+int cxg_eliminate_dense(cx_solver* S, cx_matrix* A, const double* b, const double* D, double* lhs, double* rhs);
+int cxg_back_substitute(cx_solver* S, cx_matrix* A, const double* b, const double* D, const double* z, double* x);
+int cxg_implicit_schur_multiply(cx_solver* S, cx_matrix* A, const double* D, const double* b, const double* x,
+                                double* y, double* rhs);
 
 extern "C" {
 
@@ -777,14 +716,21 @@ int cx_solver_solve(cx_solver* S, cx_matrix* A, const double* b, const cx_per_so
 int cx_schur_eliminate_dense(cx_context* ctx, cx_matrix* A, const double* b, const double* D, double* lhs,
                              double* rhs, int32_t memspace) {
   CX_CHECK_ARG(ctx && A && lhs);
-  if (!A->is239) { cx_set_error("cx_schur_eliminate_dense: matrix is not on the static <2,3,9> path; use cx_solver_solve"); return CX_ERR_UNSUPPORTED; }
-  const int64_t nf = 9 * int64_t(A->C);
+  CX_CHECK_ARG(A->nelim > 0);
+  const int64_t nf = A->num_cols_f;
   HostOrDevice hb(ctx), hD(ctx), hl(ctx), hr(ctx);
   CX_TRY(hb.in(b, size_t(A->num_rows), memspace));
   CX_TRY(hD.in(D, size_t(A->num_cols), memspace));
   CX_TRY(hl.inout(lhs, size_t(nf) * nf, memspace, false));
   CX_TRY(hr.inout(rhs, size_t(nf), memspace, false));
-  CX_TRY(cxs_eliminate_dense(A, hb.dptr, hD.dptr, true, hl.dptr, hb.dptr ? hr.dptr : nullptr));
+  if (A->is239) {
+    CX_TRY(cxs_eliminate_dense(A, hb.dptr, hD.dptr, true, hl.dptr, hb.dptr ? hr.dptr : nullptr));
+  } else {
+    cx_solver tmp;
+    tmp.ctx = ctx;
+    CX_TRY(cxg_eliminate_dense(&tmp, A, hb.dptr, hD.dptr, hl.dptr, hb.dptr ? hr.dptr : nullptr));
+    CX_HIP(hipStreamSynchronize(ctx->stream));
+  }
   CX_TRY(hl.out());
   return hr.out();
 }
@@ -792,8 +738,19 @@ int cx_schur_eliminate_dense(cx_context* ctx, cx_matrix* A, const double* b, con
 int cx_schur_back_substitute(cx_context* ctx, cx_matrix* A, const double* b, const double* D, const double* z,
                              double* x, int32_t memspace) {
   CX_CHECK_ARG(ctx && A && b && z && x);
-  if (!A->is239) { cx_set_error("cx_schur_back_substitute: matrix is not on the static <2,3,9> path"); return CX_ERR_UNSUPPORTED; }
+  CX_CHECK_ARG(A->nelim > 0);
   HostOrDevice hb(ctx), hD(ctx), hz(ctx), hx(ctx);
+  if (!A->is239) {
+    CX_TRY(hb.in(b, size_t(A->num_rows), memspace));
+    CX_TRY(hD.in(D, size_t(A->num_cols), memspace));
+    CX_TRY(hz.in(z, size_t(A->num_cols_f), memspace));
+    CX_TRY(hx.inout(x, size_t(A->num_cols), memspace, true));
+    cx_solver tmp;
+    tmp.ctx = ctx;
+    CX_TRY(cxg_back_substitute(&tmp, A, hb.dptr, hD.dptr, hz.dptr, hx.dptr));
+    CX_HIP(hipStreamSynchronize(ctx->stream));
+    return hx.out();
+  }
   DevBuf<double> ete;
   DevBuf<int> flag;
   CX_TRY(ete.alloc(9 * size_t(A->P)));
@@ -810,9 +767,23 @@ int cx_schur_back_substitute(cx_context* ctx, cx_matrix* A, const double* b, con
 int cx_implicit_schur_multiply(cx_context* ctx, cx_matrix* A, const double* D, const double* b, const double* x,
                                double* y, double* rhs, int32_t memspace) {
   CX_CHECK_ARG(ctx && A);
-  if (!A->is239) { cx_set_error("cx_implicit_schur_multiply: matrix is not on the static <2,3,9> path"); return CX_ERR_UNSUPPORTED; }
-  const int64_t nf = 9 * int64_t(A->C);
+  CX_CHECK_ARG(A->nelim > 0);
+  const int64_t nf = A->num_cols_f;
   HostOrDevice hb(ctx), hD(ctx), hx(ctx), hy(ctx), hr(ctx);
+  if (!A->is239) {
+    CX_TRY(hb.in(b, size_t(A->num_rows), memspace));
+    CX_TRY(hD.in(D, size_t(A->num_cols), memspace));
+    CX_TRY(hx.in(x, size_t(nf), memspace));
+    CX_TRY(hy.inout(y, size_t(nf), memspace, false));
+    CX_TRY(hr.inout(rhs, size_t(nf), memspace, false));
+    cx_solver tmp;
+    tmp.ctx = ctx;
+    CX_TRY(cxg_implicit_schur_multiply(&tmp, A, hD.dptr, hb.dptr, hx.dptr, hy.dptr, hb.dptr ? hr.dptr : nullptr));
+    CX_HIP(hipStreamSynchronize(ctx->stream));
+    if (hx.dptr && hy.dptr) CX_TRY(hy.out());
+    if (hb.dptr) CX_TRY(hr.out());
+    return CX_OK;
+  }
   DevBuf<double> ete, rows;
   DevBuf<int> flag;
   CX_TRY(ete.alloc(9 * size_t(A->P)));

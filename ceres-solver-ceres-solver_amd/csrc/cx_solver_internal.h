@@ -1,0 +1,94 @@
+// Declarations shared by the solver translation units (cx_solver.hip, cx_generic.hip).
+#ifndef CX_SOLVER_INTERNAL_H_
+#define CX_SOLVER_INTERNAL_H_
+
+#include "cx_internal.h"
+
+enum CgFlag : int {
+  CG_RUNNING = 0,
+  CG_CONVERGED_Q = 1,
+  CG_CONVERGED_R = 2,
+  CG_MAX_ITER = 3,
+  CG_FAIL_RHO = 4,
+  CG_FAIL_BETA = 5,
+  CG_INDEFINITE = 6,
+  CG_FAIL_ALPHA = 7
+};
+
+struct CgState {
+  double rho, last_rho, beta, pq, alpha, Q0, Q1, norm_r, zeta;
+  double tol_r, q_tol;
+  double s0, s1;  // reduction results
+  int flag, iter, min_iter, max_iter;
+};
+
+constexpr int kRedBlocks = 512;  // fixed grid of the two-stage reductions (deterministic)
+
+struct LinOp {
+  virtual ~LinOp() = default;
+  virtual int64_t size() const = 0;
+  virtual int apply(const double* x, double* y) = 0;  // y = A x
+};
+
+// Per-kernel device time of the last solve, sampled with HIP event pairs on the
+// context stream (read back after the solve; no synchronisation inside the loop).
+struct KernelTimer {
+  static constexpr int kSlots = 4, kMaxSamples = 64;
+  const char* names[kSlots] = {"k_chunk_pass<0>", "k_cam_ft+k_cam_reduce9", "k_right_239", "k_left_e_239+k_cam_ft"};
+  hipEvent_t ev[kSlots][kMaxSamples][2] = {};
+  int count[kSlots] = {};
+  int launches[kSlots] = {};
+  double total_ms[kSlots] = {};
+  bool created = false;
+  void reset() { for (int i = 0; i < kSlots; ++i) { count[i] = 0; launches[i] = 0; total_ms[i] = 0.0; } }
+  int begin(int slot, hipStream_t st) {
+    if (!created) {
+      for (auto& a : ev) for (auto& b : a) for (auto& e : b) CX_HIP(hipEventCreate(&e));
+      created = true;
+    }
+    ++launches[slot];
+    if (count[slot] < kMaxSamples) CX_HIP(hipEventRecord(ev[slot][count[slot]][0], st));
+    return CX_OK;
+  }
+  int end(int slot, hipStream_t st) {
+    if (count[slot] < kMaxSamples) { CX_HIP(hipEventRecord(ev[slot][count[slot]][1], st)); ++count[slot]; }
+    return CX_OK;
+  }
+  int collect() {  // call after the stream has been synchronised
+    for (int s = 0; s < kSlots; ++s) {
+      total_ms[s] = 0.0;
+      for (int i = 0; i < count[s]; ++i) {
+        float f = 0.f;
+        CX_HIP(hipEventElapsedTime(&f, ev[s][i][0], ev[s][i][1]));
+        total_ms[s] += f;
+      }
+    }
+    return CX_OK;
+  }
+  ~KernelTimer() {
+    if (created) for (auto& a : ev) for (auto& b : a) for (auto& e : b) (void)hipEventDestroy(e);
+  }
+};
+
+struct cx_solver {
+  cx_context* ctx = nullptr;
+  cx_solver_options opt{};
+  cx_solve_timing timing{};
+  KernelTimer ktimer;
+  // persistent device scratch
+  DevBuf<double> v_p, v_r, v_z, v_tmp, v_x, v_rhs, v_rows, v_rows2, v_cols;
+  DevBuf<double> ete_inv, cam_blocks, pt_blocks, g_e, lhs, partial;
+  DevBuf<CgState> state;
+  DevBuf<int> flag;
+};
+
+// ConjugateGradientsSolver (conjugate_gradients_solver.h:107-305) on device vectors of
+// length n; entries [shared0, n) are replicated over the ranks of a sharded CGNR solve
+// (shared0 == n otherwise).  x holds the initial guess; zero_initial says it is all zeros.
+int cx_cg_run(cx_solver* S, int64_t n, int64_t shared0, LinOp& lhs, LinOp& pre, const double* rhs, double* x,
+              bool zero_initial, double r_tol, double q_tol, cx_summary* summary);
+
+// device flag check shared by the solvers: reads S->flag, fills a FAILURE summary when set
+int cx_check_flag(cx_solver* S, const char* what, cx_summary* summary, bool* failed);
+
+#endif

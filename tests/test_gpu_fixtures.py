@@ -1,0 +1,197 @@
+"""The reference's own fixtures (linear_least_squares_problems.cc problems 0, 2-6; data in
+tests/golden/) through the HIP library's C ABI -- dynamic block sizes, rows without an
+e block, 1x1 .. 3x3 blocks -- against the comment goldens, the oracle and dense algebra.
+Mirrors schur_eliminator_test.cc, implicit_schur_complement_test.cc,
+schur_complement_solver_test.cc, iterative_schur_complement_solver_test.cc."""
+import numpy as np
+import pytest
+
+from conftest import cx, lls_problem
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    c = cx.Context(0)
+    yield c
+    c.close()
+
+
+def dense(bs, values, b, D, nelim):
+    J = bs.to_dense(values)
+    ne = int(bs.col_blocks["size"][:nelim].sum())
+    H = J.T @ J + np.diag(D ** 2)
+    g = J.T @ b
+    P, Q, R = H[:ne, :ne], H[:ne, ne:], H[ne:, ne:]
+    Pinv = np.linalg.inv(P)
+    return H, g, R - Q.T @ Pinv @ Q, g[ne:] - Q.T @ Pinv @ g[:ne], np.linalg.solve(H, g), ne
+
+
+def upper_blocks(S, bs, nelim):
+    out = np.zeros_like(S)
+    cols = bs.col_blocks[nelim:]
+    p0 = int(cols[0]["position"])
+    for i, bi in enumerate(cols):
+        for bj in cols[i:]:
+            r, rs, c, cs = int(bi["position"]) - p0, int(bi["size"]), int(bj["position"]) - p0, int(bj["size"])
+            out[r:r + rs, c:c + cs] = S[r:r + rs, c:c + cs]
+    return out
+
+
+@pytest.mark.parametrize("pid", [2, 4, 5, 6])
+def test_eliminator_and_implicit_schur_on_fixtures(ctx, oracle, pid):
+    bs, values, b, D, nelim, raw = lls_problem(pid)
+    H, g, S, rhs_ref, sol, ne = dense(bs, values, b, D, nelim)
+    nf = bs.num_cols - ne
+    A = cx.Matrix(ctx, bs, nelim)
+    assert not A.is_static_239
+    A.set_values(values)
+    lhs, rhs = cx.eliminate_dense(ctx, A, b, D, nf)
+    scale = np.abs(S).max()
+    assert np.abs(lhs - upper_blocks(S, bs, nelim)).max() <= 1e-13 * scale      # schur_eliminator_test.cc: 1e-14 rel
+    assert np.abs(rhs - rhs_ref).max() <= 1e-13 * max(1.0, np.abs(rhs_ref).max())
+    lhs_o, rhs_o = oracle.schur_eliminate_dense(bs, values, b, D, nelim)
+    assert np.abs(lhs - lhs_o).max() <= 1e-13 * scale
+    x = cx.back_substitute(ctx, A, b, D, sol[ne:])
+    np.testing.assert_allclose(x[:ne], sol[:ne], rtol=1e-10, atol=1e-13)
+    for i in range(nf):                                                          # implicit_schur_complement_test.cc
+        e = np.zeros(nf)
+        e[i] = 1.0
+        y, r = cx.implicit_schur_multiply(ctx, A, D, b, e, nf)
+        assert np.abs(y - S[:, i]).max() <= 1e-13 * scale
+    assert np.abs(r - rhs_ref).max() <= 1e-13 * max(1.0, np.abs(rhs_ref).max())
+    A.close()
+
+
+def test_problem2_comment_goldens_on_device(ctx):
+    """S, r, S\\r, A\\b printed in linear_least_squares_problems.cc:153-186 (D = 0)."""
+    bs, values, b, D, nelim, raw = lls_problem(2)
+    A = cx.Matrix(ctx, bs, nelim)
+    A.set_values(values)
+    lhs, rhs = cx.eliminate_dense(ctx, A, b, None, 3)
+    S = np.triu(lhs) + np.triu(lhs, 1).T
+    np.testing.assert_allclose(S, np.array(raw["S"]), atol=5e-5)
+    np.testing.assert_allclose(rhs, np.array(raw["r"]), atol=5e-5)
+    z, s = cx.dense_cholesky_solve(ctx, lhs, rhs)
+    np.testing.assert_allclose(z, np.array(raw["S_solve_r"]), atol=5e-5)
+    Sv = cx.Solver(ctx, type=cx.DENSE_SCHUR, num_eliminate_blocks=nelim)
+    x, summ = Sv.solve(A, b, None)
+    assert summ.termination_type == cx.SUCCESS
+    np.testing.assert_allclose(x, np.array(raw["x"]), atol=5e-5)
+    Sv.close()
+    A.close()
+
+
+def test_problem0_known_solutions_on_device(ctx):
+    bs, values, b, D, nelim, raw = lls_problem(0)
+    A = cx.Matrix(ctx, bs, 0)
+    A.set_values(values)
+    S = cx.Solver(ctx, type=cx.CGNR, preconditioner_type=cx.JACOBI, num_eliminate_blocks=0, max_num_iterations=50)
+    x, s = S.solve(A, b, None, r_tolerance=1e-14)
+    np.testing.assert_allclose(x, raw["x"], atol=1e-10)
+    x, s = S.solve(A, b, D, r_tolerance=1e-14)
+    np.testing.assert_allclose(x, raw["x_D"], atol=5e-9)
+    S.close()
+    A.close()
+
+
+@pytest.mark.parametrize("pid", [2, 3, 4, 5, 6])
+@pytest.mark.parametrize("stype", ["DENSE_SCHUR", "SPARSE_SCHUR"])
+def test_schur_solvers_on_fixtures(ctx, pid, stype):
+    """schur_complement_solver_test.cc:52-118: |x - x_dense| / n < 1e-10."""
+    bs, values, b, D, nelim, raw = lls_problem(pid)
+    H, g, S, rhs_ref, sol, ne = dense(bs, values, b, D, nelim)
+    A = cx.Matrix(ctx, bs, nelim)
+    A.set_values(values)
+    Sv = cx.Solver(ctx, type=getattr(cx, stype), num_eliminate_blocks=nelim)
+    x, s = Sv.solve(A, b, D)
+    assert s.termination_type == cx.SUCCESS, s.message
+    assert np.all(np.isfinite(x)) and np.linalg.norm(x - sol) / bs.num_cols < 1e-10
+    Sv.close()
+    A.close()
+
+
+@pytest.mark.parametrize("pid", [2, 3, 5])
+@pytest.mark.parametrize("pre", ["SCHUR_JACOBI", "JACOBI", "IDENTITY"])
+def test_iterative_schur_on_fixtures(ctx, oracle, pid, pre):
+    """iterative_schur_complement_solver_test.cc:59-149: max_iter = num_cols, r_tol = 1e-12."""
+    bs, values, b, D, nelim, raw = lls_problem(pid)
+    H, g, S, rhs_ref, sol, ne = dense(bs, values, b, D, nelim)
+    A = cx.Matrix(ctx, bs, nelim)
+    A.set_values(values)
+    Sv = cx.Solver(ctx, type=cx.ITERATIVE_SCHUR, preconditioner_type=getattr(cx, pre), num_eliminate_blocks=nelim,
+                   max_num_iterations=bs.num_cols)
+    x, s = Sv.solve(A, b, D, r_tolerance=1e-12)
+    assert s.termination_type == cx.SUCCESS, s.message
+    assert np.linalg.norm(x - sol) < 1e-11
+    o = oracle.make_options(type=oracle.ITERATIVE_SCHUR, preconditioner_type=getattr(oracle, pre),
+                            num_eliminate_blocks=nelim, max_num_iterations=bs.num_cols)
+    xo, so = oracle.solve(bs, values, b, D, o, r_tolerance=1e-12)
+    assert s.num_iterations == so.num_iterations
+    Sv.close()
+    A.close()
+
+
+@pytest.mark.parametrize("pid", [0, 2, 5])
+@pytest.mark.parametrize("pre", ["JACOBI", "IDENTITY"])
+def test_cgnr_on_fixtures(ctx, pid, pre):
+    bs, values, b, D, nelim, raw = lls_problem(pid)
+    J = bs.to_dense(values)
+    sol = np.linalg.solve(J.T @ J + np.diag(D ** 2), J.T @ b)
+    A = cx.Matrix(ctx, bs, 0)
+    A.set_values(values)
+    Sv = cx.Solver(ctx, type=cx.CGNR, preconditioner_type=getattr(cx, pre), num_eliminate_blocks=0, max_num_iterations=100)
+    x, s = Sv.solve(A, b, D, r_tolerance=1e-13)
+    assert s.termination_type == cx.SUCCESS, s.message
+    np.testing.assert_allclose(x, sol, atol=1e-10)
+    Sv.close()
+    A.close()
+
+
+def test_generic_path_on_random_block_problem(ctx, oracle):
+    """A larger random problem with mixed block sizes (e 2/3, f 4/6/9, rows 1-3, some rows with
+    two f cells, some without an e block) against the oracle."""
+    rng = np.random.default_rng(8)
+    ne_blocks, nf_blocks = 40, 7
+    col_sizes = [int(rng.choice([2, 3])) for _ in range(ne_blocks)] + [int(rng.choice([4, 6, 9])) for _ in range(nf_blocks)]
+    rows, pos = [], 0
+    for e in range(ne_blocks):
+        for _ in range(int(rng.integers(2, 6))):
+            rs = int(rng.integers(1, 4))
+            fcells = sorted(rng.choice(nf_blocks, size=int(rng.integers(1, 3)), replace=False).tolist())
+            cells = [(e, pos)]
+            pos += rs * col_sizes[e]
+            for f in fcells:
+                cells.append((ne_blocks + f, pos))
+                pos += rs * col_sizes[ne_blocks + f]
+            rows.append((rs, cells))
+    for _ in range(5):   # rows without an e block
+        rs = int(rng.integers(1, 3))
+        fcells = sorted(rng.choice(nf_blocks, size=2, replace=False).tolist())
+        cells = []
+        for f in fcells:
+            cells.append((ne_blocks + f, pos))
+            pos += rs * col_sizes[ne_blocks + f]
+        rows.append((rs, cells))
+    bs = cx.BlockStructure.from_rows(col_sizes, rows)
+    values = rng.standard_normal(pos)
+    b = rng.standard_normal(bs.num_rows)
+    D = rng.uniform(0.5, 1.5, bs.num_cols)
+    A = cx.Matrix(ctx, bs, ne_blocks)
+    A.set_values(values)
+    nf = int(sum(col_sizes[ne_blocks:]))
+    lhs, rhs = cx.eliminate_dense(ctx, A, b, D, nf)
+    lhs_o, rhs_o = oracle.schur_eliminate_dense(bs, values, b, D, ne_blocks)
+    assert np.abs(lhs - lhs_o).max() <= 1e-12 * np.abs(lhs_o).max() and np.abs(rhs - rhs_o).max() <= 1e-12 * np.abs(rhs_o).max()
+    for stype, pre in (("ITERATIVE_SCHUR", "JACOBI"), ("ITERATIVE_SCHUR", "SCHUR_JACOBI"), ("DENSE_SCHUR", "IDENTITY")):
+        Sv = cx.Solver(ctx, type=getattr(cx, stype), preconditioner_type=getattr(cx, pre), num_eliminate_blocks=ne_blocks,
+                       max_num_iterations=300)
+        x, s = Sv.solve(A, b, D, r_tolerance=-1.0, q_tolerance=0.05)
+        o = oracle.make_options(type=getattr(oracle, stype), preconditioner_type=getattr(oracle, pre),
+                                num_eliminate_blocks=ne_blocks, max_num_iterations=300)
+        xo, so = oracle.solve(bs, values, b, D, o, r_tolerance=-1.0, q_tolerance=0.05)
+        assert s.termination_type == so.termination_type and s.num_iterations == so.num_iterations, (s.message, so.message)
+        assert np.abs(x - xo).max() <= 1e-9 * np.abs(xo).max()
+        Sv.close()
+    A.close()
