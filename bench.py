@@ -125,6 +125,9 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default="final13682", choices=sorted(load_cx().bal.PRESETS))
+    ap.add_argument("--solver", default="iterative_schur", choices=["iterative_schur", "dense_schur", "cgnr"],
+                    help="linear solver of the step (the headline metric uses iterative_schur)")
+    ap.add_argument("--preconditioner", default="jacobi", choices=["jacobi", "schur_jacobi", "identity"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=0)
     args = ap.parse_args()
@@ -166,7 +169,9 @@ def main():
     t_gen = time.time() - t_gen
 
     ev, A, b, D, cost, eval_ms = lm_prepare_device(cx, ctx, prob)
-    solver_kw = dict(type=cx.ITERATIVE_SCHUR, preconditioner_type=cx.JACOBI, num_eliminate_blocks=prob.num_points,
+    stype = {"iterative_schur": cx.ITERATIVE_SCHUR, "dense_schur": cx.DENSE_SCHUR, "cgnr": cx.CGNR}[args.solver]
+    ptype = {"jacobi": cx.JACOBI, "schur_jacobi": cx.SCHUR_JACOBI, "identity": cx.IDENTITY}[args.preconditioner]
+    solver_kw = dict(type=stype, preconditioner_type=ptype, num_eliminate_blocks=prob.num_points,
                      max_num_iterations=500, min_num_iterations=0, residual_reset_period=10)
     S = cx.Solver(ctx, **solver_kw)
     x = ctx.empty(A.num_cols)
@@ -245,15 +250,16 @@ def main():
     out = None
     if rank == 0:
         cpu = None
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and args.solver == "iterative_schur" and args.preconditioner == "jacobi":
             threads = args.cpu_threads or min(16, os.cpu_count() or 1)
             cpu = cpu_baseline(cx, full, solver_kw, threads)
         out = {
             "metric": "linear_solve_ms_per_iter", "value": ms_per_step, "unit": "ms",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
             "higher_is_better": False, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "%s: ITERATIVE_SCHUR + JACOBI, q_tol=0.1, synthetic BAL-shaped J "
-                                   "(%d cameras, %d points, %d residual blocks)" % (args.workload, C, P, O),
+            "config": {"workload": "%s: %s + %s, q_tol=0.1, synthetic BAL-shaped J "
+                                   "(%d cameras, %d points, %d residual blocks)" % (args.workload, args.solver.upper(),
+                                                                                   args.preconditioner.upper(), C, P, O),
                        "cameras": C, "points": P, "residual_blocks": O, "cg_iterations": int(summ.num_iterations),
                        "termination": int(summ.termination_type), "initial_cost": cost,
                        "sharding": "points over %d rank(s), RCCL all-reduce of camera-space sums" % world},

@@ -132,10 +132,14 @@ struct cx_matrix {
   DevBuf<double> d_Ft;                   // camera-major copy of the F cells [O][18]
   bool ft_valid = false;
   DevBuf<double> d_partials;             // camera-major partial sums [S][81]
+  DevBuf<double> d_elim_blk, d_elim_ete, d_elim_diag, d_elim_rows;  // explicit-S scratch (cx_schur.hip)
+  DevBuf<int> d_elim_flag;
 
   // scratch for host-pointer calls
   DevBuf<double> d_x, d_y;
   float last_ms = 0.f;
+  // when set, the product kernels return at once if *stop != 0 (CG termination flag)
+  const int* stop = nullptr;
 };
 
 // upload/download helpers for the (memspace) convention

@@ -15,24 +15,31 @@
 
 constexpr int kBlock = 256;  // threads per workgroup = rows per tile (4 wavefronts of 64)
 
-// Stage `nvalid` (<= kBlock) consecutive cells of DPR doubles each, starting at
-// `base`, through `lds` (kBlock*DPR doubles) and return the calling thread's own
-// cell in out[].  base must be 16-byte aligned.  Contains two block barriers.
+// Stage `nvalid` (<= kBlock) consecutive cells of DPR doubles each, starting at `base`
+// (16-byte aligned), so that the calling thread ends up with its own cell.  Two steps, so a
+// kernel can put the global loads of several arrays in flight before the first barrier:
+//   load_cells      issues the coalesced 16-byte loads (piece i*kBlock + tid of the run)
+//   exchange_cells  parks the pieces in `lds` (kBlock*DPR doubles) and reads the own cell back
+//                   (two block barriers)
 template <int DPR>
-__device__ __forceinline__ void stage_cells(const double* __restrict__ base, int nvalid,
-                                            double* __restrict__ lds, double (&out)[DPR]) {
+__device__ __forceinline__ void load_cells(const double* __restrict__ base, int nvalid, double2 (&v)[DPR / 2]) {
   static_assert(DPR % 2 == 0, "cells are moved as 16-byte pieces");
-  constexpr int kPieces = DPR / 2;  // double2 pieces per row
+  constexpr int kPieces = DPR / 2;
   const int tid = threadIdx.x;
   const double2* __restrict__ src = reinterpret_cast<const double2*>(base);
-  double2* l2 = reinterpret_cast<double2*>(lds);
-  double2 v[kPieces];
   const int total = nvalid * kPieces;
 #pragma unroll
   for (int i = 0; i < kPieces; ++i) {
     const int idx = i * kBlock + tid;
     v[i] = (idx < total) ? src[idx] : make_double2(0.0, 0.0);
   }
+}
+
+template <int DPR>
+__device__ __forceinline__ void exchange_cells(const double2 (&v)[DPR / 2], double* __restrict__ lds, double (&out)[DPR]) {
+  constexpr int kPieces = DPR / 2;
+  const int tid = threadIdx.x;
+  double2* l2 = reinterpret_cast<double2*>(lds);
 #pragma unroll
   for (int i = 0; i < kPieces; ++i) l2[i * kBlock + tid] = v[i];
   __syncthreads();
@@ -44,6 +51,27 @@ __device__ __forceinline__ void stage_cells(const double* __restrict__ base, int
   }
   __syncthreads();
 }
+
+template <int DPR>
+__device__ __forceinline__ void stage_cells(const double* __restrict__ base, int nvalid,
+                                            double* __restrict__ lds, double (&out)[DPR]) {
+  double2 v[DPR / 2];
+  load_cells<DPR>(base, nvalid, v);
+  exchange_cells<DPR>(v, lds, out);
+}
+
+// XCD-aware block -> work item map for camera-major kernels.  Workgroups are dealt round-robin
+// over the 8 XCDs (blockIdx % 8 picks the XCD), so giving XCD x the contiguous range
+// [x*per, (x+1)*per) of segments makes workgroups that run at the same time on one XCD work on
+// neighbouring cameras, whose rows share cache lines of the row-sized vector they gather from
+// (each XCD has its own L2).  Launch 8*per blocks; returns -1 for the padding blocks.
+// Placement only changes speed, never results.
+__device__ __forceinline__ int xcd_segment(int num_items) {
+  const int per = (num_items + 7) >> 3;
+  const int s = int(blockIdx.x & 7) * per + int(blockIdx.x >> 3);
+  return s < num_items ? s : -1;
+}
+__host__ __device__ inline int xcd_grid(int num_items) { return ((num_items + 7) >> 3) << 3; }
 
 // Sum of v over the 64 lanes of a wavefront, returned in every lane.
 __device__ __forceinline__ double wave_sum(double v) {

@@ -23,45 +23,53 @@ __global__ __launch_bounds__(kBlock) void k_right_239(const double* __restrict__
                                                       const double* __restrict__ xe,
                                                       const double* __restrict__ xf,
                                                       double* __restrict__ y, int64_t O, int use_e,
-                                                      int use_f, int accumulate) {
+                                                      int use_f, int accumulate, const int* __restrict__ stop) {
   __shared__ double lds[kBlock * 18];
+  if (stop && *stop) return;
   const int64_t r0 = int64_t(blockIdx.x) * kBlock;
   const int nvalid = int(min(int64_t(kBlock), O - r0));
   const int tid = threadIdx.x;
   const int64_t r = r0 + tid;
+  // all HBM requests of the tile first (ids, F, E, y), then the vector gathers (L2)
+  const bool live = tid < nvalid;
+  const int cam = (use_f && live) ? row_cam[r] : 0;
+  const int pt = (use_e && live) ? row_pt[r] : 0;
+  double2 fv[9], ev[3];
+  if (use_f) load_cells<18>(F + 18 * r0, nvalid, fv);
+  if (use_e) load_cells<6>(E + 6 * r0, nvalid, ev);
+  double2 yv = make_double2(0.0, 0.0);
+  if (accumulate && live) yv = reinterpret_cast<const double2*>(y)[r];
   double acc0 = 0.0, acc1 = 0.0;
   if (use_f) {
-    double f[18];
-    stage_cells<18>(F + 18 * r0, nvalid, lds, f);
-    if (tid < nvalid) {
-      const double* xc = xf + 9 * int64_t(row_cam[r]);
+    double xv[9];
+    const double* xc = xf + 9 * int64_t(cam);
 #pragma unroll
-      for (int k = 0; k < 9; ++k) {
-        const double xv = xc[k];
-        acc0 += f[k] * xv;
-        acc1 += f[9 + k] * xv;
-      }
+    for (int k = 0; k < 9; ++k) xv[k] = live ? xc[k] : 0.0;
+    double f[18];
+    exchange_cells<18>(fv, lds, f);
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+      acc0 += f[k] * xv[k];
+      acc1 += f[9 + k] * xv[k];
     }
   }
   if (use_e) {
-    double e[6];
-    stage_cells<6>(E + 6 * r0, nvalid, lds, e);
-    if (tid < nvalid) {
-      const double* xp = xe + 3 * int64_t(row_pt[r]);
+    double xv[3];
+    const double* xp = xe + 3 * int64_t(pt);
 #pragma unroll
-      for (int k = 0; k < 3; ++k) {
-        const double xv = xp[k];
-        acc0 += e[k] * xv;
-        acc1 += e[3 + k] * xv;
-      }
+    for (int k = 0; k < 3; ++k) xv[k] = live ? xp[k] : 0.0;
+    double e[6];
+    exchange_cells<6>(ev, lds, e);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      acc0 += e[k] * xv[k];
+      acc1 += e[3 + k] * xv[k];
     }
   }
-  if (tid < nvalid) {
-    double2* yp = reinterpret_cast<double2*>(y) + r;
-    double2 v = accumulate ? *yp : make_double2(0.0, 0.0);
-    v.x += acc0;
-    v.y += acc1;
-    *yp = v;
+  if (live) {
+    yv.x += acc0;
+    yv.y += acc1;
+    reinterpret_cast<double2*>(y)[r] = yv;
   }
 }
 
@@ -71,8 +79,10 @@ __global__ __launch_bounds__(kBlock) void k_left_e_239(const double* __restrict_
                                                        const int32_t* __restrict__ tile_pt,
                                                        const int32_t* __restrict__ pt_start,
                                                        const double* __restrict__ x,
-                                                       double* __restrict__ ye, int accumulate) {
+                                                       double* __restrict__ ye, int accumulate,
+                                                       const int* __restrict__ stop) {
   __shared__ double lds[kBlock * 6];
+  if (stop && *stop) return;
   __shared__ double w[kBlock * 3];
   __shared__ double red[3 * 4];
   const int t = blockIdx.x, tid = threadIdx.x;
@@ -140,10 +150,13 @@ __global__ __launch_bounds__(kBlock) void k_cam_ft(const double* __restrict__ Ft
                                                    const int32_t* __restrict__ cam_rows,
                                                    const int32_t* __restrict__ seg_begin,
                                                    const double* __restrict__ t,
-                                                   double* __restrict__ partial) {
+                                                   double* __restrict__ partial, const int* __restrict__ stop,
+                                                   int num_segs) {
   __shared__ double lds[kBlock * 18];
   __shared__ double red[9 * 4];
-  const int s = blockIdx.x, tid = threadIdx.x;
+  if (stop && *stop) return;
+  const int s = xcd_segment(num_segs), tid = threadIdx.x;
+  if (s < 0) return;
   const int b = seg_begin[s], e = seg_begin[s + 1];
   double acc[9];
 #pragma unroll
@@ -165,7 +178,9 @@ __global__ __launch_bounds__(kBlock) void k_cam_ft(const double* __restrict__ Ft
 // optionally + d[9c+k]^2 * x[9c+k]
 __global__ void k_cam_reduce9(const double* __restrict__ partial, const int32_t* __restrict__ cam_seg_start,
                               double* __restrict__ yf, int C, int accumulate,
-                              const double* __restrict__ d, const double* __restrict__ x) {
+                              const double* __restrict__ d, const double* __restrict__ x,
+                              const int* __restrict__ stop) {
+  if (stop && *stop) return;
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= C * 9) return;
   const int c = i / 9, k = i - c * 9;
@@ -445,11 +460,11 @@ int cxk_ft_multiply(cx_matrix* A, const double* t, double* yf, bool accumulate) 
   CX_TRY(cx_matrix_ensure_ft(A));
   hipStream_t st = A->ctx->stream;
   if (A->num_segs > 0)
-    hipLaunchKernelGGL(k_cam_ft, dim3(A->num_segs), dim3(kBlock), 0, st, A->d_Ft.p, A->d_cam_rows.p,
-                       A->d_seg_begin.p, t, A->d_partials.p);
+    hipLaunchKernelGGL(k_cam_ft, dim3(xcd_grid(A->num_segs)), dim3(kBlock), 0, st, A->d_Ft.p, A->d_cam_rows.p,
+                       A->d_seg_begin.p, t, A->d_partials.p, A->stop, A->num_segs);
   hipLaunchKernelGGL(k_cam_reduce9, dim3(grid_for(int64_t(A->C) * 9, 256)), dim3(256), 0, st,
                      A->d_partials.p, A->d_cam_seg_start.p, yf, A->C, accumulate ? 1 : 0,
-                     (const double*)nullptr, (const double*)nullptr);
+                     (const double*)nullptr, (const double*)nullptr, A->stop);
   CX_HIP(hipGetLastError());
   return CX_OK;
 }
@@ -459,7 +474,7 @@ int cxk_right_multiply(cx_matrix* A, const double* x, double* y) {
   if (A->is239) {
     hipLaunchKernelGGL(k_right_239, dim3(grid_for(A->O, kBlock)), dim3(kBlock), 0, st, A->d_values.p,
                        A->d_values.p + 6 * A->O, A->d_row_pt.p, A->d_row_cam.p, x, x + 3 * int64_t(A->P), y,
-                       A->O, 1, 1, 1);
+                       A->O, 1, 1, 1, A->stop);
   } else if (A->R > 0) {
     hipLaunchKernelGGL(kg_right, dim3(grid_for(A->R, 128)), dim3(128), 0, st, A->d_rows.p, A->d_cols.p,
                        A->d_rcb.p, A->d_cells.p, A->d_values.p, x, y, A->R);
@@ -472,7 +487,7 @@ int cxk_left_multiply(cx_matrix* A, const double* x, double* y) {
   hipStream_t st = A->ctx->stream;
   if (A->is239) {
     hipLaunchKernelGGL(k_left_e_239, dim3(A->num_tiles), dim3(kBlock), 0, st, A->d_values.p, A->d_tile_row.p,
-                       A->d_tile_pt.p, A->d_pt_start.p, x, y, 1);
+                       A->d_tile_pt.p, A->d_pt_start.p, x, y, 1, A->stop);
     CX_TRY(cxk_ft_multiply(A, x, y + 3 * int64_t(A->P), true));
   } else if (A->R > 0) {
     hipLaunchKernelGGL(kg_left, dim3(grid_for(A->R, 128)), dim3(128), 0, st, A->d_rows.p, A->d_cols.p,
@@ -493,7 +508,7 @@ int cxk_squared_column_norm(cx_matrix* A, double* x) {
                          A->d_partials.p);
     hipLaunchKernelGGL(k_cam_reduce9, dim3(grid_for(int64_t(A->C) * 9, 256)), dim3(256), 0, st,
                        A->d_partials.p, A->d_cam_seg_start.p, x + 3 * int64_t(A->P), A->C, 0,
-                       (const double*)nullptr, (const double*)nullptr);
+                       (const double*)nullptr, (const double*)nullptr, (const int*)nullptr);
   } else {
     CX_HIP(hipMemsetAsync(x, 0, size_t(A->num_cols) * sizeof(double), st));
     if (A->R > 0)

@@ -18,6 +18,9 @@
 #include "cx_kernels.h"
 #include "cx_schur.h"
 
+#include <algorithm>
+#include <cstdlib>
+
 static int grid_for(int64_t n, int block) { return int((n + block - 1) / block); }
 
 // (i, j), i <= j < k, of the q-th pair in row-major order of the upper triangle
@@ -164,40 +167,54 @@ __global__ __launch_bounds__(kBlock) void k_chunk_pass(const double* __restrict_
                                                        const double* __restrict__ ete_inv,
                                                        const double* __restrict__ xf,   // camera vector (SX: x, BACKSUB: z)
                                                        const double* __restrict__ b,    // row vector (RHS, BACKSUB)
-                                                       double* __restrict__ out) {      // t' [2O]  or x_e [3P]
+                                                       double* __restrict__ out,        // t' [2O]  or x_e [3P]
+                                                       const int* __restrict__ stop, int big_only) {
+  // 36 KB of LDS per workgroup -> 4 workgroups per CU.  The staging buffer is dead once the
+  // cells are in registers (exchange_cells ends with a barrier), so the per-row / per-point
+  // scratch lives in it.
   __shared__ double lds[kBlock * 18];
-  __shared__ double w[kBlock * 3];
-  __shared__ double u[kBlock * 3];
-  __shared__ double red[3 * 4];
+  double* const w = lds;                 // [kBlock][3] per-row E' t
+  double* const u = lds + kBlock * 3;    // [kBlock][3] per-point (E'E)^-1 sum
+  double* const red = lds + kBlock * 6;  // block reduction scratch (long chunks only)
+  if (stop && *stop) return;
   const int tl = blockIdx.x, tid = threadIdx.x;
   const int r0 = tile_row[tl], r1 = tile_row[tl + 1];
   const int p0 = tile_pt[tl], p1 = tile_pt[tl + 1];
+  if (big_only && r1 - r0 <= kBlock) return;
   if (r1 - r0 <= kBlock) {
     const int nvalid = r1 - r0;
     const int r = r0 + tid;
-    const int lp = (MODE != 2 && tid < nvalid) ? row_pt[r] - p0 : 0;
+    // everything this tile needs from HBM is requested up front: ids, E, F, b; the camera
+    // vector gather (L2) follows as soon as the camera id is back
+    const bool live = tid < nvalid;
+    const int lp = (MODE != 2 && live) ? row_pt[r] - p0 : 0;
+    const int cam = (MODE != 1 && live) ? row_cam[r] : 0;
+    double2 fv[9], ev[3];
+    if (MODE != 1) load_cells<18>(F + 18 * int64_t(r0), nvalid, fv);
+    load_cells<6>(E + 6 * int64_t(r0), nvalid, ev);
+    double2 bv = make_double2(0.0, 0.0);
+    if (MODE != 0 && live) bv = reinterpret_cast<const double2*>(b)[r];
+    double xv[9];
+    if (MODE != 1) {
+      const double* xc = xf + 9 * int64_t(cam);
+#pragma unroll
+      for (int k = 0; k < 9; ++k) xv[k] = live ? xc[k] : 0.0;
+    }
     double e[6];
     double t0 = 0.0, t1 = 0.0;
     if (MODE != 1) {
       double f[18];
-      stage_cells<18>(F + 18 * int64_t(r0), nvalid, lds, f);
-      if (tid < nvalid) {
-        const double* xc = xf + 9 * int64_t(row_cam[r]);
+      exchange_cells<18>(fv, lds, f);
 #pragma unroll
-        for (int k = 0; k < 9; ++k) {
-          const double xv = xc[k];
-          t0 += f[k] * xv;
-          t1 += f[9 + k] * xv;
-        }
+      for (int k = 0; k < 9; ++k) {
+        t0 += f[k] * xv[k];
+        t1 += f[9 + k] * xv[k];
       }
     }
-    stage_cells<6>(E + 6 * int64_t(r0), nvalid, lds, e);
-    if (tid < nvalid) {
-      if (MODE != 0) {
-        const double2 bv = reinterpret_cast<const double2*>(b)[r];
-        if (MODE == 1) { t0 = bv.x; t1 = bv.y; }
-        else { t0 = bv.x - t0; t1 = bv.y - t1; }
-      }
+    exchange_cells<6>(ev, lds, e);
+    if (live) {
+      if (MODE == 1) { t0 = bv.x; t1 = bv.y; }
+      else if (MODE == 2) { t0 = bv.x - t0; t1 = bv.y - t1; }
       w[tid * 3 + 0] = e[0] * t0 + e[3] * t1;
       w[tid * 3 + 1] = e[1] * t0 + e[4] * t1;
       w[tid * 3 + 2] = e[2] * t0 + e[5] * t1;
@@ -292,6 +309,135 @@ __global__ __launch_bounds__(kBlock) void k_chunk_pass(const double* __restrict_
         t1 -= e[3] * u0 + e[4] * u1 + e[5] * u2;
         reinterpret_cast<double2*>(out)[r] = make_double2(t0, t1);
       }
+    }
+  }
+}
+
+// ------------------------------------------- S x chunk pass, software-pipelined variant
+// Same arithmetic as k_chunk_pass<0> in the same order (bitwise identical results), but a
+// workgroup walks tiles blockIdx.x, blockIdx.x + gridDim.x, ... and requests the ids, E and F
+// cells of its NEXT tile before it exchanges / computes the current one, so HBM loads stay in
+// flight during the LDS and per-point phases.  Tiles with a chunk longer than kBlock rows are
+// left to k_chunk_pass<0> (launched over those tiles only when the matrix has any).
+__global__ __launch_bounds__(kBlock) void k_chunk_sx_pipe(const double* __restrict__ E,
+                                                          const double* __restrict__ F,
+                                                          const int32_t* __restrict__ tile_row,
+                                                          const int32_t* __restrict__ tile_pt,
+                                                          const int32_t* __restrict__ pt_start,
+                                                          const int32_t* __restrict__ row_cam,
+                                                          const int32_t* __restrict__ row_pt,
+                                                          const double* __restrict__ ete_inv,
+                                                          const double* __restrict__ xf,
+                                                          double* __restrict__ out, int num_tiles,
+                                                          const int* __restrict__ stop) {
+  __shared__ double lds[kBlock * 18];
+  double* const w = lds;
+  double* const u = lds + kBlock * 3;
+  if (stop && *stop) return;
+  const int tid = threadIdx.x;
+  int tl = blockIdx.x;
+  if (tl >= num_tiles) return;
+  // ---- prologue: request tile tl
+  int r0 = tile_row[tl], r1 = tile_row[tl + 1], p0 = tile_pt[tl], p1 = tile_pt[tl + 1];
+  double2 fv[9], ev[3];
+  int cam = 0, lp = 0;
+  bool big = (r1 - r0) > kBlock;
+  if (!big) {
+    const int nvalid = r1 - r0;
+    if (tid < nvalid) { cam = row_cam[r0 + tid]; lp = row_pt[r0 + tid] - p0; }
+    load_cells<18>(F + 18 * int64_t(r0), nvalid, fv);
+    load_cells<6>(E + 6 * int64_t(r0), nvalid, ev);
+  }
+  double xv[9];
+#pragma unroll
+  for (int k = 0; k < 9; ++k) xv[k] = 0.0;
+  if (!big && tid < r1 - r0) {
+    const double* xc = xf + 9 * int64_t(cam);
+#pragma unroll
+    for (int k = 0; k < 9; ++k) xv[k] = xc[k];
+  }
+  while (true) {
+    // ---- request the next tile
+    const int tn = tl + gridDim.x;
+    const bool has_next = tn < num_tiles;
+    int nr0 = 0, nr1 = 0, np0 = 0, np1 = 0, ncam = 0, nlp = 0;
+    bool nbig = false;
+    double2 nfv[9], nev[3];
+    if (has_next) {
+      nr0 = tile_row[tn]; nr1 = tile_row[tn + 1]; np0 = tile_pt[tn]; np1 = tile_pt[tn + 1];
+      nbig = (nr1 - nr0) > kBlock;
+      if (!nbig) {
+        const int nn = nr1 - nr0;
+        if (tid < nn) { ncam = row_cam[nr0 + tid]; nlp = row_pt[nr0 + tid] - np0; }
+        load_cells<18>(F + 18 * int64_t(nr0), nn, nfv);
+        load_cells<6>(E + 6 * int64_t(nr0), nn, nev);
+      }
+    }
+    // ---- current tile
+    if (!big) {
+      const int nvalid = r1 - r0;
+      const int r = r0 + tid;
+      const bool live = tid < nvalid;
+      double f[18], e[6];
+      double t0 = 0.0, t1 = 0.0;
+      exchange_cells<18>(fv, lds, f);
+#pragma unroll
+      for (int k = 0; k < 9; ++k) {
+        t0 += f[k] * xv[k];
+        t1 += f[9 + k] * xv[k];
+      }
+      exchange_cells<6>(ev, lds, e);
+      if (live) {
+        w[tid * 3 + 0] = e[0] * t0 + e[3] * t1;
+        w[tid * 3 + 1] = e[1] * t0 + e[4] * t1;
+        w[tid * 3 + 2] = e[2] * t0 + e[5] * t1;
+      }
+      double m[9];
+      int jb = 0, je = 0;
+      if (tid < p1 - p0) {
+        const double* mp = ete_inv + 9 * int64_t(p0 + tid);
+#pragma unroll
+        for (int k = 0; k < 9; ++k) m[k] = mp[k];
+        jb = pt_start[p0 + tid] - r0;
+        je = pt_start[p0 + tid + 1] - r0;
+      }
+      __syncthreads();
+      if (tid < p1 - p0) {
+        double a0 = 0.0, a1 = 0.0, a2 = 0.0, b0 = 0.0, b1 = 0.0, b2 = 0.0;
+        double c0 = 0.0, c1 = 0.0, c2 = 0.0, d0 = 0.0, d1 = 0.0, d2 = 0.0;
+        int j = jb;
+        for (; j + 4 <= je; j += 4) {
+          a0 += w[j * 3]; a1 += w[j * 3 + 1]; a2 += w[j * 3 + 2];
+          b0 += w[j * 3 + 3]; b1 += w[j * 3 + 4]; b2 += w[j * 3 + 5];
+          c0 += w[j * 3 + 6]; c1 += w[j * 3 + 7]; c2 += w[j * 3 + 8];
+          d0 += w[j * 3 + 9]; d1 += w[j * 3 + 10]; d2 += w[j * 3 + 11];
+        }
+        for (; j < je; ++j) { a0 += w[j * 3]; a1 += w[j * 3 + 1]; a2 += w[j * 3 + 2]; }
+        const double s0 = (a0 + b0) + (c0 + d0), s1 = (a1 + b1) + (c1 + d1), s2 = (a2 + b2) + (c2 + d2);
+        u[tid * 3] = m[0] * s0 + m[1] * s1 + m[2] * s2;
+        u[tid * 3 + 1] = m[3] * s0 + m[4] * s1 + m[5] * s2;
+        u[tid * 3 + 2] = m[6] * s0 + m[7] * s1 + m[8] * s2;
+      }
+      __syncthreads();
+      if (live) {
+        const double u0 = u[lp * 3], u1 = u[lp * 3 + 1], u2 = u[lp * 3 + 2];
+        t0 -= e[0] * u0 + e[1] * u1 + e[2] * u2;
+        t1 -= e[3] * u0 + e[4] * u1 + e[5] * u2;
+        reinterpret_cast<double2*>(out)[r] = make_double2(t0, t1);
+      }
+      __syncthreads();  // w / u are overwritten by the next exchange
+    }
+    if (!has_next) break;
+    // ---- the next tile becomes current; its camera ids are back by now: gather x
+    tl = tn; r0 = nr0; r1 = nr1; p0 = np0; p1 = np1; cam = ncam; lp = nlp; big = nbig;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) fv[i] = nfv[i];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) ev[i] = nev[i];
+    if (!big && tid < r1 - r0) {
+      const double* xc = xf + 9 * int64_t(cam);
+#pragma unroll
+      for (int k = 0; k < 9; ++k) xv[k] = xc[k];
     }
   }
 }
@@ -413,11 +559,16 @@ __global__ __launch_bounds__(64) void k_block9_add_diag_invert(double* __restric
 }
 
 // ------------------------------------------------------- explicit S (dense lhs)
-// SchurEliminator<2,3,9>::Eliminate into a dense row-major lhs of order 9C
-// (BlockRandomAccessDenseMatrix): upper block triangle, full diagonal blocks.
-// Contributions of different chunks to one S cell are combined with fp64 atomics
-// (the reference serialises them with a mutex per cell, schur_eliminator_impl.h:550),
-// so like the reference with num_threads > 1 the sum order is not fixed.
+// SchurEliminator<2,3,9>::Eliminate (schur_eliminator_impl.h:177-561) for a dense reduced
+// matrix (BlockRandomAccessDenseMatrix): upper block triangle, full diagonal blocks.
+//   S(c,c)  += F'F                 EBlockRowOuterProduct :665-714  -> camera-major k_cam_diag (deterministic)
+//   rhs      = F'(b - E inv E'b)   UpdateRhs :379-420              -> k_chunk_pass<1> + k_cam_ft (deterministic)
+//   S(c1,c2) -= B1' inv B2         ChunkOuterProduct :512-561      -> here, fp64 atomics
+// The pair products of different chunks meet in the same 9x9 cell; the reference serialises
+// them with a mutex per cell (:550), here they are global_atomic_add_f64 into a BLOCK-MAJOR
+// copy of S (cell (c1,c2) = 81 contiguous doubles), so that one wavefront instruction adds 512
+// contiguous bytes -- the shape float atomics run at full rate on gfx950.  Like the reference
+// with num_threads > 1 the sum order across chunks is not fixed.
 constexpr int kMaxPtsPerTile = kBlock;
 __global__ __launch_bounds__(kBlock) void k_chunk_eliminate(const double* __restrict__ E,
                                                             const double* __restrict__ F,
@@ -425,100 +576,50 @@ __global__ __launch_bounds__(kBlock) void k_chunk_eliminate(const double* __rest
                                                             const int32_t* __restrict__ tile_pt,
                                                             const int32_t* __restrict__ pt_start,
                                                             const int32_t* __restrict__ row_cam,
-                                                            const int32_t* __restrict__ row_pt,
-                                                            const double* __restrict__ De,
-                                                            const double* __restrict__ b,  // may be null
-                                                            double* __restrict__ lhs, int64_t n,
-                                                            double* __restrict__ rhs) {    // may be null
+                                                            const double* __restrict__ ete_inv,
+                                                            double* __restrict__ blk, int C) {
   __shared__ double Bs[kBlock * 27];     // staging first, then B_r = E_r' F_r (3x9) per row
-  __shared__ double w[kBlock * 9];       // per row: E'E (6), E'b (3)
   __shared__ double inv_s[kMaxPtsPerTile * 9];
-  __shared__ double invg_s[kMaxPtsPerTile * 3];
   __shared__ int cam_s[kBlock];
   __shared__ int pair_start[kMaxPtsPerTile + 1];
+  __shared__ int start_s[kMaxPtsPerTile + 1];
   const int tl = blockIdx.x, tid = threadIdx.x;
   const int r0 = tile_row[tl], r1 = tile_row[tl + 1];
   const int p0 = tile_pt[tl], p1 = tile_pt[tl + 1];
   const int npts = p1 - p0;
-  if (r1 - r0 > kBlock) return;  // long chunks are handled by k_big_chunk_eliminate
+  if (r1 - r0 > kBlock) return;  // long chunks: k_big_chunk_eliminate
   const int nvalid = r1 - r0;
-  const int r = r0 + tid;
+  double2 fv[9], ev[3];
+  load_cells<18>(F + 18 * int64_t(r0), nvalid, fv);
+  load_cells<6>(E + 6 * int64_t(r0), nvalid, ev);
+  if (tid < nvalid) cam_s[tid] = row_cam[r0 + tid];
+  if (tid < npts) {
+    const double* m = ete_inv + 9 * int64_t(p0 + tid);
+#pragma unroll
+    for (int k = 0; k < 9; ++k) inv_s[tid * 9 + k] = m[k];
+  }
+  if (tid <= npts) start_s[tid] = pt_start[p0 + tid] - r0;
   double f[18], e[6];
-  stage_cells<18>(F + 18 * int64_t(r0), nvalid, Bs, f);
-  stage_cells<6>(E + 6 * int64_t(r0), nvalid, Bs, e);
-  double2 bv = make_double2(0.0, 0.0);
-  int cam = 0;
+  exchange_cells<18>(fv, Bs, f);
+  exchange_cells<6>(ev, Bs, e);
   if (tid < nvalid) {
-    cam = row_cam[r];
-    cam_s[tid] = cam;
-    if (b) bv = reinterpret_cast<const double2*>(b)[r];
-    double* wr = w + tid * 9;
-    wr[0] = e[0] * e[0] + e[3] * e[3];
-    wr[1] = e[0] * e[1] + e[3] * e[4];
-    wr[2] = e[0] * e[2] + e[3] * e[5];
-    wr[3] = e[1] * e[1] + e[4] * e[4];
-    wr[4] = e[1] * e[2] + e[4] * e[5];
-    wr[5] = e[2] * e[2] + e[5] * e[5];
-    wr[6] = e[0] * bv.x + e[3] * bv.y;
-    wr[7] = e[1] * bv.x + e[4] * bv.y;
-    wr[8] = e[2] * bv.x + e[5] * bv.y;
     double* Br = Bs + tid * 27;
 #pragma unroll
     for (int q = 0; q < 3; ++q)
 #pragma unroll
       for (int a = 0; a < 9; ++a) Br[q * 9 + a] = e[q] * f[a] + e[3 + q] * f[9 + a];
-    // S(c,c) += F'F  (EBlockRowOuterProduct, schur_eliminator_impl.h:665-714)
-    double* Scc = lhs + (9 * int64_t(cam)) * n + 9 * int64_t(cam);
-#pragma unroll
-    for (int a = 0; a < 9; ++a)
-#pragma unroll
-      for (int c = 0; c < 9; ++c) atomicAdd(&Scc[a * n + c], f[a] * f[c] + f[9 + a] * f[9 + c]);
   }
   __syncthreads();
-  if (tid < npts) {
-    const int p = p0 + tid;
-    double s[9];
-#pragma unroll
-    for (int k = 0; k < 9; ++k) s[k] = 0.0;
-    for (int j = pt_start[p] - r0; j < pt_start[p + 1] - r0; ++j) {
-#pragma unroll
-      for (int k = 0; k < 9; ++k) s[k] += w[j * 9 + k];
-    }
-    double m[9], inv[9];
-    m[0] = s[0]; m[1] = s[1]; m[2] = s[2]; m[4] = s[3]; m[5] = s[4]; m[8] = s[5];
-    if (De) {
-      const double* d = De + 3 * int64_t(p);
-      m[0] += d[0] * d[0]; m[4] += d[1] * d[1]; m[8] += d[2] * d[2];
-    }
-    m[3] = m[1]; m[6] = m[2]; m[7] = m[5];
-    inv3_cofactor(m, inv);
-#pragma unroll
-    for (int k = 0; k < 9; ++k) inv_s[tid * 9 + k] = inv[k];
-    invg_s[tid * 3 + 0] = inv[0] * s[6] + inv[1] * s[7] + inv[2] * s[8];
-    invg_s[tid * 3 + 1] = inv[3] * s[6] + inv[4] * s[7] + inv[5] * s[8];
-    invg_s[tid * 3 + 2] = inv[6] * s[6] + inv[7] * s[7] + inv[8] * s[8];
-  }
   if (tid == 0) {
     int acc = 0;
     for (int i = 0; i < npts; ++i) {
       pair_start[i] = acc;
-      const int k = pt_start[p0 + i + 1] - pt_start[p0 + i];
+      const int k = start_s[i + 1] - start_s[i];
       acc += k * (k + 1) / 2;
     }
     pair_start[npts] = acc;
   }
   __syncthreads();
-  // UpdateRhs (schur_eliminator_impl.h:379-420): rhs_c += F_r' (b_r - E_r inv g)
-  if (rhs && tid < nvalid) {
-    const int lo = row_pt[r] - p0;
-    const double g0 = invg_s[lo * 3], g1 = invg_s[lo * 3 + 1], g2 = invg_s[lo * 3 + 2];
-    const double s0 = bv.x - (e[0] * g0 + e[1] * g1 + e[2] * g2);
-    const double s1 = bv.y - (e[3] * g0 + e[4] * g1 + e[5] * g2);
-    double* rc = rhs + 9 * int64_t(cam);
-#pragma unroll
-    for (int a = 0; a < 9; ++a) atomicAdd(&rc[a], f[a] * s0 + f[9 + a] * s1);
-  }
-  // ChunkOuterProduct (schur_eliminator_impl.h:512-561): S(c1,c2) -= B1' inv B2, c1 <= c2
   const int total = pair_start[npts] * 81;
   for (int item = tid; item < total; item += kBlock) {
     const int pair = item / 81, el = item - pair * 81;
@@ -527,8 +628,8 @@ __global__ __launch_bounds__(kBlock) void k_chunk_eliminate(const double* __rest
       const int mid = (lo + hi + 1) >> 1;
       if (pair_start[mid] <= pair) lo = mid; else hi = mid - 1;
     }
-    const int base = pt_start[p0 + lo] - r0;
-    const int k = pt_start[p0 + lo + 1] - pt_start[p0 + lo];
+    const int base = start_s[lo];
+    const int k = start_s[lo + 1] - base;
     int i, j;
     tri_decode(pair - pair_start[lo], k, i, j);
     int ri = base + i, rj = base + j;
@@ -544,75 +645,23 @@ __global__ __launch_bounds__(kBlock) void k_chunk_eliminate(const double* __rest
       const double g = iv[pp * 3] * B2[c] + iv[pp * 3 + 1] * B2[9 + c] + iv[pp * 3 + 2] * B2[18 + c];
       sum += B1[pp * 9 + a] * g;
     }
-    atomicAdd(&lhs[(9 * int64_t(c1) + a) * n + 9 * int64_t(c2) + c], -sum);
+    atomicAdd(&blk[(int64_t(c1) * C + c2) * 81 + el], -sum);
   }
 }
 
-// Long chunks (> kBlock rows): one workgroup per such chunk, same algebra with
-// strided loops over global memory (rare; correctness path).
+// Long chunks (> kBlock rows): one workgroup per such chunk, pairs straight from global memory
+// (rare; correctness path).
 __global__ __launch_bounds__(kBlock) void k_big_chunk_eliminate(const double* __restrict__ E,
                                                                 const double* __restrict__ F,
                                                                 const int32_t* __restrict__ tile_row,
                                                                 const int32_t* __restrict__ tile_pt,
                                                                 const int32_t* __restrict__ row_cam,
-                                                                const double* __restrict__ De,
-                                                                const double* __restrict__ b,
-                                                                double* __restrict__ lhs, int64_t n,
-                                                                double* __restrict__ rhs) {
-  __shared__ double red[9 * 4];
-  __shared__ double inv_s[9], invg_s[3];
+                                                                const double* __restrict__ ete_inv,
+                                                                double* __restrict__ blk, int C) {
   const int tl = blockIdx.x, tid = threadIdx.x;
   const int r0 = tile_row[tl], r1 = tile_row[tl + 1];
   if (r1 - r0 <= kBlock) return;
-  const int p = tile_pt[tl];
-  double s[9];
-  for (int k = 0; k < 9; ++k) s[k] = 0.0;
-  for (int r = r0 + tid; r < r1; r += kBlock) {
-    const double* e = E + 6 * int64_t(r);
-    const double* f = F + 18 * int64_t(r);
-    double2 bv = make_double2(0.0, 0.0);
-    if (b) bv = reinterpret_cast<const double2*>(b)[r];
-    s[0] += e[0] * e[0] + e[3] * e[3];
-    s[1] += e[0] * e[1] + e[3] * e[4];
-    s[2] += e[0] * e[2] + e[3] * e[5];
-    s[3] += e[1] * e[1] + e[4] * e[4];
-    s[4] += e[1] * e[2] + e[4] * e[5];
-    s[5] += e[2] * e[2] + e[5] * e[5];
-    s[6] += e[0] * bv.x + e[3] * bv.y;
-    s[7] += e[1] * bv.x + e[4] * bv.y;
-    s[8] += e[2] * bv.x + e[5] * bv.y;
-    const int cam = row_cam[r];
-    double* Scc = lhs + (9 * int64_t(cam)) * n + 9 * int64_t(cam);
-    for (int a = 0; a < 9; ++a)
-      for (int c = 0; c < 9; ++c) atomicAdd(&Scc[a * n + c], f[a] * f[c] + f[9 + a] * f[9 + c]);
-  }
-  block_sum<9>(s, red);
-  if (tid == 0) {
-    double m[9], inv[9];
-    m[0] = s[0]; m[1] = s[1]; m[2] = s[2]; m[4] = s[3]; m[5] = s[4]; m[8] = s[5];
-    if (De) {
-      const double* d = De + 3 * int64_t(p);
-      m[0] += d[0] * d[0]; m[4] += d[1] * d[1]; m[8] += d[2] * d[2];
-    }
-    m[3] = m[1]; m[6] = m[2]; m[7] = m[5];
-    inv3_cofactor(m, inv);
-    for (int k = 0; k < 9; ++k) inv_s[k] = inv[k];
-    invg_s[0] = inv[0] * s[6] + inv[1] * s[7] + inv[2] * s[8];
-    invg_s[1] = inv[3] * s[6] + inv[4] * s[7] + inv[5] * s[8];
-    invg_s[2] = inv[6] * s[6] + inv[7] * s[7] + inv[8] * s[8];
-  }
-  __syncthreads();
-  if (rhs) {
-    for (int r = r0 + tid; r < r1; r += kBlock) {
-      const double* e = E + 6 * int64_t(r);
-      const double* f = F + 18 * int64_t(r);
-      const double2 bv = reinterpret_cast<const double2*>(b)[r];
-      const double s0 = bv.x - (e[0] * invg_s[0] + e[1] * invg_s[1] + e[2] * invg_s[2]);
-      const double s1 = bv.y - (e[3] * invg_s[0] + e[4] * invg_s[1] + e[5] * invg_s[2]);
-      double* rc = rhs + 9 * int64_t(row_cam[r]);
-      for (int a = 0; a < 9; ++a) atomicAdd(&rc[a], f[a] * s0 + f[9 + a] * s1);
-    }
-  }
+  const double* inv_s = ete_inv + 9 * int64_t(tile_pt[tl]);
   const int k = r1 - r0;
   const int64_t total = int64_t(k) * (k + 1) / 2;
   for (int64_t pair = tid; pair < total; pair += kBlock) {
@@ -638,12 +687,31 @@ __global__ __launch_bounds__(kBlock) void k_big_chunk_eliminate(const double* __
         for (int a = 0; a < 9; ++a)
           G2[qq * 9 + a] = inv_s[qq * 3] * B2[a] + inv_s[qq * 3 + 1] * B2[9 + a] + inv_s[qq * 3 + 2] * B2[18 + a];
     }
+    double* dst = blk + (int64_t(c1) * C + c2) * 81;
     for (int a = 0; a < 9; ++a)
-      for (int c = 0; c < 9; ++c) {
-        const double sum = B1[a] * G2[c] + B1[9 + a] * G2[9 + c] + B1[18 + a] * G2[18 + c];
-        atomicAdd(&lhs[(9 * int64_t(c1) + a) * n + 9 * int64_t(c2) + c], -sum);
-      }
+      for (int c = 0; c < 9; ++c)
+        atomicAdd(&dst[a * 9 + c], -(B1[a] * G2[c] + B1[9 + a] * G2[9 + c] + B1[18 + a] * G2[18 + c]));
   }
+}
+
+// dense row-major lhs (n = 9C) from the block-major pair sums, the F'F diagonal blocks and D_f^2;
+// blocks below the diagonal stay zero (the reference never touches them)
+__global__ void k_blocks_to_dense(const double* __restrict__ blk, const double* __restrict__ diag,
+                                  const double* __restrict__ Df, double* __restrict__ lhs, int C) {
+  const int64_t n = 9 * int64_t(C);
+  const int64_t idx = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (idx >= n * n) return;
+  const int row = int(idx / n), col = int(idx - int64_t(row) * n);
+  const int c1 = row / 9, a = row - c1 * 9, c2 = col / 9, c = col - c2 * 9;
+  double v = 0.0;
+  if (c1 <= c2) {
+    v = blk[(int64_t(c1) * C + c2) * 81 + a * 9 + c];
+    if (c1 == c2) {
+      v += diag[int64_t(c1) * 81 + a * 9 + c];
+      if (Df && a == c) v += Df[row] * Df[row];
+    }
+  }
+  lhs[idx] = v;
 }
 
 // lhs(i,i) += D_f(i)^2      (schur_eliminator_impl.h:194-213)
@@ -675,8 +743,16 @@ int cxs_chunk_pass(cx_matrix* A, int mode, const double* ete_inv, const double* 
   const double* F = A->d_values.p + 6 * A->O;
 #define CX_LAUNCH_PASS(M)                                                                                   \
   hipLaunchKernelGGL(k_chunk_pass<M>, dim3(A->num_tiles), dim3(kBlock), 0, st, E, F, A->d_tile_row.p,       \
-                     A->d_tile_pt.p, A->d_pt_start.p, A->d_row_cam.p, A->d_row_pt.p, ete_inv, xf, b, out)
-  if (mode == 0) CX_LAUNCH_PASS(0);
+                     A->d_tile_pt.p, A->d_pt_start.p, A->d_row_cam.p, A->d_row_pt.p, ete_inv, xf, b, out, A->stop, 0)
+  static const int variant = [] { const char* v = getenv("CX_CHUNK_VARIANT"); return v ? atoi(v) : 0; }();  // 0: one tile per workgroup (faster, measured r01), 1: pipelined
+  if (mode == 0 && variant == 1) {
+    const int grid = std::min(A->num_tiles, A->ctx->num_cus * 2);  // 226 VGPRs -> 2 workgroups per CU
+    hipLaunchKernelGGL(k_chunk_sx_pipe, dim3(grid), dim3(kBlock), 0, st, E, F, A->d_tile_row.p, A->d_tile_pt.p,
+                       A->d_pt_start.p, A->d_row_cam.p, A->d_row_pt.p, ete_inv, xf, out, A->num_tiles, A->stop);
+    if (A->has_big_tiles)
+      hipLaunchKernelGGL(k_chunk_pass<0>, dim3(A->num_tiles), dim3(kBlock), 0, st, E, F, A->d_tile_row.p,
+                         A->d_tile_pt.p, A->d_pt_start.p, A->d_row_cam.p, A->d_row_pt.p, ete_inv, xf, b, out, A->stop, 1);
+  } else if (mode == 0) CX_LAUNCH_PASS(0);
   else if (mode == 1) CX_LAUNCH_PASS(1);
   else CX_LAUNCH_PASS(2);
 #undef CX_LAUNCH_PASS
@@ -710,19 +786,36 @@ int cxs_block9_add_diag_invert(cx_context* ctx, double* blocks, const double* Df
 
 int cxs_eliminate_dense(cx_matrix* A, const double* b, const double* D, bool add_df, double* lhs, double* rhs) {
   hipStream_t st = A->ctx->stream;
-  const int64_t n = 9 * int64_t(A->C);
-  CX_HIP(hipMemsetAsync(lhs, 0, size_t(n) * n * sizeof(double), st));
-  if (rhs) CX_HIP(hipMemsetAsync(rhs, 0, size_t(n) * sizeof(double), st));
-  if (D && add_df && n > 0)
-    hipLaunchKernelGGL(k_add_diag_sq, dim3(grid_for(n, 256)), dim3(256), 0, st, lhs, n, D + 3 * int64_t(A->P));
+  const int C = A->C;
+  const int64_t n = 9 * int64_t(C);
+  CX_TRY(A->d_elim_blk.alloc(size_t(std::max<int64_t>(int64_t(C) * C * 81, 1))));
+  CX_TRY(A->d_elim_ete.alloc(size_t(std::max<int64_t>(9 * int64_t(A->P), 1))));
+  CX_TRY(A->d_elim_diag.alloc(size_t(std::max<int64_t>(81 * int64_t(C), 1))));
+  CX_TRY(A->d_elim_flag.alloc(1));
+  CX_HIP(hipMemsetAsync(A->d_elim_blk.p, 0, size_t(C) * C * 81 * sizeof(double), st));
+  // (E'E + D_e^2)^-1 with the closed-form inverse of InvertPSDMatrix<3>
+  CX_TRY(cxs_compute_ete_inverse(A, D, nullptr, A->d_elim_ete.p, nullptr, false, A->d_elim_flag.p));
   if (A->num_tiles > 0) {
     const double* E = A->d_values.p;
     const double* F = A->d_values.p + 6 * A->O;
     hipLaunchKernelGGL(k_chunk_eliminate, dim3(A->num_tiles), dim3(kBlock), 0, st, E, F, A->d_tile_row.p,
-                       A->d_tile_pt.p, A->d_pt_start.p, A->d_row_cam.p, A->d_row_pt.p, D, b, lhs, n, rhs);
+                       A->d_tile_pt.p, A->d_pt_start.p, A->d_row_cam.p, (const double*)A->d_elim_ete.p, A->d_elim_blk.p, C);
     if (A->has_big_tiles)
       hipLaunchKernelGGL(k_big_chunk_eliminate, dim3(A->num_tiles), dim3(kBlock), 0, st, E, F, A->d_tile_row.p,
-                       A->d_tile_pt.p, A->d_row_cam.p, D, b, lhs, n, rhs);
+                         A->d_tile_pt.p, A->d_row_cam.p, (const double*)A->d_elim_ete.p, A->d_elim_blk.p, C);
+  }
+  CX_TRY(cxs_camera_block_diagonal(A, false, nullptr, A->d_elim_diag.p));
+  if (n > 0)
+    hipLaunchKernelGGL(k_blocks_to_dense, dim3(grid_for(n * n, 256)), dim3(256), 0, st, (const double*)A->d_elim_blk.p,
+                       (const double*)A->d_elim_diag.p, (D && add_df) ? D + 3 * int64_t(A->P) : (const double*)nullptr, lhs, C);
+  if (rhs) {
+    if (b) {
+      CX_TRY(A->d_elim_rows.alloc(size_t(std::max<int64_t>(A->num_rows, 1))));
+      CX_TRY(cxs_chunk_pass(A, 1, A->d_elim_ete.p, nullptr, b, A->d_elim_rows.p));
+      CX_TRY(cxk_ft_multiply(A, A->d_elim_rows.p, rhs, false));
+    } else {
+      CX_HIP(hipMemsetAsync(rhs, 0, size_t(n) * sizeof(double), st));
+    }
   }
   CX_HIP(hipGetLastError());
   return CX_OK;

@@ -43,8 +43,14 @@ __global__ __launch_bounds__(256) void k_dot2_partial(const double* __restrict__
 // what to do with the finished sums
 enum FinOp : int { FIN_STORE = 0, FIN_RHO = 1, FIN_PQ = 2, FIN_Q = 3 };
 
-__global__ __launch_bounds__(256) void k_dot2_final(const double* __restrict__ partial, int nblocks, int op,
-                                                    CgState* __restrict__ st, double extra0, double extra1) {
+// Final stage of a two-stage reduction, plus the scalar logic of the CG step it belongs to.
+// add_prev: the sums of the rank-local part (already all-reduced into st->s0/s1) are added to
+// this launch's sums (sharded CGNR: replicated camera part counted once).
+// ring: host-pinned slots the state is published to after FIN_Q, so that the host can follow
+// the iteration without synchronising the stream.
+__global__ __launch_bounds__(256) void k_dot2_final(const double* __restrict__ partial, int nblocks, int op, int iter,
+                                                    int add_prev, CgState* __restrict__ st,
+                                                    CgState* __restrict__ ring, int ring_slots) {
   __shared__ double red[2 * 4];
   if (op != FIN_STORE && st->flag) return;
   double s[2] = {0.0, 0.0};
@@ -54,43 +60,58 @@ __global__ __launch_bounds__(256) void k_dot2_final(const double* __restrict__ p
   }
   block_sum<2>(s, red);
   if (threadIdx.x != 0) return;
-  // replicated camera part counted once in sharded CGNR: extras are added by the caller
-  s[0] += extra0;
-  s[1] += extra1;
+  if (add_prev) { s[0] += st->s0; s[1] += st->s1; }
   st->s0 = s[0];
   st->s1 = s[1];
   if (op == FIN_RHO) {
     st->last_rho = st->rho;
     st->rho = s[0];
-    if (s[0] == 0.0 || isinf(s[0])) { st->flag = CG_FAIL_RHO; return; }
-    if (st->iter > 1) {
+    if (s[0] == 0.0 || isinf(s[0])) {
+      st->flag = CG_FAIL_RHO;
+    } else if (iter > 1) {
       st->beta = st->rho / st->last_rho;
       if (st->beta == 0.0 || isinf(st->beta)) st->flag = CG_FAIL_BETA;
     }
   } else if (op == FIN_PQ) {
     st->pq = s[0];
-    if (s[0] <= 0.0 || isinf(s[0])) { st->flag = CG_INDEFINITE; return; }
-    st->alpha = st->rho / st->pq;
-    if (isinf(st->alpha)) st->flag = CG_FAIL_ALPHA;
+    if (s[0] <= 0.0 || isinf(s[0])) {
+      st->flag = CG_INDEFINITE;
+    } else {
+      st->alpha = st->rho / st->pq;
+      if (isinf(st->alpha)) st->flag = CG_FAIL_ALPHA;
+    }
   } else if (op == FIN_Q) {
     // s0 = x.(rhs + r), s1 = r.r
     st->Q1 = -s[0];
     st->norm_r = sqrt(s[1]);
-    st->zeta = st->iter * (st->Q1 - st->Q0) / st->Q1;
-    if (st->zeta < st->q_tol && st->iter >= st->min_iter) { st->flag = CG_CONVERGED_Q; return; }
-    st->Q0 = st->Q1;
-    if (st->norm_r <= st->tol_r && st->iter >= st->min_iter) { st->flag = CG_CONVERGED_R; return; }
-    if (st->iter >= st->max_iter) st->flag = CG_MAX_ITER;
+    st->zeta = iter * (st->Q1 - st->Q0) / st->Q1;
+    if (st->zeta < st->q_tol && iter >= st->min_iter) {
+      st->flag = CG_CONVERGED_Q;
+    } else {
+      st->Q0 = st->Q1;
+      if (st->norm_r <= st->tol_r && iter >= st->min_iter) st->flag = CG_CONVERGED_R;
+      else if (iter >= st->max_iter) st->flag = CG_MAX_ITER;
+    }
+  }
+  if (st->flag != CG_RUNNING || op == FIN_Q) {
+    // publish: a failure flag raised in the middle of an iteration is published at once
+    st->iter = iter;
+    if (ring) {
+      CgState* slot = ring + (iter % ring_slots);
+      *slot = *st;
+      __threadfence_system();
+      __hip_atomic_store(&slot->seq, iter, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
   }
 }
 
 // p = z (first iteration) or z + beta p
-__global__ void k_update_p(double* __restrict__ p, const double* __restrict__ z, int64_t n,
+__global__ void k_update_p(double* __restrict__ p, const double* __restrict__ z, int64_t n, int iter,
                            const CgState* __restrict__ st) {
   if (st->flag) return;
   const int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  p[i] = (st->iter == 1) ? z[i] : z[i] + st->beta * p[i];
+  p[i] = (iter == 1) ? z[i] : z[i] + st->beta * p[i];
 }
 
 // x += alpha p ; r -= alpha q (unless the residual is recomputed) ; tmp = rhs + r
@@ -184,24 +205,23 @@ struct CgDriver {
   int64_t n;
   // sharded CGNR: entries [shared0, n) are replicated over the ranks
   int64_t shared0;
+  static constexpr int kRingSlots = 16;
 
-  int dot2(const double* a, const double* b, const double* c, const double* d, int op, CgState* dst) {
+  int dot2(const double* a, const double* b, const double* c, const double* d, int op, int iter, CgState* dst) {
     const int nb = int(std::min<int64_t>(kRedBlocks, std::max<int64_t>(1, (n + 1023) / 1024)));
+    CgState* ring = S->ring_d;
     if (ctx->nranks > 1 && shared0 < n) {
-      // local part summed over the ranks, replicated part added once
-      hipLaunchKernelGGL(k_dot2_partial, dim3(nb), dim3(256), 0, st, a, b, c, d, shared0, S->partial.p, (const CgState*)nullptr);
-      hipLaunchKernelGGL(k_dot2_final, dim3(1), dim3(256), 0, st, S->partial.p, nb, int(FIN_STORE), dst, 0.0, 0.0);
+      // rank-local part: sum, all-reduce the two scalars on the device; replicated part added once
+      hipLaunchKernelGGL(k_dot2_partial, dim3(nb), dim3(256), 0, st, a, b, c, d, shared0, S->partial.p, (const CgState*)dst);
+      hipLaunchKernelGGL(k_dot2_final, dim3(1), dim3(256), 0, st, (const double*)S->partial.p, nb, int(FIN_STORE), iter, 0, dst, (CgState*)nullptr, 0);
       CX_TRY(cx_allreduce_device(ctx, &dst->s0, 2));
-      double local[2];
-      CX_HIP(hipMemcpyAsync(local, &dst->s0, 2 * sizeof(double), hipMemcpyDeviceToHost, st));
-      CX_HIP(hipStreamSynchronize(st));
       hipLaunchKernelGGL(k_dot2_partial, dim3(nb), dim3(256), 0, st, a + shared0, b + shared0,
-                         c ? c + shared0 : nullptr, d ? d + shared0 : nullptr, n - shared0, S->partial.p, (const CgState*)nullptr);
-      hipLaunchKernelGGL(k_dot2_final, dim3(1), dim3(256), 0, st, S->partial.p, nb, op, dst, local[0], local[1]);
+                         c ? c + shared0 : nullptr, d ? d + shared0 : nullptr, n - shared0, S->partial.p, (const CgState*)dst);
+      hipLaunchKernelGGL(k_dot2_final, dim3(1), dim3(256), 0, st, (const double*)S->partial.p, nb, op, iter, 1, dst, ring, kRingSlots);
     } else {
       hipLaunchKernelGGL(k_dot2_partial, dim3(nb), dim3(256), 0, st, a, b, c, d, n, S->partial.p,
                          op == FIN_STORE ? (const CgState*)nullptr : (const CgState*)dst);
-      hipLaunchKernelGGL(k_dot2_final, dim3(1), dim3(256), 0, st, S->partial.p, nb, op, dst, 0.0, 0.0);
+      hipLaunchKernelGGL(k_dot2_final, dim3(1), dim3(256), 0, st, (const double*)S->partial.p, nb, op, iter, 0, dst, ring, kRingSlots);
     }
     CX_HIP(hipGetLastError());
     return CX_OK;
@@ -213,8 +233,59 @@ struct CgDriver {
     return CX_OK;
   }
 
-  // conjugate_gradients_solver.h:107-305.  x holds the initial guess (zero_initial
-  // tells that it is all zeros so that A x can be skipped).
+  // CG iteration `iter` (conjugate_gradients_solver.h:162-301) in two parts.  The head (z = M^-1 r,
+  // rho, beta, p) is cheap and is enqueued speculatively; the tail holds the operator application.
+  int enqueue_head(int iter, LinOp& pre, double* p, double* r, double* z, CgState* ds) {
+    CX_TRY(pre.apply(r, z));
+    CX_TRY(dot2(r, z, nullptr, nullptr, FIN_RHO, iter, ds));
+    hipLaunchKernelGGL(k_update_p, dim3(grid_for(n, 256)), dim3(256), 0, st, p, (const double*)z, n, iter, (const CgState*)ds);
+    CX_HIP(hipGetLastError());
+    return CX_OK;
+  }
+  int enqueue_tail(int iter, LinOp& lhs, const double* rhs, double* x, double* p, double* r, double* z, double* tmp,
+                   CgState* ds) {
+    const cx_solver_options& o = S->opt;
+    const int g = grid_for(n, 256);
+    double* q = z;  // q aliases z, as in the reference
+    CX_TRY(lhs.apply(p, q));
+    CX_TRY(dot2(p, q, nullptr, nullptr, FIN_PQ, iter, ds));
+    const bool reset = (iter % o.residual_reset_period) == 0;
+    hipLaunchKernelGGL(k_update_xr, dim3(g), dim3(256), 0, st, x, r, (const double*)p, (const double*)q, rhs, tmp, n,
+                       reset ? 0 : 1, (const CgState*)ds);
+    if (reset) {
+      CX_TRY(lhs.apply(x, tmp));
+      hipLaunchKernelGGL(k_residual, dim3(g), dim3(256), 0, st, rhs, (const double*)tmp, r, tmp, n, (const CgState*)ds);
+    }
+    CX_TRY(dot2(x, tmp, r, r, FIN_Q, iter, ds));
+    return CX_OK;
+  }
+
+  // Wait until the device has published iteration `iter` in the host-pinned ring.
+  int wait_published(int iter, CgState* out) {
+    volatile CgState* slot = S->ring_h + (iter % kRingSlots);
+    const auto t0 = std::chrono::steady_clock::now();
+    long spins = 0;
+    while (__atomic_load_n(&slot->seq, __ATOMIC_ACQUIRE) != iter) {
+      if ((++spins & 0x3fff) == 0) {
+        if (hipStreamQuery(st) == hipSuccess && __atomic_load_n(&slot->seq, __ATOMIC_ACQUIRE) != iter) {
+          // stream drained without the slot being written: a kernel of the iteration failed
+          cx_set_error("CG iteration %d was never published (stream idle): %s", iter, hipGetErrorString(hipGetLastError()));
+          return CX_ERR_HIP;
+        }
+        if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 120.0) {
+          cx_set_error("timed out waiting for CG iteration %d", iter);
+          return CX_ERR_HIP;
+        }
+      }
+    }
+    std::memcpy(out, const_cast<CgState*>(slot), sizeof(CgState));
+    return CX_OK;
+  }
+
+  // conjugate_gradients_solver.h:107-305.  x holds the initial guess (zero_initial tells that
+  // it is all zeros so that A x can be skipped).  The loop is software-pipelined: iteration
+  // i+1 is enqueued before the host looks at the outcome of iteration i; kernels of an
+  // iteration that turns out not to be needed see the termination flag and do nothing.
   int run(LinOp& lhs, LinOp& pre, const double* rhs, double* x, bool zero_initial, double r_tol, double q_tol,
           cx_summary* summary) {
     const cx_solver_options& o = S->opt;
@@ -224,6 +295,12 @@ struct CgDriver {
     CX_TRY(S->v_tmp.alloc(n));
     CX_TRY(S->partial.alloc(2 * kRedBlocks));
     CX_TRY(S->state.alloc(1));
+    if (!S->ring_h) {
+      CX_HIP(hipHostMalloc(reinterpret_cast<void**>(&S->ring_h), kRingSlots * sizeof(CgState),
+                           hipHostMallocMapped | hipHostMallocCoherent));
+      CX_HIP(hipHostGetDevicePointer(reinterpret_cast<void**>(&S->ring_d), S->ring_h, 0));
+    }
+    for (int i = 0; i < kRingSlots; ++i) S->ring_h[i].seq = -1;
     double *p = S->v_p.p, *r = S->v_r.p, *z = S->v_z.p, *tmp = S->v_tmp.p;
     CgState* ds = S->state.p;
     const int g = grid_for(n, 256);
@@ -234,7 +311,7 @@ struct CgDriver {
 
     CgState h{};
     CX_HIP(hipMemcpyAsync(ds, &h, sizeof(h), hipMemcpyHostToDevice, st));
-    CX_TRY(dot2(rhs, rhs, nullptr, nullptr, FIN_STORE, ds));
+    CX_TRY(dot2(rhs, rhs, nullptr, nullptr, FIN_STORE, 0, ds));
     CX_TRY(read_state(&h));
     const double norm_rhs = std::sqrt(h.s0);
     if (norm_rhs == 0.0) {
@@ -249,9 +326,9 @@ struct CgDriver {
     } else {
       CX_TRY(lhs.apply(x, tmp));
     }
-    hipLaunchKernelGGL(k_residual, dim3(g), dim3(256), 0, st, rhs, tmp, r, tmp, n, (const CgState*)nullptr);
+    hipLaunchKernelGGL(k_residual, dim3(g), dim3(256), 0, st, rhs, (const double*)tmp, r, tmp, n, (const CgState*)nullptr);
     // tmp = rhs + r now;  s0 = x.tmp, s1 = r.r
-    CX_TRY(dot2(x, tmp, r, r, FIN_STORE, ds));
+    CX_TRY(dot2(x, tmp, r, r, FIN_STORE, 0, ds));
     CX_TRY(read_state(&h));
     double norm_r = std::sqrt(h.s1);
     if (o.min_num_iterations == 0 && norm_r <= tol_r) {
@@ -269,33 +346,24 @@ struct CgDriver {
     h.min_iter = o.min_num_iterations;
     h.max_iter = o.max_num_iterations;
     h.flag = CG_RUNNING;
-    for (int iter = 1;; ++iter) {
-      summary->num_iterations = iter;
-      if (iter == 1) {
-        h.iter = 1;
-        CX_HIP(hipMemcpyAsync(ds, &h, sizeof(h), hipMemcpyHostToDevice, st));
-      } else {
-        CX_HIP(hipMemcpyAsync(&ds->iter, &iter, sizeof(int), hipMemcpyHostToDevice, st));
-      }
-      // z = M^-1 r ; rho = r.z
-      CX_TRY(pre.apply(r, z));
-      CX_TRY(dot2(r, z, nullptr, nullptr, FIN_RHO, ds));
-      hipLaunchKernelGGL(k_update_p, dim3(g), dim3(256), 0, st, p, z, n, (const CgState*)ds);
-      // q = A p (q aliases z)
-      double* q = z;
-      CX_TRY(lhs.apply(p, q));
-      CX_TRY(dot2(p, q, nullptr, nullptr, FIN_PQ, ds));
-      const bool reset = (iter % o.residual_reset_period) == 0;
-      hipLaunchKernelGGL(k_update_xr, dim3(g), dim3(256), 0, st, x, r, (const double*)p, (const double*)q, rhs, tmp, n,
-                         reset ? 0 : 1, (const CgState*)ds);
-      if (reset) {
-        CX_TRY(lhs.apply(x, tmp));
-        hipLaunchKernelGGL(k_residual, dim3(g), dim3(256), 0, st, rhs, (const double*)tmp, r, tmp, n, (const CgState*)ds);
-      }
-      CX_TRY(dot2(x, tmp, r, r, FIN_Q, ds));
-      CX_TRY(read_state(&h));
+    h.seq = -1;
+    CX_HIP(hipMemcpyAsync(ds, &h, sizeof(h), hipMemcpyHostToDevice, st));
+    CX_HIP(hipStreamSynchronize(st));  // h lives on this stack frame
+
+    // Software pipeline: while the device runs the tail of iteration i the host has already
+    // enqueued the head of iteration i+1; it then learns the outcome of iteration i from the
+    // pinned ring and either enqueues the tail of i+1 or stops (the speculative head sees the
+    // termination flag and does nothing).  No stream synchronisation inside the loop.
+    CX_TRY(enqueue_head(1, pre, p, r, z, ds));
+    CX_TRY(enqueue_tail(1, lhs, rhs, x, p, r, z, tmp, ds));
+    for (int iter = 2;; ++iter) {
+      CX_TRY(enqueue_head(iter, pre, p, r, z, ds));
+      CX_TRY(wait_published(iter - 1, &h));
       if (h.flag != CG_RUNNING) break;
+      CX_TRY(enqueue_tail(iter, lhs, rhs, x, p, r, z, tmp, ds));
     }
+    CX_HIP(hipStreamSynchronize(st));
+    summary->num_iterations = h.iter;
     switch (h.flag) {
       case CG_CONVERGED_Q:
         summary->termination_type = CX_SUCCESS;
@@ -492,7 +560,11 @@ int SolveIterativeSchur239(cx_solver* S, cx_matrix* A, const double* b, const do
   id.ctx = ctx; id.n = nf;
   LinOp& pre = (o.preconditioner_type == CX_IDENTITY) ? static_cast<LinOp&>(id) : static_cast<LinOp&>(bd);
   CgDriver cg{S, ctx, st, nf, nf};
-  CX_TRY(cg.run(lhs, pre, S->v_rhs.p, S->v_x.p, true, r_tol, q_tol, summary));
+  CX_TRY(S->state.alloc(1));
+  A->stop = &S->state.p->flag;  // product kernels of a speculatively enqueued iteration exit early
+  const int cg_rc = cg.run(lhs, pre, S->v_rhs.p, S->v_x.p, true, r_tol, q_tol, summary);
+  A->stop = nullptr;
+  CX_TRY(cg_rc);
   CX_TRY(sw.stop(&S->timing.reduced_solve_ms));
 
   CX_TRY(sw.start());
@@ -545,7 +617,11 @@ int SolveCgnr239(cx_solver* S, cx_matrix* A, const double* b, const double* D, d
   id.ctx = ctx; id.n = n;
   LinOp& pre = (o.preconditioner_type == CX_IDENTITY) ? static_cast<LinOp&>(id) : static_cast<LinOp&>(jac);
   CgDriver cg{S, ctx, st, n, ctx->nranks > 1 ? ne : n};
-  CX_TRY(cg.run(lhs, pre, S->v_rhs.p, x, true, r_tol, q_tol, summary));
+  CX_TRY(S->state.alloc(1));
+  A->stop = &S->state.p->flag;
+  const int cg_rc = cg.run(lhs, pre, S->v_rhs.p, x, true, r_tol, q_tol, summary);
+  A->stop = nullptr;
+  CX_TRY(cg_rc);
   CX_TRY(sw.stop(&S->timing.reduced_solve_ms));
   return CX_OK;
 }
@@ -645,6 +721,7 @@ void cx_solver_destroy(cx_solver* s) {
   if (!s) return;
   (void)hipSetDevice(s->ctx->device);
   (void)hipStreamSynchronize(s->ctx->stream);
+  if (s->ring_h) (void)hipHostFree(s->ring_h);
   delete s;
 }
 

@@ -20,6 +20,7 @@ struct CgState {
   double tol_r, q_tol;
   double s0, s1;  // reduction results
   int flag, iter, min_iter, max_iter;
+  int seq, pad;  // seq: iteration this copy was published for (host-pinned ring only)
 };
 
 constexpr int kRedBlocks = 512;  // fixed grid of the two-stage reductions (deterministic)
@@ -79,6 +80,8 @@ struct cx_solver {
   DevBuf<double> v_p, v_r, v_z, v_tmp, v_x, v_rhs, v_rows, v_rows2, v_cols;
   DevBuf<double> ete_inv, cam_blocks, pt_blocks, g_e, lhs, partial;
   DevBuf<CgState> state;
+  CgState* ring_h = nullptr;  // host-pinned, device-visible ring of published CG states
+  CgState* ring_d = nullptr;
   DevBuf<int> flag;
 };
 
