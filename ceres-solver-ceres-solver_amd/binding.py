@@ -28,12 +28,13 @@ EXPORTED_SYMBOLS = [
     "cx_matrix_create", "cx_matrix_destroy", "cx_matrix_num_rows", "cx_matrix_num_cols",
     "cx_matrix_num_nonzeros", "cx_matrix_is_static_239", "cx_matrix_device_values", "cx_matrix_set_values",
     "cx_matrix_get_values", "cx_matrix_values_changed", "cx_matrix_set_zero", "cx_matrix_right_multiply",
-    "cx_matrix_left_multiply", "cx_matrix_squared_column_norm", "cx_matrix_scale_columns",
+    "cx_matrix_left_multiply", "cx_matrix_right_multiply_e", "cx_matrix_right_multiply_f",
+    "cx_matrix_left_multiply_e", "cx_matrix_left_multiply_f", "cx_matrix_squared_column_norm", "cx_matrix_scale_columns",
     "cx_matrix_last_kernel_ms", "cx_solver_create", "cx_solver_destroy", "cx_solver_default_options",
     "cx_solver_solve", "cx_solver_last_timing", "cx_solver_kernel_stats", "cx_schur_eliminate_dense", "cx_schur_back_substitute",
     "cx_implicit_schur_multiply", "cx_dense_cholesky_solve", "cx_evaluator_create_bal", "cx_evaluator_destroy",
     "cx_evaluator_jacobian", "cx_evaluator_row_of_observation", "cx_evaluator_evaluate",
-    "cx_evaluator_last_kernel_ms", "cx_detect_structure", "cx_partition_points",
+    "cx_evaluator_last_kernel_ms", "cx_detect_structure", "cx_partition_points", "cx_stable_schur_ordering",
 ]
 
 
@@ -308,6 +309,14 @@ class Matrix:
         _check(self.lib.cx_matrix_left_multiply(self._h, _ptr(x), _ptr(y), HOST))
         return y
 
+    def partitioned_multiply(self, part, transpose, x, y):
+        """y += E x, F x, E' x or F' x (host numpy arrays; part is "e" or "f")."""
+        fn = getattr(self.lib, "cx_matrix_%s_multiply_%s" % ("left" if transpose else "right", part))
+        x = _f64(x)
+        y = np.array(y, dtype=np.float64)
+        _check(fn(self._h, _ptr(x), _ptr(y), HOST))
+        return y
+
     def squared_column_norm(self, out=None):
         if isinstance(out, DeviceArray):
             _check(self.lib.cx_matrix_squared_column_norm(self._h, _ptr(out), DEVICE))
@@ -466,6 +475,16 @@ def detect_structure(bs, num_eliminate_blocks):
     _check(load_library().cx_detect_structure(bs.c, int(num_eliminate_blocks), ctypes.byref(r), ctypes.byref(e),
                                               ctypes.byref(f)))
     return r.value, e.value, f.value
+
+
+def stable_schur_ordering(num_cameras, num_points, camera_index, point_index):
+    camera_index = np.ascontiguousarray(camera_index, dtype=np.int32)
+    point_index = np.ascontiguousarray(point_index, dtype=np.int32)
+    ordering = np.zeros(num_cameras + num_points, dtype=np.int32)
+    k = ctypes.c_int32()
+    _check(load_library().cx_stable_schur_ordering(int(num_cameras), int(num_points), ctypes.c_int64(camera_index.shape[0]),
+                                                   _ptr(camera_index), _ptr(point_index), _ptr(ordering), ctypes.byref(k)))
+    return ordering, k.value
 
 
 def partition_points(bs, num_eliminate_blocks, nranks):

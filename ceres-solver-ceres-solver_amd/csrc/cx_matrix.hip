@@ -8,6 +8,7 @@
 //   k_cam_ft         y_f  = F' x     164 B/row block from the camera-major copy (+ 16 B gather)
 //   k_permute_ft     Ft <- F         288 B/row block, once per value update
 #include <algorithm>
+#include <cstdlib>
 #include <numeric>
 
 #include "cx_internal.h"
@@ -252,16 +253,28 @@ __global__ __launch_bounds__(kBlock) void k_scale_239(double* __restrict__ E, do
 // Dynamic block sizes: one thread per row block, atomics for transposed products.
 // This is the fallback the reference's Eigen::Dynamic template instantiations are.
 
+// sel: 0 all cells, 1 the e cell (first cell of rows r < nrows_e), 2 the f cells; col_off is
+// subtracted from column positions (num_cols_e for products with the F half alone)
+__device__ __forceinline__ void kg_cell_range(const int32_t* __restrict__ rcb, int r, int nrows_e, int sel, int& b, int& e) {
+  b = rcb[r];
+  e = rcb[r + 1];
+  const bool has_e = r < nrows_e;
+  if (sel == 1) e = has_e ? min(e, b + 1) : b;
+  else if (sel == 2 && has_e) b = min(e, b + 1);
+}
+
 __global__ void kg_right(const cx_block* __restrict__ rows, const cx_block* __restrict__ cols,
                          const int32_t* __restrict__ rcb, const cx_cell* __restrict__ cells,
                          const double* __restrict__ values, const double* __restrict__ x,
-                         double* __restrict__ y, int R) {
+                         double* __restrict__ y, int R, int nrows_e, int sel, int col_off) {
   const int r = blockIdx.x * blockDim.x + threadIdx.x;
   if (r >= R) return;
   const int rs = rows[r].size, rp = rows[r].position;
-  for (int c = rcb[r]; c < rcb[r + 1]; ++c) {
+  int cb, ce;
+  kg_cell_range(rcb, r, nrows_e, sel, cb, ce);
+  for (int c = cb; c < ce; ++c) {
     const cx_cell cell = cells[c];
-    const int cs = cols[cell.block_id].size, cp = cols[cell.block_id].position;
+    const int cs = cols[cell.block_id].size, cp = cols[cell.block_id].position - col_off;
     const double* m = values + cell.position;
     for (int i = 0; i < rs; ++i) {
       double s = 0.0;
@@ -274,13 +287,15 @@ __global__ void kg_right(const cx_block* __restrict__ rows, const cx_block* __re
 __global__ void kg_left(const cx_block* __restrict__ rows, const cx_block* __restrict__ cols,
                         const int32_t* __restrict__ rcb, const cx_cell* __restrict__ cells,
                         const double* __restrict__ values, const double* __restrict__ x,
-                        double* __restrict__ y, int R) {
+                        double* __restrict__ y, int R, int nrows_e, int sel, int col_off) {
   const int r = blockIdx.x * blockDim.x + threadIdx.x;
   if (r >= R) return;
   const int rs = rows[r].size, rp = rows[r].position;
-  for (int c = rcb[r]; c < rcb[r + 1]; ++c) {
+  int cb, ce;
+  kg_cell_range(rcb, r, nrows_e, sel, cb, ce);
+  for (int c = cb; c < ce; ++c) {
     const cx_cell cell = cells[c];
-    const int cs = cols[cell.block_id].size, cp = cols[cell.block_id].position;
+    const int cs = cols[cell.block_id].size, cp = cols[cell.block_id].position - col_off;
     const double* m = values + cell.position;
     for (int j = 0; j < cs; ++j) {
       double s = 0.0;
@@ -420,12 +435,24 @@ static int Build239(cx_matrix* A) {
     std::vector<int32_t> cur(cam_start.begin(), cam_start.end() - 1);
     for (int64_t r = 0; r < O; ++r) cam_rows[cur[row_cam[r]]++] = int32_t(r);
   }
+  // segment length: long enough that the per-segment block reduction is amortised over several
+  // rows per thread, short enough that the launch still has far more workgroups than CUs
+  static const int seg_env = [] { const char* v = getenv("CX_SEG_ROWS"); return v ? atoi(v) : 0; }();
+  int seg_rows = seg_env > 0 ? seg_env : kSegRows;
+  if (seg_env <= 0) {
+    while (seg_rows < 4096 && O / (2 * seg_rows) > int64_t(A->ctx->num_cus) * 16) seg_rows *= 2;
+  }
   std::vector<int32_t> seg_begin, seg_cam, cam_seg_start(C + 1, 0);
   for (int c = 0; c < C; ++c) {
     cam_seg_start[c] = int32_t(seg_cam.size());
-    for (int b = cam_start[c]; b < cam_start[c + 1]; b += kSegRows) {
+    // equal parts (no short tail segment): nseg = ceil(len / seg_rows)
+    const int len = cam_start[c + 1] - cam_start[c];
+    const int nseg = (len + seg_rows - 1) / seg_rows;
+    int b = cam_start[c];
+    for (int k = 0; k < nseg; ++k) {
       seg_begin.push_back(b);
       seg_cam.push_back(c);
+      b += len / nseg + (k < len % nseg ? 1 : 0);
     }
   }
   cam_seg_start[C] = int32_t(seg_cam.size());
@@ -477,7 +504,7 @@ int cxk_right_multiply(cx_matrix* A, const double* x, double* y) {
                        A->O, 1, 1, 1, A->stop);
   } else if (A->R > 0) {
     hipLaunchKernelGGL(kg_right, dim3(grid_for(A->R, 128)), dim3(128), 0, st, A->d_rows.p, A->d_cols.p,
-                       A->d_rcb.p, A->d_cells.p, A->d_values.p, x, y, A->R);
+                       A->d_rcb.p, A->d_cells.p, A->d_values.p, x, y, A->R, A->num_row_blocks_e, 0, 0);
   }
   CX_HIP(hipGetLastError());
   return CX_OK;
@@ -491,7 +518,7 @@ int cxk_left_multiply(cx_matrix* A, const double* x, double* y) {
     CX_TRY(cxk_ft_multiply(A, x, y + 3 * int64_t(A->P), true));
   } else if (A->R > 0) {
     hipLaunchKernelGGL(kg_left, dim3(grid_for(A->R, 128)), dim3(128), 0, st, A->d_rows.p, A->d_cols.p,
-                       A->d_rcb.p, A->d_cells.p, A->d_values.p, x, y, A->R);
+                       A->d_rcb.p, A->d_cells.p, A->d_values.p, x, y, A->R, A->num_row_blocks_e, 0, 0);
   }
   CX_HIP(hipGetLastError());
   return CX_OK;
@@ -725,6 +752,49 @@ int cx_matrix_scale_columns(cx_matrix* A, const double* scale, int32_t memspace)
   CX_TRY(Timed(A, [&] { return cxk_scale_columns(A, hs.dptr); }));
   return CX_OK;
 }
+
+// PartitionedMatrixView products: part 1 = E, 2 = F
+static int PartitionedMultiply(cx_matrix* A, int part, bool transpose, const double* x, double* y, int32_t memspace) {
+  CX_CHECK_ARG(A && x && y && A->nelim > 0);
+  const size_t ncol = size_t(part == 1 ? A->num_cols_e : A->num_cols_f);
+  HostOrDevice hx(A->ctx), hy(A->ctx);
+  CX_TRY(hx.in(x, transpose ? size_t(A->num_rows) : ncol, memspace));
+  CX_TRY(hy.inout(y, transpose ? ncol : size_t(A->num_rows), memspace, true));
+  if (A->is239 && part == 2 && transpose) CX_TRY(cx_matrix_ensure_ft(A));
+  CX_TRY(Timed(A, [&]() -> int {
+    hipStream_t st = A->ctx->stream;
+    if (A->is239) {
+      const double* E = A->d_values.p;
+      const double* F = A->d_values.p + 6 * A->O;
+      if (!transpose) {
+        hipLaunchKernelGGL(k_right_239, dim3(grid_for(A->O, kBlock)), dim3(kBlock), 0, st, E, F, A->d_row_pt.p,
+                           A->d_row_cam.p, (const double*)hx.dptr, (const double*)hx.dptr, hy.dptr, A->O, part == 1 ? 1 : 0,
+                           part == 2 ? 1 : 0, 1, (const int*)nullptr);
+      } else if (part == 1) {
+        hipLaunchKernelGGL(k_left_e_239, dim3(A->num_tiles), dim3(kBlock), 0, st, E, A->d_tile_row.p, A->d_tile_pt.p,
+                           A->d_pt_start.p, (const double*)hx.dptr, hy.dptr, 1, (const int*)nullptr);
+      } else {
+        CX_TRY(cxk_ft_multiply(A, hx.dptr, hy.dptr, true));
+      }
+    } else if (A->R > 0) {
+      const int off = part == 2 ? int(A->num_cols_e) : 0;
+      if (!transpose)
+        hipLaunchKernelGGL(kg_right, dim3(grid_for(A->R, 128)), dim3(128), 0, st, A->d_rows.p, A->d_cols.p, A->d_rcb.p,
+                           A->d_cells.p, A->d_values.p, (const double*)hx.dptr, hy.dptr, A->R, A->num_row_blocks_e, part, off);
+      else
+        hipLaunchKernelGGL(kg_left, dim3(grid_for(A->R, 128)), dim3(128), 0, st, A->d_rows.p, A->d_cols.p, A->d_rcb.p,
+                           A->d_cells.p, A->d_values.p, (const double*)hx.dptr, hy.dptr, A->R, A->num_row_blocks_e, part, off);
+    }
+    CX_HIP(hipGetLastError());
+    return CX_OK;
+  }));
+  return hy.out();
+}
+
+int cx_matrix_right_multiply_e(cx_matrix* A, const double* x, double* y, int32_t m) { return PartitionedMultiply(A, 1, false, x, y, m); }
+int cx_matrix_right_multiply_f(cx_matrix* A, const double* x, double* y, int32_t m) { return PartitionedMultiply(A, 2, false, x, y, m); }
+int cx_matrix_left_multiply_e(cx_matrix* A, const double* x, double* y, int32_t m) { return PartitionedMultiply(A, 1, true, x, y, m); }
+int cx_matrix_left_multiply_f(cx_matrix* A, const double* x, double* y, int32_t m) { return PartitionedMultiply(A, 2, true, x, y, m); }
 
 double cx_matrix_last_kernel_ms(const cx_matrix* A) { return A ? double(A->last_ms) : 0.0; }
 

@@ -210,6 +210,13 @@ int cx_matrix_left_multiply(cx_matrix* A, const double* x, double* y, int32_t me
 int cx_matrix_squared_column_norm(cx_matrix* A, double* x, int32_t memspace);
 /* A <- A diag(scale)  BlockSparseMatrix::ScaleColumns (block_sparse_matrix.cc:403-450) */
 int cx_matrix_scale_columns(cx_matrix* A, const double* scale, int32_t memspace);
+/* PartitionedMatrixView<2,3,9> (partitioned_matrix_view_impl.h:92-320): products with the E
+ * half (first num_eliminate_blocks column blocks) or the F half of A.  x_e / y_e have
+ * num_cols_e entries, x_f / y_f num_cols_f; all accumulate (y += ...). */
+int cx_matrix_right_multiply_e(cx_matrix* A, const double* x_e, double* y, int32_t memspace);
+int cx_matrix_right_multiply_f(cx_matrix* A, const double* x_f, double* y, int32_t memspace);
+int cx_matrix_left_multiply_e(cx_matrix* A, const double* x, double* y_e, int32_t memspace);
+int cx_matrix_left_multiply_f(cx_matrix* A, const double* x, double* y_f, int32_t memspace);
 /* device time of the last cx_matrix_* product in ms (HIP events on the context stream) */
 double cx_matrix_last_kernel_ms(const cx_matrix* A);
 
@@ -282,6 +289,13 @@ double cx_evaluator_last_kernel_ms(const cx_evaluator* e);
 /* DetectStructure (detect_structure.cc:39-120); -1 stands for Eigen::Dynamic */
 int cx_detect_structure(const cx_block_structure* bs, int32_t num_eliminate_blocks,
                         int32_t* row_block_size, int32_t* e_block_size, int32_t* f_block_size);
+/* ComputeStableSchurOrdering (parameter_block_ordering.cc:50-83, graph_algorithms.h:165-227) for a
+ * bundle-adjustment program whose parameter blocks are listed cameras 0..C-1 then points 0..P-1
+ * (bundle_adjuster.cc:253-267): vertex ids camera i -> i, point j -> C + j.  ordering has C + P
+ * entries: the independent set (eliminated first) followed by the rest. */
+int cx_stable_schur_ordering(int32_t num_cameras, int32_t num_points, int64_t num_observations,
+                             const int32_t* camera_index, const int32_t* point_index,
+                             int32_t* ordering, int32_t* independent_set_size);
 /* Partition the first num_eliminate_blocks column blocks (points) into nranks
  * contiguous ranges holding about equal numbers of non-zeros -- the balancing
  * PartitionRangeForParallelFor does on cumulative_nnz

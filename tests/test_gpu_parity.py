@@ -332,3 +332,30 @@ def test_shard_additivity_on_device(ctx, oracle):
     assert relerr(y_sum + Df2x, y_full) < 1e-12 and relerr(rhs_sum, rhs_full) < 1e-12
     assert relerr(np.triu(lhs_sum + np.diag(D[3 * P:] ** 2)), np.triu(lhs_full)) < 1e-11 and relerr(r_sum, r_full) < 1e-12
     A.close()
+
+
+def test_partitioned_products(ctx, oracle):
+    """PartitionedMatrixView E / F products (partitioned_matrix_view_test.cc:103-204) on the static
+    layout and on a fixture with dynamic blocks, against dense algebra."""
+    from conftest import lls_problem
+    prob, bs, order, vals, b, D = make(8, 120, 520, 31, "random")
+    cases = [(bs, vals, prob.num_points)]
+    for pid in (2, 4, 6):
+        fbs, fvals, fb, fD, fnelim, raw = lls_problem(pid)
+        cases.append((fbs, fvals, fnelim))
+    rng = np.random.default_rng(5)
+    for cbs, cvals, nelim in cases:
+        J = cbs.to_dense(cvals)
+        ne = int(cbs.col_blocks["size"][:nelim].sum())
+        E, F = J[:, :ne], J[:, ne:]
+        A = cx.Matrix(ctx, cbs, nelim)
+        A.set_values(cvals)
+        xe, xf = rng.standard_normal(ne), rng.standard_normal(J.shape[1] - ne)
+        yr, y0 = rng.standard_normal(J.shape[0]), rng.standard_normal(J.shape[0])
+        tol = 1e-12 * max(1.0, np.abs(J).max()) * J.shape[1]
+        assert np.abs(A.partitioned_multiply("e", False, xe, y0) - (y0 + E @ xe)).max() < tol
+        assert np.abs(A.partitioned_multiply("f", False, xf, y0) - (y0 + F @ xf)).max() < tol
+        ce, cf = rng.standard_normal(ne), rng.standard_normal(J.shape[1] - ne)
+        assert np.abs(A.partitioned_multiply("e", True, yr, ce) - (ce + E.T @ yr)).max() < tol * 10
+        assert np.abs(A.partitioned_multiply("f", True, yr, cf) - (cf + F.T @ yr)).max() < tol * 10
+        A.close()

@@ -51,3 +51,23 @@ def test_partition_points_balanced():
         assert sum(per) == prob.num_observations
         assert max(per) - min(per) <= counts.max() * 2 + 1
         assert np.array_equal(bounds, cx.bal.partition_points(prob, nranks))
+
+
+def test_stable_schur_ordering_matches_oracle(oracle):
+    """Integer outcome, must be identical: ComputeStableSchurOrdering on BAL graphs, including a
+    camera with fewer points than its points have cameras and a repeated observation."""
+    rng = np.random.default_rng(0)
+    cases = []
+    prob = cx.bal.make_bal_like(9, 300, 1300, seed=21)
+    cases.append((prob.num_cameras, prob.num_points, prob.camera_index, prob.point_index))
+    cam = np.array([0, 1, 2, 1, 2, 1, 2, 2], dtype=np.int32)       # duplicate (2, 2)
+    pt = np.array([0, 0, 0, 1, 1, 2, 2, 2], dtype=np.int32)
+    cases.append((3, 3, cam, pt))
+    C, P = 20, 60
+    cam = rng.integers(0, C, 400).astype(np.int32)
+    pt = rng.integers(0, P, 400).astype(np.int32)
+    cases.append((C, P, cam, pt))
+    for C, P, cam, pt in cases:
+        o1, k1 = cx.stable_schur_ordering(C, P, cam, pt)
+        o2, k2 = oracle.stable_schur_ordering(C, P, cam, pt)
+        assert k1 == k2 and np.array_equal(o1, o2)
