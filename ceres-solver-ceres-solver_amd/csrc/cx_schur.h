@@ -8,7 +8,7 @@
 int cxs_compute_ete_inverse(cx_matrix* A, const double* D, const double* b, double* ete_inv, double* g,
                             bool llt, int* d_flag);
 // mode 0: out[2O] = (I - E (E'E)^-1 E') F xf ; 1: out[2O] = (I - E (E'E)^-1 E') b ;
-// 2: out[3P] = (E'E)^-1 E' (b - F xf)
+// 2: out[3P] = (E'E)^-1 E' (b - F xf) ; 3: out[2O] = E (E'E)^-1 E' F xf
 int cxs_chunk_pass(cx_matrix* A, int mode, const double* ete_inv, const double* xf, const double* b, double* out);
 // blocks[81C] = block diagonal of F'F (with_schur = false) or of S without D_f^2 (true)
 int cxs_camera_block_diagonal(cx_matrix* A, bool with_schur, const double* ete_inv, double* blocks);

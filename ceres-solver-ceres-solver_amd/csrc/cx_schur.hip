@@ -156,6 +156,7 @@ __global__ __launch_bounds__(kBlock) void k_chunk_ete(const double* __restrict__
 // MODE 0 (SX)     : t = F x_f ;  t' = t - E (E'E)^-1 E' t ; write t'        (S x, first half)
 // MODE 1 (RHS)    : t = b     ;  t' = t - E (E'E)^-1 E' t ; write t'        (UpdateRhs)
 // MODE 2 (BACKSUB): s = b - F z;  x_pt = (E'E)^-1 E' s                       (BackSubstitute)
+// MODE 3 (SPSE)   : t = F x_f ;  out = E (E'E)^-1 E' t                      (power series operator)
 template <int MODE>
 __global__ __launch_bounds__(kBlock) void k_chunk_pass(const double* __restrict__ E,
                                                        const double* __restrict__ F,
@@ -193,7 +194,7 @@ __global__ __launch_bounds__(kBlock) void k_chunk_pass(const double* __restrict_
     if (MODE != 1) load_cells<18>(F + 18 * int64_t(r0), nvalid, fv);
     load_cells<6>(E + 6 * int64_t(r0), nvalid, ev);
     double2 bv = make_double2(0.0, 0.0);
-    if (MODE != 0 && live) bv = reinterpret_cast<const double2*>(b)[r];
+    if ((MODE == 1 || MODE == 2) && live) bv = reinterpret_cast<const double2*>(b)[r];
     double xv[9];
     if (MODE != 1) {
       const double* xc = xf + 9 * int64_t(cam);
@@ -260,8 +261,10 @@ __global__ __launch_bounds__(kBlock) void k_chunk_pass(const double* __restrict_
       if (tid < nvalid) {
         const int lo = lp;  // point of this row, local to the tile
         const double u0 = u[lo * 3], u1 = u[lo * 3 + 1], u2 = u[lo * 3 + 2];
-        t0 -= e[0] * u0 + e[1] * u1 + e[2] * u2;
-        t1 -= e[3] * u0 + e[4] * u1 + e[5] * u2;
+        const double eu0 = e[0] * u0 + e[1] * u1 + e[2] * u2;
+        const double eu1 = e[3] * u0 + e[4] * u1 + e[5] * u2;
+        if (MODE == 3) { t0 = eu0; t1 = eu1; }
+        else { t0 -= eu0; t1 -= eu1; }
         reinterpret_cast<double2*>(out)[r] = make_double2(t0, t1);
       }
     }
@@ -277,7 +280,7 @@ __global__ __launch_bounds__(kBlock) void k_chunk_pass(const double* __restrict_
         const double* xc = xf + 9 * int64_t(row_cam[r]);
         for (int k = 0; k < 9; ++k) { t0 += f[k] * xc[k]; t1 += f[9 + k] * xc[k]; }
       }
-      if (MODE != 0) {
+      if (MODE == 1 || MODE == 2) {
         const double2 bv = reinterpret_cast<const double2*>(b)[r];
         if (MODE == 1) { t0 = bv.x; t1 = bv.y; }
         else { t0 = bv.x - t0; t1 = bv.y - t1; }
@@ -301,12 +304,14 @@ __global__ __launch_bounds__(kBlock) void k_chunk_pass(const double* __restrict_
           const double* f = F + 18 * int64_t(r);
           const double* xc = xf + 9 * int64_t(row_cam[r]);
           for (int k = 0; k < 9; ++k) { t0 += f[k] * xc[k]; t1 += f[9 + k] * xc[k]; }
-        } else {
+        } else if (MODE == 1) {
           const double2 bv = reinterpret_cast<const double2*>(b)[r];
           t0 = bv.x; t1 = bv.y;
         }
-        t0 -= e[0] * u0 + e[1] * u1 + e[2] * u2;
-        t1 -= e[3] * u0 + e[4] * u1 + e[5] * u2;
+        const double eu0 = e[0] * u0 + e[1] * u1 + e[2] * u2;
+        const double eu1 = e[3] * u0 + e[4] * u1 + e[5] * u2;
+        if (MODE == 3) { t0 = eu0; t1 = eu1; }
+        else { t0 -= eu0; t1 -= eu1; }
         reinterpret_cast<double2*>(out)[r] = make_double2(t0, t1);
       }
     }
@@ -754,6 +759,7 @@ int cxs_chunk_pass(cx_matrix* A, int mode, const double* ete_inv, const double* 
                          A->d_tile_pt.p, A->d_pt_start.p, A->d_row_cam.p, A->d_row_pt.p, ete_inv, xf, b, out, A->stop, 1);
   } else if (mode == 0) CX_LAUNCH_PASS(0);
   else if (mode == 1) CX_LAUNCH_PASS(1);
+  else if (mode == 3) CX_LAUNCH_PASS(3);
   else CX_LAUNCH_PASS(2);
 #undef CX_LAUNCH_PASS
   CX_HIP(hipGetLastError());

@@ -426,6 +426,78 @@ struct ImplicitSchurOp : LinOp {
   }
 };
 
+__global__ void k_axpy1(double* __restrict__ y, const double* __restrict__ x, int64_t n) {
+  const int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i < n) y[i] += x[i];
+}
+
+// PowerSeriesExpansionPreconditioner::RightMultiplyAndAccumulate
+// (power_series_expansion_preconditioner.cc:57-84): y = sum_{k=0..} Z^k (F'F)^-1 x with
+// Z = (F'F)^-1 F'E (E'E)^-1 E'F  (InversePowerSeriesOperatorRightMultiplyAccumulate,
+// implicit_schur_complement.cc:146-177).  tolerance = 0 (the preconditioner setting) runs a
+// fixed max_iterations terms and needs no host round trip.
+struct SpseOp : LinOp {
+  cx_solver* S;
+  cx_matrix* A;
+  int max_iterations;
+  double tolerance;
+  int64_t size() const override { return 9 * int64_t(A->C); }
+  int norm(const double* v, double* out) {
+    const int64_t n = size();
+    const int nb = int(std::min<int64_t>(kRedBlocks, std::max<int64_t>(1, (n + 1023) / 1024)));
+    hipStream_t st = A->ctx->stream;
+    hipLaunchKernelGGL(k_dot2_partial, dim3(nb), dim3(256), 0, st, v, v, (const double*)nullptr, (const double*)nullptr, n,
+                       S->partial.p, (const CgState*)nullptr);
+    hipLaunchKernelGGL(k_dot2_final, dim3(1), dim3(256), 0, st, (const double*)S->partial.p, nb, int(FIN_STORE), 0, 0,
+                       S->spse_state.p, (CgState*)nullptr, 0);
+    CgState h;
+    CX_HIP(hipMemcpyAsync(&h, S->spse_state.p, sizeof(h), hipMemcpyDeviceToHost, st));
+    CX_HIP(hipStreamSynchronize(st));
+    *out = std::sqrt(h.s0);
+    return CX_OK;
+  }
+  int apply(const double* x, double* y) override {
+    cx_context* ctx = A->ctx;
+    hipStream_t st = ctx->stream;
+    const int64_t n = size();
+    const int g = grid_for(n, 256);
+    CX_TRY(S->v_spse.alloc(size_t(3 * n)));
+    CX_TRY(S->partial.alloc(2 * kRedBlocks));
+    CX_TRY(S->spse_state.alloc(1));
+    double* series = S->v_spse.p;
+    double* previous = S->v_spse.p + n;
+    double* tmp_f = S->v_spse.p + 2 * n;
+    const int64_t nb9 = A->C;
+    // y = (F'F)^-1 x ; previous = y
+    hipLaunchKernelGGL(k_blockdiag_multiply<9>, dim3(grid_for(9 * nb9, 256)), dim3(256), 0, st, (const double*)S->cam_blocks.p, x, y, nb9);
+    CX_HIP(hipMemcpyAsync(previous, y, size_t(n) * sizeof(double), hipMemcpyDeviceToDevice, st));
+    double threshold = 0.0;
+    if (tolerance > 0.0) {
+      double ny = 0.0;
+      CX_TRY(norm(y, &ny));
+      threshold = tolerance * ny;
+    }
+    for (int i = 1;; ++i) {
+      // series = Z previous
+      CX_TRY(cxs_chunk_pass(A, 3, S->ete_inv.p, previous, nullptr, S->v_rows.p));
+      CX_TRY(cxk_ft_multiply(A, S->v_rows.p, tmp_f, false));
+      if (ctx->nranks > 1) CX_TRY(cx_allreduce_device(ctx, tmp_f, n));
+      hipLaunchKernelGGL(k_blockdiag_multiply<9>, dim3(grid_for(9 * nb9, 256)), dim3(256), 0, st, (const double*)S->cam_blocks.p,
+                         (const double*)tmp_f, series, nb9);
+      hipLaunchKernelGGL(k_axpy1, dim3(g), dim3(256), 0, st, y, (const double*)series, n);
+      if (i >= max_iterations) break;
+      if (tolerance > 0.0) {
+        double ns = 0.0;
+        CX_TRY(norm(series, &ns));
+        if (ns < threshold) break;
+      }
+      std::swap(previous, series);
+    }
+    CX_HIP(hipGetLastError());
+    return CX_OK;
+  }
+};
+
 struct BlockDiag9Op : LinOp {
   cx_context* ctx;
   const double* blocks;
@@ -531,7 +603,13 @@ int SolveIterativeSchur239(cx_solver* S, cx_matrix* A, const double* b, const do
   // ImplicitSchurComplement::Init (implicit_schur_complement.cc:49-97)
   CX_TRY(cx_matrix_ensure_ft(A));
   CX_TRY(cxs_compute_ete_inverse(A, D, nullptr, S->ete_inv.p, nullptr, true, S->flag.p));
-  const bool need_ftf = o.preconditioner_type == CX_JACOBI;
+  // compute_ftf_inverse_ (implicit_schur_complement.cc:63-67)
+  const bool need_ftf = o.preconditioner_type == CX_JACOBI || o.preconditioner_type == CX_SCHUR_POWER_SERIES_EXPANSION ||
+                        o.use_spse_initialization;
+  if (o.use_spse_initialization && o.preconditioner_type == CX_SCHUR_JACOBI) {
+    cx_set_error("use_spse_initialization together with SCHUR_JACOBI is not available on the device");
+    return CX_ERR_UNSUPPORTED;
+  }
   if (need_ftf || o.preconditioner_type == CX_SCHUR_JACOBI) {
     CX_TRY(S->cam_blocks.alloc(81 * size_t(A->C)));
     CX_TRY(cxs_camera_block_diagonal(A, o.preconditioner_type == CX_SCHUR_JACOBI, S->ete_inv.p, S->cam_blocks.p));
@@ -558,11 +636,24 @@ int SolveIterativeSchur239(cx_solver* S, cx_matrix* A, const double* b, const do
   bd.ctx = ctx; bd.blocks = S->cam_blocks.p; bd.nblocks = A->C;
   IdentityOp id;
   id.ctx = ctx; id.n = nf;
-  LinOp& pre = (o.preconditioner_type == CX_IDENTITY) ? static_cast<LinOp&>(id) : static_cast<LinOp&>(bd);
+  // the preconditioner ignores spse_tolerance so that it stays fixed during CG
+  // (iterative_schur_complement_solver.cc:178-186)
+  SpseOp spse_pre;
+  spse_pre.S = S; spse_pre.A = A; spse_pre.max_iterations = o.max_num_spse_iterations; spse_pre.tolerance = 0.0;
+  bool zero_initial = true;
+  if (o.use_spse_initialization) {  // :100-111
+    SpseOp init;
+    init.S = S; init.A = A; init.max_iterations = o.max_num_spse_iterations; init.tolerance = o.spse_tolerance;
+    CX_TRY(init.apply(S->v_rhs.p, S->v_x.p));
+    zero_initial = false;
+  }
+  LinOp& pre = (o.preconditioner_type == CX_IDENTITY) ? static_cast<LinOp&>(id)
+               : (o.preconditioner_type == CX_SCHUR_POWER_SERIES_EXPANSION) ? static_cast<LinOp&>(spse_pre)
+                                                                          : static_cast<LinOp&>(bd);
   CgDriver cg{S, ctx, st, nf, nf};
   CX_TRY(S->state.alloc(1));
   A->stop = &S->state.p->flag;  // product kernels of a speculatively enqueued iteration exit early
-  const int cg_rc = cg.run(lhs, pre, S->v_rhs.p, S->v_x.p, true, r_tol, q_tol, summary);
+  const int cg_rc = cg.run(lhs, pre, S->v_rhs.p, S->v_x.p, zero_initial, r_tol, q_tol, summary);
   A->stop = nullptr;
   CX_TRY(cg_rc);
   CX_TRY(sw.stop(&S->timing.reduced_solve_ms));

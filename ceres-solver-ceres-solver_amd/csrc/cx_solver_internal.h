@@ -79,7 +79,8 @@ struct cx_solver {
   // persistent device scratch
   DevBuf<double> v_p, v_r, v_z, v_tmp, v_x, v_rhs, v_rows, v_rows2, v_cols;
   DevBuf<double> ete_inv, cam_blocks, pt_blocks, g_e, lhs, partial;
-  DevBuf<CgState> state;
+  DevBuf<CgState> state, spse_state;
+  DevBuf<double> v_spse;
   CgState* ring_h = nullptr;  // host-pinned, device-visible ring of published CG states
   CgState* ring_d = nullptr;
   DevBuf<int> flag;

@@ -359,3 +359,27 @@ def test_partitioned_products(ctx, oracle):
         assert np.abs(A.partitioned_multiply("e", True, yr, ce) - (ce + E.T @ yr)).max() < tol * 10
         assert np.abs(A.partitioned_multiply("f", True, yr, cf) - (cf + F.T @ yr)).max() < tol * 10
         A.close()
+
+
+@pytest.mark.parametrize("spse_init", [0, 1])
+@pytest.mark.parametrize("pre", ["SCHUR_POWER_SERIES_EXPANSION", "JACOBI"])
+def test_power_series_expansion(ctx, oracle, pre, spse_init):
+    """SCHUR_POWER_SERIES_EXPANSION preconditioner and use_spse_initialization
+    (power_series_expansion_preconditioner.cc:57-84, iterative_schur_complement_solver.cc:100-111)."""
+    if pre == "JACOBI" and not spse_init:
+        pytest.skip("covered by test_solvers_match_oracle")
+    prob, bs, order, vals, b, D = make(16, 700, 2800, 2, "eval", oracle)
+    P = prob.num_points
+    A = cx.Matrix(ctx, bs, P)
+    A.set_values(vals)
+    S = cx.Solver(ctx, type=cx.ITERATIVE_SCHUR, preconditioner_type=getattr(cx, pre), num_eliminate_blocks=P,
+                  max_num_iterations=200, max_num_spse_iterations=4, use_spse_initialization=spse_init, spse_tolerance=0.1)
+    x, s = S.solve(A, b, D, r_tolerance=-1.0, q_tolerance=0.05)
+    oo = oracle.make_options(type=oracle.ITERATIVE_SCHUR, preconditioner_type=getattr(oracle, pre), num_eliminate_blocks=P,
+                             max_num_iterations=200, max_num_spse_iterations=4, use_spse_initialization=spse_init,
+                             spse_tolerance=0.1)
+    xr, sr = oracle.solve(bs, vals, b, D, oo, r_tolerance=-1.0, q_tolerance=0.05)
+    assert s.termination_type == sr.termination_type and s.num_iterations == sr.num_iterations, (s.message, sr.message)
+    assert relerr(x, xr) < 1e-8
+    S.close()
+    A.close()
