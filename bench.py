@@ -142,6 +142,8 @@ def main():
         raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node %d"
                          % (args.gpus, world, args.gpus))
     cx = load_cx()
+    if os.environ.get("CX_BENCH_FORCE_DEVICE"):       # rehearsal of the N > 1 path on a box with one GPU
+        local_rank = int(os.environ["CX_BENCH_FORCE_DEVICE"])
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")

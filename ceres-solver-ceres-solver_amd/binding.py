@@ -22,7 +22,7 @@ SUCCESS, NO_CONVERGENCE, FAILURE, FATAL_ERROR = 0, 1, 2, 3
 
 # every symbol include/cxschur.h declares (tests check that the library exports them all)
 EXPORTED_SYMBOLS = [
-    "cx_context_create", "cx_context_destroy", "cx_comm_unique_id", "cx_context_set_comm", "cx_context_rank",
+    "cx_context_create", "cx_context_destroy", "cx_comm_unique_id", "cx_context_set_comm", "cx_context_set_comm_callback", "cx_context_rank",
     "cx_context_num_ranks", "cx_allreduce_sum", "cx_malloc", "cx_free", "cx_memcpy_h2d", "cx_memcpy_d2h",
     "cx_memset_zero", "cx_synchronize", "cx_context_stream", "cx_last_error", "cx_device_name",
     "cx_matrix_create", "cx_matrix_destroy", "cx_matrix_num_rows", "cx_matrix_num_cols",
@@ -179,6 +179,23 @@ class Context:
 
     def set_comm(self, rank, nranks, unique_id):
         _check(self.lib.cx_context_set_comm(self._h, int(rank), int(nranks), unique_id))
+
+    def set_comm_callback(self, rank, nranks, allreduce):
+        """allreduce(host_array) must sum a float64 numpy array over the ranks in place; the
+        device buffer is staged through the host (rehearsal transport, see cxschur.h)."""
+        def _cb(dptr, n, _user):
+            try:
+                host = np.empty(n, dtype=np.float64)
+                _check(self.lib.cx_memcpy_d2h(self._h, _ptr(host), ctypes.c_void_p(dptr), ctypes.c_size_t(8 * n)))
+                allreduce(host)
+                _check(self.lib.cx_memcpy_h2d(self._h, ctypes.c_void_p(dptr), _ptr(host), ctypes.c_size_t(8 * n)))
+                return 0
+            except Exception:  # pragma: no cover
+                import traceback
+                traceback.print_exc()
+                return 1
+        self._cb = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p)(_cb)
+        _check(self.lib.cx_context_set_comm_callback(self._h, int(rank), int(nranks), self._cb, None))
 
     @property
     def rank(self):

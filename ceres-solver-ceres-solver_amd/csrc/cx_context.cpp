@@ -69,6 +69,14 @@ int RcclCheck(int rc, const char* what) {
 
 int cx_allreduce_device(cx_context* ctx, double* p, int64_t n) {
   if (ctx->nranks <= 1 || n == 0) return CX_OK;
+  if (ctx->allreduce_cb) {
+    CX_HIP(hipStreamSynchronize(ctx->stream));
+    if (ctx->allreduce_cb(p, n, ctx->allreduce_cb_user) != 0) {
+      cx_set_error("all-reduce callback failed");
+      return CX_ERR_COMM;
+    }
+    return CX_OK;
+  }
   if (!ctx->comm) {
     cx_set_error("context has %d ranks but no communicator", ctx->nranks);
     return CX_ERR_COMM;
@@ -145,6 +153,15 @@ int cx_context_set_comm(cx_context* ctx, int rank, int nranks, const void* uniqu
   void* comm = nullptr;
   CX_TRY(RcclCheck(g_rccl.comm_init_rank(&comm, nranks, id, rank), "ncclCommInitRank"));
   ctx->comm = comm;
+  ctx->rank = rank;
+  ctx->nranks = nranks;
+  return CX_OK;
+}
+
+int cx_context_set_comm_callback(cx_context* ctx, int rank, int nranks, cx_allreduce_fn fn, void* user) {
+  CX_CHECK_ARG(ctx != nullptr && nranks >= 1 && rank >= 0 && rank < nranks && fn != nullptr);
+  ctx->allreduce_cb = fn;
+  ctx->allreduce_cb_user = user;
   ctx->rank = rank;
   ctx->nranks = nranks;
   return CX_OK;

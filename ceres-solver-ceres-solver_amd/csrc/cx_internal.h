@@ -46,6 +46,8 @@ struct cx_context {
   hipEvent_t ev[8] = {};
   // RCCL (resolved at run time from librccl.so.1; see cx_context.cpp)
   void* comm = nullptr;
+  int (*allreduce_cb)(double*, int64_t, void*) = nullptr;  // rehearsal transport (cx_context_set_comm_callback)
+  void* allreduce_cb_user = nullptr;
   int rank = 0;
   int nranks = 1;
   double allreduce_host_ms = 0.0;

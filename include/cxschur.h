@@ -161,6 +161,12 @@ void cx_context_destroy(cx_context* ctx);
  * a point-partitioned Jacobian and all-reduce camera-space sums. */
 int cx_comm_unique_id(void* out_128_bytes);
 int cx_context_set_comm(cx_context* ctx, int rank, int nranks, const void* unique_id_128_bytes);
+/* Alternative transport for the same exchange step: fn must sum the n doubles at device_ptr over
+ * all ranks in place and return 0 (it is called with the context's stream drained).  Meant for
+ * rehearsing the sharded path where RCCL peers are not available (two ranks sharing one GPU with
+ * a host-staged gloo all-reduce in tests/); RCCL remains the production data path. */
+typedef int (*cx_allreduce_fn)(double* device_ptr, int64_t n, void* user);
+int cx_context_set_comm_callback(cx_context* ctx, int rank, int nranks, cx_allreduce_fn fn, void* user);
 int cx_context_rank(const cx_context* ctx);
 int cx_context_num_ranks(const cx_context* ctx);
 /* sum-all-reduce of n doubles in place on the context's stream (exposed for tests) */
