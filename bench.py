@@ -128,6 +128,7 @@ def main():
     ap.add_argument("--solver", default="iterative_schur", choices=["iterative_schur", "dense_schur", "cgnr"],
                     help="linear solver of the step (the headline metric uses iterative_schur)")
     ap.add_argument("--preconditioner", default="jacobi", choices=["jacobi", "schur_jacobi", "identity"])
+    ap.add_argument("--mixed", action="store_true", help="CGNR with fp32-stored J values (BASELINE config 5)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=0)
     args = ap.parse_args()
@@ -174,7 +175,8 @@ def main():
     stype = {"iterative_schur": cx.ITERATIVE_SCHUR, "dense_schur": cx.DENSE_SCHUR, "cgnr": cx.CGNR}[args.solver]
     ptype = {"jacobi": cx.JACOBI, "schur_jacobi": cx.SCHUR_JACOBI, "identity": cx.IDENTITY}[args.preconditioner]
     solver_kw = dict(type=stype, preconditioner_type=ptype, num_eliminate_blocks=prob.num_points,
-                     max_num_iterations=500, min_num_iterations=0, residual_reset_period=10)
+                     max_num_iterations=500, min_num_iterations=0, residual_reset_period=10,
+                     use_mixed_precision_solves=1 if args.mixed else 0)
     S = cx.Solver(ctx, **solver_kw)
     x = ctx.empty(A.num_cols)
 
@@ -258,7 +260,7 @@ def main():
         out = {
             "metric": "linear_solve_ms_per_iter", "value": ms_per_step, "unit": "ms",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
-            "higher_is_better": False, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "higher_is_better": False, "scaling": "strong", "vs_baseline": None, "dtype": "f64 (J values stored fp32)" if args.mixed else "f64", "data": "synthetic",
             "config": {"workload": "%s: %s + %s, q_tol=0.1, synthetic BAL-shaped J "
                                    "(%d cameras, %d points, %d residual blocks)" % (args.workload, args.solver.upper(),
                                                                                    args.preconditioner.upper(), C, P, O),

@@ -227,10 +227,9 @@ int cxd_cholesky_solve(cx_context* ctx, int n, double* a, const double* rhs, dou
   }
   CX_HIP(hipGetLastError());
   // work = rhs (updated in place), ysol = U'^-1 rhs (then updated in place), x = U^-1 ysol
-  static DevBuf<double> scratch;  // one context per process
-  CX_TRY(scratch.alloc(2 * size_t(n)));
-  double* work = scratch.p;
-  double* ysol = scratch.p + n;
+  CX_TRY(ctx->chol_scratch.alloc(2 * size_t(n)));
+  double* work = ctx->chol_scratch.p;
+  double* ysol = ctx->chol_scratch.p + n;
   CX_HIP(hipMemcpyAsync(work, rhs, size_t(n) * sizeof(double), hipMemcpyDeviceToDevice, st));
   for (int k0 = 0; k0 < n; k0 += NB) {
     const int kb = std::min(NB, n - k0);

@@ -320,7 +320,7 @@ int cx_evaluator_evaluate(cx_evaluator* e, const double* state, double* cost, do
   if (cost) hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(256), 0, st, (const double*)e->d_partial.p, int64_t(grid), e->d_partial.p + grid);
   CX_HIP(hipGetLastError());
   CX_HIP(hipEventRecord(ctx->ev[7], st));
-  if (with_j) A->ft_valid = false;
+  if (with_j) { A->ft_valid = false; A->f32_valid = false; }
   if (gradient) {
     // g = J' r (program_evaluator.h:242-258)
     CX_HIP(hipMemsetAsync(hg.dptr, 0, size_t(ncols) * sizeof(double), st));

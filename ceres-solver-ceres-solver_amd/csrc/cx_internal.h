@@ -39,22 +39,6 @@ void cx_set_error(const char* fmt, ...);
     if (_rc != CX_OK) return _rc; \
   } while (0)
 
-// ---------------------------------------------------------------- context
-struct cx_context {
-  int device = 0;
-  hipStream_t stream = nullptr;
-  hipEvent_t ev[8] = {};
-  // RCCL (resolved at run time from librccl.so.1; see cx_context.cpp)
-  void* comm = nullptr;
-  int (*allreduce_cb)(double*, int64_t, void*) = nullptr;  // rehearsal transport (cx_context_set_comm_callback)
-  void* allreduce_cb_user = nullptr;
-  int rank = 0;
-  int nranks = 1;
-  double allreduce_host_ms = 0.0;
-  int num_cus = 256;
-  char name[128] = {};
-};
-
 // RAII device array
 template <typename T>
 struct DevBuf {
@@ -83,6 +67,23 @@ struct DevBuf {
     CX_HIP(hipStreamSynchronize(s));
     return CX_OK;
   }
+};
+
+// ---------------------------------------------------------------- context
+struct cx_context {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  hipEvent_t ev[8] = {};
+  // RCCL (resolved at run time from librccl.so.1; see cx_context.cpp)
+  void* comm = nullptr;
+  int (*allreduce_cb)(double*, int64_t, void*) = nullptr;  // rehearsal transport (cx_context_set_comm_callback)
+  void* allreduce_cb_user = nullptr;
+  int rank = 0;
+  int nranks = 1;
+  double allreduce_host_ms = 0.0;
+  int num_cus = 256;
+  char name[128] = {};
+  DevBuf<double> chol_scratch;  // dense Cholesky work vectors (cx_cholesky.hip)
 };
 
 // ----------------------------------------------------------------- matrix
@@ -133,6 +134,9 @@ struct cx_matrix {
   int32_t num_segs = 0;
   DevBuf<double> d_Ft;                   // camera-major copy of the F cells [O][18]
   bool ft_valid = false;
+  DevBuf<float> d_vals32, d_Ft32;        // fp32 copies for mixed-precision CGNR (cx_matrix_ensure_f32)
+  bool f32_valid = false;
+  bool use_f32 = false;                  // products read the fp32 copies (fp64 accumulation)
   DevBuf<double> d_partials;             // camera-major partial sums [S][81]
   DevBuf<double> d_elim_blk, d_elim_ete, d_elim_diag, d_elim_rows;  // explicit-S scratch (cx_schur.hip)
   DevBuf<int> d_elim_flag;
@@ -161,6 +165,7 @@ struct HostOrDevice {
 
 // ------------------------------------------------ kernels (cx_matrix.hip etc.)
 int cx_matrix_ensure_ft(cx_matrix* A);
+int cx_matrix_ensure_f32(cx_matrix* A);
 
 // all of these enqueue on ctx->stream and work on device pointers
 int cxk_right_multiply(cx_matrix* A, const double* x, double* y);

@@ -52,6 +52,50 @@ __device__ __forceinline__ void exchange_cells(const double2 (&v)[DPR / 2], doub
   __syncthreads();
 }
 
+// fp32-storage variants (mixed-precision CGNR): cells of DPR floats move as 8-byte pieces and
+// are widened to fp64 when the lane picks up its own cell; all arithmetic stays fp64.
+template <int DPR>
+__device__ __forceinline__ void load_cells(const float* __restrict__ base, int nvalid, float2 (&v)[DPR / 2]) {
+  constexpr int kPieces = DPR / 2;
+  const int tid = threadIdx.x;
+  const float2* __restrict__ src = reinterpret_cast<const float2*>(base);
+  const int total = nvalid * kPieces;
+#pragma unroll
+  for (int i = 0; i < kPieces; ++i) {
+    const int idx = i * kBlock + tid;
+    v[i] = (idx < total) ? src[idx] : make_float2(0.f, 0.f);
+  }
+}
+
+template <int DPR>
+__device__ __forceinline__ void exchange_cells(const float2 (&v)[DPR / 2], double* __restrict__ lds, double (&out)[DPR]) {
+  constexpr int kPieces = DPR / 2;
+  const int tid = threadIdx.x;
+  float2* l2 = reinterpret_cast<float2*>(lds);
+#pragma unroll
+  for (int i = 0; i < kPieces; ++i) l2[i * kBlock + tid] = v[i];
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < kPieces; ++i) {
+    const float2 t = l2[tid * kPieces + i];
+    out[2 * i] = double(t.x);
+    out[2 * i + 1] = double(t.y);
+  }
+  __syncthreads();
+}
+
+template <int DPR>
+__device__ __forceinline__ void stage_cells(const float* __restrict__ base, int nvalid,
+                                            double* __restrict__ lds, double (&out)[DPR]) {
+  float2 v[DPR / 2];
+  load_cells<DPR>(base, nvalid, v);
+  exchange_cells<DPR>(v, lds, out);
+}
+
+template <typename T> struct PieceOf;
+template <> struct PieceOf<double> { using type = double2; };
+template <> struct PieceOf<float> { using type = float2; };
+
 template <int DPR>
 __device__ __forceinline__ void stage_cells(const double* __restrict__ base, int nvalid,
                                             double* __restrict__ lds, double (&out)[DPR]) {

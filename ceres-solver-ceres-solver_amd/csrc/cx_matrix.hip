@@ -17,8 +17,9 @@
 // ============================================================ static 239 kernels
 
 // y[2r..2r+1] += E_r x_pt + F_r x_cam        (block_sparse_matrix.cc:239-274)
-__global__ __launch_bounds__(kBlock) void k_right_239(const double* __restrict__ E,
-                                                      const double* __restrict__ F,
+template <typename T>
+__global__ __launch_bounds__(kBlock) void k_right_239(const T* __restrict__ E,
+                                                      const T* __restrict__ F,
                                                       const int32_t* __restrict__ row_pt,
                                                       const int32_t* __restrict__ row_cam,
                                                       const double* __restrict__ xe,
@@ -35,7 +36,7 @@ __global__ __launch_bounds__(kBlock) void k_right_239(const double* __restrict__
   const bool live = tid < nvalid;
   const int cam = (use_f && live) ? row_cam[r] : 0;
   const int pt = (use_e && live) ? row_pt[r] : 0;
-  double2 fv[9], ev[3];
+  typename PieceOf<T>::type fv[9], ev[3];
   if (use_f) load_cells<18>(F + 18 * r0, nvalid, fv);
   if (use_e) load_cells<6>(E + 6 * r0, nvalid, ev);
   double2 yv = make_double2(0.0, 0.0);
@@ -75,7 +76,8 @@ __global__ __launch_bounds__(kBlock) void k_right_239(const double* __restrict__
 }
 
 // y_pt (+)= sum over the rows of the point of E_r' x_r   (chunk-aligned tiles)
-__global__ __launch_bounds__(kBlock) void k_left_e_239(const double* __restrict__ E,
+template <typename T>
+__global__ __launch_bounds__(kBlock) void k_left_e_239(const T* __restrict__ E,
                                                        const int32_t* __restrict__ tile_row,
                                                        const int32_t* __restrict__ tile_pt,
                                                        const int32_t* __restrict__ pt_start,
@@ -116,11 +118,11 @@ __global__ __launch_bounds__(kBlock) void k_left_e_239(const double* __restrict_
     // one point whose chunk is longer than a tile: strided loop + block reduction
     double s[3] = {0.0, 0.0, 0.0};
     for (int r = r0 + tid; r < r1; r += kBlock) {
-      const double* e = E + 6 * int64_t(r);
+      const T* e = E + 6 * int64_t(r);
       const double2 xv = reinterpret_cast<const double2*>(x)[r];
-      s[0] += e[0] * xv.x + e[3] * xv.y;
-      s[1] += e[1] * xv.x + e[4] * xv.y;
-      s[2] += e[2] * xv.x + e[5] * xv.y;
+      s[0] += double(e[0]) * xv.x + double(e[3]) * xv.y;
+      s[1] += double(e[1]) * xv.x + double(e[4]) * xv.y;
+      s[2] += double(e[2]) * xv.x + double(e[5]) * xv.y;
     }
     block_sum<3>(s, red);
     if (tid == 0) {
@@ -133,21 +135,34 @@ __global__ __launch_bounds__(kBlock) void k_left_e_239(const double* __restrict_
 
 // Ft[k] = F[cam_rows[k]]: camera-major copy of the F cells.  One wavefront moves
 // 64 cells: gathered 144-byte reads, contiguous writes.
-__global__ __launch_bounds__(kBlock) void k_permute_ft(const double* __restrict__ F,
+template <typename T>
+__global__ __launch_bounds__(kBlock) void k_permute_ft(const T* __restrict__ F,
                                                        const int32_t* __restrict__ cam_rows,
-                                                       double* __restrict__ Ft, int64_t O) {
+                                                       T* __restrict__ Ft, int64_t O) {
+  using P2 = typename PieceOf<T>::type;
   // 9 lanes per cell (16 B each): 256 threads move 28 cells per pass; simpler: thread per 16-byte piece
   const int64_t piece = int64_t(blockIdx.x) * kBlock + threadIdx.x;
   if (piece >= O * 9) return;
   const int64_t k = piece / 9;
   const int part = int(piece - k * 9);
   const int64_t r = cam_rows[k];
-  reinterpret_cast<double2*>(Ft)[piece] = reinterpret_cast<const double2*>(F)[r * 9 + part];
+  reinterpret_cast<P2*>(Ft)[piece] = reinterpret_cast<const P2*>(F)[r * 9 + part];
+}
+
+__global__ void k_to_float(const double* __restrict__ src, float* __restrict__ dst, int64_t n) {
+  const int64_t i = (int64_t(blockIdx.x) * blockDim.x + threadIdx.x) * 2;
+  if (i + 1 < n) {
+    const double2 v = *reinterpret_cast<const double2*>(src + i);
+    *reinterpret_cast<float2*>(dst + i) = make_float2(float(v.x), float(v.y));
+  } else if (i < n) {
+    dst[i] = float(src[i]);
+  }
 }
 
 // Camera-major pass: one workgroup per segment (<= kSegRows rows of ONE camera),
 // partial[seg][0..8] = sum over the segment of Ft_r' t_row(r).
-__global__ __launch_bounds__(kBlock) void k_cam_ft(const double* __restrict__ Ft,
+template <typename T>
+__global__ __launch_bounds__(kBlock) void k_cam_ft(const T* __restrict__ Ft,
                                                    const int32_t* __restrict__ cam_rows,
                                                    const int32_t* __restrict__ seg_begin,
                                                    const double* __restrict__ t,
@@ -475,10 +490,25 @@ int cx_matrix_ensure_ft(cx_matrix* A) {
   if (!A->is239 || A->ft_valid) return CX_OK;
   CX_TRY(A->d_Ft.alloc(size_t(A->O) * 18));
   const int64_t pieces = A->O * 9;
-  hipLaunchKernelGGL(k_permute_ft, dim3(grid_for(pieces, kBlock)), dim3(kBlock), 0, A->ctx->stream,
-                     A->d_values.p + 6 * A->O, A->d_cam_rows.p, A->d_Ft.p, A->O);
+  hipLaunchKernelGGL(k_permute_ft<double>, dim3(grid_for(pieces, kBlock)), dim3(kBlock), 0, A->ctx->stream,
+                     (const double*)(A->d_values.p + 6 * A->O), A->d_cam_rows.p, A->d_Ft.p, A->O);
   CX_HIP(hipGetLastError());
   A->ft_valid = true;
+  return CX_OK;
+}
+
+// fp32 copies of the values (row-major E, F and the camera-major Ft) for mixed-precision CGNR
+int cx_matrix_ensure_f32(cx_matrix* A) {
+  if (!A->is239 || A->f32_valid) return CX_OK;
+  hipStream_t st = A->ctx->stream;
+  CX_TRY(A->d_vals32.alloc(size_t(A->nnz)));
+  CX_TRY(A->d_Ft32.alloc(size_t(A->O) * 18));
+  hipLaunchKernelGGL(k_to_float, dim3(grid_for((A->nnz + 1) / 2, 256)), dim3(256), 0, st, (const double*)A->d_values.p,
+                     A->d_vals32.p, A->nnz);
+  hipLaunchKernelGGL(k_permute_ft<float>, dim3(grid_for(A->O * 9, kBlock)), dim3(kBlock), 0, st,
+                     (const float*)(A->d_vals32.p + 6 * A->O), A->d_cam_rows.p, A->d_Ft32.p, A->O);
+  CX_HIP(hipGetLastError());
+  A->f32_valid = true;
   return CX_OK;
 }
 
@@ -487,8 +517,14 @@ int cxk_ft_multiply(cx_matrix* A, const double* t, double* yf, bool accumulate) 
   CX_TRY(cx_matrix_ensure_ft(A));
   hipStream_t st = A->ctx->stream;
   if (A->num_segs > 0)
-    hipLaunchKernelGGL(k_cam_ft, dim3(xcd_grid(A->num_segs)), dim3(kBlock), 0, st, A->d_Ft.p, A->d_cam_rows.p,
-                       A->d_seg_begin.p, t, A->d_partials.p, A->stop, A->num_segs);
+  {
+    if (A->use_f32)
+      hipLaunchKernelGGL(k_cam_ft<float>, dim3(xcd_grid(A->num_segs)), dim3(kBlock), 0, st, (const float*)A->d_Ft32.p,
+                         A->d_cam_rows.p, A->d_seg_begin.p, t, A->d_partials.p, A->stop, A->num_segs);
+    else
+      hipLaunchKernelGGL(k_cam_ft<double>, dim3(xcd_grid(A->num_segs)), dim3(kBlock), 0, st, (const double*)A->d_Ft.p,
+                         A->d_cam_rows.p, A->d_seg_begin.p, t, A->d_partials.p, A->stop, A->num_segs);
+  }
   hipLaunchKernelGGL(k_cam_reduce9, dim3(grid_for(int64_t(A->C) * 9, 256)), dim3(256), 0, st,
                      A->d_partials.p, A->d_cam_seg_start.p, yf, A->C, accumulate ? 1 : 0,
                      (const double*)nullptr, (const double*)nullptr, A->stop);
@@ -499,9 +535,14 @@ int cxk_ft_multiply(cx_matrix* A, const double* t, double* yf, bool accumulate) 
 int cxk_right_multiply(cx_matrix* A, const double* x, double* y) {
   hipStream_t st = A->ctx->stream;
   if (A->is239) {
-    hipLaunchKernelGGL(k_right_239, dim3(grid_for(A->O, kBlock)), dim3(kBlock), 0, st, A->d_values.p,
-                       A->d_values.p + 6 * A->O, A->d_row_pt.p, A->d_row_cam.p, x, x + 3 * int64_t(A->P), y,
-                       A->O, 1, 1, 1, A->stop);
+    if (A->use_f32)
+      hipLaunchKernelGGL(k_right_239<float>, dim3(grid_for(A->O, kBlock)), dim3(kBlock), 0, st, (const float*)A->d_vals32.p,
+                         (const float*)(A->d_vals32.p + 6 * A->O), A->d_row_pt.p, A->d_row_cam.p, x, x + 3 * int64_t(A->P), y,
+                         A->O, 1, 1, 1, A->stop);
+    else
+      hipLaunchKernelGGL(k_right_239<double>, dim3(grid_for(A->O, kBlock)), dim3(kBlock), 0, st, (const double*)A->d_values.p,
+                         (const double*)(A->d_values.p + 6 * A->O), A->d_row_pt.p, A->d_row_cam.p, x, x + 3 * int64_t(A->P), y,
+                         A->O, 1, 1, 1, A->stop);
   } else if (A->R > 0) {
     hipLaunchKernelGGL(kg_right, dim3(grid_for(A->R, 128)), dim3(128), 0, st, A->d_rows.p, A->d_cols.p,
                        A->d_rcb.p, A->d_cells.p, A->d_values.p, x, y, A->R, A->num_row_blocks_e, 0, 0);
@@ -513,8 +554,12 @@ int cxk_right_multiply(cx_matrix* A, const double* x, double* y) {
 int cxk_left_multiply(cx_matrix* A, const double* x, double* y) {
   hipStream_t st = A->ctx->stream;
   if (A->is239) {
-    hipLaunchKernelGGL(k_left_e_239, dim3(A->num_tiles), dim3(kBlock), 0, st, A->d_values.p, A->d_tile_row.p,
-                       A->d_tile_pt.p, A->d_pt_start.p, x, y, 1, A->stop);
+    if (A->use_f32)
+      hipLaunchKernelGGL(k_left_e_239<float>, dim3(A->num_tiles), dim3(kBlock), 0, st, (const float*)A->d_vals32.p,
+                         A->d_tile_row.p, A->d_tile_pt.p, A->d_pt_start.p, x, y, 1, A->stop);
+    else
+      hipLaunchKernelGGL(k_left_e_239<double>, dim3(A->num_tiles), dim3(kBlock), 0, st, (const double*)A->d_values.p,
+                         A->d_tile_row.p, A->d_tile_pt.p, A->d_pt_start.p, x, y, 1, A->stop);
     CX_TRY(cxk_ft_multiply(A, x, y + 3 * int64_t(A->P), true));
   } else if (A->R > 0) {
     hipLaunchKernelGGL(kg_left, dim3(grid_for(A->R, 128)), dim3(128), 0, st, A->d_rows.p, A->d_cols.p,
@@ -557,6 +602,7 @@ int cxk_scale_columns(cx_matrix* A, const double* scale) {
                        A->d_rcb.p, A->d_cells.p, A->d_values.p, scale, A->R);
   }
   A->ft_valid = false;
+  A->f32_valid = false;
   CX_HIP(hipGetLastError());
   return CX_OK;
 }
@@ -690,6 +736,7 @@ double* cx_matrix_device_values(cx_matrix* A) { return A ? A->d_values.p : nullp
 int cx_matrix_values_changed(cx_matrix* A) {
   CX_CHECK_ARG(A);
   A->ft_valid = false;
+  A->f32_valid = false;
   return CX_OK;
 }
 
@@ -700,6 +747,7 @@ int cx_matrix_set_values(cx_matrix* A, const double* src, int32_t memspace) {
                           memspace == CX_HOST ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice, A->ctx->stream));
   CX_HIP(hipStreamSynchronize(A->ctx->stream));
   A->ft_valid = false;
+  A->f32_valid = false;
   return CX_OK;
 }
 
@@ -714,6 +762,7 @@ int cx_matrix_set_zero(cx_matrix* A) {
   CX_CHECK_ARG(A);
   if (A->nnz) CX_HIP(hipMemsetAsync(A->d_values.p, 0, size_t(A->nnz) * sizeof(double), A->ctx->stream));
   A->ft_valid = false;
+  A->f32_valid = false;
   return CX_OK;
 }
 
@@ -767,11 +816,11 @@ static int PartitionedMultiply(cx_matrix* A, int part, bool transpose, const dou
       const double* E = A->d_values.p;
       const double* F = A->d_values.p + 6 * A->O;
       if (!transpose) {
-        hipLaunchKernelGGL(k_right_239, dim3(grid_for(A->O, kBlock)), dim3(kBlock), 0, st, E, F, A->d_row_pt.p,
+        hipLaunchKernelGGL(k_right_239<double>, dim3(grid_for(A->O, kBlock)), dim3(kBlock), 0, st, E, F, A->d_row_pt.p,
                            A->d_row_cam.p, (const double*)hx.dptr, (const double*)hx.dptr, hy.dptr, A->O, part == 1 ? 1 : 0,
                            part == 2 ? 1 : 0, 1, (const int*)nullptr);
       } else if (part == 1) {
-        hipLaunchKernelGGL(k_left_e_239, dim3(A->num_tiles), dim3(kBlock), 0, st, E, A->d_tile_row.p, A->d_tile_pt.p,
+        hipLaunchKernelGGL(k_left_e_239<double>, dim3(A->num_tiles), dim3(kBlock), 0, st, E, A->d_tile_row.p, A->d_tile_pt.p,
                            A->d_pt_start.p, (const double*)hx.dptr, hy.dptr, 1, (const int*)nullptr);
       } else {
         CX_TRY(cxk_ft_multiply(A, hx.dptr, hy.dptr, true));

@@ -709,10 +709,43 @@ int SolveCgnr239(cx_solver* S, cx_matrix* A, const double* b, const double* D, d
   LinOp& pre = (o.preconditioner_type == CX_IDENTITY) ? static_cast<LinOp&>(id) : static_cast<LinOp&>(jac);
   CgDriver cg{S, ctx, st, n, ctx->nranks > 1 ? ne : n};
   CX_TRY(S->state.alloc(1));
+  // Mixed precision (new; the reference has it for Cholesky only, solver.h:572-590): the CG
+  // operator streams fp32 copies of the J values (half the HBM traffic, fp64 accumulation and
+  // fp64 vectors); optional refinement steps correct x against the fp64 operator.
+  const bool mixed = o.use_mixed_precision_solves != 0;
+  if (mixed) CX_TRY(cx_matrix_ensure_f32(A));
   A->stop = &S->state.p->flag;
-  const int cg_rc = cg.run(lhs, pre, S->v_rhs.p, x, true, r_tol, q_tol, summary);
+  A->use_f32 = mixed;
+  int cg_rc = cg.run(lhs, pre, S->v_rhs.p, x, true, r_tol, q_tol, summary);
+  A->use_f32 = false;
   A->stop = nullptr;
   CX_TRY(cg_rc);
+  if (mixed && summary->termination_type != CX_FAILURE) {
+    CX_TRY(S->v_cols.alloc(size_t(2 * n)));
+    double* resid = S->v_cols.p;
+    double* dx = S->v_cols.p + n;
+    const int total_iterations = summary->num_iterations;
+    int extra = 0;
+    for (int it = 0; it < o.max_num_refinement_iterations; ++it) {
+      // resid = J'b - (J'J + D'D) x with the fp64 values
+      CX_TRY(lhs.apply(x, dx));
+      hipLaunchKernelGGL(k_residual, dim3(grid_for(n, 256)), dim3(256), 0, st, (const double*)S->v_rhs.p, (const double*)dx,
+                         resid, dx, n, (const CgState*)nullptr);
+      CX_HIP(hipMemsetAsync(dx, 0, size_t(n) * sizeof(double), st));
+      cx_summary rs;
+      std::memset(&rs, 0, sizeof(rs));
+      A->stop = &S->state.p->flag;
+      A->use_f32 = true;
+      cg_rc = cg.run(lhs, pre, resid, dx, true, r_tol, q_tol, &rs);
+      A->use_f32 = false;
+      A->stop = nullptr;
+      CX_TRY(cg_rc);
+      if (rs.termination_type == CX_FAILURE) break;
+      hipLaunchKernelGGL(k_axpy1, dim3(grid_for(n, 256)), dim3(256), 0, st, x, (const double*)dx, n);
+      extra += rs.num_iterations;
+    }
+    summary->num_iterations = total_iterations + extra;
+  }
   CX_TRY(sw.stop(&S->timing.reduced_solve_ms));
   return CX_OK;
 }

@@ -6,6 +6,11 @@ import sys
 import numpy as np
 import pytest
 
+try:  # torch first: it brings its own HIP runtime, and the library must share that one instance
+    import torch  # noqa: F401
+except Exception:  # pragma: no cover
+    torch = None
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 PKG_DIR = os.path.join(ROOT, "ceres-solver-ceres-solver_amd")
 GOLDEN = os.path.join(ROOT, "tests", "golden")

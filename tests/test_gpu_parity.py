@@ -383,3 +383,32 @@ def test_power_series_expansion(ctx, oracle, pre, spse_init):
     assert relerr(x, xr) < 1e-8
     S.close()
     A.close()
+
+
+def test_mixed_precision_cgnr(ctx, oracle):
+    """fp32-storage CGNR (BASELINE config 5; not in the reference, whose mixed precision exists for
+    Cholesky only).  Against the fp64 solve: the truncated LM-style solve agrees to fp32 level and
+    takes the same number of iterations; with refinement steps and a tight tolerance the solution
+    reaches the dense normal-equation solution like the fp64 path."""
+    prob, bs, order, vals, b, D = make(16, 700, 2800, 2, "eval", oracle)
+    A = cx.Matrix(ctx, bs, 0)
+    A.set_values(vals)
+    kw = dict(type=cx.CGNR, preconditioner_type=cx.JACOBI, num_eliminate_blocks=0, max_num_iterations=300)
+    S64 = cx.Solver(ctx, **kw)
+    x64, s64 = S64.solve(A, b, D, r_tolerance=-1.0, q_tolerance=0.1)
+    S32 = cx.Solver(ctx, use_mixed_precision_solves=1, **kw)
+    x32, s32 = S32.solve(A, b, D, r_tolerance=-1.0, q_tolerance=0.1)
+    assert s32.termination_type == cx.SUCCESS and s32.num_iterations == s64.num_iterations
+    assert 0 < relerr(x32, x64) < 1e-5           # really took the fp32 path, and stayed close
+    # converged: a few refinement rounds against the fp64 operator
+    J = bs.to_dense(vals)
+    ref = np.linalg.solve(J.T @ J + np.diag(D ** 2), J.T @ b)
+    Sr = cx.Solver(ctx, use_mixed_precision_solves=1, max_num_refinement_iterations=3, **dict(kw, max_num_iterations=2000))
+    xr, sr = Sr.solve(A, b, D, r_tolerance=1e-10, q_tolerance=0.0)
+    S0 = cx.Solver(ctx, use_mixed_precision_solves=1, max_num_refinement_iterations=0, **dict(kw, max_num_iterations=2000))
+    x0, s0 = S0.solve(A, b, D, r_tolerance=1e-10, q_tolerance=0.0)
+    e0, er = relerr(x0, ref), relerr(xr, ref)
+    assert er < 1e-9 and er < e0 / 10, (e0, er)
+    for s in (S64, S32, Sr, S0):
+        s.close()
+    A.close()
