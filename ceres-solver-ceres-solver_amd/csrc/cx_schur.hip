@@ -185,37 +185,32 @@ __global__ __launch_bounds__(kBlock) void k_chunk_pass(const double* __restrict_
   if (r1 - r0 <= kBlock) {
     const int nvalid = r1 - r0;
     const int r = r0 + tid;
-    // everything this tile needs from HBM is requested up front: ids, E, F, b; the camera
-    // vector gather (L2) follows as soon as the camera id is back
+    // F is staged and consumed before E is requested: measured 12 % faster on MI355X than
+    // requesting everything up front (fewer live registers, see DESIGN.md "A/B notes")
     const bool live = tid < nvalid;
     const int lp = (MODE != 2 && live) ? row_pt[r] - p0 : 0;
-    const int cam = (MODE != 1 && live) ? row_cam[r] : 0;
-    double2 fv[9], ev[3];
-    if (MODE != 1) load_cells<18>(F + 18 * int64_t(r0), nvalid, fv);
-    load_cells<6>(E + 6 * int64_t(r0), nvalid, ev);
-    double2 bv = make_double2(0.0, 0.0);
-    if ((MODE == 1 || MODE == 2) && live) bv = reinterpret_cast<const double2*>(b)[r];
-    double xv[9];
-    if (MODE != 1) {
-      const double* xc = xf + 9 * int64_t(cam);
-#pragma unroll
-      for (int k = 0; k < 9; ++k) xv[k] = live ? xc[k] : 0.0;
-    }
     double e[6];
     double t0 = 0.0, t1 = 0.0;
     if (MODE != 1) {
       double f[18];
-      exchange_cells<18>(fv, lds, f);
+      stage_cells<18>(F + 18 * int64_t(r0), nvalid, lds, f);
+      if (live) {
+        const double* xc = xf + 9 * int64_t(row_cam[r]);
 #pragma unroll
-      for (int k = 0; k < 9; ++k) {
-        t0 += f[k] * xv[k];
-        t1 += f[9 + k] * xv[k];
+        for (int k = 0; k < 9; ++k) {
+          const double xv = xc[k];
+          t0 += f[k] * xv;
+          t1 += f[9 + k] * xv;
+        }
       }
     }
-    exchange_cells<6>(ev, lds, e);
+    stage_cells<6>(E + 6 * int64_t(r0), nvalid, lds, e);
     if (live) {
-      if (MODE == 1) { t0 = bv.x; t1 = bv.y; }
-      else if (MODE == 2) { t0 = bv.x - t0; t1 = bv.y - t1; }
+      if (MODE == 1 || MODE == 2) {
+        const double2 bv = reinterpret_cast<const double2*>(b)[r];
+        if (MODE == 1) { t0 = bv.x; t1 = bv.y; }
+        else { t0 = bv.x - t0; t1 = bv.y - t1; }
+      }
       w[tid * 3 + 0] = e[0] * t0 + e[3] * t1;
       w[tid * 3 + 1] = e[1] * t0 + e[4] * t1;
       w[tid * 3 + 2] = e[2] * t0 + e[5] * t1;
@@ -314,135 +309,6 @@ __global__ __launch_bounds__(kBlock) void k_chunk_pass(const double* __restrict_
         else { t0 -= eu0; t1 -= eu1; }
         reinterpret_cast<double2*>(out)[r] = make_double2(t0, t1);
       }
-    }
-  }
-}
-
-// ------------------------------------------- S x chunk pass, software-pipelined variant
-// Same arithmetic as k_chunk_pass<0> in the same order (bitwise identical results), but a
-// workgroup walks tiles blockIdx.x, blockIdx.x + gridDim.x, ... and requests the ids, E and F
-// cells of its NEXT tile before it exchanges / computes the current one, so HBM loads stay in
-// flight during the LDS and per-point phases.  Tiles with a chunk longer than kBlock rows are
-// left to k_chunk_pass<0> (launched over those tiles only when the matrix has any).
-__global__ __launch_bounds__(kBlock) void k_chunk_sx_pipe(const double* __restrict__ E,
-                                                          const double* __restrict__ F,
-                                                          const int32_t* __restrict__ tile_row,
-                                                          const int32_t* __restrict__ tile_pt,
-                                                          const int32_t* __restrict__ pt_start,
-                                                          const int32_t* __restrict__ row_cam,
-                                                          const int32_t* __restrict__ row_pt,
-                                                          const double* __restrict__ ete_inv,
-                                                          const double* __restrict__ xf,
-                                                          double* __restrict__ out, int num_tiles,
-                                                          const int* __restrict__ stop) {
-  __shared__ double lds[kBlock * 18];
-  double* const w = lds;
-  double* const u = lds + kBlock * 3;
-  if (stop && *stop) return;
-  const int tid = threadIdx.x;
-  int tl = blockIdx.x;
-  if (tl >= num_tiles) return;
-  // ---- prologue: request tile tl
-  int r0 = tile_row[tl], r1 = tile_row[tl + 1], p0 = tile_pt[tl], p1 = tile_pt[tl + 1];
-  double2 fv[9], ev[3];
-  int cam = 0, lp = 0;
-  bool big = (r1 - r0) > kBlock;
-  if (!big) {
-    const int nvalid = r1 - r0;
-    if (tid < nvalid) { cam = row_cam[r0 + tid]; lp = row_pt[r0 + tid] - p0; }
-    load_cells<18>(F + 18 * int64_t(r0), nvalid, fv);
-    load_cells<6>(E + 6 * int64_t(r0), nvalid, ev);
-  }
-  double xv[9];
-#pragma unroll
-  for (int k = 0; k < 9; ++k) xv[k] = 0.0;
-  if (!big && tid < r1 - r0) {
-    const double* xc = xf + 9 * int64_t(cam);
-#pragma unroll
-    for (int k = 0; k < 9; ++k) xv[k] = xc[k];
-  }
-  while (true) {
-    // ---- request the next tile
-    const int tn = tl + gridDim.x;
-    const bool has_next = tn < num_tiles;
-    int nr0 = 0, nr1 = 0, np0 = 0, np1 = 0, ncam = 0, nlp = 0;
-    bool nbig = false;
-    double2 nfv[9], nev[3];
-    if (has_next) {
-      nr0 = tile_row[tn]; nr1 = tile_row[tn + 1]; np0 = tile_pt[tn]; np1 = tile_pt[tn + 1];
-      nbig = (nr1 - nr0) > kBlock;
-      if (!nbig) {
-        const int nn = nr1 - nr0;
-        if (tid < nn) { ncam = row_cam[nr0 + tid]; nlp = row_pt[nr0 + tid] - np0; }
-        load_cells<18>(F + 18 * int64_t(nr0), nn, nfv);
-        load_cells<6>(E + 6 * int64_t(nr0), nn, nev);
-      }
-    }
-    // ---- current tile
-    if (!big) {
-      const int nvalid = r1 - r0;
-      const int r = r0 + tid;
-      const bool live = tid < nvalid;
-      double f[18], e[6];
-      double t0 = 0.0, t1 = 0.0;
-      exchange_cells<18>(fv, lds, f);
-#pragma unroll
-      for (int k = 0; k < 9; ++k) {
-        t0 += f[k] * xv[k];
-        t1 += f[9 + k] * xv[k];
-      }
-      exchange_cells<6>(ev, lds, e);
-      if (live) {
-        w[tid * 3 + 0] = e[0] * t0 + e[3] * t1;
-        w[tid * 3 + 1] = e[1] * t0 + e[4] * t1;
-        w[tid * 3 + 2] = e[2] * t0 + e[5] * t1;
-      }
-      double m[9];
-      int jb = 0, je = 0;
-      if (tid < p1 - p0) {
-        const double* mp = ete_inv + 9 * int64_t(p0 + tid);
-#pragma unroll
-        for (int k = 0; k < 9; ++k) m[k] = mp[k];
-        jb = pt_start[p0 + tid] - r0;
-        je = pt_start[p0 + tid + 1] - r0;
-      }
-      __syncthreads();
-      if (tid < p1 - p0) {
-        double a0 = 0.0, a1 = 0.0, a2 = 0.0, b0 = 0.0, b1 = 0.0, b2 = 0.0;
-        double c0 = 0.0, c1 = 0.0, c2 = 0.0, d0 = 0.0, d1 = 0.0, d2 = 0.0;
-        int j = jb;
-        for (; j + 4 <= je; j += 4) {
-          a0 += w[j * 3]; a1 += w[j * 3 + 1]; a2 += w[j * 3 + 2];
-          b0 += w[j * 3 + 3]; b1 += w[j * 3 + 4]; b2 += w[j * 3 + 5];
-          c0 += w[j * 3 + 6]; c1 += w[j * 3 + 7]; c2 += w[j * 3 + 8];
-          d0 += w[j * 3 + 9]; d1 += w[j * 3 + 10]; d2 += w[j * 3 + 11];
-        }
-        for (; j < je; ++j) { a0 += w[j * 3]; a1 += w[j * 3 + 1]; a2 += w[j * 3 + 2]; }
-        const double s0 = (a0 + b0) + (c0 + d0), s1 = (a1 + b1) + (c1 + d1), s2 = (a2 + b2) + (c2 + d2);
-        u[tid * 3] = m[0] * s0 + m[1] * s1 + m[2] * s2;
-        u[tid * 3 + 1] = m[3] * s0 + m[4] * s1 + m[5] * s2;
-        u[tid * 3 + 2] = m[6] * s0 + m[7] * s1 + m[8] * s2;
-      }
-      __syncthreads();
-      if (live) {
-        const double u0 = u[lp * 3], u1 = u[lp * 3 + 1], u2 = u[lp * 3 + 2];
-        t0 -= e[0] * u0 + e[1] * u1 + e[2] * u2;
-        t1 -= e[3] * u0 + e[4] * u1 + e[5] * u2;
-        reinterpret_cast<double2*>(out)[r] = make_double2(t0, t1);
-      }
-      __syncthreads();  // w / u are overwritten by the next exchange
-    }
-    if (!has_next) break;
-    // ---- the next tile becomes current; its camera ids are back by now: gather x
-    tl = tn; r0 = nr0; r1 = nr1; p0 = np0; p1 = np1; cam = ncam; lp = nlp; big = nbig;
-#pragma unroll
-    for (int i = 0; i < 9; ++i) fv[i] = nfv[i];
-#pragma unroll
-    for (int i = 0; i < 3; ++i) ev[i] = nev[i];
-    if (!big && tid < r1 - r0) {
-      const double* xc = xf + 9 * int64_t(cam);
-#pragma unroll
-      for (int k = 0; k < 9; ++k) xv[k] = xc[k];
     }
   }
 }
@@ -749,15 +615,7 @@ int cxs_chunk_pass(cx_matrix* A, int mode, const double* ete_inv, const double* 
 #define CX_LAUNCH_PASS(M)                                                                                   \
   hipLaunchKernelGGL(k_chunk_pass<M>, dim3(A->num_tiles), dim3(kBlock), 0, st, E, F, A->d_tile_row.p,       \
                      A->d_tile_pt.p, A->d_pt_start.p, A->d_row_cam.p, A->d_row_pt.p, ete_inv, xf, b, out, A->stop, 0)
-  static const int variant = [] { const char* v = getenv("CX_CHUNK_VARIANT"); return v ? atoi(v) : 0; }();  // 0: one tile per workgroup (faster, measured r01), 1: pipelined
-  if (mode == 0 && variant == 1) {
-    const int grid = std::min(A->num_tiles, A->ctx->num_cus * 2);  // 226 VGPRs -> 2 workgroups per CU
-    hipLaunchKernelGGL(k_chunk_sx_pipe, dim3(grid), dim3(kBlock), 0, st, E, F, A->d_tile_row.p, A->d_tile_pt.p,
-                       A->d_pt_start.p, A->d_row_cam.p, A->d_row_pt.p, ete_inv, xf, out, A->num_tiles, A->stop);
-    if (A->has_big_tiles)
-      hipLaunchKernelGGL(k_chunk_pass<0>, dim3(A->num_tiles), dim3(kBlock), 0, st, E, F, A->d_tile_row.p,
-                         A->d_tile_pt.p, A->d_pt_start.p, A->d_row_cam.p, A->d_row_pt.p, ete_inv, xf, b, out, A->stop, 1);
-  } else if (mode == 0) CX_LAUNCH_PASS(0);
+  if (mode == 0) CX_LAUNCH_PASS(0);
   else if (mode == 1) CX_LAUNCH_PASS(1);
   else if (mode == 3) CX_LAUNCH_PASS(3);
   else CX_LAUNCH_PASS(2);
