@@ -412,3 +412,67 @@ def test_mixed_precision_cgnr(ctx, oracle):
     for s in (S64, S32, Sr, S0):
         s.close()
     A.close()
+
+
+def _custom_problem(C, cam_lists, seed):
+    """BalProblem with explicit per-point camera lists (ascending, like BAL files)."""
+    cam, pt = [], []
+    for j, cams in enumerate(cam_lists):
+        cam.extend(sorted(cams))
+        pt.extend([j] * len(cams))
+    cam, pt = np.array(cam, dtype=np.int32), np.array(pt, dtype=np.int32)
+    O = cam.size
+    return cx.bal.BalProblem(C, len(cam_lists), cam, pt, np.zeros((O, 2)), np.zeros((C, 9)), np.zeros((len(cam_lists), 3)))
+
+
+@pytest.mark.parametrize("case", ["unseen_camera", "single_observation_points", "one_camera", "tile_boundaries"])
+def test_edge_structures(ctx, oracle, case):
+    """Edge cases of the structure: a camera nobody observes (its Schur block is D^2 only), points
+    seen once, a single camera, and chunk sizes that land exactly on / next to tile boundaries
+    (256 rows) -- all solver families against the oracle."""
+    rng = np.random.default_rng(hash(case) % 1000)
+    if case == "unseen_camera":
+        C, lists = 6, [list(rng.choice([0, 1, 2, 4, 5], size=int(rng.integers(2, 5)), replace=False)) for _ in range(60)]
+    elif case == "single_observation_points":
+        C, lists = 5, [[int(rng.integers(0, 5))] if j % 3 == 0 else list(rng.choice(5, size=3, replace=False)) for j in range(90)]
+    elif case == "one_camera":
+        C, lists = 1, [[0] for _ in range(40)]
+    else:
+        C = 300
+        sizes = [256, 1, 255, 2, 254, 3, 128, 128, 127, 129, 64] + [int(s) for s in rng.integers(2, 9, size=200)]
+        lists = [list(rng.choice(C, size=s, replace=False)) for s in sizes]
+    prob = _custom_problem(C, lists, 0)
+    P, O = prob.num_points, prob.num_observations
+    bs, order = cx.bal.build_structure(prob)
+    vals = cx.bal.random_jacobian_values(O, 3)
+    b = rng.standard_normal(2 * O)
+    D = rng.uniform(0.5, 2.0, bs.num_cols)
+    A = cx.Matrix(ctx, bs, P)
+    assert A.is_static_239
+    A.set_values(vals)
+    x = rng.standard_normal(bs.num_cols)
+    z = rng.standard_normal(bs.num_rows)
+    assert relerr(A.right_multiply(x), oracle.right_multiply(bs, vals, x)) < REL
+    assert relerr(A.left_multiply(z), oracle.left_multiply(bs, vals, z)) < REL
+    for stype, pre in (("ITERATIVE_SCHUR", "JACOBI"), ("ITERATIVE_SCHUR", "SCHUR_JACOBI"), ("DENSE_SCHUR", "IDENTITY")):
+        S = cx.Solver(ctx, type=getattr(cx, stype), preconditioner_type=getattr(cx, pre), num_eliminate_blocks=P,
+                      max_num_iterations=400)
+        xs, s = S.solve(A, b, D, r_tolerance=1e-12, q_tolerance=0.0)
+        oo = oracle.make_options(type=getattr(oracle, stype), preconditioner_type=getattr(oracle, pre),
+                                 num_eliminate_blocks=P, max_num_iterations=400)
+        xr, sr = oracle.solve(bs, vals, b, D, oo, r_tolerance=1e-12, q_tolerance=0.0)
+        assert s.termination_type == cx.SUCCESS, (case, stype, pre, s.message)
+        assert relerr(xs, xr) < 1e-8, (case, stype, pre)
+        S.close()
+    A.close()
+    # CGNR uses the unpartitioned matrix
+    A0 = cx.Matrix(ctx, bs, 0)
+    A0.set_values(vals)
+    S = cx.Solver(ctx, type=cx.CGNR, preconditioner_type=cx.JACOBI, num_eliminate_blocks=0, max_num_iterations=2000)
+    xs, s = S.solve(A0, b, D, r_tolerance=1e-12, q_tolerance=0.0)
+    J = bs.to_dense(vals) if bs.num_rows * bs.num_cols < 4e7 else None
+    if J is not None:
+        ref = np.linalg.solve(J.T @ J + np.diag(D ** 2), J.T @ b)
+        assert relerr(xs, ref) < 1e-8
+    S.close()
+    A0.close()
