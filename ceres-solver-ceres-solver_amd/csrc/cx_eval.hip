@@ -149,27 +149,6 @@ __device__ __forceinline__ void snavely_jet(const double* camv, const double* pt
   for (int i = 0; i < 3; ++i) { jp[i] = px.v[9 + i]; jp[3 + i] = py.v[9 + i]; }
 }
 
-// reverse of stage_cells: every thread hands in its own cell, the workgroup stores
-// the nvalid cells as one contiguous run of 16-byte pieces
-template <int DPR>
-__device__ __forceinline__ void unstage_cells(double* __restrict__ base, int nvalid, double* __restrict__ lds,
-                                              const double (&in)[DPR]) {
-  constexpr int kPieces = DPR / 2;
-  const int tid = threadIdx.x;
-  double2* l2 = reinterpret_cast<double2*>(lds);
-#pragma unroll
-  for (int i = 0; i < kPieces; ++i) l2[tid * kPieces + i] = make_double2(in[2 * i], in[2 * i + 1]);
-  __syncthreads();
-  double2* dst = reinterpret_cast<double2*>(base);
-  const int total = nvalid * kPieces;
-#pragma unroll
-  for (int i = 0; i < kPieces; ++i) {
-    const int idx = i * kBlock + tid;
-    if (idx < total) dst[idx] = l2[idx];
-  }
-  __syncthreads();
-}
-
 template <bool WITH_J>
 __global__ __launch_bounds__(kBlock) void k_bal_evaluate(const double* __restrict__ state,
                                                          const double* __restrict__ obs,

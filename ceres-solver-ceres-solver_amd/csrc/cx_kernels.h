@@ -104,6 +104,27 @@ __device__ __forceinline__ void stage_cells(const double* __restrict__ base, int
   exchange_cells<DPR>(v, lds, out);
 }
 
+// reverse of stage_cells: every thread hands in its own cell, the workgroup stores
+// the nvalid cells as one contiguous run of 16-byte pieces
+template <int DPR>
+__device__ __forceinline__ void unstage_cells(double* __restrict__ base, int nvalid, double* __restrict__ lds,
+                                              const double (&in)[DPR]) {
+  constexpr int kPieces = DPR / 2;
+  const int tid = threadIdx.x;
+  double2* l2 = reinterpret_cast<double2*>(lds);
+#pragma unroll
+  for (int i = 0; i < kPieces; ++i) l2[tid * kPieces + i] = make_double2(in[2 * i], in[2 * i + 1]);
+  __syncthreads();
+  double2* dst = reinterpret_cast<double2*>(base);
+  const int total = nvalid * kPieces;
+#pragma unroll
+  for (int i = 0; i < kPieces; ++i) {
+    const int idx = i * kBlock + tid;
+    if (idx < total) dst[idx] = l2[idx];
+  }
+  __syncthreads();
+}
+
 // XCD-aware block -> work item map for camera-major kernels.  Workgroups are dealt round-robin
 // over the 8 XCDs (blockIdx % 8 picks the XCD), so giving XCD x the contiguous range
 // [x*per, (x+1)*per) of segments makes workgroups that run at the same time on one XCD work on

@@ -242,22 +242,38 @@ __global__ __launch_bounds__(kBlock) void k_cam_sqnorm(const double* __restrict_
   block_sum_store<9>(acc, red, partial + int64_t(s) * 9);
 }
 
-// J <- J diag(scale)   (block_sparse_matrix.cc:403-450): thread per 16-byte piece
+// J <- J diag(scale)   (block_sparse_matrix.cc:403-450): cells in through LDS, scaled in
+// registers, out through LDS -- coalesced both ways (416 B per residual block incl. ids)
 __global__ __launch_bounds__(kBlock) void k_scale_239(double* __restrict__ E, double* __restrict__ F,
                                                       const int32_t* __restrict__ row_pt,
                                                       const int32_t* __restrict__ row_cam,
                                                       const double* __restrict__ scale, int64_t O,
                                                       int64_t xf_off) {
-  const int64_t r = int64_t(blockIdx.x) * kBlock + threadIdx.x;
-  if (r >= O) return;
-  const double* sp = scale + 3 * int64_t(row_pt[r]);
-  const double* sc = scale + xf_off + 9 * int64_t(row_cam[r]);
-  double* e = E + 6 * r;
-  double* f = F + 18 * r;
+  __shared__ double lds[kBlock * 18];
+  const int64_t r0 = int64_t(blockIdx.x) * kBlock;
+  const int nvalid = int(min(int64_t(kBlock), O - r0));
+  const int tid = threadIdx.x;
+  const bool live = tid < nvalid;
+  {
+    double f[18];
+    stage_cells<18>(F + 18 * r0, nvalid, lds, f);
+    if (live) {
+      const double* sc = scale + xf_off + 9 * int64_t(row_cam[r0 + tid]);
 #pragma unroll
-  for (int k = 0; k < 3; ++k) { e[k] *= sp[k]; e[3 + k] *= sp[k]; }
+      for (int k = 0; k < 9; ++k) { const double sv = sc[k]; f[k] *= sv; f[9 + k] *= sv; }
+    }
+    unstage_cells<18>(F + 18 * r0, nvalid, lds, f);
+  }
+  {
+    double e[6];
+    stage_cells<6>(E + 6 * r0, nvalid, lds, e);
+    if (live) {
+      const double* sp = scale + 3 * int64_t(row_pt[r0 + tid]);
 #pragma unroll
-  for (int k = 0; k < 9; ++k) { f[k] *= sc[k]; f[9 + k] *= sc[k]; }
+      for (int k = 0; k < 3; ++k) { const double sv = sp[k]; e[k] *= sv; e[3 + k] *= sv; }
+    }
+    unstage_cells<6>(E + 6 * r0, nvalid, lds, e);
+  }
 }
 
 // ============================================================== generic kernels

@@ -296,7 +296,7 @@ struct CgDriver {
     CX_TRY(S->partial.alloc(2 * kRedBlocks));
     CX_TRY(S->state.alloc(1));
     if (!S->ring_h) {
-      CX_HIP(hipHostMalloc(reinterpret_cast<void**>(&S->ring_h), kRingSlots * sizeof(CgState),
+      CX_HIP(hipHostMalloc(reinterpret_cast<void**>(&S->ring_h), (kRingSlots + 1) * sizeof(CgState),
                            hipHostMallocMapped | hipHostMallocCoherent));
       CX_HIP(hipHostGetDevicePointer(reinterpret_cast<void**>(&S->ring_d), S->ring_h, 0));
     }
@@ -321,34 +321,38 @@ struct CgDriver {
       return CX_OK;
     }
     const double tol_r = r_tol * norm_rhs;
+    double norm_r, Q0;
     if (zero_initial) {
-      CX_HIP(hipMemsetAsync(tmp, 0, n * sizeof(double), st));
+      // x = 0: r = rhs, |r| = |rhs|, Q0 = -x.(rhs + r) = 0 -- nothing to compute or to wait for
+      CX_HIP(hipMemcpyAsync(r, rhs, n * sizeof(double), hipMemcpyDeviceToDevice, st));
+      norm_r = norm_rhs;
+      Q0 = 0.0;
     } else {
       CX_TRY(lhs.apply(x, tmp));
+      hipLaunchKernelGGL(k_residual, dim3(g), dim3(256), 0, st, rhs, (const double*)tmp, r, tmp, n, (const CgState*)nullptr);
+      // tmp = rhs + r now;  s0 = x.tmp, s1 = r.r
+      CX_TRY(dot2(x, tmp, r, r, FIN_STORE, 0, ds));
+      CX_TRY(read_state(&h));
+      norm_r = std::sqrt(h.s1);
+      Q0 = -h.s0;  // Q0 = -x.(rhs + r)   (conjugate_gradients_solver.h:155-158)
     }
-    hipLaunchKernelGGL(k_residual, dim3(g), dim3(256), 0, st, rhs, (const double*)tmp, r, tmp, n, (const CgState*)nullptr);
-    // tmp = rhs + r now;  s0 = x.tmp, s1 = r.r
-    CX_TRY(dot2(x, tmp, r, r, FIN_STORE, 0, ds));
-    CX_TRY(read_state(&h));
-    double norm_r = std::sqrt(h.s1);
     if (o.min_num_iterations == 0 && norm_r <= tol_r) {
       summary->termination_type = CX_SUCCESS;
       std::snprintf(summary->message, sizeof(summary->message), "Convergence. |r| = %e <= %e.", norm_r, tol_r);
       return CX_OK;
     }
-    // Q0 = -x.(rhs + r)   (conjugate_gradients_solver.h:155-158)
-    const double Q0 = -h.s0;
-    h = CgState{};
-    h.rho = 1.0;
-    h.Q0 = Q0;
-    h.tol_r = tol_r;
-    h.q_tol = q_tol;
-    h.min_iter = o.min_num_iterations;
-    h.max_iter = o.max_num_iterations;
-    h.flag = CG_RUNNING;
-    h.seq = -1;
-    CX_HIP(hipMemcpyAsync(ds, &h, sizeof(h), hipMemcpyHostToDevice, st));
-    CX_HIP(hipStreamSynchronize(st));  // h lives on this stack frame
+    // initial device state, staged through the pinned ring's spare slot (no stack buffer, no sync)
+    CgState* init = S->ring_h + kRingSlots;
+    *init = CgState{};
+    init->rho = 1.0;
+    init->Q0 = Q0;
+    init->tol_r = tol_r;
+    init->q_tol = q_tol;
+    init->min_iter = o.min_num_iterations;
+    init->max_iter = o.max_num_iterations;
+    init->flag = CG_RUNNING;
+    init->seq = -1;
+    CX_HIP(hipMemcpyAsync(ds, init, sizeof(CgState), hipMemcpyHostToDevice, st));
 
     // Software pipeline: while the device runs the tail of iteration i the host has already
     // enqueued the head of iteration i+1; it then learns the outcome of iteration i from the

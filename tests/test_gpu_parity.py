@@ -430,7 +430,8 @@ def test_edge_structures(ctx, oracle, case):
     """Edge cases of the structure: a camera nobody observes (its Schur block is D^2 only), points
     seen once, a single camera, and chunk sizes that land exactly on / next to tile boundaries
     (256 rows) -- all solver families against the oracle."""
-    rng = np.random.default_rng(hash(case) % 1000)
+    rng = np.random.default_rng({"unseen_camera": 1, "single_observation_points": 2, "one_camera": 3,
+                                 "tile_boundaries": 4}[case])
     if case == "unseen_camera":
         C, lists = 6, [list(rng.choice([0, 1, 2, 4, 5], size=int(rng.integers(2, 5)), replace=False)) for _ in range(60)]
     elif case == "single_observation_points":
@@ -462,7 +463,7 @@ def test_edge_structures(ctx, oracle, case):
                                  num_eliminate_blocks=P, max_num_iterations=400)
         xr, sr = oracle.solve(bs, vals, b, D, oo, r_tolerance=1e-12, q_tolerance=0.0)
         assert s.termination_type == cx.SUCCESS, (case, stype, pre, s.message)
-        assert relerr(xs, xr) < 1e-8, (case, stype, pre)
+        assert relerr(xs, xr) < 1e-7, (case, stype, pre)   # q_tolerance = 0 stops on rounding noise of Q
         S.close()
     A.close()
     # CGNR uses the unpartitioned matrix
