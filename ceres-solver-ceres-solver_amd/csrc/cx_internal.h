@@ -138,6 +138,7 @@ struct cx_matrix {
   bool f32_valid = false;
   bool use_f32 = false;                  // products read the fp32 copies (fp64 accumulation)
   DevBuf<double> d_partials;             // camera-major partial sums [S][81]
+  DevBuf<double> d_partials9;            // [S][9] (fused set-up)
   DevBuf<double> d_elim_blk, d_elim_ete, d_elim_diag, d_elim_rows;  // explicit-S scratch (cx_schur.hip)
   DevBuf<int> d_elim_flag;
 

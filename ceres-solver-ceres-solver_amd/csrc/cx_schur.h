@@ -12,6 +12,9 @@ int cxs_compute_ete_inverse(cx_matrix* A, const double* D, const double* b, doub
 int cxs_chunk_pass(cx_matrix* A, int mode, const double* ete_inv, const double* xf, const double* b, double* out);
 // blocks[81C] = block diagonal of F'F (with_schur = false) or of S without D_f^2 (true)
 int cxs_camera_block_diagonal(cx_matrix* A, bool with_schur, const double* ete_inv, double* blocks);
+// fused set-up of the implicit Schur complement (k_chunk_init + k_cam_init), see cx_schur.hip
+int cxs_implicit_init(cx_matrix* A, const double* D, const double* b, bool want_blocks, bool with_schur,
+                      double* ete_inv, double* rows_scratch, double* blocks, double* rhs_out, int* d_flag);
 int cxs_block9_add_diag_invert(cx_context* ctx, double* blocks, const double* Df, int C, int* d_flag);
 // dense lhs (9C x 9C row-major, upper block triangle) and rhs of the reduced system
 int cxs_eliminate_dense(cx_matrix* A, const double* b, const double* D, bool add_df, double* lhs, double* rhs);

@@ -313,6 +313,217 @@ __global__ __launch_bounds__(kBlock) void k_chunk_pass(const double* __restrict_
   }
 }
 
+// -------------------------------------------------- fused set-up of the implicit S
+// ImplicitSchurComplement::Init in two passes over J instead of five:
+//   k_chunk_init : one pass over E:  (E'E + D_e^2)^-1 per point (stored) and
+//                  t' = b - E (E'E)^-1 E'b per row (first half of UpdateRhs)
+//   k_cam_init   : one pass over the camera-major Ft: the per-camera blocks of F'F (or of S) and
+//                  F't' (the reduced rhs) from the same registers
+// (gathering F inside k_cam_init, to save the separate k_permute_ft, was measured 1.6x slower: two
+// dependent loads per piece at 2 workgroups per CU do not hide their latency)
+// Same per-point / per-segment summation orders as the separate kernels.
+template <bool USE_LLT>
+__global__ __launch_bounds__(kBlock) void k_chunk_init(const double* __restrict__ E,
+                                                       const int32_t* __restrict__ tile_row,
+                                                       const int32_t* __restrict__ tile_pt,
+                                                       const int32_t* __restrict__ pt_start,
+                                                       const int32_t* __restrict__ row_pt,
+                                                       const double* __restrict__ De,
+                                                       const double* __restrict__ b,
+                                                       double* __restrict__ ete_inv,
+                                                       double* __restrict__ tprime,
+                                                       int* __restrict__ not_pd) {
+  __shared__ double lds[kBlock * 9];     // staging (6 per row) first, then 9 partials per row
+  __shared__ double u[kBlock * 3];
+  __shared__ double red[9 * 4];
+  const int t = blockIdx.x, tid = threadIdx.x;
+  const int r0 = tile_row[t], r1 = tile_row[t + 1];
+  const int p0 = tile_pt[t], p1 = tile_pt[t + 1];
+  if (r1 - r0 <= kBlock) {
+    const int nvalid = r1 - r0;
+    const bool live = tid < nvalid;
+    double e[6];
+    stage_cells<6>(E + 6 * int64_t(r0), nvalid, lds, e);
+    double2 bv = make_double2(0.0, 0.0);
+    int lp = 0;
+    if (live) {
+      bv = reinterpret_cast<const double2*>(b)[r0 + tid];
+      lp = row_pt[r0 + tid] - p0;
+      double* wr = lds + tid * 9;
+      wr[0] = e[0] * e[0] + e[3] * e[3];
+      wr[1] = e[0] * e[1] + e[3] * e[4];
+      wr[2] = e[0] * e[2] + e[3] * e[5];
+      wr[3] = e[1] * e[1] + e[4] * e[4];
+      wr[4] = e[1] * e[2] + e[4] * e[5];
+      wr[5] = e[2] * e[2] + e[5] * e[5];
+      wr[6] = e[0] * bv.x + e[3] * bv.y;
+      wr[7] = e[1] * bv.x + e[4] * bv.y;
+      wr[8] = e[2] * bv.x + e[5] * bv.y;
+    }
+    int jb = 0, je = 0;
+    if (tid < p1 - p0) {
+      jb = pt_start[p0 + tid] - r0;
+      je = pt_start[p0 + tid + 1] - r0;
+    }
+    __syncthreads();
+    if (tid < p1 - p0) {
+      const int p = p0 + tid;
+      double sacc[9], s2[9];
+#pragma unroll
+      for (int k = 0; k < 9; ++k) { sacc[k] = 0.0; s2[k] = 0.0; }
+      int j = jb;
+      for (; j + 2 <= je; j += 2) {
+#pragma unroll
+        for (int k = 0; k < 9; ++k) { sacc[k] += lds[j * 9 + k]; s2[k] += lds[j * 9 + 9 + k]; }
+      }
+      if (j < je) {
+#pragma unroll
+        for (int k = 0; k < 9; ++k) sacc[k] += lds[j * 9 + k];
+      }
+#pragma unroll
+      for (int k = 0; k < 9; ++k) sacc[k] += s2[k];
+      double m[9], inv[9];
+      m[0] = sacc[0]; m[1] = sacc[1]; m[2] = sacc[2]; m[4] = sacc[3]; m[5] = sacc[4]; m[8] = sacc[5];
+      if (De) {
+        const double* d = De + 3 * int64_t(p);
+        m[0] += d[0] * d[0]; m[4] += d[1] * d[1]; m[8] += d[2] * d[2];
+      }
+      m[3] = m[1]; m[6] = m[2]; m[7] = m[5];
+      if (USE_LLT) {
+        bool ok;
+        inv3_llt(m, inv, ok);
+        if (!ok) *not_pd = 1;
+      } else {
+        inv3_cofactor(m, inv);
+      }
+      double* o = ete_inv + 9 * int64_t(p);
+#pragma unroll
+      for (int k = 0; k < 9; ++k) o[k] = inv[k];
+      u[tid * 3] = inv[0] * sacc[6] + inv[1] * sacc[7] + inv[2] * sacc[8];
+      u[tid * 3 + 1] = inv[3] * sacc[6] + inv[4] * sacc[7] + inv[5] * sacc[8];
+      u[tid * 3 + 2] = inv[6] * sacc[6] + inv[7] * sacc[7] + inv[8] * sacc[8];
+    }
+    __syncthreads();
+    if (live) {
+      const double u0 = u[lp * 3], u1 = u[lp * 3 + 1], u2 = u[lp * 3 + 2];
+      reinterpret_cast<double2*>(tprime)[r0 + tid] =
+          make_double2(bv.x - (e[0] * u0 + e[1] * u1 + e[2] * u2), bv.y - (e[3] * u0 + e[4] * u1 + e[5] * u2));
+    }
+  } else {
+    // one long chunk: strided loops and a block reduction
+    double sacc[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) sacc[k] = 0.0;
+    for (int r = r0 + tid; r < r1; r += kBlock) {
+      const double* e = E + 6 * int64_t(r);
+      const double2 bv = reinterpret_cast<const double2*>(b)[r];
+      sacc[0] += e[0] * e[0] + e[3] * e[3];
+      sacc[1] += e[0] * e[1] + e[3] * e[4];
+      sacc[2] += e[0] * e[2] + e[3] * e[5];
+      sacc[3] += e[1] * e[1] + e[4] * e[4];
+      sacc[4] += e[1] * e[2] + e[4] * e[5];
+      sacc[5] += e[2] * e[2] + e[5] * e[5];
+      sacc[6] += e[0] * bv.x + e[3] * bv.y;
+      sacc[7] += e[1] * bv.x + e[4] * bv.y;
+      sacc[8] += e[2] * bv.x + e[5] * bv.y;
+    }
+    block_sum<9>(sacc, red);
+    double m[9], inv[9];
+    m[0] = sacc[0]; m[1] = sacc[1]; m[2] = sacc[2]; m[4] = sacc[3]; m[5] = sacc[4]; m[8] = sacc[5];
+    if (De) {
+      const double* d = De + 3 * int64_t(p0);
+      m[0] += d[0] * d[0]; m[4] += d[1] * d[1]; m[8] += d[2] * d[2];
+    }
+    m[3] = m[1]; m[6] = m[2]; m[7] = m[5];
+    if (USE_LLT) {
+      bool ok;
+      inv3_llt(m, inv, ok);
+      if (!ok && tid == 0) *not_pd = 1;
+    } else {
+      inv3_cofactor(m, inv);
+    }
+    if (tid == 0) {
+#pragma unroll
+      for (int k = 0; k < 9; ++k) ete_inv[9 * int64_t(p0) + k] = inv[k];
+    }
+    const double u0 = inv[0] * sacc[6] + inv[1] * sacc[7] + inv[2] * sacc[8];
+    const double u1 = inv[3] * sacc[6] + inv[4] * sacc[7] + inv[5] * sacc[8];
+    const double u2 = inv[6] * sacc[6] + inv[7] * sacc[7] + inv[8] * sacc[8];
+    for (int r = r0 + tid; r < r1; r += kBlock) {
+      const double* e = E + 6 * int64_t(r);
+      const double2 bv = reinterpret_cast<const double2*>(b)[r];
+      reinterpret_cast<double2*>(tprime)[r] =
+          make_double2(bv.x - (e[0] * u0 + e[1] * u1 + e[2] * u2), bv.y - (e[3] * u0 + e[4] * u1 + e[5] * u2));
+    }
+  }
+}
+
+// One workgroup per camera-major segment of Ft.
+template <bool WITH_SCHUR>
+__global__ __launch_bounds__(kBlock) void k_cam_init(const double* __restrict__ F, const double* __restrict__ E,
+                                                     const int32_t* __restrict__ cam_rows,
+                                                     const int32_t* __restrict__ row_pt,
+                                                     const int32_t* __restrict__ seg_begin,
+                                                     const double* __restrict__ ete_inv,
+                                                     const double* __restrict__ tprime,   // may be null
+                                                     const double* __restrict__ Ft,
+                                                     double* __restrict__ partial45, double* __restrict__ partial9,
+                                                     int num_segs) {
+  __shared__ double lds[kBlock * 18];
+  __shared__ double red[45 * 4];
+  const int sgm = xcd_segment(num_segs), tid = threadIdx.x;
+  if (sgm < 0) return;
+  const int b0 = seg_begin[sgm], e0 = seg_begin[sgm + 1];
+  double acc[45], acc9[9];
+#pragma unroll
+  for (int k = 0; k < 45; ++k) acc[k] = 0.0;
+#pragma unroll
+  for (int k = 0; k < 9; ++k) acc9[k] = 0.0;
+  for (int k0 = b0; k0 < e0; k0 += kBlock) {
+    const int nvalid = min(kBlock, e0 - k0);
+    double f[18];
+    stage_cells<18>(Ft + 18 * int64_t(k0), nvalid, lds, f);
+    if (tid < nvalid) {
+      const int r = cam_rows[k0 + tid];
+#pragma unroll
+      for (int a = 0; a < 9; ++a)
+#pragma unroll
+        for (int c = a; c < 9; ++c) acc[a * 9 - a * (a - 1) / 2 + c - a] += f[a] * f[c] + f[9 + a] * f[9 + c];
+      if (WITH_SCHUR) {
+        const double* e = E + 6 * int64_t(r);
+        const double* m = ete_inv + 9 * int64_t(row_pt[r]);
+        double e6[6], mi[9];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) e6[k] = e[k];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) mi[k] = m[k];
+        double B[27], G[27];
+#pragma unroll
+        for (int q = 0; q < 3; ++q)
+#pragma unroll
+          for (int a = 0; a < 9; ++a) B[q * 9 + a] = e6[q] * f[a] + e6[3 + q] * f[9 + a];
+#pragma unroll
+        for (int q = 0; q < 3; ++q)
+#pragma unroll
+          for (int a = 0; a < 9; ++a) G[q * 9 + a] = mi[q * 3] * B[a] + mi[q * 3 + 1] * B[9 + a] + mi[q * 3 + 2] * B[18 + a];
+#pragma unroll
+        for (int a = 0; a < 9; ++a)
+#pragma unroll
+          for (int c = a; c < 9; ++c)
+            acc[a * 9 - a * (a - 1) / 2 + c - a] -= B[a] * G[c] + B[9 + a] * G[9 + c] + B[18 + a] * G[18 + c];
+      }
+      if (tprime) {
+        const double2 tv = reinterpret_cast<const double2*>(tprime)[r];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) acc9[k] += f[k] * tv.x + f[9 + k] * tv.y;
+      }
+    }
+    __syncthreads();
+  }
+  block_sum_store<45>(acc, red, partial45 + int64_t(sgm) * 45);
+  if (tprime) block_sum_store<9>(acc9, red, partial9 + int64_t(sgm) * 9);
+}
+
 // ---------------------------------------------- camera-major 9x9 block diagonals
 // WITH_SCHUR = false: partial[seg] = sum F_r' F_r                      (block diagonal of F'F)
 // WITH_SCHUR = true : partial[seg] = sum F_r'F_r - (E_r'F_r)'(E'E)^-1(E_r'F_r)   (block diagonal of S)
@@ -369,6 +580,17 @@ __global__ __launch_bounds__(kBlock) void k_cam_diag(const double* __restrict__ 
     }
   }
   block_sum_store<45>(acc, red, partial + int64_t(s) * 45);
+}
+
+// out[9c + k] = sum of the camera's 9-wide segment partials, in segment order
+__global__ void k_sum_segments9(const double* __restrict__ partial, const int32_t* __restrict__ cam_seg_start,
+                                double* __restrict__ out, int C) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= C * 9) return;
+  const int c = i / 9, k = i - c * 9;
+  double sum = 0.0;
+  for (int sg = cam_seg_start[c]; sg < cam_seg_start[c + 1]; ++sg) sum += partial[int64_t(sg) * 9 + k];
+  out[i] = sum;
 }
 
 // blocks[c] (81, row-major, full) = sum of the camera's packed segment partials
@@ -681,6 +903,40 @@ int cxs_eliminate_dense(cx_matrix* A, const double* b, const double* D, bool add
       CX_HIP(hipMemsetAsync(rhs, 0, size_t(n) * sizeof(double), st));
     }
   }
+  CX_HIP(hipGetLastError());
+  return CX_OK;
+}
+
+// Fused ImplicitSchurComplement::Init for the static layout: ete_inv[9P], the inverse of the
+// per-camera preconditioner blocks is left to the caller (blocks[81C] = F'F or S diagonal blocks,
+// D_f^2 not yet added), rhs_out[9C] = F'(b - E (E'E)^-1 E'b).
+int cxs_implicit_init(cx_matrix* A, const double* D, const double* b, bool want_blocks, bool with_schur,
+                      double* ete_inv, double* rows_scratch, double* blocks, double* rhs_out, int* d_flag) {
+  hipStream_t st = A->ctx->stream;
+  if (A->num_tiles == 0 || A->num_segs == 0) {
+    if (want_blocks) CX_HIP(hipMemsetAsync(blocks, 0, 81 * size_t(A->C) * sizeof(double), st));
+    CX_HIP(hipMemsetAsync(rhs_out, 0, 9 * size_t(A->C) * sizeof(double), st));
+    return CX_OK;
+  }
+  const double* E = A->d_values.p;
+  const double* F = A->d_values.p + 6 * A->O;
+  hipLaunchKernelGGL(k_chunk_init<true>, dim3(A->num_tiles), dim3(kBlock), 0, st, E, A->d_tile_row.p, A->d_tile_pt.p,
+                     A->d_pt_start.p, A->d_row_pt.p, D, b, ete_inv, rows_scratch, d_flag);
+  CX_TRY(cx_matrix_ensure_ft(A));
+  CX_TRY(A->d_partials9.alloc(size_t(A->num_segs) * 9));
+  if (with_schur)
+    hipLaunchKernelGGL(k_cam_init<true>, dim3(xcd_grid(A->num_segs)), dim3(kBlock), 0, st, F, E, A->d_cam_rows.p,
+                       A->d_row_pt.p, A->d_seg_begin.p, (const double*)ete_inv, (const double*)rows_scratch, (const double*)A->d_Ft.p,
+                       A->d_partials.p, A->d_partials9.p, A->num_segs);
+  else
+    hipLaunchKernelGGL(k_cam_init<false>, dim3(xcd_grid(A->num_segs)), dim3(kBlock), 0, st, F, E, A->d_cam_rows.p,
+                       A->d_row_pt.p, A->d_seg_begin.p, (const double*)ete_inv, (const double*)rows_scratch, (const double*)A->d_Ft.p,
+                       A->d_partials.p, A->d_partials9.p, A->num_segs);
+  if (want_blocks)
+    hipLaunchKernelGGL(k_cam_diag_reduce, dim3(grid_for(int64_t(A->C) * 45, 256)), dim3(256), 0, st,
+                       (const double*)A->d_partials.p, A->d_cam_seg_start.p, blocks, A->C);
+  hipLaunchKernelGGL(k_sum_segments9, dim3(grid_for(int64_t(A->C) * 9, 256)), dim3(256), 0, st,
+                     (const double*)A->d_partials9.p, A->d_cam_seg_start.p, rhs_out, A->C);
   CX_HIP(hipGetLastError());
   return CX_OK;
 }

@@ -604,9 +604,8 @@ int SolveIterativeSchur239(cx_solver* S, cx_matrix* A, const double* b, const do
   CX_TRY(S->flag.alloc(1));
   CX_HIP(hipMemsetAsync(S->flag.p, 0, sizeof(int), st));
   CX_TRY(sw.start());
-  // ImplicitSchurComplement::Init (implicit_schur_complement.cc:49-97)
-  CX_TRY(cx_matrix_ensure_ft(A));
-  CX_TRY(cxs_compute_ete_inverse(A, D, nullptr, S->ete_inv.p, nullptr, true, S->flag.p));
+  // ImplicitSchurComplement::Init + UpdateRhs (implicit_schur_complement.cc:49-97, 251-276) fused into
+  // one pass over E and one over F (cxs_implicit_init)
   // compute_ftf_inverse_ (implicit_schur_complement.cc:63-67)
   const bool need_ftf = o.preconditioner_type == CX_JACOBI || o.preconditioner_type == CX_SCHUR_POWER_SERIES_EXPANSION ||
                         o.use_spse_initialization;
@@ -614,18 +613,18 @@ int SolveIterativeSchur239(cx_solver* S, cx_matrix* A, const double* b, const do
     cx_set_error("use_spse_initialization together with SCHUR_JACOBI is not available on the device");
     return CX_ERR_UNSUPPORTED;
   }
-  if (need_ftf || o.preconditioner_type == CX_SCHUR_JACOBI) {
-    CX_TRY(S->cam_blocks.alloc(81 * size_t(A->C)));
-    CX_TRY(cxs_camera_block_diagonal(A, o.preconditioner_type == CX_SCHUR_JACOBI, S->ete_inv.p, S->cam_blocks.p));
-    if (ctx->nranks > 1) CX_TRY(cx_allreduce_device(ctx, S->cam_blocks.p, 81 * int64_t(A->C)));
-    CX_TRY(cxs_block9_add_diag_invert(ctx, S->cam_blocks.p, D ? D + ne : nullptr, A->C, S->flag.p));
-  } else if (o.preconditioner_type != CX_IDENTITY) {
+  const bool want_blocks = need_ftf || o.preconditioner_type == CX_SCHUR_JACOBI;
+  if (!want_blocks && o.preconditioner_type != CX_IDENTITY) {
     cx_set_error("preconditioner %d is not available for ITERATIVE_SCHUR on the device", o.preconditioner_type);
     return CX_ERR_UNSUPPORTED;
   }
-  // UpdateRhs (:251-276): rhs = F'(b - E (E'E)^-1 E'b)
-  CX_TRY(cxs_chunk_pass(A, 1, S->ete_inv.p, nullptr, b, S->v_rows.p));
-  CX_TRY(cxk_ft_multiply(A, S->v_rows.p, S->v_rhs.p, false));
+  CX_TRY(S->cam_blocks.alloc(81 * size_t(std::max(A->C, 1))));
+  CX_TRY(cxs_implicit_init(A, D, b, want_blocks, o.preconditioner_type == CX_SCHUR_JACOBI, S->ete_inv.p, S->v_rows.p,
+                           S->cam_blocks.p, S->v_rhs.p, S->flag.p));
+  if (want_blocks) {
+    if (ctx->nranks > 1) CX_TRY(cx_allreduce_device(ctx, S->cam_blocks.p, 81 * int64_t(A->C)));
+    CX_TRY(cxs_block9_add_diag_invert(ctx, S->cam_blocks.p, D ? D + ne : nullptr, A->C, S->flag.p));
+  }
   if (ctx->nranks > 1) CX_TRY(cx_allreduce_device(ctx, S->v_rhs.p, nf));
   CX_TRY(sw.stop(&S->timing.eliminate_ms));
   bool failed = false;
