@@ -17,6 +17,7 @@ _lib = None
 
 HOST, DEVICE = 0, 1
 DENSE_SCHUR, SPARSE_SCHUR, ITERATIVE_SCHUR, CGNR = 0, 1, 2, 3
+LOSS_NONE, LOSS_HUBER, LOSS_SOFT_L_ONE, LOSS_CAUCHY, LOSS_ARCTAN, LOSS_TOLERANT, LOSS_TUKEY = range(7)
 IDENTITY, JACOBI, SCHUR_JACOBI, SCHUR_POWER_SERIES_EXPANSION = 0, 1, 2, 3
 SUCCESS, NO_CONVERGENCE, FAILURE, FATAL_ERROR = 0, 1, 2, 3
 
@@ -33,7 +34,7 @@ EXPORTED_SYMBOLS = [
     "cx_matrix_last_kernel_ms", "cx_solver_create", "cx_solver_destroy", "cx_solver_default_options",
     "cx_solver_solve", "cx_solver_last_timing", "cx_solver_kernel_stats", "cx_schur_eliminate_dense", "cx_schur_back_substitute",
     "cx_implicit_schur_multiply", "cx_dense_cholesky_solve", "cx_evaluator_create_bal", "cx_evaluator_destroy",
-    "cx_evaluator_jacobian", "cx_evaluator_row_of_observation", "cx_evaluator_evaluate",
+    "cx_evaluator_jacobian", "cx_evaluator_row_of_observation", "cx_evaluator_evaluate", "cx_evaluator_set_loss",
     "cx_evaluator_last_kernel_ms", "cx_detect_structure", "cx_partition_points", "cx_stable_schur_ordering",
 ]
 
@@ -470,6 +471,10 @@ class Evaluator:
         return out
 
     last_kernel_ms = property(lambda s: s.lib.cx_evaluator_last_kernel_ms(s._h))
+
+    def set_loss(self, loss_type, a=1.0, b=0.0):
+        """loss_type: one of LOSS_* (cx_loss_type); a, b the LossFunction constructor arguments."""
+        _check(self.lib.cx_evaluator_set_loss(self._h, int(loss_type), ctypes.c_double(a), ctypes.c_double(b)))
 
     def evaluate(self, state, want_residuals=True, want_gradient=True, want_jacobian=True, residuals=None,
                  gradient=None):

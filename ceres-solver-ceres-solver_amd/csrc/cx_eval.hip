@@ -24,9 +24,95 @@ struct cx_evaluator {
   DevBuf<double> d_obs;              // [2O] in row order
   DevBuf<double> d_partial, d_state, d_res;
   float last_ms = 0.f;
+  int32_t loss_type = CX_LOSS_NONE;
+  double loss_a = 0.0, loss_b = 0.0;
 };
 
 namespace {
+
+struct LossParams {
+  int32_t type;
+  double a, b;
+};
+
+// LossFunction::Evaluate of the built-in losses (loss_function.cc:46-144)
+__device__ __forceinline__ void loss_evaluate(const LossParams& L, double s, double rho[3]) {
+  const double kMin = 2.2250738585072014e-308;  // std::numeric_limits<double>::min()
+  rho[0] = s; rho[1] = 1.0; rho[2] = 0.0;
+  switch (L.type) {
+    case CX_LOSS_HUBER: {
+      const double b = L.a * L.a;
+      if (s > b) {
+        const double r = sqrt(s);
+        rho[0] = 2.0 * L.a * r - b;
+        rho[1] = fmax(kMin, L.a / r);
+        rho[2] = -rho[1] / (2.0 * s);
+      }
+      break;
+    }
+    case CX_LOSS_SOFT_L_ONE: {
+      const double b = L.a * L.a, c = 1 / b;
+      const double sum = 1.0 + s * c, tmp = sqrt(sum);
+      rho[0] = 2.0 * b * (tmp - 1.0);
+      rho[1] = fmax(kMin, 1.0 / tmp);
+      rho[2] = -(c * rho[1]) / (2.0 * sum);
+      break;
+    }
+    case CX_LOSS_CAUCHY: {
+      const double b = L.a * L.a, c = 1 / b;
+      const double sum = 1.0 + s * c, inv = 1.0 / sum;
+      rho[0] = b * log(sum);
+      rho[1] = fmax(kMin, inv);
+      rho[2] = -c * (inv * inv);
+      break;
+    }
+    case CX_LOSS_ARCTAN: {
+      const double b = 1 / (L.a * L.a);
+      const double sum = 1 + s * s * b, inv = 1 / sum;
+      rho[0] = L.a * atan2(s, L.a);
+      rho[1] = fmax(kMin, inv);
+      rho[2] = -2.0 * s * b * (inv * inv);
+      break;
+    }
+    case CX_LOSS_TOLERANT: {
+      const double c = L.b * log(1.0 + exp(-L.a / L.b));
+      const double x = (s - L.a) / L.b;
+      if (x > 36.7) {
+        rho[0] = s - L.a - c;
+      } else {
+        const double e_x = exp(x);
+        rho[0] = L.b * log(1.0 + e_x) - c;
+        rho[1] = fmax(kMin, e_x / (1.0 + e_x));
+        rho[2] = 0.5 / (L.b * (1.0 + cosh(x)));
+      }
+      break;
+    }
+    case CX_LOSS_TUKEY: {
+      const double a2 = L.a * L.a;
+      if (s <= a2) {
+        const double value = 1.0 - s / a2, value_sq = value * value;
+        rho[0] = a2 / 3.0 * (1.0 - value_sq * value);
+        rho[1] = value_sq;
+        rho[2] = -2.0 / a2 * value;
+      } else {
+        rho[0] = a2 / 3.0; rho[1] = 0.0; rho[2] = 0.0;
+      }
+      break;
+    }
+    default: break;
+  }
+}
+
+// Corrector::CorrectJacobian for a 2 x N row-major block (corrector.cc:118-153)
+template <int N>
+__device__ __forceinline__ void correct_jacobian(double sqrt_rho1, double alpha_sq_norm, double r0, double r1, double* j) {
+#pragma unroll
+  for (int c = 0; c < N; ++c) {
+    const double rtj = j[c] * r0 + j[N + c] * r1;
+    j[c] = sqrt_rho1 * (j[c] - alpha_sq_norm * r0 * rtj);
+    j[N + c] = sqrt_rho1 * (j[N + c] - alpha_sq_norm * r1 * rtj);
+  }
+}
 
 template <int N>
 struct Jet {
@@ -156,14 +242,14 @@ __global__ __launch_bounds__(kBlock) void k_bal_evaluate(const double* __restric
                                                          const int32_t* __restrict__ row_cam, int64_t O,
                                                          int64_t cam_off, double* __restrict__ residuals,
                                                          double* __restrict__ E, double* __restrict__ F,
-                                                         double* __restrict__ cost_partial) {
+                                                         double* __restrict__ cost_partial, LossParams loss) {
   __shared__ double lds[kBlock * 18];
   __shared__ double red[4];
   const int64_t r0i = int64_t(blockIdx.x) * kBlock;
   const int nvalid = int(min(int64_t(kBlock), O - r0i));
   const int tid = threadIdx.x;
   const int64_t r = r0i + tid;
-  double res0 = 0.0, res1 = 0.0;
+  double res0 = 0.0, res1 = 0.0, cost_term = 0.0;
   double jc[18], jp[6];
   if (tid < nvalid) {
     double cam[9], pt[3];
@@ -176,6 +262,29 @@ __global__ __launch_bounds__(kBlock) void k_bal_evaluate(const double* __restric
     const double2 o = reinterpret_cast<const double2*>(obs)[r];
     if (WITH_J) snavely_jet(cam, pt, o.x, o.y, res0, res1, jc, jp);
     else snavely_value(cam, pt, o.x, o.y, res0, res1);
+    const double sq = res0 * res0 + res1 * res1;
+    cost_term = 0.5 * sq;
+    if (loss.type != CX_LOSS_NONE) {
+      // residual_block.cc:165-196 with Corrector (corrector.cc:41-116): Jacobians first, with
+      // the uncorrected residuals, then the residuals
+      double rho[3];
+      loss_evaluate(loss, sq, rho);
+      cost_term = 0.5 * rho[0];
+      const double sqrt_rho1 = sqrt(rho[1]);
+      double residual_scaling = sqrt_rho1, alpha_sq_norm = 0.0;
+      if (sq != 0.0 && rho[2] > 0.0) {
+        const double D = 1.0 + 2.0 * sq * rho[2] / rho[1];
+        const double alpha = 1.0 - sqrt(D);
+        residual_scaling = sqrt_rho1 / (1 - alpha);
+        alpha_sq_norm = alpha / sq;
+      }
+      if (WITH_J) {
+        correct_jacobian<9>(sqrt_rho1, alpha_sq_norm, res0, res1, jc);
+        correct_jacobian<3>(sqrt_rho1, alpha_sq_norm, res0, res1, jp);
+      }
+      res0 *= residual_scaling;
+      res1 *= residual_scaling;
+    }
     if (residuals) reinterpret_cast<double2*>(residuals)[r] = make_double2(res0, res1);
   }
   if (WITH_J) {
@@ -183,7 +292,7 @@ __global__ __launch_bounds__(kBlock) void k_bal_evaluate(const double* __restric
     unstage_cells<6>(E + 6 * r0i, nvalid, lds, jp);
   }
   if (cost_partial) {
-    double c[1] = {(tid < nvalid) ? 0.5 * (res0 * res0 + res1 * res1) : 0.0};
+    double c[1] = {cost_term};
     block_sum<1>(c, red);
     if (tid == 0) cost_partial[blockIdx.x] = c[0];
   }
@@ -287,15 +396,16 @@ int cx_evaluator_evaluate(cx_evaluator* e, const double* state, double* cost, do
   const int grid = int((e->O + kBlock - 1) / kBlock);
   double* E = A->d_values.p;
   double* F = A->d_values.p + 6 * e->O;
+  const LossParams loss{e->loss_type, e->loss_a, e->loss_b};
   CX_HIP(hipEventRecord(ctx->ev[6], st));
   if (with_j)
     hipLaunchKernelGGL(k_bal_evaluate<true>, dim3(grid), dim3(kBlock), 0, st, (const double*)hs.dptr, (const double*)e->d_obs.p,
                        (const int32_t*)A->d_row_pt.p, (const int32_t*)A->d_row_cam.p, e->O, 3 * int64_t(e->P), res_dev, E, F,
-                       cost ? e->d_partial.p : nullptr);
+                       cost ? e->d_partial.p : nullptr, loss);
   else
     hipLaunchKernelGGL(k_bal_evaluate<false>, dim3(grid), dim3(kBlock), 0, st, (const double*)hs.dptr, (const double*)e->d_obs.p,
                        (const int32_t*)A->d_row_pt.p, (const int32_t*)A->d_row_cam.p, e->O, 3 * int64_t(e->P), res_dev, E, F,
-                       cost ? e->d_partial.p : nullptr);
+                       cost ? e->d_partial.p : nullptr, loss);
   if (cost) hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(256), 0, st, (const double*)e->d_partial.p, int64_t(grid), e->d_partial.p + grid);
   CX_HIP(hipGetLastError());
   CX_HIP(hipEventRecord(ctx->ev[7], st));
@@ -315,6 +425,16 @@ int cx_evaluator_evaluate(cx_evaluator* e, const double* state, double* cost, do
   CX_TRY(hr.out());
   CX_TRY(hg.out());
   CX_HIP(hipStreamSynchronize(st));
+  return CX_OK;
+}
+
+int cx_evaluator_set_loss(cx_evaluator* e, int32_t loss_type, double a, double b) {
+  CX_CHECK_ARG(e != nullptr && loss_type >= CX_LOSS_NONE && loss_type <= CX_LOSS_TUKEY);
+  if (loss_type != CX_LOSS_NONE) CX_CHECK_ARG(a > 0.0 || (loss_type == CX_LOSS_TOLERANT && a >= 0.0));
+  if (loss_type == CX_LOSS_TOLERANT) CX_CHECK_ARG(b > 0.0);
+  e->loss_type = loss_type;
+  e->loss_a = a;
+  e->loss_b = b;
   return CX_OK;
 }
 

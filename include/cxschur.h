@@ -82,6 +82,18 @@ typedef enum {
   CX_SCHUR_POWER_SERIES_EXPANSION = 3
 } cx_preconditioner_type;
 
+/* Built-in LossFunction of a residual block (include/ceres/loss_function.h:171-292); a, b are
+ * the constructor arguments (b only for TOLERANT). */
+typedef enum {
+  CX_LOSS_NONE = 0, /* loss_function == nullptr / TrivialLoss */
+  CX_LOSS_HUBER = 1,
+  CX_LOSS_SOFT_L_ONE = 2,
+  CX_LOSS_CAUCHY = 3,
+  CX_LOSS_ARCTAN = 4,
+  CX_LOSS_TOLERANT = 5,
+  CX_LOSS_TUKEY = 6
+} cx_loss_type;
+
 /* Where b, D, x, state ... pointers of a call live. */
 typedef enum { CX_HOST = 0, CX_DEVICE = 1 } cx_memspace;
 
@@ -288,6 +300,12 @@ int cx_evaluator_row_of_observation(const cx_evaluator* e, int64_t* out_host);
 int cx_evaluator_evaluate(cx_evaluator* e, const double* state, double* cost,
                           double* residuals, double* gradient, int32_t evaluate_jacobian,
                           int32_t memspace);
+/* Robust loss applied to every residual block: cost = 1/2 rho(|r|^2), residuals and Jacobian
+ * corrected as Corrector does (residual_block.cc:160-196, corrector.cc:41-155,
+ * loss_function.cc:46-144; bundle_adjuster --robustify uses HuberLoss(1.0), bundle_adjuster.cc:327).
+ * CX_LOSS_NONE restores the plain squared loss (also what Evaluate does with
+ * apply_loss_function = false, evaluator.h:84-92). */
+int cx_evaluator_set_loss(cx_evaluator* e, int32_t loss_type, double a, double b);
 double cx_evaluator_last_kernel_ms(const cx_evaluator* e);
 
 /* ------------------------------------------------------ host-side helpers */

@@ -271,8 +271,37 @@ def bal_structure_arrays(num_cameras, num_points, camera_index, point_index, ord
     return rb, cb, rcb, cells
 
 
+def loss_evaluate(loss_type, a, b, s):
+    rho = np.zeros(3)
+    lib().orc_loss_evaluate(int(loss_type), ctypes.c_double(a), ctypes.c_double(b), ctypes.c_double(s), _p(rho))
+    return rho
+
+
+def corrector_apply(sq_norm, rho, residuals, jacobian=None):
+    """Returns (corrected residuals, corrected jacobian)."""
+    r = np.array(residuals, dtype=np.float64).copy()
+    j = None if jacobian is None else np.array(jacobian, dtype=np.float64).copy()
+    ncols = 0 if j is None else j.shape[1]
+    lib().orc_corrector_apply(ctypes.c_double(sq_norm), _p(_f64(rho)), int(r.shape[0]), int(ncols), _p(r), _p(j))
+    return r, j
+
+
 def bal_evaluate(bs, num_cameras, num_points, camera_index, point_index, observations, order, state,
-                 want_residuals=True, want_gradient=True, want_jacobian=True):
+                 want_residuals=True, want_gradient=True, want_jacobian=True, loss=None):
+    if loss is not None:
+        O = int(camera_index.shape[0])
+        cost = ctypes.c_double()
+        res = np.zeros(2 * O) if want_residuals else None
+        grad = np.zeros(3 * num_points + 9 * num_cameras) if want_gradient else None
+        vals = np.zeros(24 * O) if want_jacobian else None
+        ltype, la, lb = loss
+        lib().orc_bal_evaluate_robust(bs.c, int(num_cameras), int(num_points), ctypes.c_int64(O),
+                                      _p(np.ascontiguousarray(camera_index, dtype=np.int32)),
+                                      _p(np.ascontiguousarray(point_index, dtype=np.int32)),
+                                      _p(_f64(observations)), _p(np.ascontiguousarray(order, dtype=np.int64)),
+                                      _p(_f64(state)), int(ltype), ctypes.c_double(la), ctypes.c_double(lb),
+                                      ctypes.byref(cost), _p(res), _p(grad), _p(vals))
+        return cost.value, res, grad, vals
     O = int(camera_index.shape[0])
     cost = ctypes.c_double()
     res = np.zeros(2 * O) if want_residuals else None

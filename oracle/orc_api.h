@@ -103,6 +103,18 @@ void orc_bal_evaluate(const cx_block_structure* bs, int num_cameras, int num_poi
                       int64_t num_obs, const int32_t* camera_index, const int32_t* point_index,
                       const double* observations, const int64_t* order, const double* state,
                       double* cost, double* residuals, double* gradient, double* values);
+/* LossFunction::Evaluate (loss_function.cc:46-144) for cx_loss_type; rho[3] */
+void orc_loss_evaluate(int type, double a, double b, double s, double* rho);
+/* Corrector (corrector.cc:41-155): corrects jacobian (row-major num_rows x num_cols, may be
+ * NULL) and then residuals in place */
+void orc_corrector_apply(double sq_norm, const double* rho, int num_rows, int num_cols,
+                         double* residuals, double* jacobian);
+/* orc_bal_evaluate with a robust loss on every residual block (residual_block.cc:160-196) */
+void orc_bal_evaluate_robust(const cx_block_structure* bs, int num_cameras, int num_points,
+                             int64_t num_obs, const int32_t* camera_index, const int32_t* point_index,
+                             const double* observations, const int64_t* order, const double* state,
+                             int loss_type, double loss_a, double loss_b, double* cost,
+                             double* residuals, double* gradient, double* values);
 
 #ifdef __cplusplus
 }

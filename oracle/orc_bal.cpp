@@ -14,6 +14,7 @@
 #include <omp.h>
 
 #include <algorithm>
+#include <limits>
 #include <numeric>
 
 #include "orc_api.h"
@@ -216,17 +217,118 @@ void orc_bal_structure(int C, int P, int64_t O, const int32_t* cam, const int32_
 
 // program_evaluator.h:137-304 (no loss function, no manifolds: bundle_adjuster
 // defaults, bundle_adjuster.cc:112,327-328)
-void orc_bal_evaluate(const cx_block_structure* s, int C, int P, int64_t O, const int32_t* cam,
-                      const int32_t* pt, const double* observations, const int64_t* order,
-                      const double* state, double* cost, double* residuals, double* gradient,
-                      double* values) {
-  BS bs(s);
+// LossFunction::Evaluate for the built-in losses (loss_function.cc:46-144, constructors
+// include/ceres/loss_function.h:176-292); type codes are cx_loss_type of include/cxschur.h.
+void orc_loss_evaluate(int type, double a, double b, double s, double* rho) {
+  const double kMin = std::numeric_limits<double>::min();
+  switch (type) {
+    case CX_LOSS_HUBER: {
+      const double b_ = a * a;
+      if (s > b_) {
+        const double r = std::sqrt(s);
+        rho[0] = 2.0 * a * r - b_;
+        rho[1] = std::max(kMin, a / r);
+        rho[2] = -rho[1] / (2.0 * s);
+      } else {
+        rho[0] = s; rho[1] = 1.0; rho[2] = 0.0;
+      }
+      return;
+    }
+    case CX_LOSS_SOFT_L_ONE: {
+      const double b_ = a * a, c_ = 1 / b_;
+      const double sum = 1.0 + s * c_, tmp = std::sqrt(sum);
+      rho[0] = 2.0 * b_ * (tmp - 1.0);
+      rho[1] = std::max(kMin, 1.0 / tmp);
+      rho[2] = -(c_ * rho[1]) / (2.0 * sum);
+      return;
+    }
+    case CX_LOSS_CAUCHY: {
+      const double b_ = a * a, c_ = 1 / b_;
+      const double sum = 1.0 + s * c_, inv = 1.0 / sum;
+      rho[0] = b_ * std::log(sum);
+      rho[1] = std::max(kMin, inv);
+      rho[2] = -c_ * (inv * inv);
+      return;
+    }
+    case CX_LOSS_ARCTAN: {
+      const double b_ = 1 / (a * a);
+      const double sum = 1 + s * s * b_, inv = 1 / sum;
+      rho[0] = a * std::atan2(s, a);
+      rho[1] = std::max(kMin, inv);
+      rho[2] = -2.0 * s * b_ * (inv * inv);
+      return;
+    }
+    case CX_LOSS_TOLERANT: {
+      const double c_ = b * std::log(1.0 + std::exp(-a / b));
+      const double x = (s - a) / b;
+      if (x > 36.7) {
+        rho[0] = s - a - c_; rho[1] = 1.0; rho[2] = 0.0;
+      } else {
+        const double e_x = std::exp(x);
+        rho[0] = b * std::log(1.0 + e_x) - c_;
+        rho[1] = std::max(kMin, e_x / (1.0 + e_x));
+        rho[2] = 0.5 / (b * (1.0 + std::cosh(x)));
+      }
+      return;
+    }
+    case CX_LOSS_TUKEY: {
+      const double a2 = a * a;
+      if (s <= a2) {
+        const double value = 1.0 - s / a2, value_sq = value * value;
+        rho[0] = a2 / 3.0 * (1.0 - value_sq * value);
+        rho[1] = value_sq;
+        rho[2] = -2.0 / a2 * value;
+      } else {
+        rho[0] = a2 / 3.0; rho[1] = 0.0; rho[2] = 0.0;
+      }
+      return;
+    }
+    default:
+      rho[0] = s; rho[1] = 1.0; rho[2] = 0.0;
+  }
+}
+
+// Corrector (corrector.cc:41-155): jacobian (may be NULL) is corrected first, with the
+// uncorrected residuals, then the residuals (residual_block.cc:176-196).
+void orc_corrector_apply(double sq_norm, const double* rho, int num_rows, int num_cols,
+                         double* residuals, double* jacobian) {
+  const double sqrt_rho1 = std::sqrt(rho[1]);
+  double residual_scaling, alpha_sq_norm;
+  if (sq_norm == 0.0 || rho[2] <= 0.0) {
+    residual_scaling = sqrt_rho1;
+    alpha_sq_norm = 0.0;
+  } else {
+    const double D = 1.0 + 2.0 * sq_norm * rho[2] / rho[1];
+    const double alpha = 1.0 - std::sqrt(D);
+    residual_scaling = sqrt_rho1 / (1 - alpha);
+    alpha_sq_norm = alpha / sq_norm;
+  }
+  if (jacobian) {
+    if (alpha_sq_norm == 0.0) {
+      for (int i = 0; i < num_rows * num_cols; ++i) jacobian[i] *= sqrt_rho1;
+    } else {
+      for (int c = 0; c < num_cols; ++c) {
+        double r_transpose_j = 0.0;
+        for (int r = 0; r < num_rows; ++r) r_transpose_j += jacobian[r * num_cols + c] * residuals[r];
+        for (int r = 0; r < num_rows; ++r)
+          jacobian[r * num_cols + c] =
+              sqrt_rho1 * (jacobian[r * num_cols + c] - alpha_sq_norm * residuals[r] * r_transpose_j);
+      }
+    }
+  }
+  for (int r = 0; r < num_rows; ++r) residuals[r] *= residual_scaling;
+}
+
+void orc_bal_evaluate_robust(const cx_block_structure* s, int C, int P, int64_t O, const int32_t* cam,
+                             const int32_t* pt, const double* observations, const int64_t* order,
+                             const double* state, int loss_type, double loss_a, double loss_b,
+                             double* cost, double* residuals, double* gradient, double* values) {
+  (void)s;
   const int threads = orc_get_num_threads();
   double total = 0.0;
   const int num_cols = 3 * P + 9 * C;
   std::vector<std::vector<double>> grads;
   if (gradient) grads.assign(threads, std::vector<double>(num_cols, 0.0));
-  (void)bs;
 #pragma omp parallel for schedule(static) num_threads(threads) reduction(+ : total)
   for (int64_t k = 0; k < O; ++k) {
     const int64_t i = order[k];
@@ -235,7 +337,21 @@ void orc_bal_evaluate(const cx_block_structure* s, int C, int P, int64_t O, cons
     double r[2], jc[18], jp[6];
     const bool need_j = values || gradient;
     SnavelyAutoDiff(camera, point, observations + 2 * i, r, need_j ? jc : nullptr, need_j ? jp : nullptr);
-    total += 0.5 * (r[0] * r[0] + r[1] * r[1]);
+    const double sq = r[0] * r[0] + r[1] * r[1];
+    if (loss_type == CX_LOSS_NONE) {
+      total += 0.5 * sq;                       // residual_block.cc:160-163
+    } else {
+      double rho[3];
+      orc_loss_evaluate(loss_type, loss_a, loss_b, sq, rho);
+      total += 0.5 * rho[0];                   // residual_block.cc:165-167
+      if (need_j) {
+        double r_copy[2] = {r[0], r[1]};
+        orc_corrector_apply(sq, rho, 2, 9, r_copy, jc);
+        r_copy[0] = r[0]; r_copy[1] = r[1];
+        orc_corrector_apply(sq, rho, 2, 3, r_copy, jp);
+      }
+      orc_corrector_apply(sq, rho, 2, 0, r, nullptr);
+    }
     if (residuals) { residuals[2 * k] = r[0]; residuals[2 * k + 1] = r[1]; }
     if (values) {
       std::copy(jp, jp + 6, values + 6 * k);
@@ -252,6 +368,14 @@ void orc_bal_evaluate(const cx_block_structure* s, int C, int P, int64_t O, cons
     std::fill(gradient, gradient + num_cols, 0.0);
     for (auto& g : grads) for (int i = 0; i < num_cols; ++i) gradient[i] += g[i];
   }
+}
+
+void orc_bal_evaluate(const cx_block_structure* s, int C, int P, int64_t O, const int32_t* cam,
+                      const int32_t* pt, const double* observations, const int64_t* order,
+                      const double* state, double* cost, double* residuals, double* gradient,
+                      double* values) {
+  orc_bal_evaluate_robust(s, C, P, O, cam, pt, observations, order, state, CX_LOSS_NONE, 0.0, 0.0, cost,
+                          residuals, gradient, values);
 }
 
 }  // extern "C"

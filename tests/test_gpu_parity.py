@@ -212,6 +212,37 @@ def test_evaluator(ctx, oracle, C, P, O, seed):
     ev.close()
 
 
+@pytest.mark.parametrize("loss", [(cx.binding.LOSS_HUBER, 1.0, 0.0), (cx.binding.LOSS_HUBER, 0.25, 0.0),
+                                  (cx.binding.LOSS_SOFT_L_ONE, 0.7, 0.0), (cx.binding.LOSS_CAUCHY, 1.3, 0.0),
+                                  (cx.binding.LOSS_ARCTAN, 0.7, 0.0), (cx.binding.LOSS_TOLERANT, 0.7, 0.4),
+                                  (cx.binding.LOSS_TUKEY, 1.3, 0.0)])
+def test_evaluator_robust_loss(ctx, oracle, loss):
+    """Corrector + LossFunction inside the Jacobian kernel (residual_block.cc:160-196): noisy
+    observations put residual blocks on both sides of every loss's inlier/outlier boundary."""
+    C, P, O = 12, 300, 2400
+    prob = cx.bal.make_bal_like(C, P, O, 3)
+    bs, order = cx.bal.build_structure(prob)
+    ev = cx.Evaluator(ctx, prob)
+    ev.set_loss(*loss)
+    state = prob.state()
+    cost, res, grad = ev.evaluate(state)
+    cost_r, res_r, grad_r, vals_r = oracle.bal_evaluate(bs, C, P, prob.camera_index, prob.point_index,
+                                                        prob.observations, order, state, loss=loss)
+    cost_plain = oracle.bal_evaluate(bs, C, P, prob.camera_index, prob.point_index, prob.observations, order,
+                                     state)[0]
+    assert abs(cost_plain - cost_r) > 1e-3 * cost_plain  # the loss is active on this input
+    vals = ev.jacobian(bs).get_values()
+    assert relerr(res, res_r) < 1e-11 and relerr(vals, vals_r) < 1e-11
+    assert abs(cost - cost_r) <= 1e-11 * abs(cost_r)
+    assert relerr(grad, grad_r) < 1e-10
+    cost2, res2, _ = ev.evaluate(state, want_gradient=False, want_jacobian=False)
+    assert relerr(res2, res_r) < 1e-11 and abs(cost2 - cost_r) <= 1e-11 * abs(cost_r)
+    ev.set_loss(cx.binding.LOSS_NONE)
+    cost3, _, _ = ev.evaluate(state, want_gradient=False, want_jacobian=False)
+    assert abs(cost3 - cost_plain) <= 1e-11 * cost_plain
+    ev.close()
+
+
 def test_big_chunk_paths(ctx, oracle):
     """A point seen by more cameras than a tile has rows exercises the long-chunk code paths."""
     C, P = 300, 40
