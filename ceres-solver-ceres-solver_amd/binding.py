@@ -34,7 +34,7 @@ EXPORTED_SYMBOLS = [
     "cx_matrix_last_kernel_ms", "cx_solver_create", "cx_solver_destroy", "cx_solver_default_options",
     "cx_solver_solve", "cx_solver_last_timing", "cx_solver_kernel_stats", "cx_schur_eliminate_dense", "cx_schur_back_substitute",
     "cx_implicit_schur_multiply", "cx_dense_cholesky_solve", "cx_evaluator_create_bal", "cx_evaluator_destroy",
-    "cx_evaluator_jacobian", "cx_evaluator_row_of_observation", "cx_evaluator_evaluate", "cx_evaluator_set_loss",
+    "cx_evaluator_jacobian", "cx_evaluator_row_of_observation", "cx_evaluator_evaluate", "cx_evaluator_set_loss", "cx_minimizer_default_options", "cx_minimize",
     "cx_evaluator_last_kernel_ms", "cx_detect_structure", "cx_partition_points", "cx_stable_schur_ordering",
 ]
 
@@ -88,6 +88,50 @@ class cx_solve_timing(ctypes.Structure):
 class cx_kernel_stat(ctypes.Structure):
     _fields_ = [("name", ctypes.c_char * 64), ("sampled_ms", ctypes.c_double),
                 ("sampled_launches", ctypes.c_int32), ("launches", ctypes.c_int32)]
+
+
+class cx_minimizer_options(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_int32) for n in
+                ("max_num_iterations", "max_num_consecutive_invalid_steps", "jacobi_scaling",
+                 "use_nonmonotonic_steps", "max_consecutive_nonmonotonic_steps", "reserved")] + \
+               [(n, ctypes.c_double) for n in
+                ("initial_trust_region_radius", "max_trust_region_radius", "min_trust_region_radius",
+                 "min_relative_decrease", "min_lm_diagonal", "max_lm_diagonal", "function_tolerance",
+                 "gradient_tolerance", "parameter_tolerance", "eta")]
+
+
+class cx_iteration_summary(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_int32) for n in
+                ("iteration", "step_is_valid", "step_is_nonmonotonic", "step_is_successful")] + \
+               [(n, ctypes.c_double) for n in
+                ("cost", "cost_change", "gradient_max_norm", "gradient_norm", "step_norm", "relative_decrease",
+                 "trust_region_radius", "eta")] + \
+               [("linear_solver_iterations", ctypes.c_int32), ("reserved", ctypes.c_int32)] + \
+               [(n, ctypes.c_double) for n in ("iteration_ms", "linear_solver_ms", "jacobian_ms", "residual_ms")]
+
+
+class cx_minimizer_summary(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_int32) for n in
+                ("termination_type", "num_successful_steps", "num_unsuccessful_steps", "num_iterations")] + \
+               [(n, ctypes.c_double) for n in ("initial_cost", "final_cost", "total_ms")] + \
+               [("message", ctypes.c_char * 256)]
+
+
+CONVERGENCE, MIN_NO_CONVERGENCE, MIN_FAILURE = 0, 1, 2
+
+
+def minimizer_options(**kw):
+    """Solver::Options defaults (include/ceres/solver.h:250-330, 620-640)."""
+    o = cx_minimizer_options(50, 5, 1, 0, 5, 0, 1e4, 1e16, 1e-32, 1e-3, 1e-6, 1e32, 1e-6, 1e-10, 1e-8, 1e-1)
+    for k, v in kw.items():
+        if not hasattr(o, k):
+            raise AttributeError(k)
+        setattr(o, k, v)
+    return o
+
+
+def _summary_dict(s):
+    return {n: (getattr(s, n).decode() if n == "message" else getattr(s, n)) for n, _ in s._fields_ if n != "reserved"}
 
 
 def library_path():
@@ -490,6 +534,29 @@ class Evaluator:
         _check(self.lib.cx_evaluator_evaluate(self._h, _ptr(state), ctypes.byref(cost), _ptr(res), _ptr(grad),
                                               int(want_jacobian), HOST))
         return cost.value, res, grad
+
+
+def minimize(evaluator, solver, state, options=None, max_summaries=None):
+    """cx_minimize: TrustRegionMinimizer + LevenbergMarquardtStrategy with device-resident state.
+    state: numpy array (updated copy returned) or DeviceArray (updated in place).
+    Returns (state, summary dict, list of iteration summary dicts)."""
+    lib = evaluator.lib
+    if options is None:
+        options = cx_minimizer_options()
+        lib.cx_minimizer_default_options(ctypes.byref(options))
+    cap = int(max_summaries if max_summaries is not None else options.max_num_iterations + 2)
+    its = (cx_iteration_summary * cap)()
+    summ = cx_minimizer_summary()
+    if isinstance(state, DeviceArray):
+        _check(lib.cx_minimize(evaluator._h, solver._h, ctypes.byref(options), _ptr(state), DEVICE,
+                               ctypes.byref(summ), its, cap))
+        out = state
+    else:
+        out = np.array(state, dtype=np.float64).copy()
+        _check(lib.cx_minimize(evaluator._h, solver._h, ctypes.byref(options), _ptr(out), HOST, ctypes.byref(summ),
+                               its, cap))
+    n = min(cap, summ.num_iterations)
+    return out, _summary_dict(summ), [_summary_dict(its[i]) for i in range(n)]
 
 
 def detect_structure(bs, num_eliminate_blocks):

@@ -15,18 +15,6 @@
 #include "cx_internal.h"
 #include "cx_kernels.h"
 
-struct cx_evaluator {
-  cx_context* ctx = nullptr;
-  cx_matrix* J = nullptr;
-  int32_t C = 0, P = 0;
-  int64_t O = 0;
-  std::vector<int64_t> row_of_obs;   // input observation -> row block
-  DevBuf<double> d_obs;              // [2O] in row order
-  DevBuf<double> d_partial, d_state, d_res;
-  float last_ms = 0.f;
-  int32_t loss_type = CX_LOSS_NONE;
-  double loss_a = 0.0, loss_b = 0.0;
-};
 
 namespace {
 

@@ -179,4 +179,18 @@ int cxk_ft_multiply(cx_matrix* A, const double* t, double* y_f, bool accumulate)
 
 int cx_allreduce_device(cx_context* ctx, double* p, int64_t n);
 
+// ---------------------------------------------------------------- evaluator (cx_eval.hip)
+struct cx_evaluator {
+  cx_context* ctx = nullptr;
+  cx_matrix* J = nullptr;
+  int32_t C = 0, P = 0;
+  int64_t O = 0;
+  std::vector<int64_t> row_of_obs;   // input observation -> row block
+  DevBuf<double> d_obs;              // [2O] in row order
+  DevBuf<double> d_partial, d_state, d_res;
+  float last_ms = 0.f;
+  int32_t loss_type = CX_LOSS_NONE;
+  double loss_a = 0.0, loss_b = 0.0;
+};
+
 #endif

@@ -308,6 +308,78 @@ int cx_evaluator_evaluate(cx_evaluator* e, const double* state, double* cost,
 int cx_evaluator_set_loss(cx_evaluator* e, int32_t loss_type, double a, double b);
 double cx_evaluator_last_kernel_ms(const cx_evaluator* e);
 
+/* -------------------------------------------------------------- minimizer */
+
+/* Minimizer::Options for TRUST_REGION + LEVENBERG_MARQUARDT (include/ceres/solver.h:250-330,
+ * 620-640; minimizer.h:60-190); defaults are Solver::Options' defaults. */
+typedef struct {
+  int32_t max_num_iterations;                 /* 50   */
+  int32_t max_num_consecutive_invalid_steps;  /* 5    */
+  int32_t jacobi_scaling;                     /* 1    */
+  int32_t use_nonmonotonic_steps;             /* 0    */
+  int32_t max_consecutive_nonmonotonic_steps; /* 5    */
+  int32_t reserved;
+  double initial_trust_region_radius;         /* 1e4  */
+  double max_trust_region_radius;             /* 1e16 */
+  double min_trust_region_radius;             /* 1e-32 */
+  double min_relative_decrease;               /* 1e-3 */
+  double min_lm_diagonal;                     /* 1e-6 */
+  double max_lm_diagonal;                     /* 1e32 */
+  double function_tolerance;                  /* 1e-6 */
+  double gradient_tolerance;                  /* 1e-10 */
+  double parameter_tolerance;                 /* 1e-8 */
+  double eta;                                 /* 1e-1 */
+} cx_minimizer_options;
+
+/* IterationSummary (include/ceres/iteration_callback.h:45-160); times in ms */
+typedef struct {
+  int32_t iteration;
+  int32_t step_is_valid;
+  int32_t step_is_nonmonotonic;
+  int32_t step_is_successful;
+  double cost;
+  double cost_change;
+  double gradient_max_norm;
+  double gradient_norm;
+  double step_norm;
+  double relative_decrease;
+  double trust_region_radius;
+  double eta;
+  int32_t linear_solver_iterations;
+  int32_t reserved;
+  double iteration_ms;      /* wall time of the iteration                          */
+  double linear_solver_ms;  /* wall time inside LinearSolver::Solve                 */
+  double jacobian_ms;       /* device time of the residual + Jacobian evaluation     */
+  double residual_ms;       /* device time of the candidate-point cost evaluation    */
+} cx_iteration_summary;
+
+/* TerminationType (include/ceres/types.h:401-432) restricted to what the minimizer sets */
+typedef enum { CX_CONVERGENCE = 0, CX_MIN_NO_CONVERGENCE = 1, CX_MIN_FAILURE = 2 } cx_minimizer_termination;
+
+typedef struct {
+  int32_t termination_type;  /* cx_minimizer_termination */
+  int32_t num_successful_steps;
+  int32_t num_unsuccessful_steps;
+  int32_t num_iterations;    /* iteration summaries produced (iteration 0 included) */
+  double initial_cost;
+  double final_cost;         /* cost at the returned state (the minimum-cost iterate) */
+  double total_ms;
+  char message[256];
+} cx_minimizer_summary;
+
+void cx_minimizer_default_options(cx_minimizer_options* options);
+/* TrustRegionMinimizer::Minimize (trust_region_minimizer.cc:68-840) with
+ * LevenbergMarquardtStrategy (levenberg_marquardt_strategy.cc:50-175) and
+ * TrustRegionStepEvaluator (trust_region_step_evaluator.cc:40-117), for the bundle-adjustment
+ * evaluator: state, residuals, gradient, step, LM diagonal, Jacobi scaling and J stay in HBM for
+ * the whole minimisation; per iteration only the handful of scalars the control flow needs
+ * cross to the host.  state ([points | cameras], like cx_evaluator_evaluate) is updated in place
+ * to the minimum-cost iterate.  iterations (may be NULL) receives up to capacity summaries.
+ * On a sharded context state holds this rank's points and all cameras. */
+int cx_minimize(cx_evaluator* e, cx_solver* s, const cx_minimizer_options* options, double* state,
+                int32_t memspace, cx_minimizer_summary* summary, cx_iteration_summary* iterations,
+                int32_t capacity);
+
 /* ------------------------------------------------------ host-side helpers */
 
 /* DetectStructure (detect_structure.cc:39-120); -1 stands for Eigen::Dynamic */

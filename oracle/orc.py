@@ -43,6 +43,64 @@ class cx_summary(ctypes.Structure):
     ]
 
 
+class cx_minimizer_options(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_int32) for n in
+                ("max_num_iterations", "max_num_consecutive_invalid_steps", "jacobi_scaling",
+                 "use_nonmonotonic_steps", "max_consecutive_nonmonotonic_steps", "reserved")] + \
+               [(n, ctypes.c_double) for n in
+                ("initial_trust_region_radius", "max_trust_region_radius", "min_trust_region_radius",
+                 "min_relative_decrease", "min_lm_diagonal", "max_lm_diagonal", "function_tolerance",
+                 "gradient_tolerance", "parameter_tolerance", "eta")]
+
+
+class cx_iteration_summary(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_int32) for n in
+                ("iteration", "step_is_valid", "step_is_nonmonotonic", "step_is_successful")] + \
+               [(n, ctypes.c_double) for n in
+                ("cost", "cost_change", "gradient_max_norm", "gradient_norm", "step_norm", "relative_decrease",
+                 "trust_region_radius", "eta")] + \
+               [("linear_solver_iterations", ctypes.c_int32), ("reserved", ctypes.c_int32)] + \
+               [(n, ctypes.c_double) for n in ("iteration_ms", "linear_solver_ms", "jacobian_ms", "residual_ms")]
+
+
+class cx_minimizer_summary(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_int32) for n in
+                ("termination_type", "num_successful_steps", "num_unsuccessful_steps", "num_iterations")] + \
+               [(n, ctypes.c_double) for n in ("initial_cost", "final_cost", "total_ms")] + \
+               [("message", ctypes.c_char * 256)]
+
+
+CONVERGENCE, MIN_NO_CONVERGENCE, MIN_FAILURE = 0, 1, 2
+
+
+def minimizer_options(**kw):
+    """Solver::Options defaults (include/ceres/solver.h:250-330, 620-640)."""
+    o = cx_minimizer_options(50, 5, 1, 0, 5, 0, 1e4, 1e16, 1e-32, 1e-3, 1e-6, 1e32, 1e-6, 1e-10, 1e-8, 1e-1)
+    for k, v in kw.items():
+        if not hasattr(o, k):
+            raise AttributeError(k)
+        setattr(o, k, v)
+    return o
+
+
+def _summary_dict(s):
+    return {n: (getattr(s, n).decode() if n == "message" else getattr(s, n)) for n, _ in s._fields_ if n != "reserved"}
+
+
+EVALUATE_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, c_double_p, c_double_p, c_double_p, c_double_p,
+                               ctypes.c_int)
+VEC_OUT_FN = ctypes.CFUNCTYPE(None, ctypes.c_void_p, c_double_p)
+VEC_IN_FN = ctypes.CFUNCTYPE(None, ctypes.c_void_p, c_double_p)
+MULT_FN = ctypes.CFUNCTYPE(None, ctypes.c_void_p, c_double_p, c_double_p)
+SOLVE_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, c_double_p, c_double_p, ctypes.c_double, c_double_p,
+                            ctypes.POINTER(ctypes.c_int))
+
+
+class orc_min_problem(ctypes.Structure):
+    _fields_ = [("num_parameters", ctypes.c_int32), ("num_residuals", ctypes.c_int32), ("user", ctypes.c_void_p),
+                ("evaluate", EVALUATE_FN), ("squared_column_norm", VEC_OUT_FN), ("scale_columns", VEC_IN_FN),
+                ("right_multiply", MULT_FN), ("solve", SOLVE_FN)]
+
 DENSE_SCHUR, SPARSE_SCHUR, ITERATIVE_SCHUR, CGNR = 0, 1, 2, 3
 IDENTITY, JACOBI, SCHUR_JACOBI, SCHUR_POWER_SERIES_EXPANSION = 0, 1, 2, 3
 SUCCESS, NO_CONVERGENCE, FAILURE, FATAL_ERROR = 0, 1, 2, 3
@@ -313,3 +371,70 @@ def bal_evaluate(bs, num_cameras, num_points, camera_index, point_index, observa
                            _p(_f64(observations)), _p(np.ascontiguousarray(order, dtype=np.int64)),
                            _p(_f64(state)), ctypes.byref(cost), _p(res), _p(grad), _p(vals))
     return cost.value, res, grad, vals
+
+
+def minimize_dense(fun, x0, options=None):
+    """orc_minimize on a small dense problem: fun(x) -> (residuals[m], jacobian[m, n]).  The linear
+    solver stands in for DenseQRSolver (dense_qr_solver.cc): least squares on [J; diag(D)]."""
+    x0 = np.array(x0, dtype=np.float64).copy()
+    n = x0.size
+    r0, _ = fun(x0)
+    m = int(np.asarray(r0).size)
+    st = {"J": np.zeros((m, n))}
+
+    def evaluate(_u, x, cost, residuals, gradient, want_j):
+        xv = np.ctypeslib.as_array(x, (n,))
+        r, J = fun(xv.copy())
+        r = np.asarray(r, dtype=np.float64)
+        cost[0] = 0.5 * float(r @ r)
+        if residuals:
+            np.ctypeslib.as_array(residuals, (m,))[:] = r
+        if gradient:
+            np.ctypeslib.as_array(gradient, (n,))[:] = np.asarray(J).T @ r
+        if want_j:
+            st["J"] = np.array(J, dtype=np.float64)
+        return 1
+
+    def sqnorm(_u, out):
+        np.ctypeslib.as_array(out, (n,))[:] = (st["J"] ** 2).sum(axis=0)
+
+    def scale(_u, sc):
+        st["J"] = st["J"] * np.ctypeslib.as_array(sc, (n,))[None, :]
+
+    def mult(_u, x, y):
+        np.ctypeslib.as_array(y, (m,))[:] += st["J"] @ np.ctypeslib.as_array(x, (n,))
+
+    def solve(_u, b, D, _q, x, iters):
+        A = np.vstack([st["J"], np.diag(np.ctypeslib.as_array(D, (n,)))])
+        rhs = np.concatenate([np.ctypeslib.as_array(b, (m,)), np.zeros(n)])
+        np.ctypeslib.as_array(x, (n,))[:] = np.linalg.lstsq(A, rhs, rcond=None)[0]
+        iters[0] = 1
+        return SUCCESS
+
+    cbs = (EVALUATE_FN(evaluate), VEC_OUT_FN(sqnorm), VEC_IN_FN(scale), MULT_FN(mult), SOLVE_FN(solve))
+    prob = orc_min_problem(n, m, None, *cbs)
+    options = options or minimizer_options()
+    cap = options.max_num_iterations + 2
+    its = (cx_iteration_summary * cap)()
+    summ = cx_minimizer_summary()
+    lib().orc_minimize(ctypes.byref(prob), ctypes.byref(options), _p(x0), ctypes.byref(summ), its, cap)
+    k = min(cap, summ.num_iterations)
+    return x0, _summary_dict(summ), [_summary_dict(its[i]) for i in range(k)]
+
+
+def minimize_bal(num_cameras, num_points, camera_index, point_index, observations, state, solver_options,
+                 options=None, loss=None):
+    state = np.array(state, dtype=np.float64).copy()
+    options = options or minimizer_options()
+    cap = options.max_num_iterations + 2
+    its = (cx_iteration_summary * cap)()
+    summ = cx_minimizer_summary()
+    ltype, la, lb = loss if loss is not None else (0, 0.0, 0.0)
+    O = int(np.asarray(camera_index).shape[0])
+    lib().orc_minimize_bal(int(num_cameras), int(num_points), ctypes.c_int64(O),
+                           _p(np.ascontiguousarray(camera_index, dtype=np.int32)),
+                           _p(np.ascontiguousarray(point_index, dtype=np.int32)), _p(_f64(observations)),
+                           int(ltype), ctypes.c_double(la), ctypes.c_double(lb), ctypes.byref(solver_options),
+                           ctypes.byref(options), _p(state), ctypes.byref(summ), its, cap)
+    k = min(cap, summ.num_iterations)
+    return state, _summary_dict(summ), [_summary_dict(its[i]) for i in range(k)]

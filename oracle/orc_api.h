@@ -116,6 +116,35 @@ void orc_bal_evaluate_robust(const cx_block_structure* bs, int num_cameras, int 
                              int loss_type, double loss_a, double loss_b, double* cost,
                              double* residuals, double* gradient, double* values);
 
+/* ---- trust region minimizer ---- */
+/* The Evaluator / SparseMatrix / LinearSolver operations TrustRegionMinimizer and
+ * LevenbergMarquardtStrategy call, as callbacks so that tests can drive the loop with the
+ * reference's own test problem (PowellEvaluator2, trust_region_minimizer_test.cc:63-213). */
+typedef struct {
+  int32_t num_parameters;
+  int32_t num_residuals;
+  void* user;
+  /* Evaluator::Evaluate: returns nonzero on success; residuals/gradient may be NULL;
+   * want_jacobian != 0 refreshes the Jacobian the other callbacks act on */
+  int (*evaluate)(void* user, const double* x, double* cost, double* residuals, double* gradient,
+                  int want_jacobian);
+  void (*squared_column_norm)(void* user, double* out);
+  void (*scale_columns)(void* user, const double* scale);
+  void (*right_multiply)(void* user, const double* x, double* y); /* y += J x */
+  /* LinearSolver::Solve: min |J x - b|^2 + |D x|^2; returns cx_termination */
+  int (*solve)(void* user, const double* b, const double* D, double q_tolerance, double* x,
+               int* num_iterations);
+} orc_min_problem;
+int orc_minimize(const orc_min_problem* problem, const cx_minimizer_options* options,
+                 double* parameters, cx_minimizer_summary* summary,
+                 cx_iteration_summary* iterations, int capacity);
+/* the same loop on the BAL program with orc_bal_evaluate_robust and orc_solve */
+int orc_minimize_bal(int num_cameras, int num_points, int64_t num_obs, const int32_t* camera_index,
+                     const int32_t* point_index, const double* observations, int loss_type,
+                     double loss_a, double loss_b, const cx_solver_options* solver_options,
+                     const cx_minimizer_options* options, double* state,
+                     cx_minimizer_summary* summary, cx_iteration_summary* iterations, int capacity);
+
 #ifdef __cplusplus
 }
 #endif

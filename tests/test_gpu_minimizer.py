@@ -1,0 +1,93 @@
+"""cx_minimize (device-resident TrustRegionMinimizer + LevenbergMarquardtStrategy) against the
+oracle's restatement of trust_region_minimizer.cc on the same bundle-adjustment inputs."""
+import numpy as np
+import pytest
+
+from conftest import cx
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    c = cx.Context(0)
+    yield c
+    c.close()
+
+
+def relerr(a, b):
+    return float(np.max(np.abs(np.asarray(a) - np.asarray(b))) / max(1e-300, float(np.max(np.abs(b)))))
+
+
+CASES = [
+    ("ITERATIVE_SCHUR", "JACOBI", None),
+    ("ITERATIVE_SCHUR", "SCHUR_JACOBI", None),
+    ("DENSE_SCHUR", "IDENTITY", None),
+    ("CGNR", "JACOBI", None),
+    ("DENSE_SCHUR", "IDENTITY", (cx.binding.LOSS_HUBER, 1.0, 0.0)),
+    ("ITERATIVE_SCHUR", "JACOBI", (cx.binding.LOSS_CAUCHY, 2.0, 0.0)),
+]
+
+
+@pytest.mark.parametrize("stype,ptype,loss", CASES)
+def test_minimize_matches_oracle(ctx, oracle, stype, ptype, loss):
+    C, P, O = 12, 300, 2400
+    prob = cx.bal.make_bal_like(C, P, O, 3)
+    nelim = 0 if stype == "CGNR" else P
+    max_lin = 500 if stype != "CGNR" else 2000
+    mo = cx.binding.minimizer_options(max_num_iterations=8)
+    ev = cx.Evaluator(ctx, prob)
+    if loss:
+        ev.set_loss(*loss)
+    solver = cx.Solver(ctx, type=getattr(cx.binding, stype), preconditioner_type=getattr(cx.binding, ptype),
+                       num_eliminate_blocks=nelim, max_num_iterations=max_lin)
+    x, summ, its = cx.binding.minimize(ev, solver, prob.state(), mo)
+    so = oracle.make_options(type=getattr(oracle, stype), preconditioner_type=getattr(oracle, ptype),
+                             num_eliminate_blocks=nelim, max_num_iterations=max_lin)
+    omo = oracle.minimizer_options(max_num_iterations=8)
+    x_r, summ_r, its_r = oracle.minimize_bal(C, P, prob.camera_index, prob.point_index, prob.observations, prob.state(),
+                                             so, omo, loss=loss)
+    assert summ["termination_type"] == summ_r["termination_type"], (summ, summ_r)
+    assert len(its) == len(its_r)
+    assert summ["num_successful_steps"] == summ_r["num_successful_steps"]
+    assert summ["num_unsuccessful_steps"] == summ_r["num_unsuccessful_steps"]
+    # fp64 tolerance: an inexact (CG) step differs between device and host at the CG tolerance, so the
+    # iterates agree to ~1e-6 relative while the flags / iteration counts (integers) agree exactly
+    tol = 1e-9 if stype == "DENSE_SCHUR" else 1e-5
+    for a, b in zip(its, its_r):
+        assert a["iteration"] == b["iteration"]
+        assert a["step_is_valid"] == b["step_is_valid"] and a["step_is_successful"] == b["step_is_successful"]
+        assert abs(a["cost"] - b["cost"]) <= tol * abs(b["cost"])
+        assert abs(a["trust_region_radius"] - b["trust_region_radius"]) <= 1e-4 * b["trust_region_radius"]
+        assert abs(a["gradient_max_norm"] - b["gradient_max_norm"]) <= 1e-3 * its_r[0]["gradient_max_norm"]
+        if stype == "DENSE_SCHUR":
+            assert abs(a["step_norm"] - b["step_norm"]) <= 1e-7 * max(1.0, b["step_norm"])
+            assert abs(a["relative_decrease"] - b["relative_decrease"]) <= 1e-6
+    assert abs(summ["final_cost"] - summ_r["final_cost"]) <= tol * summ_r["final_cost"]
+    assert summ["final_cost"] < 0.05 * summ["initial_cost"]
+    assert relerr(x, x_r) < (1e-8 if stype == "DENSE_SCHUR" else 1e-4)
+    # the returned state is the minimum-cost iterate
+    cost_at_x = ev.evaluate(x, want_gradient=False, want_jacobian=False)[0]
+    assert abs(cost_at_x - summ["final_cost"]) <= 1e-12 * summ["final_cost"]
+    solver.close()
+    ev.close()
+
+
+def test_minimize_device_state_and_limits(ctx, oracle):
+    """DEVICE memspace updates the caller's array in place; max_num_iterations = 0 evaluates only."""
+    C, P, O = 8, 120, 900
+    prob = cx.bal.make_bal_like(C, P, O, 11)
+    ev = cx.Evaluator(ctx, prob)
+    solver = cx.Solver(ctx, type=cx.binding.DENSE_SCHUR, num_eliminate_blocks=P)
+    d_state = ctx.to_device(prob.state())
+    _, summ0, its0 = cx.binding.minimize(ev, solver, d_state, cx.binding.minimizer_options(max_num_iterations=0))
+    assert summ0["termination_type"] == cx.binding.MIN_NO_CONVERGENCE and len(its0) == 1
+    assert np.array_equal(d_state.to_host(), prob.state())
+    _, summ, its = cx.binding.minimize(ev, solver, d_state, cx.binding.minimizer_options(max_num_iterations=20))
+    assert summ["termination_type"] == cx.binding.CONVERGENCE
+    x_host, summ_h, _ = cx.binding.minimize(ev, solver, prob.state(), cx.binding.minimizer_options(max_num_iterations=20))
+    # same result through either memspace (S is accumulated with fp64 atomics, so not bitwise)
+    assert relerr(d_state.to_host(), x_host) < 1e-9
+    assert abs(summ["final_cost"] - summ_h["final_cost"]) <= 1e-12 * summ_h["final_cost"]
+    solver.close()
+    ev.close()
