@@ -7,6 +7,7 @@ parameters (angle-axis, translation, focal, k1, k2 -- the camera model of
 examples/snavely_reprojection_error.h:53-104), P points, O observations listed
 point-major like BAL files (examples/bal_problem.cc:73-130).
 """
+import dataclasses
 from dataclasses import dataclass
 
 import numpy as np
@@ -214,3 +215,88 @@ def shard(problem, lo, hi):
     return BalProblem(problem.num_cameras, hi - lo, problem.camera_index[sel],
                       (problem.point_index[sel] - lo).astype(np.int32), problem.observations[sel],
                       problem.cameras, problem.points[lo:hi])
+
+
+# ----------------------------------------------------------------------------------------------
+# BAL text files (examples/bal_problem.cc:73-130 reader, :137-176 writer), Normalize (:249-292)
+# and Perturb (:294-333).  Host-side I/O only; nothing here touches the device.
+# ----------------------------------------------------------------------------------------------
+def read_bal(path):
+    """BALProblem::BALProblem: '<C> <P> <O>', O lines 'cam pt x y', then 9C camera and 3P point
+    parameters, one per line.  Every token is whitespace separated, as fscanf reads it."""
+    with open(path, "r") as f:
+        header = []
+        while len(header) < 3:
+            header += f.readline().split()
+        C, P, O = (int(v) for v in header[:3])
+        rest = header[3:]
+        data = np.fromfile(f, dtype=np.float64, sep=" ")
+    if rest:
+        data = np.concatenate([np.array([float(v) for v in rest]), data])
+    need = 4 * O + 9 * C + 3 * P
+    if data.size < need:
+        raise ValueError("%s: expected %d numbers after the header, found %d" % (path, need, data.size))
+    obs = data[:4 * O].reshape(O, 4)
+    cam_idx = obs[:, 0].astype(np.int32)
+    pt_idx = obs[:, 1].astype(np.int32)
+    if O and (cam_idx.min() < 0 or cam_idx.max() >= C or pt_idx.min() < 0 or pt_idx.max() >= P):
+        raise ValueError("%s: observation index out of range" % path)
+    cams = data[4 * O:4 * O + 9 * C].reshape(C, 9).copy()
+    pts = data[4 * O + 9 * C:need].reshape(P, 3).copy()
+    return BalProblem(C, P, cam_idx, pt_idx, np.ascontiguousarray(obs[:, 2:4]), cams, pts)
+
+
+def write_bal(path, prob):
+    """BALProblem::WriteToFile: observations with %g, parameters with %.16g."""
+    with open(path, "w") as f:
+        f.write("%d %d %d\n" % (prob.num_cameras, prob.num_points, prob.num_observations))
+        for c, q, (x, y) in zip(prob.camera_index, prob.point_index, prob.observations):
+            f.write("%d %d %g %g\n" % (c, q, x, y))
+        for v in prob.cameras.ravel():
+            f.write("%.16g\n" % v)
+        for v in prob.points.ravel():
+            f.write("%.16g\n" % v)
+
+
+def _median_nth(values):
+    """Median() of bal_problem.cc:66-70: the element at index size/2 after nth_element."""
+    v = np.asarray(values)
+    k = v.size // 2
+    return float(np.partition(v, k)[k])
+
+
+def camera_centers(cameras):
+    """CameraToAngleAxisAndCenter: c = -R' t."""
+    return -_rodrigues(-cameras[:, 0:3], cameras[:, 3:6])
+
+
+def normalize(prob):
+    """BALProblem::Normalize: marginal median to the origin, median absolute deviation (l1) to 100."""
+    pts = prob.points
+    median = np.array([_median_nth(pts[:, i]) for i in range(3)])
+    mad = _median_nth(np.abs(pts - median).sum(axis=1))
+    scale = 100.0 / mad
+    new_pts = scale * (pts - median)
+    cams = prob.cameras.copy()
+    center = scale * (camera_centers(cams) - median)
+    cams[:, 3:6] = -_rodrigues(cams[:, 0:3], center)  # t = -R c
+    return dataclasses.replace(prob, cameras=cams, points=new_pts)
+
+
+def perturb(prob, rotation_sigma, translation_sigma, point_sigma, seed=0):
+    """BALProblem::Perturb.  The reference draws from a default-seeded std::mt19937 through
+    std::normal_distribution, whose stream numpy cannot reproduce: same distributions, other
+    draws.  (As in the reference, the rotation noise uses point_sigma, bal_problem.cc:310-311.)"""
+    assert rotation_sigma >= 0 and translation_sigma >= 0 and point_sigma >= 0
+    rng = np.random.default_rng(seed)
+    pts = prob.points.copy()
+    if point_sigma > 0:
+        pts += rng.normal(0.0, point_sigma, pts.shape)
+    cams = prob.cameras.copy()
+    center = camera_centers(cams)
+    if rotation_sigma > 0:
+        cams[:, 0:3] += rng.normal(0.0, point_sigma, (prob.num_cameras, 3))
+    cams[:, 3:6] = -_rodrigues(cams[:, 0:3], center)
+    if translation_sigma > 0:
+        cams[:, 3:6] += rng.normal(0.0, translation_sigma, (prob.num_cameras, 3))
+    return dataclasses.replace(prob, cameras=cams, points=pts)

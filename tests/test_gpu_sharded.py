@@ -72,6 +72,23 @@ def _worker(rank, port, results_dir):
         out.append((stype + "+" + pre, s.termination_type == s_full.termination_type and
                     s.num_iterations == s_full.num_iterations and err < 1e-8, err, s.num_iterations, s_full.num_iterations))
         S.close()
+    # sharded trust-region loop: every rank must walk the same iterations as the unsharded oracle loop
+    mo = cx.binding.minimizer_options(max_num_iterations=6)
+    S = cx.Solver(ctx, type=cx.ITERATIVE_SCHUR, preconditioner_type=cx.JACOBI, num_eliminate_blocks=sub.num_points)
+    x_min, summ, its = cx.binding.minimize(ev, S, sub.state(), mo)
+    so = orc.make_options(type=orc.ITERATIVE_SCHUR, preconditioner_type=orc.JACOBI, num_eliminate_blocks=P)
+    x_ref, summ_r, its_r = orc.minimize_bal(C, P, full.camera_index, full.point_index, full.observations, full.state(),
+                                            so, orc.minimizer_options(max_num_iterations=6))
+    expect = np.concatenate([x_ref[3 * lo:3 * hi], x_ref[3 * P:]])
+    same_path = len(its) == len(its_r) and all(
+        a["step_is_successful"] == b["step_is_successful"] and abs(a["cost"] - b["cost"]) <= 1e-5 * b["cost"] and
+        abs(a["gradient_max_norm"] - b["gradient_max_norm"]) <= 1e-3 * its_r[0]["gradient_max_norm"] and
+        abs(a["step_norm"] - b["step_norm"]) <= 1e-4 * max(1.0, b["step_norm"])
+        for a, b in zip(its, its_r))
+    err = float(np.abs(x_min - expect).max() / np.abs(expect).max())
+    out.append(("minimize", same_path and summ["termination_type"] == summ_r["termination_type"] and err < 1e-4, err,
+                len(its), len(its_r)))
+    S.close()
     with open(os.path.join(results_dir, "rank%d.txt" % rank), "w") as f:
         for o in out:
             f.write(repr(o) + "\n")
@@ -87,7 +104,7 @@ def test_two_ranks_one_gpu(tmp_path, oracle):
     mp.spawn(_worker, args=(port, str(tmp_path)), nprocs=WORLD, join=True)
     for rank in range(WORLD):
         lines = open(tmp_path / ("rank%d.txt" % rank)).read().strip().splitlines()
-        assert len(lines) == 7
+        assert len(lines) == 8
         for line in lines:
             rec = eval(line)
             assert rec[1], line
