@@ -50,7 +50,7 @@ HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec
 HBM_COPY_GBPS = 6290.0          # measured float4 copy
 MIN_LM_DIAGONAL, MAX_LM_DIAGONAL = 1e-6, 1e32   # solver.h:294-295
 INITIAL_RADIUS = 1e4            # solver.h initial_trust_region_radius
-ETA = 0.1                       # solver.h eta -> q_tolerance
+ETA = 0.1                       # overwritten from --eta in main()
 
 
 def lm_prepare_device(cx, ctx, prob):
@@ -129,9 +129,14 @@ def main():
                     help="linear solver of the step (the headline metric uses iterative_schur)")
     ap.add_argument("--preconditioner", default="jacobi", choices=["jacobi", "schur_jacobi", "identity"])
     ap.add_argument("--mixed", action="store_true", help="CGNR with fp32-stored J values (BASELINE config 5)")
+    ap.add_argument("--eta", type=float, default=0.1,
+                    help="q_tolerance of the inexact step: Solver::Options::eta default 0.1 (solver.h:628); "
+                         "bundle_adjuster's flag default is 1e-2 (bundle_adjuster.cc:114)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=0)
     args = ap.parse_args()
+    global ETA
+    ETA = args.eta
 
     import torch  # first, so that libcxschur shares torch's HIP runtime instance
     import torch.distributed as dist
@@ -261,9 +266,9 @@ def main():
             "metric": "linear_solve_ms_per_iter", "value": ms_per_step, "unit": "ms",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
             "higher_is_better": False, "scaling": "strong", "vs_baseline": None, "dtype": "f64 (J values stored fp32)" if args.mixed else "f64", "data": "synthetic",
-            "config": {"workload": "%s: %s + %s, q_tol=0.1, synthetic BAL-shaped J "
+            "config": {"workload": "%s: %s + %s, q_tol=%g, synthetic BAL-shaped J "
                                    "(%d cameras, %d points, %d residual blocks)" % (args.workload, args.solver.upper(),
-                                                                                   args.preconditioner.upper(), C, P, O),
+                                                                                   args.preconditioner.upper(), ETA, C, P, O),
                        "cameras": C, "points": P, "residual_blocks": O, "cg_iterations": int(summ.num_iterations),
                        "termination": int(summ.termination_type), "initial_cost": cost,
                        "sharding": "points over %d rank(s), RCCL all-reduce of camera-space sums" % world},

@@ -176,6 +176,8 @@ int cxk_scale_columns(cx_matrix* A, const double* scale);
 
 // y_f (+)= F' t  for the static path; t is row-sized
 int cxk_ft_multiply(cx_matrix* A, const double* t, double* y_f, bool accumulate);
+// first half of it: the per-segment partial sums only (A->d_partials, 9 per segment)
+int cxk_ft_partials(cx_matrix* A, const double* t);
 
 int cx_allreduce_device(cx_context* ctx, double* p, int64_t n);
 

@@ -525,11 +525,12 @@ int cx_matrix_ensure_f32(cx_matrix* A) {
 }
 
 // ------------------------------------------------------------ product drivers
-int cxk_ft_multiply(cx_matrix* A, const double* t, double* yf, bool accumulate) {
+// per-segment partial sums of F' t into A->d_partials (9 per segment); cxk_ft_multiply or a fused
+// consumer (cx_solver.hip: k_cam_reduce9_dot) adds them up per camera in segment order
+int cxk_ft_partials(cx_matrix* A, const double* t) {
   CX_TRY(cx_matrix_ensure_ft(A));
   hipStream_t st = A->ctx->stream;
-  if (A->num_segs > 0)
-  {
+  if (A->num_segs > 0) {
     if (A->use_f32)
       hipLaunchKernelGGL(k_cam_ft<float>, dim3(xcd_grid(A->num_segs)), dim3(kBlock), 0, st, (const float*)A->d_Ft32.p,
                          A->d_cam_rows.p, A->d_seg_begin.p, t, A->d_partials.p, A->stop, A->num_segs);
@@ -537,7 +538,13 @@ int cxk_ft_multiply(cx_matrix* A, const double* t, double* yf, bool accumulate) 
       hipLaunchKernelGGL(k_cam_ft<double>, dim3(xcd_grid(A->num_segs)), dim3(kBlock), 0, st, (const double*)A->d_Ft.p,
                          A->d_cam_rows.p, A->d_seg_begin.p, t, A->d_partials.p, A->stop, A->num_segs);
   }
-  hipLaunchKernelGGL(k_cam_reduce9, dim3(grid_for(int64_t(A->C) * 9, 256)), dim3(256), 0, st,
+  CX_HIP(hipGetLastError());
+  return CX_OK;
+}
+
+int cxk_ft_multiply(cx_matrix* A, const double* t, double* yf, bool accumulate) {
+  CX_TRY(cxk_ft_partials(A, t));
+  hipLaunchKernelGGL(k_cam_reduce9, dim3(grid_for(int64_t(A->C) * 9, 256)), dim3(256), 0, A->ctx->stream,
                      A->d_partials.p, A->d_cam_seg_start.p, yf, A->C, accumulate ? 1 : 0,
                      (const double*)nullptr, (const double*)nullptr, A->stop);
   CX_HIP(hipGetLastError());

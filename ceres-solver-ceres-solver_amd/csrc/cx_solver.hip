@@ -48,18 +48,9 @@ enum FinOp : int { FIN_STORE = 0, FIN_RHO = 1, FIN_PQ = 2, FIN_Q = 3 };
 // this launch's sums (sharded CGNR: replicated camera part counted once).
 // ring: host-pinned slots the state is published to after FIN_Q, so that the host can follow
 // the iteration without synchronising the stream.
-__global__ __launch_bounds__(256) void k_dot2_final(const double* __restrict__ partial, int nblocks, int op, int iter,
-                                                    int add_prev, CgState* __restrict__ st,
-                                                    CgState* __restrict__ ring, int ring_slots) {
-  __shared__ double red[2 * 4];
-  if (op != FIN_STORE && st->flag) return;
-  double s[2] = {0.0, 0.0};
-  for (int i = threadIdx.x; i < nblocks; i += 256) {
-    s[0] += partial[i];
-    s[1] += partial[kRedBlocks + i];
-  }
-  block_sum<2>(s, red);
-  if (threadIdx.x != 0) return;
+__device__ __forceinline__ void cg_scalar_step(double s0, double s1, int op, int iter, int add_prev, CgState* __restrict__ st,
+                                               CgState* __restrict__ ring, int ring_slots) {
+  double s[2] = {s0, s1};
   if (add_prev) { s[0] += st->s0; s[1] += st->s1; }
   st->s0 = s[0];
   st->s1 = s[1];
@@ -103,6 +94,160 @@ __global__ __launch_bounds__(256) void k_dot2_final(const double* __restrict__ p
       __hip_atomic_store(&slot->seq, iter, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
   }
+}
+
+__global__ __launch_bounds__(256) void k_dot2_final(const double* __restrict__ partial, int nblocks, int op, int iter,
+                                                    int add_prev, CgState* __restrict__ st,
+                                                    CgState* __restrict__ ring, int ring_slots) {
+  __shared__ double red[2 * 4];
+  if (op != FIN_STORE && st->flag) return;
+  double s[2] = {0.0, 0.0};
+  for (int i = threadIdx.x; i < nblocks; i += 256) {
+    s[0] += partial[i];
+    s[1] += partial[kRedBlocks + i];
+  }
+  block_sum<2>(s, red);
+  if (threadIdx.x != 0) return;
+  cg_scalar_step(s[0], s[1], op, iter, add_prev, st, ring, ring_slots);
+}
+
+// ---------------------------------------------------------------- fused reductions
+// One-kernel form of partial + final: every workgroup stores its two sums, takes a ticket, and
+// the workgroup that draws the last ticket adds the partials up in index order (so the result
+// does not depend on which workgroup that is) and performs the scalar step.  Stores, ticket and
+// loads are agent-scope atomics, which keeps them coherent across the XCDs' L2s.
+__device__ __forceinline__ void dot2_finish(double a0, double a1, const DotTail& t, double* red) {
+  __shared__ int is_last;
+  double s[2] = {a0, a1};
+  block_sum<2>(s, red);
+  if (threadIdx.x == 0) {
+    __hip_atomic_store(&t.partial[blockIdx.x], s[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(&t.partial[kRedBlocks + blockIdx.x], s[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned ticket = __hip_atomic_fetch_add(t.ticket, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+    is_last = (ticket == gridDim.x - 1) ? 1 : 0;
+  }
+  __syncthreads();
+  if (!is_last) return;
+  double v[2] = {0.0, 0.0};
+  for (int i = threadIdx.x; i < int(gridDim.x); i += 256) {
+    v[0] += __hip_atomic_load(&t.partial[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    v[1] += __hip_atomic_load(&t.partial[kRedBlocks + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  block_sum<2>(v, red);
+  if (threadIdx.x != 0) return;
+  __hip_atomic_store(t.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  cg_scalar_step(v[0], v[1], t.op, t.iter, 0, t.st, t.ring, t.ring_slots);
+}
+
+// s0 = a.b, s1 = c.d (second pair optional)
+__global__ __launch_bounds__(256) void k_dot2_fused(const double* __restrict__ a, const double* __restrict__ b,
+                                                    const double* __restrict__ c, const double* __restrict__ d, int64_t n,
+                                                    DotTail t) {
+  __shared__ double red[8];
+  if (t.op != FIN_STORE && t.st->flag) return;
+  double s0 = 0.0, s1 = 0.0;
+  for (int64_t i = int64_t(blockIdx.x) * 256 + threadIdx.x; i < n; i += int64_t(gridDim.x) * 256) {
+    s0 += a[i] * b[i];
+    if (c) s1 += c[i] * d[i];
+  }
+  dot2_finish(s0, s1, t, red);
+}
+
+// z = blockdiag(M) r for 9x9 blocks and s0 = r.z  (preconditioner + rho)
+__global__ __launch_bounds__(256) void k_blockdiag9_dot(const double* __restrict__ blocks, const double* __restrict__ r,
+                                                        double* __restrict__ z, int64_t n, DotTail t) {
+  __shared__ double red[8];
+  if (t.st->flag) return;
+  double s0 = 0.0;
+  for (int64_t i = int64_t(blockIdx.x) * 256 + threadIdx.x; i < n; i += int64_t(gridDim.x) * 256) {
+    const int64_t blk = i / 9;
+    const int row = int(i - blk * 9);
+    const double* m = blocks + blk * 81 + row * 9;
+    const double* rv = r + blk * 9;
+    double s = 0.0;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) s += m[k] * rv[k];
+    z[i] = s;
+    s0 += rv[row] * s;
+  }
+  dot2_finish(s0, 0.0, t, red);
+}
+
+// y[9c+k] = sum of camera c's segment partials (segment order) + d^2 x ; s0 = x.y
+// (second half of F't, the LM diagonal and p.q of the implicit Schur product in one launch)
+__global__ __launch_bounds__(256) void k_cam_reduce9_dot(const double* __restrict__ partial9,
+                                                         const int32_t* __restrict__ cam_seg_start, double* __restrict__ y,
+                                                         int64_t n, const double* __restrict__ d, const double* __restrict__ x,
+                                                         DotTail t) {
+  __shared__ double red[8];
+  if (t.st->flag) return;
+  double s0 = 0.0;
+  for (int64_t i = int64_t(blockIdx.x) * 256 + threadIdx.x; i < n; i += int64_t(gridDim.x) * 256) {
+    const int c = int(i / 9), k = int(i - int64_t(c) * 9);
+    double s = 0.0;
+    for (int sg = cam_seg_start[c]; sg < cam_seg_start[c + 1]; ++sg) s += partial9[int64_t(sg) * 9 + k];
+    const double xv = x[i];
+    if (d) s += d[i] * d[i] * xv;
+    y[i] = s;
+    s0 += xv * s;
+  }
+  dot2_finish(s0, 0.0, t, red);
+}
+
+// y += d^2 x (d optional) ; s0 = x.y   (after the all-reduce of a sharded product)
+__global__ __launch_bounds__(256) void k_d2x_dot(double* __restrict__ y, const double* __restrict__ d, const double* __restrict__ x,
+                                                 int64_t n, DotTail t) {
+  __shared__ double red[8];
+  if (t.st->flag) return;
+  double s0 = 0.0;
+  for (int64_t i = int64_t(blockIdx.x) * 256 + threadIdx.x; i < n; i += int64_t(gridDim.x) * 256) {
+    const double xv = x[i];
+    double yv = y[i];
+    if (d) {
+      yv += d[i] * d[i] * xv;
+      y[i] = yv;
+    }
+    s0 += xv * yv;
+  }
+  dot2_finish(s0, 0.0, t, red);
+}
+
+// x += alpha p ; r -= alpha q ; tmp = rhs + r ; s0 = x.tmp, s1 = r.r
+__global__ __launch_bounds__(256) void k_update_xr_dot(double* __restrict__ x, double* __restrict__ r, const double* __restrict__ p,
+                                                       const double* __restrict__ q, const double* __restrict__ rhs,
+                                                       double* __restrict__ tmp, int64_t n, DotTail t) {
+  __shared__ double red[8];
+  if (t.st->flag) return;
+  const double alpha = t.st->alpha;
+  double s0 = 0.0, s1 = 0.0;
+  for (int64_t i = int64_t(blockIdx.x) * 256 + threadIdx.x; i < n; i += int64_t(gridDim.x) * 256) {
+    const double xv = x[i] + alpha * p[i];
+    const double rv = r[i] - alpha * q[i];
+    const double tv = rhs[i] + rv;
+    x[i] = xv;
+    r[i] = rv;
+    tmp[i] = tv;
+    s0 += xv * tv;
+    s1 += rv * rv;
+  }
+  dot2_finish(s0, s1, t, red);
+}
+
+// r = rhs - ax ; tmp = rhs + r ; s0 = x.tmp, s1 = r.r   (ax and tmp may alias)
+__global__ __launch_bounds__(256) void k_residual_dot(const double* __restrict__ rhs, const double* ax, double* __restrict__ r,
+                                                      double* tmp, const double* __restrict__ x, int64_t n, DotTail t) {
+  __shared__ double red[8];
+  if (t.st->flag) return;
+  double s0 = 0.0, s1 = 0.0;
+  for (int64_t i = int64_t(blockIdx.x) * 256 + threadIdx.x; i < n; i += int64_t(gridDim.x) * 256) {
+    const double rv = rhs[i] - ax[i];
+    const double tv = rhs[i] + rv;
+    r[i] = rv;
+    tmp[i] = tv;
+    s0 += x[i] * tv;
+    s1 += rv * rv;
+  }
+  dot2_finish(s0, s1, t, red);
 }
 
 // p = z (first iteration) or z + beta p
@@ -207,9 +352,19 @@ struct CgDriver {
   int64_t shared0;
   static constexpr int kRingSlots = 16;
 
+  // vectors replicated on every rank (or a single rank): dot products need no exchange
+  bool fused() const { return !(ctx->nranks > 1 && shared0 < n); }
+  DotTail tail(int op, int iter, CgState* ds) const { return DotTail{S->partial.p, S->ticket.p, ds, S->ring_d, kRingSlots, op, iter}; }
+  int vec_grid() const { return int(std::min<int64_t>(kRedBlocks, std::max<int64_t>(1, (n + 255) / 256))); }
+
   int dot2(const double* a, const double* b, const double* c, const double* d, int op, int iter, CgState* dst) {
     const int nb = int(std::min<int64_t>(kRedBlocks, std::max<int64_t>(1, (n + 1023) / 1024)));
     CgState* ring = S->ring_d;
+    if (fused()) {
+      hipLaunchKernelGGL(k_dot2_fused, dim3(nb), dim3(256), 0, st, a, b, c, d, n, tail(op, iter, dst));
+      CX_HIP(hipGetLastError());
+      return CX_OK;
+    }
     if (ctx->nranks > 1 && shared0 < n) {
       // rank-local part: sum, all-reduce the two scalars on the device; replicated part added once
       hipLaunchKernelGGL(k_dot2_partial, dim3(nb), dim3(256), 0, st, a, b, c, d, shared0, S->partial.p, (const CgState*)dst);
@@ -236,8 +391,12 @@ struct CgDriver {
   // CG iteration `iter` (conjugate_gradients_solver.h:162-301) in two parts.  The head (z = M^-1 r,
   // rho, beta, p) is cheap and is enqueued speculatively; the tail holds the operator application.
   int enqueue_head(int iter, LinOp& pre, double* p, double* r, double* z, CgState* ds) {
-    CX_TRY(pre.apply(r, z));
-    CX_TRY(dot2(r, z, nullptr, nullptr, FIN_RHO, iter, ds));
+    bool done = false;
+    if (fused()) CX_TRY(pre.apply_dot(r, z, tail(FIN_RHO, iter, ds), &done));
+    if (!done) {
+      CX_TRY(pre.apply(r, z));
+      CX_TRY(dot2(r, z, nullptr, nullptr, FIN_RHO, iter, ds));
+    }
     hipLaunchKernelGGL(k_update_p, dim3(grid_for(n, 256)), dim3(256), 0, st, p, (const double*)z, n, iter, (const CgState*)ds);
     CX_HIP(hipGetLastError());
     return CX_OK;
@@ -247,9 +406,27 @@ struct CgDriver {
     const cx_solver_options& o = S->opt;
     const int g = grid_for(n, 256);
     double* q = z;  // q aliases z, as in the reference
-    CX_TRY(lhs.apply(p, q));
-    CX_TRY(dot2(p, q, nullptr, nullptr, FIN_PQ, iter, ds));
+    bool done = false;
+    if (fused()) CX_TRY(lhs.apply_dot(p, q, tail(FIN_PQ, iter, ds), &done));
+    if (!done) {
+      CX_TRY(lhs.apply(p, q));
+      CX_TRY(dot2(p, q, nullptr, nullptr, FIN_PQ, iter, ds));
+    }
     const bool reset = (iter % o.residual_reset_period) == 0;
+    if (fused()) {
+      if (!reset) {
+        hipLaunchKernelGGL(k_update_xr_dot, dim3(vec_grid()), dim3(256), 0, st, x, r, (const double*)p, (const double*)q, rhs, tmp,
+                           n, tail(FIN_Q, iter, ds));
+      } else {
+        hipLaunchKernelGGL(k_update_xr, dim3(g), dim3(256), 0, st, x, r, (const double*)p, (const double*)q, rhs, tmp, n, 0,
+                           (const CgState*)ds);
+        CX_TRY(lhs.apply(x, tmp));
+        hipLaunchKernelGGL(k_residual_dot, dim3(vec_grid()), dim3(256), 0, st, rhs, (const double*)tmp, r, tmp, (const double*)x, n,
+                           tail(FIN_Q, iter, ds));
+      }
+      CX_HIP(hipGetLastError());
+      return CX_OK;
+    }
     hipLaunchKernelGGL(k_update_xr, dim3(g), dim3(256), 0, st, x, r, (const double*)p, (const double*)q, rhs, tmp, n,
                        reset ? 0 : 1, (const CgState*)ds);
     if (reset) {
@@ -295,6 +472,10 @@ struct CgDriver {
     CX_TRY(S->v_tmp.alloc(n));
     CX_TRY(S->partial.alloc(2 * kRedBlocks));
     CX_TRY(S->state.alloc(1));
+    if (!S->ticket.p) {
+      CX_TRY(S->ticket.alloc(1));
+      CX_HIP(hipMemsetAsync(S->ticket.p, 0, sizeof(unsigned), st));
+    }
     if (!S->ring_h) {
       CX_HIP(hipHostMalloc(reinterpret_cast<void**>(&S->ring_h), (kRingSlots + 1) * sizeof(CgState),
                            hipHostMallocMapped | hipHostMallocCoherent));
@@ -428,6 +609,31 @@ struct ImplicitSchurOp : LinOp {
     CX_HIP(hipGetLastError());
     return CX_OK;
   }
+  // the same product with the LM diagonal and x.y folded into the camera reduction
+  int apply_dot(const double* x, double* y, const DotTail& tail, bool* done) override {
+    cx_context* ctx = A->ctx;
+    const int64_t n = size();
+    const int grid = int(std::min<int64_t>(kRedBlocks, std::max<int64_t>(1, (n + 255) / 256)));
+    const double* d = D ? D + 3 * int64_t(A->P) : nullptr;
+    CX_TRY(S->ktimer.begin(0, ctx->stream));
+    CX_TRY(cxs_chunk_pass(A, 0, S->ete_inv.p, x, nullptr, S->v_rows.p));
+    CX_TRY(S->ktimer.end(0, ctx->stream));
+    CX_TRY(S->ktimer.begin(1, ctx->stream));
+    if (ctx->nranks <= 1) {
+      CX_TRY(cxk_ft_partials(A, S->v_rows.p));
+      hipLaunchKernelGGL(k_cam_reduce9_dot, dim3(grid), dim3(256), 0, ctx->stream, (const double*)A->d_partials.p,
+                         (const int32_t*)A->d_cam_seg_start.p, y, n, d, x, tail);
+      CX_TRY(S->ktimer.end(1, ctx->stream));
+    } else {
+      CX_TRY(cxk_ft_multiply(A, S->v_rows.p, y, false));
+      CX_TRY(S->ktimer.end(1, ctx->stream));
+      CX_TRY(cx_allreduce_device(ctx, y, n));
+      hipLaunchKernelGGL(k_d2x_dot, dim3(grid), dim3(256), 0, ctx->stream, y, d, x, n, tail);
+    }
+    CX_HIP(hipGetLastError());
+    *done = true;
+    return CX_OK;
+  }
 };
 
 __global__ void k_axpy1(double* __restrict__ y, const double* __restrict__ x, int64_t n) {
@@ -510,6 +716,15 @@ struct BlockDiag9Op : LinOp {
   int apply(const double* x, double* y) override {
     if (nblocks)
       hipLaunchKernelGGL(k_blockdiag_multiply<9>, dim3(grid_for(9 * nblocks, 256)), dim3(256), 0, ctx->stream, blocks, x, y, nblocks);
+    CX_HIP(hipGetLastError());
+    return CX_OK;
+  }
+  int apply_dot(const double* x, double* y, const DotTail& tail, bool* done) override {
+    *done = nblocks > 0;
+    if (!nblocks) return CX_OK;
+    const int64_t n = 9 * nblocks;
+    const int grid = int(std::min<int64_t>(kRedBlocks, (n + 255) / 256));
+    hipLaunchKernelGGL(k_blockdiag9_dot, dim3(grid), dim3(256), 0, ctx->stream, blocks, x, y, n, tail);
     CX_HIP(hipGetLastError());
     return CX_OK;
   }

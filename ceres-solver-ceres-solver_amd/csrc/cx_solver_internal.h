@@ -23,19 +23,36 @@ struct CgState {
   int seq, pad;  // seq: iteration this copy was published for (host-pinned ring only)
 };
 
-constexpr int kRedBlocks = 512;  // fixed grid of the two-stage reductions (deterministic)
+constexpr int kRedBlocks = 2048;  // upper bound of the reduction grids (deterministic for a given n)
+
+// Where a fused "apply + dot product" kernel leaves its sums and which CG scalar step follows
+// (cx_solver.hip: dot2_finish).
+struct DotTail {
+  double* partial;
+  unsigned* ticket;
+  CgState* st;
+  CgState* ring;
+  int ring_slots, op, iter;
+};
 
 struct LinOp {
   virtual ~LinOp() = default;
   virtual int64_t size() const = 0;
   virtual int apply(const double* x, double* y) = 0;  // y = A x
+  // y = A x and the CG dot product x.y with its scalar step in the operator's last kernel;
+  // *done = false when the operator has no fused form (the caller then applies and reduces).
+  virtual int apply_dot(const double* x, double* y, const DotTail& tail, bool* done) {
+    (void)x; (void)y; (void)tail;
+    *done = false;
+    return CX_OK;
+  }
 };
 
 // Per-kernel device time of the last solve, sampled with HIP event pairs on the
 // context stream (read back after the solve; no synchronisation inside the loop).
 struct KernelTimer {
   static constexpr int kSlots = 4, kMaxSamples = 64;
-  const char* names[kSlots] = {"k_chunk_pass<0>", "k_cam_ft+k_cam_reduce9", "k_right_239", "k_left_e_239+k_cam_ft"};
+  const char* names[kSlots] = {"k_chunk_pass<0>", "k_cam_ft+k_cam_reduce9_dot", "k_right_239", "k_left_e_239+k_cam_ft"};
   hipEvent_t ev[kSlots][kMaxSamples][2] = {};
   int count[kSlots] = {};
   int launches[kSlots] = {};
@@ -84,6 +101,7 @@ struct cx_solver {
   CgState* ring_h = nullptr;  // host-pinned, device-visible ring of published CG states
   CgState* ring_d = nullptr;
   DevBuf<int> flag;
+  DevBuf<unsigned> ticket;  // arrival counter of the fused reductions (zero between kernels)
 };
 
 // ConjugateGradientsSolver (conjugate_gradients_solver.h:107-305) on device vectors of
