@@ -141,6 +141,15 @@ struct cx_matrix {
   DevBuf<double> d_partials9;            // [S][9] (fused set-up)
   DevBuf<double> d_elim_blk, d_elim_ete, d_elim_diag, d_elim_rows;  // explicit-S scratch (cx_schur.hip)
   DevBuf<int> d_elim_flag;
+  // explicit S without atomics: for every upper block (c1 <= c2) the co-observing row pairs, in chunk order
+  DevBuf<int32_t> d_pair_rows;           // [2 * num_pairs] (row of camera c1, row of camera c2)
+  DevBuf<int64_t> d_item_begin;          // [num_items + 1] work items: runs of <= kPairItem pairs of one cell
+  DevBuf<int32_t> d_cell_item_start;     // [C * C + 1] items of cell c1 * C + c2
+  DevBuf<double> d_item_partial;         // [num_items][81]
+  int64_t num_items = 0;
+  DevBuf<double> d_elim_bg0, d_elim_bg1, d_elim_bg2;  // per row B = E'F (3x9) and G = (E'E)^-1 B, 3 x 18 doubles
+  int pairs_state = 0;                   // 0 not built, 1 ready, 2 too many pairs (atomic path)
+  int64_t num_pairs = 0;
 
   // scratch for host-pointer calls
   DevBuf<double> d_x, d_y;

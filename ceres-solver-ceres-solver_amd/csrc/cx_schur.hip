@@ -787,6 +787,198 @@ __global__ __launch_bounds__(kBlock) void k_big_chunk_eliminate(const double* __
   }
 }
 
+// ---- explicit S without atomics (the default): gather instead of scatter.
+// The structure is fixed over the LM iterations, so the list of row pairs (ri, rj) of one chunk whose
+// cameras are (c1, c2) is built once per matrix, grouped by the S cell they update (the role of the
+// reference's cell map + mutex, block_random_access_dense_matrix.cc:41-72, schur_eliminator_impl.h:550).
+// Per solve: k_row_bg writes B_r = E_r' F_r and G_r = (E'E + D^2)^-1 B_r for every row (one streaming
+// pass over J), then one workgroup per cell adds its pairs' -B_ri' G_rj in list order and writes the cell
+// of the dense matrix.  Sums are in a fixed order: bitwise reproducible, unlike the reference with
+// num_threads > 1.
+constexpr int64_t kMaxPairs = int64_t(1) << 28;
+constexpr int kPairGroups = 28;             // 28 groups of 9 threads, each thread a 3x3 piece of the 9x9 product
+constexpr int kPairItem = kPairGroups * 8;  // pairs per work item
+
+int cxs_build_pair_lists(cx_matrix* A) {
+  if (A->pairs_state != 0) return CX_OK;
+  const int C = A->C;
+  const int64_t O = A->O;
+  int64_t total = 0;
+  std::vector<int32_t> start(size_t(A->P) + 1, 0);
+  {
+    // rows are sorted by point: chunk of point p = rows with cells[2r].block_id == p
+    int64_t r = 0;
+    for (int p = 0; p < A->P; ++p) {
+      start[p] = int32_t(r);
+      while (r < O && A->cells[2 * r].block_id == p) ++r;
+      const int64_t k = r - start[p];
+      total += k * (k + 1) / 2;
+    }
+    start[A->P] = int32_t(r);
+  }
+  // CX_ELIM_ATOMICS=1 selects the scatter (fp64 atomics) path, otherwise only used when the list would be huge
+  const char* force = std::getenv("CX_ELIM_ATOMICS");
+  if (total > kMaxPairs || (force && force[0] == '1')) {
+    A->pairs_state = 2;
+    return CX_OK;
+  }
+  std::vector<int64_t> begin(size_t(C) * C + 1, 0);
+  auto cam_of = [&](int64_t r) { return A->cells[2 * r + 1].block_id - A->P; };
+  for (int p = 0; p < A->P; ++p)
+    for (int64_t i = start[p]; i < start[p + 1]; ++i)
+      for (int64_t j = i; j < start[p + 1]; ++j) {
+        const int ci = cam_of(i), cj = cam_of(j);
+        begin[size_t(std::min(ci, cj)) * C + std::max(ci, cj) + 1]++;
+      }
+  for (size_t k = 0; k < size_t(C) * C; ++k) begin[k + 1] += begin[k];
+  std::vector<int32_t> pairs(size_t(2 * total));
+  {
+    std::vector<int64_t> fill(begin.begin(), begin.end() - 1);
+    for (int p = 0; p < A->P; ++p)
+      for (int64_t i = start[p]; i < start[p + 1]; ++i)
+        for (int64_t j = i; j < start[p + 1]; ++j) {
+          const int ci = cam_of(i), cj = cam_of(j);
+          const int64_t slot = fill[size_t(std::min(ci, cj)) * C + std::max(ci, cj)]++;
+          pairs[2 * slot] = int32_t(ci <= cj ? i : j);
+          pairs[2 * slot + 1] = int32_t(ci <= cj ? j : i);
+        }
+  }
+  // work items: a cell's pair run cut into pieces of at most kPairItem pairs
+  std::vector<int64_t> item_begin;
+  std::vector<int32_t> cell_item_start(size_t(C) * C + 1, 0);
+  for (size_t key = 0; key < size_t(C) * C; ++key) {
+    cell_item_start[key] = int32_t(item_begin.size());
+    for (int64_t b0 = begin[key]; b0 < begin[key + 1]; b0 += kPairItem) item_begin.push_back(b0);
+  }
+  cell_item_start[size_t(C) * C] = int32_t(item_begin.size());
+  A->num_items = int64_t(item_begin.size());
+  item_begin.push_back(total);
+  // an item must not run into the next cell: its end is min(next item's begin, its cell's end); the cut
+  // above only starts items inside one cell, and consecutive items of different cells meet at a cell boundary
+  hipStream_t st = A->ctx->stream;
+  CX_TRY(A->d_pair_rows.upload(pairs, st));
+  CX_TRY(A->d_item_begin.upload(item_begin, st));
+  CX_TRY(A->d_cell_item_start.upload(cell_item_start, st));
+  CX_TRY(A->d_item_partial.alloc(size_t(std::max<int64_t>(A->num_items, 1)) * 81));
+  A->num_pairs = total;
+  A->pairs_state = 1;
+  return CX_OK;
+}
+
+// B_r and G_r of every row, 54 doubles per row in three [O][18] arrays:
+//   bg0 = B rows 0,1 ; bg1 = B row 2 | G row 0 ; bg2 = G rows 1,2
+__global__ __launch_bounds__(kBlock) void k_row_bg(const double* __restrict__ E, const double* __restrict__ F,
+                                                   const int32_t* __restrict__ row_pt, const double* __restrict__ ete_inv,
+                                                   int64_t O, double* __restrict__ bg0, double* __restrict__ bg1,
+                                                   double* __restrict__ bg2) {
+  __shared__ double lds[kBlock * 18];
+  const int64_t r0 = int64_t(blockIdx.x) * kBlock;
+  const int nvalid = int(min(int64_t(kBlock), O - r0));
+  const int tid = threadIdx.x;
+  double f[18], e[6];
+  stage_cells<18>(F + 18 * r0, nvalid, lds, f);
+  stage_cells<6>(E + 6 * r0, nvalid, lds, e);
+  double o0[18], o1[18], o2[18];
+#pragma unroll
+  for (int k = 0; k < 18; ++k) { o0[k] = 0.0; o1[k] = 0.0; o2[k] = 0.0; }
+  if (tid < nvalid) {
+    double B[27], iv[9];
+    const double* m = ete_inv + 9 * int64_t(row_pt[r0 + tid]);
+#pragma unroll
+    for (int k = 0; k < 9; ++k) iv[k] = m[k];
+#pragma unroll
+    for (int q = 0; q < 3; ++q)
+#pragma unroll
+      for (int a = 0; a < 9; ++a) B[q * 9 + a] = e[q] * f[a] + e[3 + q] * f[9 + a];
+#pragma unroll
+    for (int a = 0; a < 9; ++a) {
+      o0[a] = B[a];
+      o0[9 + a] = B[9 + a];
+      o1[a] = B[18 + a];
+      o1[9 + a] = iv[0] * B[a] + iv[1] * B[9 + a] + iv[2] * B[18 + a];
+      o2[a] = iv[3] * B[a] + iv[4] * B[9 + a] + iv[5] * B[18 + a];
+      o2[9 + a] = iv[6] * B[a] + iv[7] * B[9 + a] + iv[8] * B[18 + a];
+    }
+  }
+  unstage_cells<18>(bg0 + 18 * r0, nvalid, lds, o0);
+  unstage_cells<18>(bg1 + 18 * r0, nvalid, lds, o1);
+  unstage_cells<18>(bg2 + 18 * r0, nvalid, lds, o2);
+}
+
+// Stage 1, one workgroup per work item: sum of B_ri' G_rj over the item's pairs.  Thread t of the
+// first 252 belongs to group t / 9 and owns the 3x3 piece (a0.., c0..) of the 9x9 product, so a pair
+// costs it 18 loads for 27 FMAs; group g takes pairs g, g + 28, ... of the item and the 28 group
+// sums are added in group order.
+__global__ __launch_bounds__(kBlock) void k_pair_items(const int32_t* __restrict__ pair_rows,
+                                                       const int64_t* __restrict__ item_begin,
+                                                       const double* __restrict__ bg0, const double* __restrict__ bg1,
+                                                       const double* __restrict__ bg2, double* __restrict__ item_partial) {
+  __shared__ double part[kPairGroups * 81];
+  const int tid = threadIdx.x;
+  const int64_t p0 = item_begin[blockIdx.x], p1 = item_begin[blockIdx.x + 1];
+  const int g = tid / 9, sub = tid - g * 9;
+  const int a0 = 3 * (sub / 3), c0 = 3 * (sub - 3 * (sub / 3));
+  if (g < kPairGroups) {
+    double acc[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) acc[k] = 0.0;
+    for (int64_t k = p0 + g; k < p1; k += kPairGroups) {
+      const int64_t ri = pair_rows[2 * k], rj = pair_rows[2 * k + 1];
+      double B[9], G[9];
+#pragma unroll
+      for (int i = 0; i < 3; ++i) {
+        B[i] = bg0[18 * ri + a0 + i];
+        B[3 + i] = bg0[18 * ri + 9 + a0 + i];
+        B[6 + i] = bg1[18 * ri + a0 + i];
+        G[i] = bg1[18 * rj + 9 + c0 + i];
+        G[3 + i] = bg2[18 * rj + c0 + i];
+        G[6 + i] = bg2[18 * rj + 9 + c0 + i];
+      }
+#pragma unroll
+      for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) acc[i * 3 + j] += (B[i] * G[j] + B[3 + i] * G[3 + j]) + B[6 + i] * G[6 + j];
+    }
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+      for (int j = 0; j < 3; ++j) part[g * 81 + (a0 + i) * 9 + c0 + j] = acc[i * 3 + j];
+  }
+  __syncthreads();
+  if (tid < 81) {
+    double v = 0.0;
+#pragma unroll 4
+    for (int q = 0; q < kPairGroups; ++q) v += part[q * 81 + tid];
+    item_partial[int64_t(blockIdx.x) * 81 + tid] = v;
+  }
+}
+
+// Stage 2, 81 threads per 9x9 cell (c1, c2) of the dense lhs: cells below the diagonal are zeroed (the
+// reference never touches them), the others receive [c1 == c2] (F'F + D_f^2) - sum of the cell's items.
+__global__ __launch_bounds__(3 * 81) void k_pair_cells(const int32_t* __restrict__ cell_item_start,
+                                                       const double* __restrict__ item_partial,
+                                                       const double* __restrict__ diag, const double* __restrict__ Df,
+                                                       double* __restrict__ lhs, int C) {
+  const int64_t cell = int64_t(blockIdx.x) * 3 + threadIdx.x / 81;
+  if (cell >= int64_t(C) * C) return;
+  const int el = threadIdx.x % 81;
+  const int c1 = int(cell / C), c2 = int(cell - int64_t(c1) * C);
+  const int a = el / 9, c = el - a * 9;
+  const int64_t n = 9 * int64_t(C);
+  double v = 0.0;
+  if (c1 <= c2) {
+    for (int it = cell_item_start[cell]; it < cell_item_start[cell + 1]; ++it) v -= item_partial[int64_t(it) * 81 + el];
+    if (c1 == c2) {
+      v += diag[int64_t(c1) * 81 + el];
+      if (Df && a == c) {
+        const double d = Df[9 * int64_t(c1) + a];
+        v += d * d;
+      }
+    }
+  }
+  lhs[(9 * int64_t(c1) + a) * n + 9 * int64_t(c2) + c] = v;
+}
+
 // dense row-major lhs (n = 9C) from the block-major pair sums, the F'F diagonal blocks and D_f^2;
 // blocks below the diagonal stay zero (the reference never touches them)
 __global__ void k_blocks_to_dense(const double* __restrict__ blk, const double* __restrict__ diag,
@@ -874,14 +1066,36 @@ int cxs_eliminate_dense(cx_matrix* A, const double* b, const double* D, bool add
   hipStream_t st = A->ctx->stream;
   const int C = A->C;
   const int64_t n = 9 * int64_t(C);
-  CX_TRY(A->d_elim_blk.alloc(size_t(std::max<int64_t>(int64_t(C) * C * 81, 1))));
+  CX_TRY(cxs_build_pair_lists(A));
+  const bool gather = A->pairs_state == 1;
   CX_TRY(A->d_elim_ete.alloc(size_t(std::max<int64_t>(9 * int64_t(A->P), 1))));
   CX_TRY(A->d_elim_diag.alloc(size_t(std::max<int64_t>(81 * int64_t(C), 1))));
   CX_TRY(A->d_elim_flag.alloc(1));
-  CX_HIP(hipMemsetAsync(A->d_elim_blk.p, 0, size_t(C) * C * 81 * sizeof(double), st));
   // (E'E + D_e^2)^-1 with the closed-form inverse of InvertPSDMatrix<3>
   CX_TRY(cxs_compute_ete_inverse(A, D, nullptr, A->d_elim_ete.p, nullptr, false, A->d_elim_flag.p));
-  if (A->num_tiles > 0) {
+  if (gather) {
+    const size_t rows18 = size_t(std::max<int64_t>(18 * A->O, 1));
+    CX_TRY(A->d_elim_bg0.alloc(rows18));
+    CX_TRY(A->d_elim_bg1.alloc(rows18));
+    CX_TRY(A->d_elim_bg2.alloc(rows18));
+    if (A->O > 0)
+      hipLaunchKernelGGL(k_row_bg, dim3(grid_for(A->O, kBlock)), dim3(kBlock), 0, st, (const double*)A->d_values.p,
+                         (const double*)(A->d_values.p + 6 * A->O), (const int32_t*)A->d_row_pt.p,
+                         (const double*)A->d_elim_ete.p, A->O, A->d_elim_bg0.p, A->d_elim_bg1.p, A->d_elim_bg2.p);
+    CX_TRY(cxs_camera_block_diagonal(A, false, nullptr, A->d_elim_diag.p));
+    if (A->num_items > 0)
+      hipLaunchKernelGGL(k_pair_items, dim3(unsigned(A->num_items)), dim3(kBlock), 0, st, (const int32_t*)A->d_pair_rows.p,
+                         (const int64_t*)A->d_item_begin.p, (const double*)A->d_elim_bg0.p, (const double*)A->d_elim_bg1.p,
+                         (const double*)A->d_elim_bg2.p, A->d_item_partial.p);
+    if (C > 0)
+      hipLaunchKernelGGL(k_pair_cells, dim3(unsigned((int64_t(C) * C + 2) / 3)), dim3(3 * 81), 0, st,
+                         (const int32_t*)A->d_cell_item_start.p, (const double*)A->d_item_partial.p,
+                         (const double*)A->d_elim_diag.p, (D && add_df) ? D + 3 * int64_t(A->P) : (const double*)nullptr, lhs, C);
+  } else {
+    CX_TRY(A->d_elim_blk.alloc(size_t(std::max<int64_t>(int64_t(C) * C * 81, 1))));
+    CX_HIP(hipMemsetAsync(A->d_elim_blk.p, 0, size_t(C) * C * 81 * sizeof(double), st));
+  }
+  if (!gather && A->num_tiles > 0) {
     const double* E = A->d_values.p;
     const double* F = A->d_values.p + 6 * A->O;
     hipLaunchKernelGGL(k_chunk_eliminate, dim3(A->num_tiles), dim3(kBlock), 0, st, E, F, A->d_tile_row.p,
@@ -890,8 +1104,8 @@ int cxs_eliminate_dense(cx_matrix* A, const double* b, const double* D, bool add
       hipLaunchKernelGGL(k_big_chunk_eliminate, dim3(A->num_tiles), dim3(kBlock), 0, st, E, F, A->d_tile_row.p,
                          A->d_tile_pt.p, A->d_row_cam.p, (const double*)A->d_elim_ete.p, A->d_elim_blk.p, C);
   }
-  CX_TRY(cxs_camera_block_diagonal(A, false, nullptr, A->d_elim_diag.p));
-  if (n > 0)
+  if (!gather) CX_TRY(cxs_camera_block_diagonal(A, false, nullptr, A->d_elim_diag.p));
+  if (!gather && n > 0)
     hipLaunchKernelGGL(k_blocks_to_dense, dim3(grid_for(n * n, 256)), dim3(256), 0, st, (const double*)A->d_elim_blk.p,
                        (const double*)A->d_elim_diag.p, (D && add_df) ? D + 3 * int64_t(A->P) : (const double*)nullptr, lhs, C);
   if (rhs) {

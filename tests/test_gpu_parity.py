@@ -1,6 +1,8 @@
 """Parity of the HIP path (libcxschur.so through its C ABI) against the oracle on
 seeded BAL-shaped problems.  fp64 tolerances are stated per test; integer
 structure (ordering, layout) is compared exactly."""
+import os
+
 import numpy as np
 import pytest
 
@@ -99,7 +101,22 @@ def test_implicit_schur_and_eliminator(ctx, oracle, C, P, O, seed):
     xb_ref = oracle.schur_back_substitute(bs, vals, b, D, P, z)
     xb = cx.back_substitute(ctx, A, b, D, z)
     assert relerr(xb[:3 * P], xb_ref[:3 * P]) < 1e-10
+    # the gather path sums every cell in a fixed order: bitwise reproducible
+    lhs2, _ = cx.eliminate_dense(ctx, A, b, D, nf)
+    assert np.array_equal(lhs, lhs2)
     A.close()
+    # the scatter (atomics) path, used when the pair list would be too large
+    os.environ["CX_ELIM_ATOMICS"] = "1"
+    try:
+        A2 = cx.Matrix(ctx, bs, P)
+        A2.set_values(vals)
+        lhs3, r3 = cx.eliminate_dense(ctx, A2, b, D, nf)
+        A2.close()
+    finally:
+        del os.environ["CX_ELIM_ATOMICS"]
+    assert relerr(np.triu(lhs3), np.triu(lhs_ref)) < 1e-11 and relerr(r3, r_ref) < 1e-11
+    for i in range(C):
+        assert not lhs3[9 * i:9 * i + 9, :9 * i].any()
 
 
 @pytest.mark.parametrize("n", [9, 64, 200, 441])
