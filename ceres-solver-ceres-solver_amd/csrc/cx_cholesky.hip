@@ -2,19 +2,32 @@
 // FactorAndSolve, dense_cholesky.cc:139-207; the reference's device variant is
 // cusolverDnDpotrf/Dpotrs, dense_cholesky.cc:360-444).
 //
-// A (n x n, row-major, upper triangle valid) = U'U, blocked right-looking with
-// 32-wide panels:
-//   k_potrf_diag   factor the 32x32 diagonal block, one wavefront, columns in registers
-//   k_trsm_panel   U(k, j>k) = U_kk^-T A(k, j>k)       one thread per column
-//   k_syrk_mfma    A(i,j) -= U(k,i)' U(k,j), i <= j     v_mfma_f64_16x16x4_f64, 64x64 tile per
-//                  workgroup, 32x32 per wavefront -- the one genuinely dense, MFMA-bound piece
-// followed by blocked forward / backward substitution.
+// A (n x n, row-major, upper triangle valid) = U'U, blocked right-looking with 32-wide panels on a
+// working copy W that carries the right-hand side as column n (so the forward substitution happens
+// inside the factorisation).  The factorisation is a chain of n / 32 dependent steps, each far too
+// short to amortise several kernel launches (~12 us per dependent launch on this part), so a step is
+// ONE launch, k_chol_step:
+//   * every workgroup owns a 64x64 tile of the trailing matrix (32x32 per wavefront) and first forms
+//     the panel rows it needs itself, X = U_kk^-T W(k, .), as an MFMA product with the explicit
+//     inverse of the 32x32 diagonal block (v_mfma_f64_16x16x4_f64; the result registers are already
+//     in the operand layout of the next product), then subtracts X_i' X_j -- the one genuinely
+//     dense, MFMA-bound piece;
+//   * tiles of the first tile row store X: together they write rows k.. of the factor;
+//   * the workgroup of tile (0,0) goes on to factor and invert the next diagonal block (look-ahead).
+// Backward substitution follows, one launch per block (k_trsv_bwd).
+//
+// Measured alternatives (n = 3204, Dubrovnik-356): five kernels per step (potrf, per-column trsm,
+// syrk, blocked forward/backward substitution) 8.2 ms; the whole solve as one cooperative kernel with
+// grid barriers 10.2 ms (one workgroup per CU cannot hide the memory latency of its tiles after every
+// barrier's L2 invalidation); this file 3.x ms.
+#include <cstdlib>
+
 #include "cx_internal.h"
 #include "cx_schur.h"
 
 namespace {
 
-constexpr int NB = 32;  // panel width: 32 keeps the wave-level factor/solve kernels in registers (64 spills)
+constexpr int NB = 32;  // panel width: the wave-level diagonal factorisation keeps a 32x32 block in registers
 
 typedef double double4_t __attribute__((ext_vector_type(4)));
 
@@ -26,101 +39,161 @@ __device__ __forceinline__ double readlane_f64(double v, int l) {
   return __longlong_as_double((static_cast<unsigned long long>(hi) << 32) | lo);
 }
 
-// Diagonal block: ONE wavefront, lane c owns column c of the NB x NB block in NB registers.
-// Right-looking, fully unrolled: the pivot and the scaled pivot row reach the other lanes
-// through v_readlane (scalar broadcast), so the NB-step dependency chain contains no LDS
-// round trip and no barrier.
-__global__ __launch_bounds__(64) void k_potrf_diag(double* __restrict__ A, int n, int k0, int kb,
-                                                   int* __restrict__ not_pd) {
-  const int lane = threadIdx.x;
-  double T[NB];  // T[r] = block(r, lane); identity padding beyond kb keeps the recurrence valid
+// One wavefront: factor the kb x kb diagonal block of W at k0 (upper, U'U), store U_kk into the factor
+// F (ld n) and U_kk^-1 (NB x NB row-major, identity-padded) into uinv.  Lane c owns column c of the block
+// in NB registers; right-looking, fully unrolled, pivot row broadcast by v_readlane (no LDS round trip
+// or barrier in the 32-step chain).  The inverse is then formed column by column from an LDS copy of U
+// (broadcast reads), lds: NB * NB + NB doubles.
+__device__ __forceinline__ void potrf_inverse_block(const double* __restrict__ W, int ldw, double* __restrict__ F, int n,
+                                                    int k0, int kb, double* __restrict__ uinv, int* __restrict__ not_pd,
+                                                    double* __restrict__ lds) {
+  const int lane = threadIdx.x & 63;
+  double T[NB];
+  {
+    // branch-free: every lane loads from a clamped (always valid) address, padding is selected afterwards
+    const int cc = min(lane, kb - 1);
+    const double* __restrict__ base = W + size_t(k0) * ldw + k0 + cc;
 #pragma unroll
-  for (int r = 0; r < NB; ++r) {
-    const bool in = r < kb && lane < kb && lane >= r;
-    T[r] = (r == lane) ? 1.0 : 0.0;
-    if (in) T[r] = A[size_t(k0 + r) * n + k0 + lane];
+    for (int r = 0; r < NB; ++r) {
+      const double v = base[size_t(min(r, kb - 1)) * ldw];
+      const bool in = r < kb && lane < kb && lane >= r;
+      T[r] = in ? v : ((r == lane) ? 1.0 : 0.0);
+    }
   }
   bool ok = true;
 #pragma unroll
   for (int j = 0; j < NB; ++j) {
     const double d = readlane_f64(T[j], j);
     ok = ok && (d > 0.0);
-    const double sq = sqrt(d);
-    const double rs = 1.0 / sq;
+    // 1 / sqrt(d) from the hardware estimate and two Newton steps (a correctly rounded sqrt and a
+    // division cost ~45 instructions of this single wavefront's 32-step serial chain)
+    double rs = __builtin_amdgcn_rsq(d);
+    rs = rs * (1.5 - 0.5 * d * rs * rs);
+    rs = rs * (1.5 - 0.5 * d * rs * rs);
+    const double sq = d * rs;
     T[j] = (lane == j) ? sq : T[j] * rs;
-    const double uj = T[j];  // U(j, own column)
+    if (lane == 0) lds[NB * NB + j] = rs;  // 1 / U(j, j) for the inverse below
+    const double uj = T[j];
 #pragma unroll
     for (int i = j + 1; i < NB; ++i) {
-      const double uji = readlane_f64(T[j], i);  // U(j, i)
-      T[i] = (lane >= i) ? T[i] - uji * uj : T[i];
+      // entries below the diagonal (lane < i) are updated too; they are never read
+      T[i] -= readlane_f64(T[j], i) * uj;
     }
+    __builtin_amdgcn_sched_barrier(0);  // keep the broadcasts of step j + 1 out of step j (SGPR pressure)
   }
   if (!ok && lane == 0) *not_pd = 1;
 #pragma unroll
-  for (int r = 0; r < NB; ++r)
-    if (r < kb && lane < kb && lane >= r) A[size_t(k0 + r) * n + k0 + lane] = T[r];
+  for (int r = 0; r < NB; ++r) {
+    if (r < kb && lane < kb && lane >= r) F[size_t(k0 + r) * n + k0 + lane] = T[r];
+    if (lane < NB) lds[r * NB + lane] = (lane >= r) ? T[r] : 0.0;  // U(r, lane)
+  }
+  // (single wavefront: its LDS writes are ordered before its LDS reads, no barrier needed)
+  // V = U^-1, column `lane`: U V = I by back substitution
+  double V[NB];
+#pragma unroll
+  for (int r = NB - 1; r >= 0; --r) {
+    double sum = (r == lane) ? 1.0 : 0.0;
+#pragma unroll
+    for (int k = r + 1; k < NB; ++k) sum -= lds[r * NB + k] * V[k];
+    V[r] = (lane >= r) ? sum * lds[NB * NB + r] : 0.0;
+  }
+  if (lane < NB) {
+#pragma unroll
+    for (int r = 0; r < NB; ++r) uinv[r * NB + lane] = V[r];
+  }
 }
 
-// Panel: columns c >= k0 + kb, solve U_kk' x = a(:, c).  One lane per column with the NB
-// unknowns in registers; U_kk is wave-uniform and arrives through scalar loads (SGPR operands).
-// (An LDS-broadcast variant of the same loop makes hipcc 7.2 spill 2.4 KB per lane.)
-__global__ __launch_bounds__(256) void k_trsm_panel(double* __restrict__ A, int n, int k0, int kb) {
-  const int c = k0 + kb + blockIdx.x * 256 + threadIdx.x;
-  const bool live = c < n;
-  const double* __restrict__ Ukk = A + size_t(k0) * n + k0;
-  double x[NB];
+// X = U_kk^-T W(k-rows, c0 .. c0 + 32) by MFMA: X[m][c] = sum_r Uinv[r][m] W[k0 + r][c], m, r < NB.
+// Result tile (mt, nt) register g of lane l is X[16 mt + (l >> 4) + 4 g][c0 + 16 nt + (l & 15)] -- which is
+// exactly the operand layout of the trailing update (K index m = 4 (4 mt + g) + (l >> 4)), so X feeds
+// the next MFMA without leaving the registers.  Columns > cmax and rows >= kb read as zero.
+__device__ __forceinline__ void panel_x(const double* __restrict__ W, int ldw, const double* __restrict__ uinv, int k0, int kb,
+                                        int c0, int cmax, double4_t (&X)[2][2]) {
+  const int lane = threadIdx.x & 63;
+  const int li = lane & 15, lk = lane >> 4;
+  double bop[8][2], aop[8][2];
 #pragma unroll
-  for (int i = 0; i < NB; ++i) x[i] = (live && i < kb) ? A[size_t(k0 + i) * n + c] : 0.0;
+  for (int s = 0; s < 8; ++s) {
+    const int r = 4 * s + lk;
 #pragma unroll
-  for (int i = 0; i < NB; ++i) {
-    if (i < kb) {
-      double sum = x[i];
-#pragma unroll
-      for (int k = 0; k < i; ++k) sum -= Ukk[size_t(k) * n + i] * x[k];
-      x[i] = sum / Ukk[size_t(i) * n + i];
+    for (int nt = 0; nt < 2; ++nt) {
+      const int c = c0 + 16 * nt + li;
+      bop[s][nt] = (r < kb && c <= cmax) ? W[size_t(k0 + r) * ldw + c] : 0.0;
     }
-  }
-  if (live) {
 #pragma unroll
-    for (int i = 0; i < NB; ++i)
-      if (i < kb) A[size_t(k0 + i) * n + c] = x[i];
+    for (int mt = 0; mt < 2; ++mt) aop[s][mt] = uinv[r * NB + 16 * mt + li];  // A(m, r) = Uinv[r][m]
   }
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) X[mt][nt] = double4_t{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+  for (int s = 0; s < 8; ++s)
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt) X[mt][nt] = __builtin_amdgcn_mfma_f64_16x16x4f64(aop[s][mt], bop[s][nt], X[mt][nt], 0, 0, 0);
 }
 
-// trailing update with fp64 MFMA.  Workgroup = 64x64 tile of the trailing matrix,
-// wavefront w = 32x32 quadrant, 2x2 MFMA 16x16 tiles, K = kb in steps of 4.
-// Operand maps (cdna guide, f64 16x16x4): lane l holds A[i = l & 15][k = l >> 4] and
-// B[k = l >> 4][j = l & 15]; result reg g of lane l is C[(l >> 4) + 4 g][l & 15].
-__global__ __launch_bounds__(256) void k_syrk_mfma(double* __restrict__ A, int n, int k0, int kb) {
+// store X (see panel_x) as rows k0.. of the factor: columns < n into F, column n (the right-hand side) into y
+__device__ __forceinline__ void store_x(const double4_t (&X)[2][2], double* __restrict__ F, int n, double* __restrict__ y,
+                                        int k0, int kb, int c0) {
+  const int lane = threadIdx.x & 63;
+  const int li = lane & 15, lk = lane >> 4;
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int m = 16 * mt + lk + 4 * g;
+        const int c = c0 + 16 * nt + li;
+        if (m < kb) {
+          if (c < n) F[size_t(k0 + m) * n + c] = X[mt][nt][g];
+          else if (c == n) y[k0 + m] = X[mt][nt][g];
+        }
+      }
+}
+
+// Tile (ti, tj) of step k0 by the whole workgroup: wavefront w owns the 32 x 32 quadrant
+// rows i0 = rest + 64 ti + 32 (w >> 1), columns j0 = rest + 64 tj + 32 (w & 1) of the trailing matrix
+// (column n = right-hand side).  It forms X_i and X_j itself (the triangular solve of the panel, redone
+// per tile on the matrix cores instead of a separate step with its own barrier) and subtracts X_i' X_j.
+// Tiles of the first tile row also store X_j: together they write rows k0.. of the factor.
+__device__ __forceinline__ void fused_tile(double* __restrict__ W, int ldw, double* __restrict__ F, int n, double* __restrict__ y,
+                                           const double* __restrict__ uinv, int k0, int kb, int ti, int tj, bool update) {
   const int rest = k0 + kb;
-  const int ti = blockIdx.y, tj = blockIdx.x;
-  if (ti > tj) return;  // upper block triangle only
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int li = lane & 15, lk = lane >> 4;
   const int i0 = rest + ti * 64 + (wave >> 1) * 32;
   const int j0 = rest + tj * 64 + (wave & 1) * 32;
-  const int li = lane & 15, lk = lane >> 4;
+  double4_t Xj[2][2];
+  panel_x(W, ldw, uinv, k0, kb, j0, n, Xj);
+  if (ti == 0 && (wave >> 1) == 0) store_x(Xj, F, n, y, k0, kb, j0);
+  if (!update) return;
+  double4_t Xi[2][2];
+  if (i0 == j0) {
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt) Xi[mt][nt] = Xj[mt][nt];
+  } else {
+    panel_x(W, ldw, uinv, k0, kb, i0, n, Xi);
+  }
   double4_t acc[2][2];
 #pragma unroll
   for (int a = 0; a < 2; ++a)
 #pragma unroll
     for (int b = 0; b < 2; ++b) acc[a][b] = double4_t{0.0, 0.0, 0.0, 0.0};
-  for (int kk = 0; kk < kb; kk += 4) {
-    const int k = kk + lk;
-    const bool kv = k < kb;
-    const double* Urow = A + size_t(k0 + (kv ? k : 0)) * n;
-    double av[2], bv[2];
 #pragma unroll
-    for (int a = 0; a < 2; ++a) {
-      const int i = i0 + a * 16 + li;
-      av[a] = (kv && i < n) ? Urow[i] : 0.0;
-      const int j = j0 + a * 16 + li;
-      bv[a] = (kv && j < n) ? Urow[j] : 0.0;
-    }
+  for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-    for (int a = 0; a < 2; ++a)
+    for (int g = 0; g < 4; ++g)
 #pragma unroll
-      for (int b = 0; b < 2; ++b) acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[a], bv[b], acc[a][b], 0, 0, 0);
-  }
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+          acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(Xi[mt][a][g], Xj[mt][b][g], acc[a][b], 0, 0, 0);
 #pragma unroll
   for (int a = 0; a < 2; ++a)
 #pragma unroll
@@ -129,44 +202,52 @@ __global__ __launch_bounds__(256) void k_syrk_mfma(double* __restrict__ A, int n
       for (int g = 0; g < 4; ++g) {
         const int i = i0 + a * 16 + lk + 4 * g;
         const int j = j0 + b * 16 + li;
-        if (i < n && j < n && j >= i) A[size_t(i) * n + j] -= acc[a][b][g];
+        if (i < n && j <= n && j >= i) W[size_t(i) * ldw + j] -= acc[a][b][g];
       }
 }
 
-// Forward substitution, one launch per panel: every workgroup first solves the small system
-// U_kk' y_blk = y_blk itself (redundantly, in its first wavefront: lane t owns column t of U_kk,
-// 32 steps of one multiply + one lane broadcast; the reciprocals of the diagonal are formed
-// beforehand so no division sits in the chain), then subtracts U(blk, j)' y_blk from its slice
-// of the remaining right-hand side.  Workgroup 0 stores y_blk.
-__global__ __launch_bounds__(256) void k_trsv_fwd(const double* __restrict__ A, int n, int k0, int kb,
-                                                  double* __restrict__ y, double* __restrict__ sol) {
-  __shared__ double ys[NB];
-  const int t = threadIdx.x;
-  if (t < 64) {
-    double Ucol[NB];  // Ucol[i] = U(i, t)
-#pragma unroll
-    for (int i = 0; i < NB; ++i) Ucol[i] = (i < kb && t < kb && t >= i) ? A[size_t(k0 + i) * n + k0 + t] : ((i == t) ? 1.0 : 0.0);
-    double diag = 1.0;
-#pragma unroll
-    for (int i = 0; i < NB; ++i) if (i == t) diag = Ucol[i];
-    const double rdiag = 1.0 / diag;
-    double yt = (t < kb) ? y[k0 + t] : 0.0;
-#pragma unroll
-    for (int i = 0; i < NB; ++i) {
-      const double yi = readlane_f64(yt * rdiag, i);  // y_i is final once steps < i are subtracted
-      if (t == i) yt = yi;
-      if (t > i) yt -= Ucol[i] * yi;
-    }
-    if (t < NB) ys[t] = yt;
-    if (blockIdx.x == 0 && t < kb) sol[k0 + t] = yt;  // not into y: other workgroups still read y_blk
+// W (n x ldw, ldw > n) = upper triangle of A with the right-hand side as column n
+__global__ __launch_bounds__(256) void k_chol_augment(const double* __restrict__ A, const double* __restrict__ rhs, int n, int ldw,
+                                                      double* __restrict__ W) {
+  const int i = blockIdx.y;
+  const int j = blockIdx.x * 256 + threadIdx.x;
+  if (j < n) { if (j >= i) W[size_t(i) * ldw + j] = A[size_t(i) * n + j]; }
+  else if (j == n) W[size_t(i) * ldw + n] = rhs[i];
+}
+
+// first diagonal block
+__global__ __launch_bounds__(64) void k_chol_first(const double* __restrict__ W, int ldw, double* __restrict__ F, int n,
+                                                   double* __restrict__ uinv, int* __restrict__ not_pd) {
+  __shared__ double lds[NB * NB + NB];
+  potrf_inverse_block(W, ldw, F, n, 0, min(NB, n), uinv, not_pd, lds);
+}
+
+// One block step (see the file header).  Block b > 0 owns tile number b of the upper block trapezoid of
+// the trailing matrix (row ti has Tc - ti tiles; the last column tile holds the right-hand side); block
+// 0 owns tile (0,0) and the look-ahead.  Tr == 0 (last block step): only the right-hand side is left.
+__global__ __launch_bounds__(256) void k_chol_step(double* __restrict__ W, int ldw, double* __restrict__ F, int n,
+                                                   double* __restrict__ y, double* __restrict__ uinv, int k0, int parity,
+                                                   int* __restrict__ not_pd) {
+  __shared__ double lds[NB * NB + NB];
+  const int kb = min(NB, n - k0);
+  const int rest = k0 + kb;
+  const int rem = n - rest;
+  const double* ui = uinv + parity * NB * NB;
+  const int Tr = (rem + 63) / 64;
+  const int Tc = (rem + 1 + 63) / 64;
+  if (Tr == 0) {
+    fused_tile(W, ldw, F, n, y, ui, k0, kb, 0, 0, false);
+    return;
   }
-  __syncthreads();
-  const int j = k0 + kb + blockIdx.x * 256 + t;
-  if (j >= n) return;
-  double s = 0.0;
-#pragma unroll 8
-  for (int k = 0; k < kb; ++k) s += A[size_t(k0 + k) * n + j] * ys[k];
-  y[j] -= s;
+  int ti = 0, first = 0;
+  const int t = blockIdx.x;
+  while (t >= first + (Tc - ti)) { first += Tc - ti; ++ti; }
+  fused_tile(W, ldw, F, n, y, ui, k0, kb, ti, ti + (t - first), true);
+  if (t == 0) {
+    __threadfence();
+    __syncthreads();
+    if (threadIdx.x < 64) potrf_inverse_block(W, ldw, F, n, rest, min(NB, n - rest), uinv + (parity ^ 1) * NB * NB, not_pd, lds);
+  }
 }
 
 // Backward substitution, same scheme: U_kk x_blk = x_blk (lane t owns row t of U_kk), then
@@ -214,32 +295,28 @@ __global__ __launch_bounds__(256) void k_trsv_bwd(const double* __restrict__ A, 
 }  // namespace
 
 int cxd_cholesky_solve(cx_context* ctx, int n, double* a, const double* rhs, double* x, int* d_flag) {
+  if (n <= 0) return CX_OK;
   hipStream_t st = ctx->stream;
-  for (int k0 = 0; k0 < n; k0 += NB) {
-    const int kb = std::min(NB, n - k0);
-    hipLaunchKernelGGL(k_potrf_diag, dim3(1), dim3(64), 0, st, a, n, k0, kb, d_flag);
-    const int rem = n - k0 - kb;
-    if (rem > 0) {
-      hipLaunchKernelGGL(k_trsm_panel, dim3((rem + 255) / 256), dim3(256), 0, st, a, n, k0, kb);
-      const int T = (rem + 63) / 64;
-      hipLaunchKernelGGL(k_syrk_mfma, dim3(T, T), dim3(256), 0, st, a, n, k0, kb);
-    }
+  const int ldw = ((n + 1 + 15) / 16) * 16;
+  const size_t wsize = size_t(n) * ldw;
+  CX_TRY(ctx->chol_scratch.alloc(wsize + size_t(n) + 2 * NB * NB));
+  double* W = ctx->chol_scratch.p;
+  double* y = W + wsize;  // U^-T rhs, then updated in place by the backward substitution
+  double* uinv = y + n;
+  hipLaunchKernelGGL(k_chol_augment, dim3((n + 1 + 255) / 256, n), dim3(256), 0, st, (const double*)a, rhs, n, ldw, W);
+  hipLaunchKernelGGL(k_chol_first, dim3(1), dim3(64), 0, st, (const double*)W, ldw, a, n, uinv, d_flag);
+  int parity = 0;
+  for (int k0 = 0; k0 < n; k0 += NB, parity ^= 1) {
+    const int rem = n - std::min(n, k0 + NB);
+    const int Tr = (rem + 63) / 64, Tc = (rem + 1 + 63) / 64;
+    const int NT = Tr == 0 ? 1 : Tr * Tc - Tr * (Tr - 1) / 2;
+    hipLaunchKernelGGL(k_chol_step, dim3(NT), dim3(256), 0, st, W, ldw, a, n, y, uinv, k0, parity, d_flag);
   }
   CX_HIP(hipGetLastError());
-  // work = rhs (updated in place), ysol = U'^-1 rhs (then updated in place), x = U^-1 ysol
-  CX_TRY(ctx->chol_scratch.alloc(2 * size_t(n)));
-  double* work = ctx->chol_scratch.p;
-  double* ysol = ctx->chol_scratch.p + n;
-  CX_HIP(hipMemcpyAsync(work, rhs, size_t(n) * sizeof(double), hipMemcpyDeviceToDevice, st));
-  for (int k0 = 0; k0 < n; k0 += NB) {
-    const int kb = std::min(NB, n - k0);
-    const int rem = n - k0 - kb;
-    hipLaunchKernelGGL(k_trsv_fwd, dim3(std::max(1, (rem + 255) / 256)), dim3(256), 0, st, (const double*)a, n, k0, kb, work, ysol);
-  }
   const int last = ((n - 1) / NB) * NB;
   for (int k0 = last; k0 >= 0; k0 -= NB) {
     const int kb = std::min(NB, n - k0);
-    hipLaunchKernelGGL(k_trsv_bwd, dim3(std::max(1, (k0 + 63) / 64)), dim3(256), 0, st, (const double*)a, n, k0, kb, ysol, x);
+    hipLaunchKernelGGL(k_trsv_bwd, dim3(std::max(1, (k0 + 63) / 64)), dim3(256), 0, st, (const double*)a, n, k0, kb, y, x);
   }
   CX_HIP(hipGetLastError());
   return CX_OK;

@@ -119,7 +119,7 @@ def test_implicit_schur_and_eliminator(ctx, oracle, C, P, O, seed):
         assert not lhs3[9 * i:9 * i + 9, :9 * i].any()
 
 
-@pytest.mark.parametrize("n", [9, 64, 200, 441])
+@pytest.mark.parametrize("n", [9, 31, 64, 96, 97, 200, 441, 1000])
 def test_dense_cholesky(ctx, oracle, n):
     rng = np.random.default_rng(n)
     M = rng.standard_normal((n, n + 5))
