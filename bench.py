@@ -211,6 +211,20 @@ def main():
         elapsed = float(tt[0])
     ms_per_step = elapsed * 1e3 / max(1, args.steps)
 
+    # ---- the same solve at bundle_adjuster's tighter default (eta = 1e-2, bundle_adjuster.cc:114): many more
+    # CG iterations, so this is the per-iteration cost of S x; informational, outside the timed region
+    tight = None
+    if args.solver != "dense_schur" and args.eta != 0.01:
+        S.solve(A, b, D, r_tolerance=-1.0, q_tolerance=0.01, x=x)
+        barrier()
+        t1 = time.perf_counter()
+        _, summ_t = S.solve(A, b, D, r_tolerance=-1.0, q_tolerance=0.01, x=x)
+        barrier()
+        t_tight = (time.perf_counter() - t1) * 1e3
+        tm = S.timing()
+        tight = {"eta": 0.01, "ms": t_tight, "cg_iterations": int(summ_t.num_iterations),
+                 "cg_ms_per_iteration": tm["reduced_solve_ms"] / max(1, int(summ_t.num_iterations))}
+
     # ---- J SpMV GB/s (block_sparse_matrix.cc:239-349 replacement), this rank's shard
     Ol, Pl = prob.num_observations, prob.num_points
     n_c, n_r = 3 * Pl + 9 * C, 2 * Ol
@@ -273,6 +287,7 @@ def main():
                        "termination": int(summ.termination_type), "initial_cost": cost,
                        "sharding": "points over %d rank(s), RCCL all-reduce of camera-space sums" % world},
             "phases_ms_per_solve": {k: v / max(1, args.steps) for k, v in phases.items()},
+            "at_bundle_adjuster_eta": tight,
             "jacobian_eval_ms": eval_ms,
             "spmv": spmv,
             "kernels": {k: {"avg_ms": v[0] / max(1, v[1]), "launches_per_solve": v[2] / max(1, args.steps)} for k, v in kstats.items()},
