@@ -19,7 +19,7 @@
 // Measured alternatives (n = 3204, Dubrovnik-356): five kernels per step (potrf, per-column trsm,
 // syrk, blocked forward/backward substitution) 8.2 ms; the whole solve as one cooperative kernel with
 // grid barriers 10.2 ms (one workgroup per CU cannot hide the memory latency of its tiles after every
-// barrier's L2 invalidation); this file 3.x ms.
+// barrier's L2 invalidation); this file 4.6 ms (3.3 ms factor + 1.2 ms backward substitution).
 #include <cstdlib>
 
 #include "cx_internal.h"
