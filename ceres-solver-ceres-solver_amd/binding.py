@@ -34,7 +34,7 @@ EXPORTED_SYMBOLS = [
     "cx_matrix_last_kernel_ms", "cx_solver_create", "cx_solver_destroy", "cx_solver_default_options",
     "cx_solver_solve", "cx_solver_last_timing", "cx_solver_kernel_stats", "cx_schur_eliminate_dense", "cx_schur_back_substitute",
     "cx_implicit_schur_multiply", "cx_dense_cholesky_solve", "cx_evaluator_create_bal", "cx_evaluator_destroy",
-    "cx_evaluator_jacobian", "cx_evaluator_row_of_observation", "cx_evaluator_evaluate", "cx_evaluator_set_loss", "cx_minimizer_default_options", "cx_minimize",
+    "cx_evaluator_jacobian", "cx_evaluator_row_of_observation", "cx_evaluator_evaluate", "cx_evaluator_set_loss", "cx_minimizer_default_options", "cx_minimize", "cx_schur_sparse_structure",
     "cx_evaluator_last_kernel_ms", "cx_detect_structure", "cx_partition_points", "cx_stable_schur_ordering",
 ]
 
@@ -57,7 +57,7 @@ class cx_solver_options(ctypes.Structure):
         ("use_spse_initialization", ctypes.c_int32),
         ("spse_tolerance", ctypes.c_double),
         ("deterministic", ctypes.c_int32),
-        ("reserved", ctypes.c_int32),
+        ("use_explicit_schur_complement", ctypes.c_int32),
     ]
 
 
@@ -557,6 +557,17 @@ def minimize(evaluator, solver, state, options=None, max_summaries=None):
                                its, cap))
     n = min(cap, summ.num_iterations)
     return out, _summary_dict(summ), [_summary_dict(its[i]) for i in range(n)]
+
+
+def schur_sparse_structure(A):
+    """Cell list (row block, column block) of the block-sparse reduced camera matrix, InitStorage order."""
+    lib = A.lib
+    n = ctypes.c_int64()
+    _check(lib.cx_schur_sparse_structure(A._h, ctypes.byref(n), None, None, ctypes.c_int64(0)))
+    r = np.zeros(n.value, dtype=np.int32)
+    c = np.zeros(n.value, dtype=np.int32)
+    _check(lib.cx_schur_sparse_structure(A._h, ctypes.byref(n), _ptr(r), _ptr(c), ctypes.c_int64(n.value)))
+    return r, c
 
 
 def detect_structure(bs, num_eliminate_blocks):

@@ -141,12 +141,21 @@ struct cx_matrix {
   DevBuf<double> d_partials9;            // [S][9] (fused set-up)
   DevBuf<double> d_elim_blk, d_elim_ete, d_elim_diag, d_elim_rows;  // explicit-S scratch (cx_schur.hip)
   DevBuf<int> d_elim_flag;
-  // explicit S without atomics: for every upper block (c1 <= c2) the co-observing row pairs, in chunk order
+  // explicit S without atomics (cx_schur.hip): the non-zero cells of the upper block triangle of S in
+  // the order SparseSchurComplementSolver::InitStorage lists them (every (c,c), then co-visible c1 < c2,
+  // lexicographic -- schur_complement_solver.cc:224-290) and per cell the co-observing row pairs in chunk order
+  std::vector<int32_t> h_cell_c1, h_cell_c2;  // host copy of the cell list (parity tests, sparse consumers)
+  DevBuf<int32_t> d_cell_c1, d_cell_c2;  // [num_cells]
+  DevBuf<int32_t> d_cell_row_start;      // [C + 1] cells of block row c1 (contiguous, sorted by c2)
+  DevBuf<int32_t> d_col_cell_start;      // [C + 1] off-diagonal cells of block column c2 ...
+  DevBuf<int32_t> d_col_cells;           // ... as cell ids sorted by c1
   DevBuf<int32_t> d_pair_rows;           // [2 * num_pairs] (row of camera c1, row of camera c2)
   DevBuf<int64_t> d_item_begin;          // [num_items + 1] work items: runs of <= kPairItem pairs of one cell
-  DevBuf<int32_t> d_cell_item_start;     // [C * C + 1] items of cell c1 * C + c2
+  DevBuf<int32_t> d_cell_item_start;     // [num_cells + 1] items of each cell
   DevBuf<double> d_item_partial;         // [num_items][81]
+  DevBuf<double> d_S;                    // [num_cells][81] sparse S values (without D_f^2), ExplicitSchur
   int64_t num_items = 0;
+  int64_t num_cells = 0;
   DevBuf<double> d_elim_bg0, d_elim_bg1, d_elim_bg2;  // per row B = E'F (3x9) and G = (E'E)^-1 B, 3 x 18 doubles
   int pairs_state = 0;                   // 0 not built, 1 ready, 2 too many pairs (atomic path)
   int64_t num_pairs = 0;

@@ -18,6 +18,13 @@ int cxs_implicit_init(cx_matrix* A, const double* D, const double* b, bool want_
 int cxs_block9_add_diag_invert(cx_context* ctx, double* blocks, const double* Df, int C, int* d_flag);
 // dense lhs (9C x 9C row-major, upper block triangle) and rhs of the reduced system
 int cxs_eliminate_dense(cx_matrix* A, const double* b, const double* D, bool add_df, double* lhs, double* rhs);
+// the same elimination into the block-sparse upper-stored S of the matrix (A->d_S, cell list A->d_cell_*;
+// D_f^2 NOT added, see k_pair_cells); CX_ERR_UNSUPPORTED when the pair list is too large to build
+int cxs_build_pair_lists(cx_matrix* A);
+int cxs_eliminate_sparse(cx_matrix* A, const double* b, const double* D, double* rhs);
+// y = S x with that storage (BlockRandomAccessSparseMatrix::SymmetricRightMultiplyAndAccumulate); blocks[c] = S(c,c)
+int cxs_sparse_multiply(cx_matrix* A, const double* x, double* y);
+int cxs_sparse_diagonal(cx_matrix* A, double* blocks);
 
 // dense Cholesky (cx_cholesky.hip): factor the upper triangle of row-major a (n x n) in
 // place (a = U'U) and solve a x = rhs.  *d_flag set to 1 when not positive definite.

@@ -19,6 +19,7 @@
 #include "cx_schur.h"
 
 #include <algorithm>
+#include <thread>
 #include <cstdlib>
 
 static int grid_for(int64_t n, int block) { return int((n + block - 1) / block); }
@@ -822,45 +823,112 @@ int cxs_build_pair_lists(cx_matrix* A) {
     A->pairs_state = 2;
     return CX_OK;
   }
-  std::vector<int64_t> begin(size_t(C) * C + 1, 0);
   auto cam_of = [&](int64_t r) { return A->cells[2 * r + 1].block_id - A->P; };
+  // 1. bucket the pairs by their smaller camera c1 (stable: chunk order inside a bucket)
+  struct Pair { int32_t c2, ri, rj; };
+  std::vector<int64_t> bucket(size_t(C) + 1, 0);
   for (int p = 0; p < A->P; ++p)
     for (int64_t i = start[p]; i < start[p + 1]; ++i)
-      for (int64_t j = i; j < start[p + 1]; ++j) {
-        const int ci = cam_of(i), cj = cam_of(j);
-        begin[size_t(std::min(ci, cj)) * C + std::max(ci, cj) + 1]++;
-      }
-  for (size_t k = 0; k < size_t(C) * C; ++k) begin[k + 1] += begin[k];
-  std::vector<int32_t> pairs(size_t(2 * total));
+      for (int64_t j = i; j < start[p + 1]; ++j) bucket[size_t(std::min(cam_of(i), cam_of(j))) + 1]++;
+  for (int c = 0; c < C; ++c) bucket[c + 1] += bucket[c];
+  std::vector<Pair> tmp(static_cast<size_t>(total));
   {
-    std::vector<int64_t> fill(begin.begin(), begin.end() - 1);
+    std::vector<int64_t> fill(bucket.begin(), bucket.end() - 1);
     for (int p = 0; p < A->P; ++p)
       for (int64_t i = start[p]; i < start[p + 1]; ++i)
         for (int64_t j = i; j < start[p + 1]; ++j) {
           const int ci = cam_of(i), cj = cam_of(j);
-          const int64_t slot = fill[size_t(std::min(ci, cj)) * C + std::max(ci, cj)]++;
-          pairs[2 * slot] = int32_t(ci <= cj ? i : j);
-          pairs[2 * slot + 1] = int32_t(ci <= cj ? j : i);
+          Pair& q = tmp[size_t(fill[std::min(ci, cj)]++)];
+          q.c2 = std::max(ci, cj);
+          q.ri = int32_t(ci <= cj ? i : j);
+          q.rj = int32_t(ci <= cj ? j : i);
         }
   }
-  // work items: a cell's pair run cut into pieces of at most kPairItem pairs
-  std::vector<int64_t> item_begin;
-  std::vector<int32_t> cell_item_start(size_t(C) * C + 1, 0);
-  for (size_t key = 0; key < size_t(C) * C; ++key) {
-    cell_item_start[key] = int32_t(item_begin.size());
-    for (int64_t b0 = begin[key]; b0 < begin[key + 1]; b0 += kPairItem) item_begin.push_back(b0);
+  // 2. inside every bucket a stable counting sort by c2 gives the cells of block row c1 in order, each with
+  //    its pairs in chunk order; the diagonal cell (c1, c1) exists even without pairs.  Buckets are
+  //    independent: worker threads take them round-robin.
+  std::vector<int32_t> row_cells(size_t(C) + 1, 0);  // cells per block row, then prefix sums
+  std::vector<int32_t> pairs(static_cast<size_t>(2 * total));
+  std::vector<std::vector<int32_t>> row_c2(static_cast<size_t>(C));     // c2 of the row's cells
+  std::vector<std::vector<int64_t>> row_begin(static_cast<size_t>(C));  // first pair of each of them
+  {
+    const unsigned hw = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
+    std::vector<std::thread> workers;
+    for (unsigned t = 0; t < hw; ++t)
+      workers.emplace_back([&, t]() {
+        std::vector<int64_t> cnt(size_t(C) + 1);
+        for (int c1 = int(t); c1 < C; c1 += int(hw)) {
+          const int64_t b0 = bucket[c1], b1 = bucket[c1 + 1];
+          std::fill(cnt.begin() + c1, cnt.end(), 0);
+          for (int64_t k = b0; k < b1; ++k) cnt[size_t(tmp[size_t(k)].c2) + 1]++;
+          std::vector<int32_t>& c2s = row_c2[size_t(c1)];
+          std::vector<int64_t>& begins = row_begin[size_t(c1)];
+          int64_t acc = b0;
+          for (int c2 = c1; c2 < C; ++c2) {
+            const int64_t n = cnt[size_t(c2) + 1];
+            cnt[size_t(c2) + 1] = acc;  // becomes the fill cursor of c2
+            if (n > 0 || c2 == c1) {
+              c2s.push_back(c2);
+              begins.push_back(acc);
+            }
+            acc += n;
+          }
+          for (int64_t k = b0; k < b1; ++k) {
+            const Pair& q = tmp[size_t(k)];
+            const int64_t slot = cnt[size_t(q.c2) + 1]++;
+            pairs[size_t(2 * slot)] = q.ri;
+            pairs[size_t(2 * slot + 1)] = q.rj;
+          }
+        }
+      });
+    for (auto& w : workers) w.join();
   }
-  cell_item_start[size_t(C) * C] = int32_t(item_begin.size());
+  std::vector<Pair>().swap(tmp);
+  for (int c = 0; c < C; ++c) row_cells[size_t(c) + 1] = row_cells[size_t(c)] + int32_t(row_c2[size_t(c)].size());
+  const int64_t ncell = row_cells[size_t(C)];
+  A->h_cell_c1.resize(size_t(ncell));
+  A->h_cell_c2.resize(size_t(ncell));
+  std::vector<int64_t> item_begin;
+  std::vector<int32_t> cell_item_start(size_t(ncell) + 1, 0);
+  std::vector<int32_t> col_count(size_t(C) + 1, 0);
+  for (int c1 = 0; c1 < C; ++c1) {
+    const auto& c2s = row_c2[size_t(c1)];
+    const auto& begins = row_begin[size_t(c1)];
+    for (size_t k = 0; k < c2s.size(); ++k) {
+      const int64_t cell = row_cells[size_t(c1)] + int64_t(k);
+      A->h_cell_c1[size_t(cell)] = c1;
+      A->h_cell_c2[size_t(cell)] = c2s[k];
+      if (c2s[k] != c1) col_count[size_t(c2s[k]) + 1]++;
+      // work items: the cell's pair run cut into pieces of at most kPairItem pairs
+      const int64_t b0 = begins[k];
+      const int64_t b1 = (k + 1 < c2s.size()) ? begins[k + 1] : bucket[size_t(c1) + 1];
+      cell_item_start[size_t(cell)] = int32_t(item_begin.size());
+      for (int64_t q = b0; q < b1; q += kPairItem) item_begin.push_back(q);
+    }
+  }
+  cell_item_start[size_t(ncell)] = int32_t(item_begin.size());
   A->num_items = int64_t(item_begin.size());
-  item_begin.push_back(total);
-  // an item must not run into the next cell: its end is min(next item's begin, its cell's end); the cut
-  // above only starts items inside one cell, and consecutive items of different cells meet at a cell boundary
+  item_begin.push_back(total);  // consecutive items meet at a cell boundary, so item i ends where item i + 1 begins
+  // transposed index: the off-diagonal cells of block column c2, by ascending c1
+  for (int c = 0; c < C; ++c) col_count[size_t(c) + 1] += col_count[size_t(c)];
+  std::vector<int32_t> col_cells(static_cast<size_t>(col_count[size_t(C)]), 0);
+  {
+    std::vector<int32_t> fill(col_count.begin(), col_count.end() - 1);
+    for (int64_t cell = 0; cell < ncell; ++cell)
+      if (A->h_cell_c1[size_t(cell)] != A->h_cell_c2[size_t(cell)]) col_cells[size_t(fill[size_t(A->h_cell_c2[size_t(cell)])]++)] = int32_t(cell);
+  }
   hipStream_t st = A->ctx->stream;
   CX_TRY(A->d_pair_rows.upload(pairs, st));
   CX_TRY(A->d_item_begin.upload(item_begin, st));
   CX_TRY(A->d_cell_item_start.upload(cell_item_start, st));
+  CX_TRY(A->d_cell_c1.upload(A->h_cell_c1, st));
+  CX_TRY(A->d_cell_c2.upload(A->h_cell_c2, st));
+  CX_TRY(A->d_cell_row_start.upload(row_cells, st));
+  CX_TRY(A->d_col_cell_start.upload(col_count, st));
+  CX_TRY(A->d_col_cells.upload(col_cells, st));
   CX_TRY(A->d_item_partial.alloc(size_t(std::max<int64_t>(A->num_items, 1)) * 81));
   A->num_pairs = total;
+  A->num_cells = ncell;
   A->pairs_state = 1;
   return CX_OK;
 }
@@ -953,30 +1021,86 @@ __global__ __launch_bounds__(kBlock) void k_pair_items(const int32_t* __restrict
   }
 }
 
-// Stage 2, 81 threads per 9x9 cell (c1, c2) of the dense lhs: cells below the diagonal are zeroed (the
-// reference never touches them), the others receive [c1 == c2] (F'F + D_f^2) - sum of the cell's items.
-__global__ __launch_bounds__(3 * 81) void k_pair_cells(const int32_t* __restrict__ cell_item_start,
+// Stage 2, 81 threads per non-zero cell (c1 <= c2): [c1 == c2] F'F - sum of the cell's items, written either
+// into the dense row-major lhs (pre-zeroed; D_f^2 added on the diagonal -- the reference's dense S) or
+// into the cell-major sparse value array (81 contiguous doubles per cell, D_f^2 NOT added: the sparse
+// consumers add it after the cross-rank sum).
+__global__ __launch_bounds__(3 * 81) void k_pair_cells(const int32_t* __restrict__ cell_c1, const int32_t* __restrict__ cell_c2,
+                                                       const int32_t* __restrict__ cell_item_start,
                                                        const double* __restrict__ item_partial,
                                                        const double* __restrict__ diag, const double* __restrict__ Df,
-                                                       double* __restrict__ lhs, int C) {
+                                                       double* __restrict__ lhs, double* __restrict__ sparse, int C,
+                                                       int64_t num_cells) {
   const int64_t cell = int64_t(blockIdx.x) * 3 + threadIdx.x / 81;
-  if (cell >= int64_t(C) * C) return;
+  if (cell >= num_cells) return;
   const int el = threadIdx.x % 81;
-  const int c1 = int(cell / C), c2 = int(cell - int64_t(c1) * C);
+  const int c1 = cell_c1[cell], c2 = cell_c2[cell];
   const int a = el / 9, c = el - a * 9;
-  const int64_t n = 9 * int64_t(C);
   double v = 0.0;
-  if (c1 <= c2) {
-    for (int it = cell_item_start[cell]; it < cell_item_start[cell + 1]; ++it) v -= item_partial[int64_t(it) * 81 + el];
-    if (c1 == c2) {
-      v += diag[int64_t(c1) * 81 + el];
-      if (Df && a == c) {
-        const double d = Df[9 * int64_t(c1) + a];
-        v += d * d;
-      }
-    }
+  for (int it = cell_item_start[cell]; it < cell_item_start[cell + 1]; ++it) v -= item_partial[int64_t(it) * 81 + el];
+  if (c1 == c2) v += diag[int64_t(c1) * 81 + el];
+  if (sparse) {
+    sparse[cell * 81 + el] = v;
+    return;
   }
+  if (c1 == c2 && Df && a == c) {
+    const double d = Df[9 * int64_t(c1) + a];
+    v += d * d;
+  }
+  const int64_t n = 9 * int64_t(C);
   lhs[(9 * int64_t(c1) + a) * n + 9 * int64_t(c2) + c] = v;
+}
+
+// BlockRandomAccessSparseMatrix::SymmetricRightMultiplyAndAccumulate (block_random_access_sparse_matrix.cc:
+// 124-163) for the cell-major upper-stored S: y_c = sum_{(c, c2)} S_cell x_c2 + sum_{(c1 < c, c)} S_cell' x_c1.
+// One wavefront per block row c: 7 groups of 9 lanes (lane = one entry of y_c) take every 7th cell of the
+// row list, then of the column list; the 7 group sums are added in group order, so y is reproducible
+// (the reference walks the cells serially and scatters into y).
+__global__ __launch_bounds__(256) void k_sym_spmv(const double* __restrict__ S, const int32_t* __restrict__ cell_c2,
+                                                  const int32_t* __restrict__ cell_c1,
+                                                  const int32_t* __restrict__ row_start,
+                                                  const int32_t* __restrict__ col_start,
+                                                  const int32_t* __restrict__ col_cells, const double* __restrict__ x,
+                                                  double* __restrict__ y, int C, const int* __restrict__ stop) {
+  __shared__ double part[4][63];
+  if (stop && *stop) return;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int c = blockIdx.x * 4 + wave;
+  if (c >= C) return;
+  const int g = lane / 9, a = lane - g * 9;
+  double sum = 0.0;
+  if (g < 7) {
+    for (int k = row_start[c] + g; k < row_start[c + 1]; k += 7) {
+      const double* __restrict__ B = S + int64_t(k) * 81 + a * 9;   // row a of the cell
+      const double* __restrict__ xv = x + 9 * int64_t(cell_c2[k]);
+#pragma unroll
+      for (int j = 0; j < 9; ++j) sum += B[j] * xv[j];
+    }
+    for (int k = col_start[c] + g; k < col_start[c + 1]; k += 7) {
+      const int cell = col_cells[k];
+      const double* __restrict__ B = S + int64_t(cell) * 81 + a;    // column a of the cell
+      const double* __restrict__ xv = x + 9 * int64_t(cell_c1[cell]);
+#pragma unroll
+      for (int j = 0; j < 9; ++j) sum += B[j * 9] * xv[j];
+    }
+    part[wave][lane] = sum;
+  }
+  __syncthreads();
+  if (lane < 9) {
+    double v = 0.0;
+#pragma unroll
+    for (int q = 0; q < 7; ++q) v += part[wave][q * 9 + lane];
+    y[9 * int64_t(c) + lane] = v;
+  }
+}
+
+// blocks[c] = S(c, c) (first cell of every block row)
+__global__ void k_extract_diag_cells(const double* __restrict__ S, const int32_t* __restrict__ row_start,
+                                     double* __restrict__ blocks, int C) {
+  const int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i >= int64_t(C) * 81) return;
+  const int c = int(i / 81);
+  blocks[i] = S[int64_t(row_start[c]) * 81 + (i - int64_t(c) * 81)];
 }
 
 // dense row-major lhs (n = 9C) from the block-major pair sums, the F'F diagonal blocks and D_f^2;
@@ -1087,10 +1211,12 @@ int cxs_eliminate_dense(cx_matrix* A, const double* b, const double* D, bool add
       hipLaunchKernelGGL(k_pair_items, dim3(unsigned(A->num_items)), dim3(kBlock), 0, st, (const int32_t*)A->d_pair_rows.p,
                          (const int64_t*)A->d_item_begin.p, (const double*)A->d_elim_bg0.p, (const double*)A->d_elim_bg1.p,
                          (const double*)A->d_elim_bg2.p, A->d_item_partial.p);
-    if (C > 0)
-      hipLaunchKernelGGL(k_pair_cells, dim3(unsigned((int64_t(C) * C + 2) / 3)), dim3(3 * 81), 0, st,
-                         (const int32_t*)A->d_cell_item_start.p, (const double*)A->d_item_partial.p,
-                         (const double*)A->d_elim_diag.p, (D && add_df) ? D + 3 * int64_t(A->P) : (const double*)nullptr, lhs, C);
+    if (n > 0) CX_HIP(hipMemsetAsync(lhs, 0, size_t(n) * n * sizeof(double), st));
+    if (A->num_cells > 0)
+      hipLaunchKernelGGL(k_pair_cells, dim3(unsigned((A->num_cells + 2) / 3)), dim3(3 * 81), 0, st,
+                         (const int32_t*)A->d_cell_c1.p, (const int32_t*)A->d_cell_c2.p, (const int32_t*)A->d_cell_item_start.p,
+                         (const double*)A->d_item_partial.p, (const double*)A->d_elim_diag.p,
+                         (D && add_df) ? D + 3 * int64_t(A->P) : (const double*)nullptr, lhs, (double*)nullptr, C, A->num_cells);
   } else {
     CX_TRY(A->d_elim_blk.alloc(size_t(std::max<int64_t>(int64_t(C) * C * 81, 1))));
     CX_HIP(hipMemsetAsync(A->d_elim_blk.p, 0, size_t(C) * C * 81 * sizeof(double), st));
@@ -1117,6 +1243,67 @@ int cxs_eliminate_dense(cx_matrix* A, const double* b, const double* D, bool add
       CX_HIP(hipMemsetAsync(rhs, 0, size_t(n) * sizeof(double), st));
     }
   }
+  CX_HIP(hipGetLastError());
+  return CX_OK;
+}
+
+int cxs_eliminate_sparse(cx_matrix* A, const double* b, const double* D, double* rhs) {
+  hipStream_t st = A->ctx->stream;
+  const int C = A->C;
+  CX_TRY(cxs_build_pair_lists(A));
+  if (A->pairs_state != 1) {
+    cx_set_error("the explicit Schur complement of this structure needs more than 2^28 row pairs");
+    return CX_ERR_UNSUPPORTED;
+  }
+  CX_TRY(A->d_elim_ete.alloc(size_t(std::max<int64_t>(9 * int64_t(A->P), 1))));
+  CX_TRY(A->d_elim_diag.alloc(size_t(std::max<int64_t>(81 * int64_t(C), 1))));
+  CX_TRY(A->d_elim_flag.alloc(1));
+  CX_TRY(A->d_S.alloc(size_t(std::max<int64_t>(A->num_cells, 1)) * 81));
+  CX_TRY(cxs_compute_ete_inverse(A, D, nullptr, A->d_elim_ete.p, nullptr, false, A->d_elim_flag.p));
+  const size_t rows18 = size_t(std::max<int64_t>(18 * A->O, 1));
+  CX_TRY(A->d_elim_bg0.alloc(rows18));
+  CX_TRY(A->d_elim_bg1.alloc(rows18));
+  CX_TRY(A->d_elim_bg2.alloc(rows18));
+  if (A->O > 0)
+    hipLaunchKernelGGL(k_row_bg, dim3(grid_for(A->O, kBlock)), dim3(kBlock), 0, st, (const double*)A->d_values.p,
+                       (const double*)(A->d_values.p + 6 * A->O), (const int32_t*)A->d_row_pt.p,
+                       (const double*)A->d_elim_ete.p, A->O, A->d_elim_bg0.p, A->d_elim_bg1.p, A->d_elim_bg2.p);
+  CX_TRY(cxs_camera_block_diagonal(A, false, nullptr, A->d_elim_diag.p));
+  if (A->num_items > 0)
+    hipLaunchKernelGGL(k_pair_items, dim3(unsigned(A->num_items)), dim3(kBlock), 0, st, (const int32_t*)A->d_pair_rows.p,
+                       (const int64_t*)A->d_item_begin.p, (const double*)A->d_elim_bg0.p, (const double*)A->d_elim_bg1.p,
+                       (const double*)A->d_elim_bg2.p, A->d_item_partial.p);
+  if (A->num_cells > 0)
+    hipLaunchKernelGGL(k_pair_cells, dim3(unsigned((A->num_cells + 2) / 3)), dim3(3 * 81), 0, st,
+                       (const int32_t*)A->d_cell_c1.p, (const int32_t*)A->d_cell_c2.p, (const int32_t*)A->d_cell_item_start.p,
+                       (const double*)A->d_item_partial.p, (const double*)A->d_elim_diag.p, (const double*)nullptr,
+                       (double*)nullptr, A->d_S.p, C, A->num_cells);
+  if (rhs) {
+    if (b) {
+      CX_TRY(A->d_elim_rows.alloc(size_t(std::max<int64_t>(A->num_rows, 1))));
+      CX_TRY(cxs_chunk_pass(A, 1, A->d_elim_ete.p, nullptr, b, A->d_elim_rows.p));
+      CX_TRY(cxk_ft_multiply(A, A->d_elim_rows.p, rhs, false));
+    } else {
+      CX_HIP(hipMemsetAsync(rhs, 0, size_t(9) * C * sizeof(double), st));
+    }
+  }
+  CX_HIP(hipGetLastError());
+  return CX_OK;
+}
+
+int cxs_sparse_multiply(cx_matrix* A, const double* x, double* y) {
+  if (A->C == 0) return CX_OK;
+  hipLaunchKernelGGL(k_sym_spmv, dim3((A->C + 3) / 4), dim3(256), 0, A->ctx->stream, (const double*)A->d_S.p,
+                     (const int32_t*)A->d_cell_c2.p, (const int32_t*)A->d_cell_c1.p, (const int32_t*)A->d_cell_row_start.p,
+                     (const int32_t*)A->d_col_cell_start.p, (const int32_t*)A->d_col_cells.p, x, y, A->C, A->stop);
+  CX_HIP(hipGetLastError());
+  return CX_OK;
+}
+
+int cxs_sparse_diagonal(cx_matrix* A, double* blocks) {
+  if (A->C == 0) return CX_OK;
+  hipLaunchKernelGGL(k_extract_diag_cells, dim3(grid_for(int64_t(A->C) * 81, 256)), dim3(256), 0, A->ctx->stream,
+                     (const double*)A->d_S.p, (const int32_t*)A->d_cell_row_start.p, blocks, A->C);
   CX_HIP(hipGetLastError());
   return CX_OK;
 }

@@ -640,6 +640,40 @@ struct ImplicitSchurOp : LinOp {
   }
 };
 
+// S x with the explicitly computed block-sparse Schur complement (BlockRandomAccessSparseMatrixAdapter,
+// schur_complement_solver.cc:60-75 -> SymmetricRightMultiplyAndAccumulate); D_f^2 is added after the
+// cross-rank sum because every rank holds the S of its own points only.
+struct ExplicitSchurOp : LinOp {
+  cx_solver* S;
+  cx_matrix* A;
+  const double* D;
+  int64_t size() const override { return 9 * int64_t(A->C); }
+  int apply(const double* x, double* y) override {
+    cx_context* ctx = A->ctx;
+    CX_TRY(S->ktimer.begin(4, ctx->stream));
+    CX_TRY(cxs_sparse_multiply(A, x, y));
+    CX_TRY(S->ktimer.end(4, ctx->stream));
+    if (ctx->nranks > 1) CX_TRY(cx_allreduce_device(ctx, y, size()));
+    if (D)
+      hipLaunchKernelGGL(k_add_d2x, dim3(grid_for(size(), 256)), dim3(256), 0, ctx->stream, y, D + 3 * int64_t(A->P), x, size());
+    CX_HIP(hipGetLastError());
+    return CX_OK;
+  }
+  int apply_dot(const double* x, double* y, const DotTail& tail, bool* done) override {
+    cx_context* ctx = A->ctx;
+    const int64_t n = size();
+    const int grid = int(std::min<int64_t>(kRedBlocks, std::max<int64_t>(1, (n + 255) / 256)));
+    CX_TRY(S->ktimer.begin(4, ctx->stream));
+    CX_TRY(cxs_sparse_multiply(A, x, y));
+    CX_TRY(S->ktimer.end(4, ctx->stream));
+    if (ctx->nranks > 1) CX_TRY(cx_allreduce_device(ctx, y, n));
+    hipLaunchKernelGGL(k_d2x_dot, dim3(grid), dim3(256), 0, ctx->stream, y, D ? D + 3 * int64_t(A->P) : (const double*)nullptr, x, n, tail);
+    CX_HIP(hipGetLastError());
+    *done = true;
+    return CX_OK;
+  }
+};
+
 __global__ void k_axpy1(double* __restrict__ y, const double* __restrict__ x, int64_t n) {
   const int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
   if (i < n) y[i] += x[i];
@@ -890,6 +924,59 @@ int SolveIterativeSchur239(cx_solver* S, cx_matrix* A, const double* b, const do
   return CX_OK;
 }
 
+// ITERATIVE_SCHUR with use_explicit_schur_complement: SparseSchurComplementSolver with the CG reduced solve
+// (linear_solver.cc:111-116, schur_complement_solver.cc:101-159 + 337-420): Eliminate into the block-sparse S,
+// block-Jacobi preconditioner from its diagonal cells (= SCHUR_JACOBI), CG, BackSubstitute.
+int SolveExplicitSchur239(cx_solver* S, cx_matrix* A, const double* b, const double* D, double r_tol, double q_tol,
+                          double* x, cx_summary* summary) {
+  cx_context* ctx = S->ctx;
+  hipStream_t st = ctx->stream;
+  const int64_t nf = 9 * int64_t(A->C), ne = 3 * int64_t(A->P);
+  Stopwatch sw{st, ctx->ev[2], ctx->ev[3]};
+  CX_TRY(S->ete_inv.alloc(9 * size_t(A->P)));
+  CX_TRY(S->v_rhs.alloc(nf));
+  CX_TRY(S->v_x.alloc(nf));
+  CX_TRY(S->cam_blocks.alloc(81 * size_t(std::max(A->C, 1))));
+  CX_TRY(S->flag.alloc(1));
+  CX_HIP(hipMemsetAsync(S->flag.p, 0, sizeof(int), st));
+  CX_TRY(sw.start());
+  CX_TRY(cxs_eliminate_sparse(A, b, D, S->v_rhs.p));
+  CX_TRY(cxs_sparse_diagonal(A, S->cam_blocks.p));
+  if (ctx->nranks > 1) {
+    CX_TRY(cx_allreduce_device(ctx, S->cam_blocks.p, 81 * int64_t(A->C)));
+    CX_TRY(cx_allreduce_device(ctx, S->v_rhs.p, nf));
+  }
+  // preconditioner_->Invert() on S(c,c) + D_f^2 (schur_complement_solver.cc:360-383)
+  CX_TRY(cxs_block9_add_diag_invert(ctx, S->cam_blocks.p, D ? D + ne : nullptr, A->C, S->flag.p));
+  CX_TRY(sw.stop(&S->timing.eliminate_ms));
+  bool failed = false;
+  CX_TRY(CheckFlag(S, "Preconditioner update failed.", summary, &failed));
+  if (failed) return CX_OK;
+
+  CX_TRY(sw.start());
+  CX_HIP(hipMemsetAsync(S->v_x.p, 0, nf * sizeof(double), st));
+  ExplicitSchurOp lhs;
+  lhs.S = S; lhs.A = A; lhs.D = D;
+  BlockDiag9Op bd;
+  bd.ctx = ctx; bd.blocks = S->cam_blocks.p; bd.nblocks = A->C;
+  CgDriver cg{S, ctx, st, nf, nf};
+  CX_TRY(S->state.alloc(1));
+  A->stop = &S->state.p->flag;
+  const int cg_rc = cg.run(lhs, bd, S->v_rhs.p, S->v_x.p, true, r_tol, q_tol, summary);
+  A->stop = nullptr;
+  CX_TRY(cg_rc);
+  CX_TRY(sw.stop(&S->timing.reduced_solve_ms));
+
+  CX_TRY(sw.start());
+  if (summary->termination_type != CX_FAILURE && summary->termination_type != CX_FATAL_ERROR) {
+    // SchurEliminator::BackSubstitute (schur_eliminator_impl.h:307-373); (E'E + D^2)^-1 is the eliminator's
+    CX_TRY(cxs_chunk_pass(A, 2, A->d_elim_ete.p, S->v_x.p, b, x));
+    CX_HIP(hipMemcpyAsync(x + ne, S->v_x.p, nf * sizeof(double), hipMemcpyDeviceToDevice, st));
+  }
+  CX_TRY(sw.stop(&S->timing.back_substitute_ms));
+  return CX_OK;
+}
+
 int SolveCgnr239(cx_solver* S, cx_matrix* A, const double* b, const double* D, double r_tol, double q_tol,
                  double* x, cx_summary* summary) {
   cx_context* ctx = S->ctx;
@@ -1056,6 +1143,17 @@ int cx_solver_create(cx_context* ctx, const cx_solver_options* options, cx_solve
   CX_CHECK_ARG(options->type >= CX_DENSE_SCHUR && options->type <= CX_CGNR);
   CX_CHECK_ARG(options->residual_reset_period > 0 && options->max_num_iterations >= 0);
   if (options->type != CX_CGNR) CX_CHECK_ARG(options->num_eliminate_blocks > 0);
+  if (options->type == CX_ITERATIVE_SCHUR && options->use_explicit_schur_complement) {
+    // the reference's option validation (solver.cc:277-290)
+    if (options->preconditioner_type != CX_SCHUR_JACOBI) {
+      cx_set_error("use_explicit_schur_complement only supports SCHUR_JACOBI as the preconditioner.");
+      return CX_ERR_INVALID_ARGUMENT;
+    }
+    if (options->use_spse_initialization) {
+      cx_set_error("use_explicit_schur_complement does not support use_spse_initialization.");
+      return CX_ERR_INVALID_ARGUMENT;
+    }
+  }
   auto* s = new cx_solver;
   s->ctx = ctx;
   s->opt = *options;
@@ -1113,10 +1211,17 @@ int cx_solver_solve(cx_solver* S, cx_matrix* A, const double* b, const cx_per_so
   int rc;
   if (A->is239) {
     switch (o.type) {
-      case CX_ITERATIVE_SCHUR: rc = SolveIterativeSchur239(S, A, hb.dptr, hD.dptr, ps->r_tolerance, ps->q_tolerance, hx.dptr, summary); break;
+      case CX_ITERATIVE_SCHUR:
+        rc = o.use_explicit_schur_complement
+                 ? SolveExplicitSchur239(S, A, hb.dptr, hD.dptr, ps->r_tolerance, ps->q_tolerance, hx.dptr, summary)
+                 : SolveIterativeSchur239(S, A, hb.dptr, hD.dptr, ps->r_tolerance, ps->q_tolerance, hx.dptr, summary);
+        break;
       case CX_CGNR: rc = SolveCgnr239(S, A, hb.dptr, hD.dptr, ps->r_tolerance, ps->q_tolerance, hx.dptr, summary); break;
       default: rc = SolveDenseSchur239(S, A, hb.dptr, hD.dptr, hx.dptr, summary); break;
     }
+  } else if (o.type == CX_ITERATIVE_SCHUR && o.use_explicit_schur_complement) {
+    cx_set_error("use_explicit_schur_complement needs the static <2,3,9> layout");
+    rc = CX_ERR_UNSUPPORTED;
   } else {
     rc = cxg_solve(S, A, hb.dptr, hD.dptr, ps->r_tolerance, ps->q_tolerance, hx.dptr, summary);
   }
@@ -1136,6 +1241,26 @@ int cx_solver_solve(cx_solver* S, cx_matrix* A, const double* b, const cx_per_so
 }
 
 // ---- Schur pieces on their own (parity tests)
+int cx_schur_sparse_structure(cx_matrix* A, int64_t* num_cells, int32_t* cell_row, int32_t* cell_col, int64_t capacity) {
+  CX_CHECK_ARG(A && num_cells && capacity >= 0);
+  if (!A->is239) {
+    cx_set_error("cx_schur_sparse_structure needs the static <2,3,9> layout");
+    return CX_ERR_UNSUPPORTED;
+  }
+  CX_HIP(hipSetDevice(A->ctx->device));
+  CX_TRY(cxs_build_pair_lists(A));
+  if (A->pairs_state != 1) {
+    cx_set_error("the pair list of this structure is too large to build");
+    return CX_ERR_UNSUPPORTED;
+  }
+  *num_cells = A->num_cells;
+  const int64_t m = std::min<int64_t>(capacity, A->num_cells);
+  for (int64_t i = 0; i < m; ++i) {
+    if (cell_row) cell_row[i] = A->h_cell_c1[size_t(i)];
+    if (cell_col) cell_col[i] = A->h_cell_c2[size_t(i)];
+  }
+  return CX_OK;
+}
 int cx_schur_eliminate_dense(cx_context* ctx, cx_matrix* A, const double* b, const double* D, double* lhs,
                              double* rhs, int32_t memspace) {
   CX_CHECK_ARG(ctx && A && lhs);

@@ -51,8 +51,8 @@ struct LinOp {
 // Per-kernel device time of the last solve, sampled with HIP event pairs on the
 // context stream (read back after the solve; no synchronisation inside the loop).
 struct KernelTimer {
-  static constexpr int kSlots = 4, kMaxSamples = 64;
-  const char* names[kSlots] = {"k_chunk_pass<0>", "k_cam_ft+k_cam_reduce9_dot", "k_right_239", "k_left_e_239+k_cam_ft"};
+  static constexpr int kSlots = 5, kMaxSamples = 64;
+  const char* names[kSlots] = {"k_chunk_pass<0>", "k_cam_ft+k_cam_reduce9_dot", "k_right_239", "k_left_e_239+k_cam_ft", "k_sym_spmv"};
   hipEvent_t ev[kSlots][kMaxSamples][2] = {};
   int count[kSlots] = {};
   int launches[kSlots] = {};

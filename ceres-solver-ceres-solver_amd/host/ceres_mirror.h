@@ -102,6 +102,7 @@ class LinearSolver {
     int residual_reset_period = 10;
     std::vector<int> elimination_groups;
     int row_block_size = -1, e_block_size = -1, f_block_size = -1;
+    bool use_explicit_schur_complement = false;  // linear_solver.h:161
     bool use_mixed_precision_solves = false;
     int max_num_refinement_iterations = 0;
     int max_num_spse_iterations = 5;

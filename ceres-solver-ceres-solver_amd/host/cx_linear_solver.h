@@ -108,6 +108,7 @@ class CxLinearSolver final : public BlockSparseMatrixSolver {
       o.max_num_spse_iterations = options_.max_num_spse_iterations;
       o.use_spse_initialization = options_.use_spse_initialization;
       o.spse_tolerance = options_.spse_tolerance;
+      o.use_explicit_schur_complement = options_.use_explicit_schur_complement;
       if (cx_solver_create(ctx, &o, &solver_) != CX_OK) return Fatal(&summary);
     }
     // Values change every LM iteration: upload them verbatim (same cell layout).

@@ -111,7 +111,7 @@ typedef struct {
   int32_t use_spse_initialization;    /* default 0 */
   double spse_tolerance;              /* default 0.1 */
   int32_t deterministic;              /* 1: camera-space sums in fixed order (bitwise reproducible) */
-  int32_t reserved;
+  int32_t use_explicit_schur_complement; /* ITERATIVE_SCHUR on an explicitly computed block-sparse S (solver.h:518-540) */
 } cx_solver_options;
 
 /* LinearSolver::PerSolveOptions (linear_solver.h:232-318) */
@@ -261,6 +261,12 @@ int cx_schur_eliminate_dense(cx_context* ctx, cx_matrix* A, const double* b, con
                              double* lhs, double* rhs, int32_t memspace);
 /* SchurEliminator::BackSubstitute (schur_eliminator_impl.h:307-373): z has
  * num_cols_f entries, x num_cols; only the e-part of x is written. */
+/* The cell set of the block-sparse reduced camera matrix, in the order
+ * SparseSchurComplementSolver::InitStorage creates it (schur_complement_solver.cc:224-290): every diagonal
+ * cell (i, i) and every (i, j), i < j, of two f-blocks observed together in some chunk, lexicographic.
+ * Static <2,3,9> matrices only.  *num_cells is always set; the arrays (may be NULL) receive up to
+ * capacity entries of the (row block, column block) ids. */
+int cx_schur_sparse_structure(cx_matrix* A, int64_t* num_cells, int32_t* cell_row, int32_t* cell_col, int64_t capacity);
 int cx_schur_back_substitute(cx_context* ctx, cx_matrix* A, const double* b, const double* D,
                              const double* z, double* x, int32_t memspace);
 /* ImplicitSchurComplement: Init + RightMultiplyAndAccumulate

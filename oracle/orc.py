@@ -30,7 +30,7 @@ class cx_solver_options(ctypes.Structure):
         ("use_spse_initialization", ctypes.c_int32),
         ("spse_tolerance", ctypes.c_double),
         ("deterministic", ctypes.c_int32),
-        ("reserved", ctypes.c_int32),
+        ("use_explicit_schur_complement", ctypes.c_int32),
     ]
 
 
@@ -122,6 +122,7 @@ def lib():
         _LIB.orc_to_crs.restype = ctypes.c_int64
         _LIB.orc_stable_schur_ordering.restype = ctypes.c_int
         _LIB.orc_last_solve_seconds.restype = ctypes.c_double
+        _LIB.orc_schur_sparse_structure.restype = ctypes.c_int64
     return _LIB
 
 
@@ -140,9 +141,18 @@ def set_num_threads(n):
     lib().orc_set_num_threads(int(n))
 
 
+def schur_sparse_structure(bs, num_eliminate_blocks):
+    n = lib().orc_schur_sparse_structure(bs.c, int(num_eliminate_blocks), None, None, ctypes.c_int64(0))
+    r = np.zeros(n, dtype=np.int32)
+    c = np.zeros(n, dtype=np.int32)
+    lib().orc_schur_sparse_structure(bs.c, int(num_eliminate_blocks), _p(r), _p(c), ctypes.c_int64(n))
+    return r, c
+
+
 def make_options(type=ITERATIVE_SCHUR, preconditioner_type=JACOBI, num_eliminate_blocks=0,
                  min_num_iterations=0, max_num_iterations=500, residual_reset_period=10,
-                 max_num_spse_iterations=5, use_spse_initialization=0, spse_tolerance=0.1):
+                 max_num_spse_iterations=5, use_spse_initialization=0, spse_tolerance=0.1,
+                 use_explicit_schur_complement=0):
     o = cx_solver_options()
     o.type = type
     o.preconditioner_type = preconditioner_type
@@ -153,6 +163,7 @@ def make_options(type=ITERATIVE_SCHUR, preconditioner_type=JACOBI, num_eliminate
     o.max_num_spse_iterations = max_num_spse_iterations
     o.use_spse_initialization = use_spse_initialization
     o.spse_tolerance = spse_tolerance
+    o.use_explicit_schur_complement = use_explicit_schur_complement
     return o
 
 

@@ -55,6 +55,11 @@ int orc_solve(const cx_block_structure* bs, const double* values, const double* 
               const cx_solver_options* options, double r_tolerance, double q_tolerance, double* x,
               cx_summary* summary);
 
+/* SparseSchurComplementSolver::InitStorage (schur_complement_solver.cc:224-290): the (row, column) f-block
+ * ids of the cells of the block-sparse reduced matrix in creation order; returns their number */
+int64_t orc_schur_sparse_structure(const cx_block_structure* bs, int num_eliminate_blocks, int32_t* cell_row,
+                                   int32_t* cell_col, int64_t capacity);
+
 /* wall seconds of the numeric part of the last orc_solve (structure set-up excluded) */
 double orc_last_solve_seconds(void);
 

@@ -10,6 +10,8 @@
 // can check sharded == unsharded.
 #include <omp.h>
 
+#include <set>
+
 #include <cstdio>
 #include <functional>
 
@@ -621,6 +623,138 @@ static cx_summary SolveDenseSchur(const cx_block_structure* s, const double* val
   return summary;
 }
 
+// SparseSchurComplementSolver::InitStorage (schur_complement_solver.cc:224-290): the cell set of the
+// block-sparse reduced matrix -- every (i, i), every (i, j), i < j, of f-blocks met in one chunk, and the
+// f x f cells of rows without an e-block; std::set order = lexicographic.
+static std::vector<std::pair<int, int>> SparseSchurCells(const cx_block_structure* s, int num_eliminate_blocks) {
+  BS bs(s);
+  std::set<std::pair<int, int>> block_pairs;
+  const int num_f = bs.C - num_eliminate_blocks;
+  for (int i = 0; i < num_f; ++i) block_pairs.emplace(i, i);
+  int r = 0;
+  while (r < bs.R) {
+    const int e_block_id = bs.cells[bs.rcb[r]].block_id;
+    if (e_block_id >= num_eliminate_blocks) break;
+    std::vector<int> f_blocks;
+    for (; r < bs.R; ++r) {
+      if (bs.cells[bs.rcb[r]].block_id != e_block_id) break;
+      for (int c = bs.rcb[r] + 1; c < bs.rcb[r + 1]; ++c) f_blocks.push_back(bs.cells[c].block_id - num_eliminate_blocks);
+    }
+    std::sort(f_blocks.begin(), f_blocks.end());
+    f_blocks.erase(std::unique(f_blocks.begin(), f_blocks.end()), f_blocks.end());
+    for (size_t i = 0; i < f_blocks.size(); ++i)
+      for (size_t j = i + 1; j < f_blocks.size(); ++j) block_pairs.emplace(f_blocks[i], f_blocks[j]);
+  }
+  for (; r < bs.R; ++r) {
+    for (int i = bs.rcb[r]; i < bs.rcb[r + 1]; ++i) {
+      const int b1 = bs.cells[i].block_id - num_eliminate_blocks;
+      for (int j = bs.rcb[r]; j < bs.rcb[r + 1]; ++j) {
+        const int b2 = bs.cells[j].block_id - num_eliminate_blocks;
+        if (b1 <= b2) block_pairs.emplace(b1, b2);
+      }
+    }
+  }
+  return std::vector<std::pair<int, int>>(block_pairs.begin(), block_pairs.end());
+}
+
+// ITERATIVE_SCHUR with use_explicit_schur_complement: SparseSchurComplementSolver (linear_solver.cc:111-116)
+// with SolveReducedLinearSystemUsingConjugateGradients (schur_complement_solver.cc:337-420).  The eliminator
+// writes the same cells into a dense matrix here (identical arithmetic per cell); the operator walks the
+// InitStorage cell list as BlockRandomAccessSparseMatrix::SymmetricRightMultiplyAndAccumulate does
+// (block_random_access_sparse_matrix.cc:124-163).
+static cx_summary SolveExplicitSchur(const cx_block_structure* s, const double* values, const double* b,
+                                     const double* D, const cx_solver_options& o, double r_tol, double q_tol,
+                                     double* x, const Comm& comm, int threads) {
+  const int nelim = o.num_eliminate_blocks;
+  Eliminator el(s, values, nelim);
+  auto sizes = el.FBlockSizes();
+  int n = 0;
+  std::vector<int> pos;
+  for (int f : sizes) { pos.push_back(n); n += f; }
+  const int num_cols = el.bs.num_cols();
+  Vec lhs(size_t(n) * n), rhs(n);
+  DenseBRAM m(lhs.data(), sizes);
+  const auto cells = SparseSchurCells(s, nelim);
+  MarkSolveStart();
+  std::fill(x, x + num_cols, 0.0);
+  if (!comm.active()) {
+    el.Eliminate(b, D, &m, rhs.data(), threads);
+  } else {
+    Vec Dmod;
+    const double* Duse = nullptr;
+    if (D) {
+      Dmod.assign(D, D + num_cols);
+      std::fill(Dmod.begin() + (num_cols - n), Dmod.end(), 0.0);
+      Duse = Dmod.data();
+    }
+    el.Eliminate(b, Duse, &m, rhs.data(), threads);
+    comm.Sum(lhs.data(), int64_t(lhs.size()));
+    comm.Sum(rhs.data(), n);
+    if (D) for (int i = 0; i < n; ++i) lhs[size_t(i) * n + i] += D[num_cols - n + i] * D[num_cols - n + i];
+  }
+  cx_summary summary;
+  std::memset(&summary, 0, sizeof(summary));
+  if (n == 0) {
+    summary.termination_type = CX_SUCCESS;
+    SetMessage(&summary, "Success.");
+    el.BackSubstitute(b, D, x + num_cols, x, threads);
+    return summary;
+  }
+  // block Jacobi preconditioner: diagonal cells, BlockRandomAccessDiagonalMatrix::Invert (LLT per block)
+  std::vector<Vec> pre(sizes.size());
+  for (size_t i = 0; i < sizes.size(); ++i) {
+    const int f = sizes[i];
+    pre[i].resize(size_t(f) * f);
+    for (int a = 0; a < f; ++a)
+      for (int c = 0; c < f; ++c) pre[i][a * f + c] = lhs[size_t(pos[i] + a) * n + pos[i] + c];
+    if (!InvertPSD(pre[i].data(), f)) {
+      summary.termination_type = CX_FAILURE;
+      SetMessage(&summary, "Preconditioner update failed.");
+      return summary;
+    }
+  }
+  Op op = [&](const Vec& xx, Vec& y) {
+    for (const auto& cell : cells) {
+      const int r = cell.first, c = cell.second;
+      const int fr = sizes[r], fc = sizes[c];
+      for (int a = 0; a < fr; ++a) {
+        double sum = 0.0;
+        for (int k = 0; k < fc; ++k) sum += lhs[size_t(pos[r] + a) * n + pos[c] + k] * xx[pos[c] + k];
+        y[pos[r] + a] += sum;
+      }
+      if (r == c) continue;
+      for (int k = 0; k < fc; ++k) {
+        double sum = 0.0;
+        for (int a = 0; a < fr; ++a) sum += lhs[size_t(pos[r] + a) * n + pos[c] + k] * xx[pos[r] + a];
+        y[pos[c] + k] += sum;
+      }
+    }
+  };
+  Op precond = [&](const Vec& r, Vec& z) {
+    for (size_t i = 0; i < sizes.size(); ++i) {
+      const int f = sizes[i];
+      for (int a = 0; a < f; ++a) {
+        double sum = 0.0;
+        for (int k = 0; k < f; ++k) sum += pre[i][a * f + k] * r[pos[i] + k];
+        z[pos[i] + a] += sum;
+      }
+    }
+  };
+  CGOptions cg;
+  cg.min_num_iterations = o.min_num_iterations;
+  cg.max_num_iterations = o.max_num_iterations;
+  cg.residual_reset_period = o.residual_reset_period;
+  cg.q_tolerance = q_tol;
+  cg.r_tolerance = r_tol;
+  Vec sol(n, 0.0);
+  summary = ConjugateGradients(cg, op, rhs, precond, PlainDot, sol);
+  double* reduced = x + num_cols - n;
+  std::copy(sol.begin(), sol.end(), reduced);
+  if (summary.termination_type != CX_FAILURE && summary.termination_type != CX_FATAL_ERROR)
+    el.BackSubstitute(b, D, reduced, x, threads);
+  return summary;
+}
+
 static int Solve(const cx_block_structure* bs, const double* values, const double* b, const double* D,
                  const cx_solver_options* o, double r_tol, double q_tol, double* x, cx_summary* out,
                  const Comm& comm) {
@@ -629,7 +763,10 @@ static int Solve(const cx_block_structure* bs, const double* values, const doubl
   MarkSolveStart();
   switch (o->type) {
     case CX_CGNR: s = SolveCgnr(bs, values, b, D, *o, r_tol, q_tol, x, comm, threads); break;
-    case CX_ITERATIVE_SCHUR: s = SolveIterativeSchur(bs, values, b, D, *o, r_tol, q_tol, x, comm, threads); break;
+    case CX_ITERATIVE_SCHUR:
+      s = o->use_explicit_schur_complement ? SolveExplicitSchur(bs, values, b, D, *o, r_tol, q_tol, x, comm, threads)
+                                           : SolveIterativeSchur(bs, values, b, D, *o, r_tol, q_tol, x, comm, threads);
+      break;
     case CX_DENSE_SCHUR:
     case CX_SPARSE_SCHUR: s = SolveDenseSchur(bs, values, b, D, *o, x, comm, threads); break;
     default: return -1;
@@ -646,6 +783,16 @@ using namespace orc;
 extern "C" {
 
 double orc_last_solve_seconds(void) { return g_last_solve_seconds; }
+
+int64_t orc_schur_sparse_structure(const cx_block_structure* bs, int num_eliminate_blocks, int32_t* cell_row,
+                                   int32_t* cell_col, int64_t capacity) {
+  const auto cells = SparseSchurCells(bs, num_eliminate_blocks);
+  for (int64_t i = 0; i < std::min<int64_t>(capacity, int64_t(cells.size())); ++i) {
+    if (cell_row) cell_row[i] = cells[size_t(i)].first;
+    if (cell_col) cell_col[i] = cells[size_t(i)].second;
+  }
+  return int64_t(cells.size());
+}
 
 int orc_solve(const cx_block_structure* bs, const double* values, const double* b, const double* D,
               const cx_solver_options* o, double r_tol, double q_tol, double* x, cx_summary* out) {

@@ -169,6 +169,40 @@ def test_solvers_match_oracle(ctx, oracle, stype, pre, C, P, O, seed):
     A.close()
 
 
+@pytest.mark.parametrize("C,P,O,seed", PROBLEMS[:2])
+def test_explicit_schur_complement(ctx, oracle, C, P, O, seed):
+    """ITERATIVE_SCHUR with use_explicit_schur_complement (solver.h:518-540): CG on the block-sparse S with
+    the block Jacobi of S (schur_complement_solver.cc:337-420).  Cell set bit-exact with InitStorage's; same
+    iteration count as the oracle; the step equals the implicit SCHUR_JACOBI solve's to CG accuracy."""
+    prob, bs, order, vals, b, D = make(C, P, O, seed, "eval", oracle)
+    A = cx.Matrix(ctx, bs, P)
+    A.set_values(vals)
+    r, c = cx.binding.schur_sparse_structure(A)
+    r_ref, c_ref = oracle.schur_sparse_structure(bs, P)
+    assert np.array_equal(r, r_ref) and np.array_equal(c, c_ref)        # integer structure: exact
+    kw = dict(type=cx.ITERATIVE_SCHUR, preconditioner_type=cx.SCHUR_JACOBI, num_eliminate_blocks=P, max_num_iterations=200)
+    S = cx.Solver(ctx, use_explicit_schur_complement=1, **kw)
+    x, s = S.solve(A, b, D, r_tolerance=-1.0, q_tolerance=0.1)
+    oo = oracle.make_options(type=oracle.ITERATIVE_SCHUR, preconditioner_type=oracle.SCHUR_JACOBI, num_eliminate_blocks=P,
+                             max_num_iterations=200, use_explicit_schur_complement=1)
+    xr, sr = oracle.solve(bs, vals, b, D, oo, r_tolerance=-1.0, q_tolerance=0.1)
+    assert s.termination_type == sr.termination_type, (s.message, sr.message)
+    assert s.num_iterations == sr.num_iterations, (s.message, sr.message)
+    assert relerr(x, xr) < 1e-8
+    x2, s2 = S.solve(A, b, D, r_tolerance=-1.0, q_tolerance=0.1)
+    assert np.array_equal(x, x2)                                          # fixed summation order
+    Si = cx.Solver(ctx, **kw)
+    xi, si = Si.solve(A, b, D, r_tolerance=-1.0, q_tolerance=0.1)
+    assert si.num_iterations == s.num_iterations and relerr(x, xi) < 1e-7
+    # option validation of the reference (solver.cc:277-290)
+    with pytest.raises(cx.CxError):
+        cx.Solver(ctx, type=cx.ITERATIVE_SCHUR, preconditioner_type=cx.JACOBI, num_eliminate_blocks=P,
+                  use_explicit_schur_complement=1)
+    Si.close()
+    S.close()
+    A.close()
+
+
 @pytest.mark.parametrize("stype,pre", [("ITERATIVE_SCHUR", "JACOBI"), ("CGNR", "JACOBI"), ("DENSE_SCHUR", "IDENTITY")])
 def test_solvers_converged_solution(ctx, oracle, stype, pre):
     """Run to r_tolerance 1e-12 and compare with the dense normal-equation solution

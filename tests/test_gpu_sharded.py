@@ -59,17 +59,18 @@ def _worker(rank, port, results_dir):
     out.append(("cost", abs(cost - cost_f) <= 1e-11 * cost_f))
     out.append(("grad_cam", float(np.abs(grad[3 * sub.num_points:] - grad_f[3 * P:]).max() / np.abs(grad_f).max()) < 1e-10))
     A = ev.jacobian()
-    for stype, pre in (("ITERATIVE_SCHUR", "JACOBI"), ("ITERATIVE_SCHUR", "SCHUR_JACOBI"),
-                       ("ITERATIVE_SCHUR", "SCHUR_POWER_SERIES_EXPANSION"), ("CGNR", "JACOBI"), ("DENSE_SCHUR", "IDENTITY")):
+    for stype, pre, explicit in (("ITERATIVE_SCHUR", "JACOBI", 0), ("ITERATIVE_SCHUR", "SCHUR_JACOBI", 0),
+                                 ("ITERATIVE_SCHUR", "SCHUR_POWER_SERIES_EXPANSION", 0), ("CGNR", "JACOBI", 0),
+                                 ("DENSE_SCHUR", "IDENTITY", 0), ("ITERATIVE_SCHUR", "SCHUR_JACOBI", 1)):
         o_full = orc.make_options(type=getattr(orc, stype), preconditioner_type=getattr(orc, pre),
-                                  num_eliminate_blocks=P, max_num_iterations=300)
+                                  num_eliminate_blocks=P, max_num_iterations=300, use_explicit_schur_complement=explicit)
         x_full, s_full = orc.solve(bs_full, vals_f, res_f, D_full, o_full, r_tolerance=-1.0, q_tolerance=0.1)
         S = cx.Solver(ctx, type=getattr(cx, stype), preconditioner_type=getattr(cx, pre),
-                      num_eliminate_blocks=sub.num_points, max_num_iterations=300)
+                      num_eliminate_blocks=sub.num_points, max_num_iterations=300, use_explicit_schur_complement=explicit)
         x, s = S.solve(A, res, D, r_tolerance=-1.0, q_tolerance=0.1)
         expect = np.concatenate([x_full[3 * lo:3 * hi], x_full[3 * P:]])
         err = float(np.abs(x - expect).max() / np.abs(expect).max())
-        out.append((stype + "+" + pre, s.termination_type == s_full.termination_type and
+        out.append((stype + "+" + pre + ("+explicit" if explicit else ""), s.termination_type == s_full.termination_type and
                     s.num_iterations == s_full.num_iterations and err < 1e-8, err, s.num_iterations, s_full.num_iterations))
         S.close()
     # sharded trust-region loop: every rank must walk the same iterations as the unsharded oracle loop
@@ -104,7 +105,7 @@ def test_two_ranks_one_gpu(tmp_path, oracle):
     mp.spawn(_worker, args=(port, str(tmp_path)), nprocs=WORLD, join=True)
     for rank in range(WORLD):
         lines = open(tmp_path / ("rank%d.txt" % rank)).read().strip().splitlines()
-        assert len(lines) == 8
+        assert len(lines) == 9
         for line in lines:
             rec = eval(line)
             assert rec[1], line

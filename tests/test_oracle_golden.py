@@ -158,6 +158,50 @@ def test_iterative_schur_vs_dense(oracle, pid, pre):
     assert np.linalg.norm(x - sol) < 1e-11
 
 
+@pytest.mark.parametrize("pid", [2, 3, 4, 5, 6])
+def test_explicit_schur_complement_cg_vs_dense(oracle, pid):
+    """use_explicit_schur_complement (ITERATIVE_SCHUR on the block-sparse S, SCHUR_JACOBI): the procedure of
+    iterative_schur_complement_solver_test.cc:59-149 (max_iter = num_cols, r_tol 1e-12, dense gold) applied to
+    SparseSchurComplementSolver::SolveReducedLinearSystemUsingConjugateGradients (schur_complement_solver.cc:337-420)."""
+    bs, values, b, D, nelim, raw = lls_problem(pid)
+    J, H, g, S, rhs_ref, sol = dense_reference(bs, values, b, D, nelim)
+    o = oracle.make_options(type=oracle.ITERATIVE_SCHUR, preconditioner_type=oracle.SCHUR_JACOBI,
+                            num_eliminate_blocks=nelim, max_num_iterations=bs.num_cols, use_explicit_schur_complement=1)
+    x, s = oracle.solve(bs, values, b, D, o, r_tolerance=1e-12)
+    assert s.termination_type == oracle.SUCCESS, s.message
+    assert np.linalg.norm(x - sol) < 1e-11
+
+
+@pytest.mark.parametrize("pid", [2, 3, 4, 5, 6])
+def test_sparse_schur_cell_structure(oracle, pid):
+    """SparseSchurComplementSolver::InitStorage (schur_complement_solver.cc:224-290): the cell set is exactly the
+    upper block triangle of the non-zero pattern of S (plus every diagonal cell), in lexicographic order."""
+    bs, values, b, D, nelim, raw = lls_problem(pid)
+    r, c = oracle.schur_sparse_structure(bs, nelim)
+    cells = list(zip(r.tolist(), c.tolist()))
+    assert cells == sorted(set(cells)) and all(i <= j for i, j in cells)
+    nf = bs.num_col_blocks - nelim
+    assert all((i, i) in cells for i in range(nf))
+    # structural pattern from the Jacobian: f-blocks sharing an e-block, or a row without e-block
+    pat = set((i, i) for i in range(nf))
+    rows = {}
+    for rb in range(bs.num_row_blocks):
+        ids = [int(bs.cells["block_id"][k]) for k in range(bs.row_cell_begin[rb], bs.row_cell_begin[rb + 1])]
+        if ids[0] < nelim:
+            rows.setdefault(ids[0], set()).update(i - nelim for i in ids[1:])
+        else:
+            for i in ids:
+                for j in ids:
+                    if i <= j:
+                        pat.add((i - nelim, j - nelim))
+    for fs in rows.values():
+        for i in fs:
+            for j in fs:
+                if i < j:
+                    pat.add((i, j))
+    assert set(cells) == pat
+
+
 @pytest.mark.parametrize("pid", [0, 2, 5])
 @pytest.mark.parametrize("pre", ["JACOBI", "IDENTITY"])
 def test_cgnr_vs_dense(oracle, pid, pre):
