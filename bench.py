@@ -129,6 +129,9 @@ def main():
                     help="linear solver of the step (the headline metric uses iterative_schur)")
     ap.add_argument("--preconditioner", default="jacobi", choices=["jacobi", "schur_jacobi", "identity"])
     ap.add_argument("--mixed", action="store_true", help="CGNR with fp32-stored J values (BASELINE config 5)")
+    ap.add_argument("--explicit-schur", action="store_true",
+                    help="ITERATIVE_SCHUR on the explicitly computed block-sparse S (Solver::Options::"
+                         "use_explicit_schur_complement, solver.h:518-540); needs --preconditioner schur_jacobi")
     ap.add_argument("--eta", type=float, default=0.1,
                     help="q_tolerance of the inexact step: Solver::Options::eta default 0.1 (solver.h:628); "
                          "bundle_adjuster's flag default is 1e-2 (bundle_adjuster.cc:114)")
@@ -181,7 +184,8 @@ def main():
     ptype = {"jacobi": cx.JACOBI, "schur_jacobi": cx.SCHUR_JACOBI, "identity": cx.IDENTITY}[args.preconditioner]
     solver_kw = dict(type=stype, preconditioner_type=ptype, num_eliminate_blocks=prob.num_points,
                      max_num_iterations=500, min_num_iterations=0, residual_reset_period=10,
-                     use_mixed_precision_solves=1 if args.mixed else 0)
+                     use_mixed_precision_solves=1 if args.mixed else 0,
+                     use_explicit_schur_complement=1 if args.explicit_schur else 0)
     S = cx.Solver(ctx, **solver_kw)
     x = ctx.empty(A.num_cols)
 
@@ -224,6 +228,11 @@ def main():
         tm = S.timing()
         tight = {"eta": 0.01, "ms": t_tight, "cg_iterations": int(summ_t.num_iterations),
                  "cg_ms_per_iteration": tm["reduced_solve_ms"] / max(1, int(summ_t.num_iterations))}
+
+    explicit_info = None
+    if args.explicit_schur:
+        cr, _ = cx.binding.schur_sparse_structure(A)
+        explicit_info = {"cells": int(cr.size), "bytes_per_s_times_x": int(648 * (2 * cr.size - C))}
 
     # ---- J SpMV GB/s (block_sparse_matrix.cc:239-349 replacement), this rank's shard
     Ol, Pl = prob.num_observations, prob.num_points
@@ -280,14 +289,16 @@ def main():
             "metric": "linear_solve_ms_per_iter", "value": ms_per_step, "unit": "ms",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
             "higher_is_better": False, "scaling": "strong", "vs_baseline": None, "dtype": "f64 (J values stored fp32)" if args.mixed else "f64", "data": "synthetic",
-            "config": {"workload": "%s: %s + %s, q_tol=%g, synthetic BAL-shaped J "
+            "config": {"workload": "%s: %s%s + %s, q_tol=%g, synthetic BAL-shaped J "
                                    "(%d cameras, %d points, %d residual blocks)" % (args.workload, args.solver.upper(),
+                                                                                   " (explicit S)" if args.explicit_schur else "",
                                                                                    args.preconditioner.upper(), ETA, C, P, O),
                        "cameras": C, "points": P, "residual_blocks": O, "cg_iterations": int(summ.num_iterations),
                        "termination": int(summ.termination_type), "initial_cost": cost,
                        "sharding": "points over %d rank(s), RCCL all-reduce of camera-space sums" % world},
             "phases_ms_per_solve": {k: v / max(1, args.steps) for k, v in phases.items()},
             "at_bundle_adjuster_eta": tight,
+            "explicit_s": explicit_info,
             "jacobian_eval_ms": eval_ms,
             "spmv": spmv,
             "kernels": {k: {"avg_ms": v[0] / max(1, v[1]), "launches_per_solve": v[2] / max(1, args.steps)} for k, v in kstats.items()},

@@ -40,6 +40,8 @@ def main(argv=None):
                     choices=["dense_schur", "sparse_schur", "iterative_schur", "cgnr"])
     ap.add_argument("--preconditioner", default="jacobi",
                     choices=["identity", "jacobi", "schur_jacobi", "schur_power_series_expansion"])
+    ap.add_argument("--explicit_schur_complement", action="store_true",
+                    help="ITERATIVE_SCHUR on the explicitly computed block-sparse S (needs schur_jacobi)")
     ap.add_argument("--num_iterations", type=int, default=5)
     ap.add_argument("--max_linear_solver_iterations", type=int, default=500)
     ap.add_argument("--eta", type=float, default=1e-2)
@@ -79,7 +81,8 @@ def main(argv=None):
     stype = getattr(cx.binding, args.linear_solver.upper())
     solver = cx.Solver(ctx, type=stype, preconditioner_type=getattr(cx.binding, args.preconditioner.upper()),
                        num_eliminate_blocks=0 if stype == cx.binding.CGNR else prob.num_points,
-                       max_num_iterations=args.max_linear_solver_iterations)
+                       max_num_iterations=args.max_linear_solver_iterations,
+                       use_explicit_schur_complement=int(args.explicit_schur_complement))
     preprocess_s = time.time() - t0
     opts = cx.binding.minimizer_options(max_num_iterations=args.num_iterations, eta=args.eta,
                                         use_nonmonotonic_steps=int(args.nonmonotonic_steps))
