@@ -11,7 +11,7 @@ int cxs_compute_ete_inverse(cx_matrix* A, const double* D, const double* b, doub
 // 2: out[3P] = (E'E)^-1 E' (b - F xf) ; 3: out[2O] = E (E'E)^-1 E' F xf
 int cxs_chunk_pass(cx_matrix* A, int mode, const double* ete_inv, const double* xf, const double* b, double* out);
 // blocks[81C] = block diagonal of F'F (with_schur = false) or of S without D_f^2 (true)
-int cxs_camera_block_diagonal(cx_matrix* A, bool with_schur, const double* ete_inv, double* blocks);
+int cxs_camera_block_diagonal(cx_matrix* A, double* blocks);
 // fused set-up of the implicit Schur complement (k_chunk_init + k_cam_init), see cx_schur.hip
 int cxs_implicit_init(cx_matrix* A, const double* D, const double* b, bool want_blocks, bool with_schur,
                       double* ete_inv, double* rows_scratch, double* blocks, double* rhs_out, int* d_flag);

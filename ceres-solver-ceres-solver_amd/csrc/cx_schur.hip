@@ -1123,12 +1123,6 @@ __global__ void k_blocks_to_dense(const double* __restrict__ blk, const double* 
   lhs[idx] = v;
 }
 
-// lhs(i,i) += D_f(i)^2      (schur_eliminator_impl.h:194-213)
-__global__ void k_add_diag_sq(double* __restrict__ lhs, int64_t n, const double* __restrict__ Df) {
-  const int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
-  if (i < n) lhs[i * n + i] += Df[i] * Df[i];
-}
-
 // ================================================================ host drivers
 
 int cxs_compute_ete_inverse(cx_matrix* A, const double* D, const double* b, double* ete_inv, double* g,
@@ -1162,17 +1156,12 @@ int cxs_chunk_pass(cx_matrix* A, int mode, const double* ete_inv, const double* 
   return CX_OK;
 }
 
-int cxs_camera_block_diagonal(cx_matrix* A, bool with_schur, const double* ete_inv, double* blocks) {
+int cxs_camera_block_diagonal(cx_matrix* A, double* blocks) {
   hipStream_t st = A->ctx->stream;
   CX_TRY(cx_matrix_ensure_ft(A));
-  if (A->num_segs > 0) {
-    if (with_schur)
-      hipLaunchKernelGGL(k_cam_diag<true>, dim3(A->num_segs), dim3(kBlock), 0, st, A->d_Ft.p, A->d_values.p,
-                         A->d_cam_rows.p, A->d_row_pt.p, A->d_seg_begin.p, ete_inv, A->d_partials.p);
-    else
-      hipLaunchKernelGGL(k_cam_diag<false>, dim3(A->num_segs), dim3(kBlock), 0, st, A->d_Ft.p, A->d_values.p,
-                         A->d_cam_rows.p, A->d_row_pt.p, A->d_seg_begin.p, ete_inv, A->d_partials.p);
-  }
+  if (A->num_segs > 0)
+    hipLaunchKernelGGL(k_cam_diag<false>, dim3(A->num_segs), dim3(kBlock), 0, st, A->d_Ft.p, A->d_values.p,
+                       A->d_cam_rows.p, A->d_row_pt.p, A->d_seg_begin.p, (const double*)nullptr, A->d_partials.p);
   hipLaunchKernelGGL(k_cam_diag_reduce, dim3(grid_for(int64_t(A->C) * 45, 256)), dim3(256), 0, st,
                      A->d_partials.p, A->d_cam_seg_start.p, blocks, A->C);
   CX_HIP(hipGetLastError());
@@ -1186,79 +1175,13 @@ int cxs_block9_add_diag_invert(cx_context* ctx, double* blocks, const double* Df
   return CX_OK;
 }
 
-int cxs_eliminate_dense(cx_matrix* A, const double* b, const double* D, bool add_df, double* lhs, double* rhs) {
+// Gather assembly shared by the dense and the block-sparse explicit S: (E'E + D_e^2)^-1 (closed-form inverse
+// of InvertPSDMatrix<3>), B / G of every row, F'F diagonal blocks, per-item pair sums.
+static int AssemblePairItems(cx_matrix* A, const double* D) {
   hipStream_t st = A->ctx->stream;
-  const int C = A->C;
-  const int64_t n = 9 * int64_t(C);
-  CX_TRY(cxs_build_pair_lists(A));
-  const bool gather = A->pairs_state == 1;
   CX_TRY(A->d_elim_ete.alloc(size_t(std::max<int64_t>(9 * int64_t(A->P), 1))));
-  CX_TRY(A->d_elim_diag.alloc(size_t(std::max<int64_t>(81 * int64_t(C), 1))));
+  CX_TRY(A->d_elim_diag.alloc(size_t(std::max<int64_t>(81 * int64_t(A->C), 1))));
   CX_TRY(A->d_elim_flag.alloc(1));
-  // (E'E + D_e^2)^-1 with the closed-form inverse of InvertPSDMatrix<3>
-  CX_TRY(cxs_compute_ete_inverse(A, D, nullptr, A->d_elim_ete.p, nullptr, false, A->d_elim_flag.p));
-  if (gather) {
-    const size_t rows18 = size_t(std::max<int64_t>(18 * A->O, 1));
-    CX_TRY(A->d_elim_bg0.alloc(rows18));
-    CX_TRY(A->d_elim_bg1.alloc(rows18));
-    CX_TRY(A->d_elim_bg2.alloc(rows18));
-    if (A->O > 0)
-      hipLaunchKernelGGL(k_row_bg, dim3(grid_for(A->O, kBlock)), dim3(kBlock), 0, st, (const double*)A->d_values.p,
-                         (const double*)(A->d_values.p + 6 * A->O), (const int32_t*)A->d_row_pt.p,
-                         (const double*)A->d_elim_ete.p, A->O, A->d_elim_bg0.p, A->d_elim_bg1.p, A->d_elim_bg2.p);
-    CX_TRY(cxs_camera_block_diagonal(A, false, nullptr, A->d_elim_diag.p));
-    if (A->num_items > 0)
-      hipLaunchKernelGGL(k_pair_items, dim3(unsigned(A->num_items)), dim3(kBlock), 0, st, (const int32_t*)A->d_pair_rows.p,
-                         (const int64_t*)A->d_item_begin.p, (const double*)A->d_elim_bg0.p, (const double*)A->d_elim_bg1.p,
-                         (const double*)A->d_elim_bg2.p, A->d_item_partial.p);
-    if (n > 0) CX_HIP(hipMemsetAsync(lhs, 0, size_t(n) * n * sizeof(double), st));
-    if (A->num_cells > 0)
-      hipLaunchKernelGGL(k_pair_cells, dim3(unsigned((A->num_cells + 2) / 3)), dim3(3 * 81), 0, st,
-                         (const int32_t*)A->d_cell_c1.p, (const int32_t*)A->d_cell_c2.p, (const int32_t*)A->d_cell_item_start.p,
-                         (const double*)A->d_item_partial.p, (const double*)A->d_elim_diag.p,
-                         (D && add_df) ? D + 3 * int64_t(A->P) : (const double*)nullptr, lhs, (double*)nullptr, C, A->num_cells);
-  } else {
-    CX_TRY(A->d_elim_blk.alloc(size_t(std::max<int64_t>(int64_t(C) * C * 81, 1))));
-    CX_HIP(hipMemsetAsync(A->d_elim_blk.p, 0, size_t(C) * C * 81 * sizeof(double), st));
-  }
-  if (!gather && A->num_tiles > 0) {
-    const double* E = A->d_values.p;
-    const double* F = A->d_values.p + 6 * A->O;
-    hipLaunchKernelGGL(k_chunk_eliminate, dim3(A->num_tiles), dim3(kBlock), 0, st, E, F, A->d_tile_row.p,
-                       A->d_tile_pt.p, A->d_pt_start.p, A->d_row_cam.p, (const double*)A->d_elim_ete.p, A->d_elim_blk.p, C);
-    if (A->has_big_tiles)
-      hipLaunchKernelGGL(k_big_chunk_eliminate, dim3(A->num_tiles), dim3(kBlock), 0, st, E, F, A->d_tile_row.p,
-                         A->d_tile_pt.p, A->d_row_cam.p, (const double*)A->d_elim_ete.p, A->d_elim_blk.p, C);
-  }
-  if (!gather) CX_TRY(cxs_camera_block_diagonal(A, false, nullptr, A->d_elim_diag.p));
-  if (!gather && n > 0)
-    hipLaunchKernelGGL(k_blocks_to_dense, dim3(grid_for(n * n, 256)), dim3(256), 0, st, (const double*)A->d_elim_blk.p,
-                       (const double*)A->d_elim_diag.p, (D && add_df) ? D + 3 * int64_t(A->P) : (const double*)nullptr, lhs, C);
-  if (rhs) {
-    if (b) {
-      CX_TRY(A->d_elim_rows.alloc(size_t(std::max<int64_t>(A->num_rows, 1))));
-      CX_TRY(cxs_chunk_pass(A, 1, A->d_elim_ete.p, nullptr, b, A->d_elim_rows.p));
-      CX_TRY(cxk_ft_multiply(A, A->d_elim_rows.p, rhs, false));
-    } else {
-      CX_HIP(hipMemsetAsync(rhs, 0, size_t(n) * sizeof(double), st));
-    }
-  }
-  CX_HIP(hipGetLastError());
-  return CX_OK;
-}
-
-int cxs_eliminate_sparse(cx_matrix* A, const double* b, const double* D, double* rhs) {
-  hipStream_t st = A->ctx->stream;
-  const int C = A->C;
-  CX_TRY(cxs_build_pair_lists(A));
-  if (A->pairs_state != 1) {
-    cx_set_error("the explicit Schur complement of this structure needs more than 2^28 row pairs");
-    return CX_ERR_UNSUPPORTED;
-  }
-  CX_TRY(A->d_elim_ete.alloc(size_t(std::max<int64_t>(9 * int64_t(A->P), 1))));
-  CX_TRY(A->d_elim_diag.alloc(size_t(std::max<int64_t>(81 * int64_t(C), 1))));
-  CX_TRY(A->d_elim_flag.alloc(1));
-  CX_TRY(A->d_S.alloc(size_t(std::max<int64_t>(A->num_cells, 1)) * 81));
   CX_TRY(cxs_compute_ete_inverse(A, D, nullptr, A->d_elim_ete.p, nullptr, false, A->d_elim_flag.p));
   const size_t rows18 = size_t(std::max<int64_t>(18 * A->O, 1));
   CX_TRY(A->d_elim_bg0.alloc(rows18));
@@ -1268,27 +1191,82 @@ int cxs_eliminate_sparse(cx_matrix* A, const double* b, const double* D, double*
     hipLaunchKernelGGL(k_row_bg, dim3(grid_for(A->O, kBlock)), dim3(kBlock), 0, st, (const double*)A->d_values.p,
                        (const double*)(A->d_values.p + 6 * A->O), (const int32_t*)A->d_row_pt.p,
                        (const double*)A->d_elim_ete.p, A->O, A->d_elim_bg0.p, A->d_elim_bg1.p, A->d_elim_bg2.p);
-  CX_TRY(cxs_camera_block_diagonal(A, false, nullptr, A->d_elim_diag.p));
+  CX_TRY(cxs_camera_block_diagonal(A, A->d_elim_diag.p));
   if (A->num_items > 0)
     hipLaunchKernelGGL(k_pair_items, dim3(unsigned(A->num_items)), dim3(kBlock), 0, st, (const int32_t*)A->d_pair_rows.p,
                        (const int64_t*)A->d_item_begin.p, (const double*)A->d_elim_bg0.p, (const double*)A->d_elim_bg1.p,
                        (const double*)A->d_elim_bg2.p, A->d_item_partial.p);
-  if (A->num_cells > 0)
-    hipLaunchKernelGGL(k_pair_cells, dim3(unsigned((A->num_cells + 2) / 3)), dim3(3 * 81), 0, st,
-                       (const int32_t*)A->d_cell_c1.p, (const int32_t*)A->d_cell_c2.p, (const int32_t*)A->d_cell_item_start.p,
-                       (const double*)A->d_item_partial.p, (const double*)A->d_elim_diag.p, (const double*)nullptr,
-                       (double*)nullptr, A->d_S.p, C, A->num_cells);
-  if (rhs) {
-    if (b) {
-      CX_TRY(A->d_elim_rows.alloc(size_t(std::max<int64_t>(A->num_rows, 1))));
-      CX_TRY(cxs_chunk_pass(A, 1, A->d_elim_ete.p, nullptr, b, A->d_elim_rows.p));
-      CX_TRY(cxk_ft_multiply(A, A->d_elim_rows.p, rhs, false));
-    } else {
-      CX_HIP(hipMemsetAsync(rhs, 0, size_t(9) * C * sizeof(double), st));
-    }
-  }
   CX_HIP(hipGetLastError());
   return CX_OK;
+}
+
+// rhs = F'(b - E (E'E)^-1 E'b)  (UpdateRhs, schur_eliminator_impl.h:379-420); A->d_elim_ete must be current
+static int EliminateRhs(cx_matrix* A, const double* b, double* rhs) {
+  if (!rhs) return CX_OK;
+  if (!b) {
+    CX_HIP(hipMemsetAsync(rhs, 0, size_t(9) * A->C * sizeof(double), A->ctx->stream));
+    return CX_OK;
+  }
+  CX_TRY(A->d_elim_rows.alloc(size_t(std::max<int64_t>(A->num_rows, 1))));
+  CX_TRY(cxs_chunk_pass(A, 1, A->d_elim_ete.p, nullptr, b, A->d_elim_rows.p));
+  return cxk_ft_multiply(A, A->d_elim_rows.p, rhs, false);
+}
+
+int cxs_eliminate_dense(cx_matrix* A, const double* b, const double* D, bool add_df, double* lhs, double* rhs) {
+  hipStream_t st = A->ctx->stream;
+  const int C = A->C;
+  const int64_t n = 9 * int64_t(C);
+  const double* Df = (D && add_df) ? D + 3 * int64_t(A->P) : nullptr;
+  CX_TRY(cxs_build_pair_lists(A));
+  if (A->pairs_state == 1) {
+    CX_TRY(AssemblePairItems(A, D));
+    if (n > 0) CX_HIP(hipMemsetAsync(lhs, 0, size_t(n) * n * sizeof(double), st));
+    if (A->num_cells > 0)
+      hipLaunchKernelGGL(k_pair_cells, dim3(unsigned((A->num_cells + 2) / 3)), dim3(3 * 81), 0, st,
+                         (const int32_t*)A->d_cell_c1.p, (const int32_t*)A->d_cell_c2.p, (const int32_t*)A->d_cell_item_start.p,
+                         (const double*)A->d_item_partial.p, (const double*)A->d_elim_diag.p, Df, lhs, (double*)nullptr, C,
+                         A->num_cells);
+  } else {
+    // scatter path: fp64 atomics into a block-major copy of S
+    CX_TRY(A->d_elim_ete.alloc(size_t(std::max<int64_t>(9 * int64_t(A->P), 1))));
+    CX_TRY(A->d_elim_diag.alloc(size_t(std::max<int64_t>(81 * int64_t(C), 1))));
+    CX_TRY(A->d_elim_flag.alloc(1));
+    CX_TRY(cxs_compute_ete_inverse(A, D, nullptr, A->d_elim_ete.p, nullptr, false, A->d_elim_flag.p));
+    CX_TRY(A->d_elim_blk.alloc(size_t(std::max<int64_t>(int64_t(C) * C * 81, 1))));
+    CX_HIP(hipMemsetAsync(A->d_elim_blk.p, 0, size_t(C) * C * 81 * sizeof(double), st));
+    if (A->num_tiles > 0) {
+      const double* E = A->d_values.p;
+      const double* F = A->d_values.p + 6 * A->O;
+      hipLaunchKernelGGL(k_chunk_eliminate, dim3(A->num_tiles), dim3(kBlock), 0, st, E, F, A->d_tile_row.p,
+                         A->d_tile_pt.p, A->d_pt_start.p, A->d_row_cam.p, (const double*)A->d_elim_ete.p, A->d_elim_blk.p, C);
+      if (A->has_big_tiles)
+        hipLaunchKernelGGL(k_big_chunk_eliminate, dim3(A->num_tiles), dim3(kBlock), 0, st, E, F, A->d_tile_row.p,
+                           A->d_tile_pt.p, A->d_row_cam.p, (const double*)A->d_elim_ete.p, A->d_elim_blk.p, C);
+    }
+    CX_TRY(cxs_camera_block_diagonal(A, A->d_elim_diag.p));
+    if (n > 0)
+      hipLaunchKernelGGL(k_blocks_to_dense, dim3(grid_for(n * n, 256)), dim3(256), 0, st, (const double*)A->d_elim_blk.p,
+                         (const double*)A->d_elim_diag.p, Df, lhs, C);
+  }
+  CX_HIP(hipGetLastError());
+  return EliminateRhs(A, b, rhs);
+}
+
+int cxs_eliminate_sparse(cx_matrix* A, const double* b, const double* D, double* rhs) {
+  CX_TRY(cxs_build_pair_lists(A));
+  if (A->pairs_state != 1) {
+    cx_set_error("the explicit Schur complement of this structure needs more than 2^28 row pairs");
+    return CX_ERR_UNSUPPORTED;
+  }
+  CX_TRY(A->d_S.alloc(size_t(std::max<int64_t>(A->num_cells, 1)) * 81));
+  CX_TRY(AssemblePairItems(A, D));
+  if (A->num_cells > 0)
+    hipLaunchKernelGGL(k_pair_cells, dim3(unsigned((A->num_cells + 2) / 3)), dim3(3 * 81), 0, A->ctx->stream,
+                       (const int32_t*)A->d_cell_c1.p, (const int32_t*)A->d_cell_c2.p, (const int32_t*)A->d_cell_item_start.p,
+                       (const double*)A->d_item_partial.p, (const double*)A->d_elim_diag.p, (const double*)nullptr,
+                       (double*)nullptr, A->d_S.p, A->C, A->num_cells);
+  CX_HIP(hipGetLastError());
+  return EliminateRhs(A, b, rhs);
 }
 
 int cxs_sparse_multiply(cx_matrix* A, const double* x, double* y) {

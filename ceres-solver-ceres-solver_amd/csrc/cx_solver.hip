@@ -995,7 +995,7 @@ int SolveCgnr239(cx_solver* S, cx_matrix* A, const double* b, const double* D, d
     CX_TRY(S->pt_blocks.alloc(9 * size_t(A->P)));
     CX_TRY(S->cam_blocks.alloc(81 * size_t(A->C)));
     if (A->P) hipLaunchKernelGGL(k_point_jacobi, dim3(grid_for(A->P, kBlock)), dim3(kBlock), 0, st, A->d_values.p, A->d_pt_start.p, D, S->pt_blocks.p, A->P, S->flag.p);
-    CX_TRY(cxs_camera_block_diagonal(A, false, nullptr, S->cam_blocks.p));
+    CX_TRY(cxs_camera_block_diagonal(A, S->cam_blocks.p));
     if (ctx->nranks > 1) CX_TRY(cx_allreduce_device(ctx, S->cam_blocks.p, 81 * int64_t(A->C)));
     CX_TRY(cxs_block9_add_diag_invert(ctx, S->cam_blocks.p, D ? D + ne : nullptr, A->C, S->flag.p));
   } else if (o.preconditioner_type != CX_IDENTITY) {

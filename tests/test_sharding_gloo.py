@@ -69,13 +69,14 @@ def _worker(rank, port, results_dir):
     D_full = rng.uniform(0.5, 2.0, 3 * P + 9 * C) * 1e-2 * np.sqrt(np.abs(vals_f).mean())
     D = np.concatenate([D_full[3 * lo:3 * hi], D_full[3 * P:]])
     outcomes = []
-    for stype, pre in (("ITERATIVE_SCHUR", "JACOBI"), ("ITERATIVE_SCHUR", "SCHUR_JACOBI"), ("CGNR", "JACOBI"),
-                       ("DENSE_SCHUR", "IDENTITY")):
+    for stype, pre, explicit in (("ITERATIVE_SCHUR", "JACOBI", 0), ("ITERATIVE_SCHUR", "SCHUR_JACOBI", 0), ("CGNR", "JACOBI", 0),
+                                 ("DENSE_SCHUR", "IDENTITY", 0), ("ITERATIVE_SCHUR", "SCHUR_JACOBI", 1)):
         o_full = orc.make_options(type=getattr(orc, stype), preconditioner_type=getattr(orc, pre),
-                                  num_eliminate_blocks=P, max_num_iterations=300)
+                                  num_eliminate_blocks=P, max_num_iterations=300, use_explicit_schur_complement=explicit)
         x_full, s_full = orc.solve(bs_full, vals_f, res_f, D_full, o_full, r_tolerance=-1.0, q_tolerance=0.1)
         o = orc.make_options(type=getattr(orc, stype), preconditioner_type=getattr(orc, pre),
-                             num_eliminate_blocks=sub.num_points, max_num_iterations=300)
+                             num_eliminate_blocks=sub.num_points, max_num_iterations=300,
+                             use_explicit_schur_complement=explicit)
         x, s = orc.solve(bs, vals_s, res_s, D, o, r_tolerance=-1.0, q_tolerance=0.1, allreduce=allreduce)
         expect = np.concatenate([x_full[3 * lo:3 * hi], x_full[3 * P:]])
         err = np.abs(x - expect).max() / np.abs(expect).max()
@@ -94,7 +95,7 @@ def test_sharded_solves_match_unsharded(tmp_path, oracle):
     mp.spawn(_worker, args=(port, str(tmp_path)), nprocs=WORLD, join=True)
     for rank in range(WORLD):
         lines = open(tmp_path / ("rank%d.txt" % rank)).read().strip().splitlines()
-        assert len(lines) == 4
+        assert len(lines) == 5
         for line in lines:
             stype, pre, same_term, same_iters, err = eval(line)
             assert same_term and same_iters, line
