@@ -73,6 +73,39 @@ def test_minimize_matches_oracle(ctx, oracle, stype, ptype, loss):
     ev.close()
 
 
+def test_minimize_nonmonotonic_and_rejected_steps(ctx, oracle):
+    """A perturbed start (BALProblem::Perturb) produces rejected steps (radius halving, quartering, ...) and, with
+    use_nonmonotonic_steps, accepted steps that raise the cost: the strategy's and the step evaluator's
+    bookkeeping (levenberg_marquardt_strategy.cc:153-169, trust_region_step_evaluator.cc:40-117) must walk the
+    same path as the oracle.  DENSE_SCHUR so that every step is exact."""
+    C, P, O = 10, 200, 1500
+    prob = cx.bal.make_bal_like(C, P, O, 5)
+    prob = cx.bal.perturb(prob, 0.01, 0.3, 0.5, seed=2)
+    for nonmono in (0, 1):
+        kw = dict(max_num_iterations=15, use_nonmonotonic_steps=nonmono, max_consecutive_nonmonotonic_steps=3,
+                  function_tolerance=1e-12)
+        ev = cx.Evaluator(ctx, prob)
+        solver = cx.Solver(ctx, type=cx.binding.DENSE_SCHUR, num_eliminate_blocks=P)
+        x, summ, its = cx.binding.minimize(ev, solver, prob.state(), cx.binding.minimizer_options(**kw))
+        so = oracle.make_options(type=oracle.DENSE_SCHUR, num_eliminate_blocks=P)
+        x_r, summ_r, its_r = oracle.minimize_bal(C, P, prob.camera_index, prob.point_index, prob.observations,
+                                                 prob.state(), so, oracle.minimizer_options(**kw))
+        assert len(its) == len(its_r) and summ["termination_type"] == summ_r["termination_type"]
+        assert [i["step_is_successful"] for i in its] == [i["step_is_successful"] for i in its_r]
+        assert [i["step_is_nonmonotonic"] for i in its] == [i["step_is_nonmonotonic"] for i in its_r]
+        assert 0 in [i["step_is_successful"] for i in its]
+        if nonmono:
+            assert 1 in [i["step_is_nonmonotonic"] for i in its]
+        for a, b in zip(its, its_r):
+            assert abs(a["cost"] - b["cost"]) <= 1e-5 * abs(b["cost"])  # ill-conditioned start: rounding differences grow along the path
+            assert abs(a["trust_region_radius"] - b["trust_region_radius"]) <= 1e-4 * b["trust_region_radius"]
+            assert abs(a["relative_decrease"] - b["relative_decrease"]) <= 1e-3 * max(1.0, abs(b["relative_decrease"]))
+        assert abs(summ["final_cost"] - summ_r["final_cost"]) <= 1e-5 * summ_r["final_cost"]
+        assert relerr(x, x_r) < 1e-3
+        solver.close()
+        ev.close()
+
+
 def test_minimize_device_state_and_limits(ctx, oracle):
     """DEVICE memspace updates the caller's array in place; max_num_iterations = 0 evaluates only."""
     C, P, O = 8, 120, 900
