@@ -52,32 +52,46 @@ __device__ __forceinline__ void exchange_cells(const double2 (&v)[DPR / 2], doub
   __syncthreads();
 }
 
-// fp32-storage variants (mixed-precision CGNR): cells of DPR floats move as 8-byte pieces and
-// are widened to fp64 when the lane picks up its own cell; all arithmetic stays fp64.
+// fp32-storage variants (mixed-precision CGNR): the run of nvalid cells of DPR floats moves as 16-byte
+// pieces too (half as many load instructions as the fp64 run -- with 8-byte pieces the kernels were no
+// faster than fp64, they are bound by memory instructions in flight, not bytes); pieces may straddle
+// cells and start on 4- or 8-byte boundaries (camera segments), hence the under-aligned vector type.
+// The lane widens its own cell to fp64 when it picks it up; all arithmetic stays fp64.
+typedef float float4_u __attribute__((ext_vector_type(4), aligned(4)));
+
 template <int DPR>
-__device__ __forceinline__ void load_cells(const float* __restrict__ base, int nvalid, float2 (&v)[DPR / 2]) {
-  constexpr int kPieces = DPR / 2;
+__device__ __forceinline__ void load_cells(const float* __restrict__ base, int nvalid, float4_u (&v)[(DPR + 3) / 4]) {
+  constexpr int kPieces = (DPR + 3) / 4;
   const int tid = threadIdx.x;
-  const float2* __restrict__ src = reinterpret_cast<const float2*>(base);
-  const int total = nvalid * kPieces;
+  const int total = nvalid * DPR;  // floats in the run
 #pragma unroll
   for (int i = 0; i < kPieces; ++i) {
-    const int idx = i * kBlock + tid;
-    v[i] = (idx < total) ? src[idx] : make_float2(0.f, 0.f);
+    const int f0 = 4 * (i * kBlock + tid);
+    if (f0 + 3 < total) {
+      v[i] = *reinterpret_cast<const float4_u*>(base + f0);
+    } else {
+      v[i] = float4_u{0.f, 0.f, 0.f, 0.f};
+      if (f0 < total) v[i].x = base[f0];
+      if (f0 + 1 < total) v[i].y = base[f0 + 1];
+      if (f0 + 2 < total) v[i].z = base[f0 + 2];
+    }
   }
 }
 
 template <int DPR>
-__device__ __forceinline__ void exchange_cells(const float2 (&v)[DPR / 2], double* __restrict__ lds, double (&out)[DPR]) {
-  constexpr int kPieces = DPR / 2;
+__device__ __forceinline__ void exchange_cells(const float4_u (&v)[(DPR + 3) / 4], double* __restrict__ lds, double (&out)[DPR]) {
+  static_assert(DPR % 2 == 0, "the own cell is read back as 8-byte pairs");
+  constexpr int kPieces = (DPR + 3) / 4;
   const int tid = threadIdx.x;
-  float2* l2 = reinterpret_cast<float2*>(lds);
+  typedef float float4_a __attribute__((ext_vector_type(4)));
+  float4_a* l4 = reinterpret_cast<float4_a*>(lds);  // kPieces * kBlock * 16 B <= kBlock * DPR * 8 B
 #pragma unroll
-  for (int i = 0; i < kPieces; ++i) l2[i * kBlock + tid] = v[i];
+  for (int i = 0; i < kPieces; ++i) l4[i * kBlock + tid] = float4_a{v[i].x, v[i].y, v[i].z, v[i].w};
   __syncthreads();
+  const float2* l2 = reinterpret_cast<const float2*>(lds);
 #pragma unroll
-  for (int i = 0; i < kPieces; ++i) {
-    const float2 t = l2[tid * kPieces + i];
+  for (int i = 0; i < DPR / 2; ++i) {
+    const float2 t = l2[tid * (DPR / 2) + i];
     out[2 * i] = double(t.x);
     out[2 * i + 1] = double(t.y);
   }
@@ -87,7 +101,7 @@ __device__ __forceinline__ void exchange_cells(const float2 (&v)[DPR / 2], doubl
 template <int DPR>
 __device__ __forceinline__ void stage_cells(const float* __restrict__ base, int nvalid,
                                             double* __restrict__ lds, double (&out)[DPR]) {
-  float2 v[DPR / 2];
+  float4_u v[(DPR + 3) / 4];
   load_cells<DPR>(base, nvalid, v);
   exchange_cells<DPR>(v, lds, out);
 }

@@ -73,17 +73,17 @@ def test_minimize_matches_oracle(ctx, oracle, stype, ptype, loss):
     ev.close()
 
 
-def test_minimize_nonmonotonic_and_rejected_steps(ctx, oracle):
-    """A perturbed start (BALProblem::Perturb) produces rejected steps (radius halving, quartering, ...) and, with
-    use_nonmonotonic_steps, accepted steps that raise the cost: the strategy's and the step evaluator's
-    bookkeeping (levenberg_marquardt_strategy.cc:153-169, trust_region_step_evaluator.cc:40-117) must walk the
-    same path as the oracle.  DENSE_SCHUR so that every step is exact."""
+def test_minimize_rejected_steps_and_nonmonotonic_option(ctx, oracle):
+    """Bundle adjustment from a perturbed start is so close to Gauss-Newton-ideal that no step is ever rejected
+    (and starts that do get rejections are singular: costs ~1e30).  Rejections are therefore forced through
+    min_relative_decrease = 0.99: the strategy's radius halving / quartering and reuse of the LM diagonal
+    (levenberg_marquardt_strategy.cc:153-169) and the step evaluator with and without the non-monotonic option
+    (trust_region_step_evaluator.cc:40-117) must walk the oracle's path.  DENSE_SCHUR: every step exact."""
     C, P, O = 10, 200, 1500
-    prob = cx.bal.make_bal_like(C, P, O, 5)
-    prob = cx.bal.perturb(prob, 0.01, 0.3, 0.5, seed=2)
+    prob = cx.bal.perturb(cx.bal.make_bal_like(C, P, O, 5), 1, 0, 0.15, seed=2)
     for nonmono in (0, 1):
-        kw = dict(max_num_iterations=15, use_nonmonotonic_steps=nonmono, max_consecutive_nonmonotonic_steps=3,
-                  function_tolerance=1e-12)
+        kw = dict(max_num_iterations=12, min_relative_decrease=0.99, use_nonmonotonic_steps=nonmono,
+                  max_consecutive_nonmonotonic_steps=3, function_tolerance=1e-12)
         ev = cx.Evaluator(ctx, prob)
         solver = cx.Solver(ctx, type=cx.binding.DENSE_SCHUR, num_eliminate_blocks=P)
         x, summ, its = cx.binding.minimize(ev, solver, prob.state(), cx.binding.minimizer_options(**kw))
@@ -91,17 +91,15 @@ def test_minimize_nonmonotonic_and_rejected_steps(ctx, oracle):
         x_r, summ_r, its_r = oracle.minimize_bal(C, P, prob.camera_index, prob.point_index, prob.observations,
                                                  prob.state(), so, oracle.minimizer_options(**kw))
         assert len(its) == len(its_r) and summ["termination_type"] == summ_r["termination_type"]
-        assert [i["step_is_successful"] for i in its] == [i["step_is_successful"] for i in its_r]
-        assert [i["step_is_nonmonotonic"] for i in its] == [i["step_is_nonmonotonic"] for i in its_r]
-        assert 0 in [i["step_is_successful"] for i in its]
-        if nonmono:
-            assert 1 in [i["step_is_nonmonotonic"] for i in its]
+        flags = [i["step_is_successful"] for i in its]
+        assert flags == [i["step_is_successful"] for i in its_r]
+        assert flags.count(0) >= 4 and flags.count(1) >= 4
+        assert summ["num_unsuccessful_steps"] == summ_r["num_unsuccessful_steps"]
         for a, b in zip(its, its_r):
-            assert abs(a["cost"] - b["cost"]) <= 1e-5 * abs(b["cost"])  # ill-conditioned start: rounding differences grow along the path
-            assert abs(a["trust_region_radius"] - b["trust_region_radius"]) <= 1e-4 * b["trust_region_radius"]
-            assert abs(a["relative_decrease"] - b["relative_decrease"]) <= 1e-3 * max(1.0, abs(b["relative_decrease"]))
-        assert abs(summ["final_cost"] - summ_r["final_cost"]) <= 1e-5 * summ_r["final_cost"]
-        assert relerr(x, x_r) < 1e-3
+            assert abs(a["cost"] - b["cost"]) <= 1e-8 * abs(b["cost"])
+            assert abs(a["trust_region_radius"] - b["trust_region_radius"]) <= 1e-5 * b["trust_region_radius"]
+            assert abs(a["relative_decrease"] - b["relative_decrease"]) <= 1e-5
+        assert relerr(x, x_r) < 1e-7
         solver.close()
         ev.close()
 
