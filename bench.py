@@ -129,7 +129,8 @@ def main():
     ap.add_argument("--solver", default="iterative_schur", choices=["iterative_schur", "dense_schur", "cgnr"],
                     help="linear solver of the step (the headline metric uses iterative_schur)")
     ap.add_argument("--preconditioner", default="jacobi", choices=["jacobi", "schur_jacobi", "identity"])
-    ap.add_argument("--mixed", action="store_true", help="CGNR with fp32-stored J values (BASELINE config 5)")
+    ap.add_argument("--mixed", action="store_true", help="CG products on fp32 copies of the J values: CGNR (BASELINE config 5) or ITERATIVE_SCHUR; "
+                                                     "fp64 accumulation, vectors, set-up and back substitution")
     ap.add_argument("--explicit-schur", action="store_true",
                     help="ITERATIVE_SCHUR on the explicitly computed block-sparse S (Solver::Options::"
                          "use_explicit_schur_complement, solver.h:518-540); needs --preconditioner schur_jacobi")

@@ -158,9 +158,10 @@ __global__ __launch_bounds__(kBlock) void k_chunk_ete(const double* __restrict__
 // MODE 1 (RHS)    : t = b     ;  t' = t - E (E'E)^-1 E' t ; write t'        (UpdateRhs)
 // MODE 2 (BACKSUB): s = b - F z;  x_pt = (E'E)^-1 E' s                       (BackSubstitute)
 // MODE 3 (SPSE)   : t = F x_f ;  out = E (E'E)^-1 E' t                      (power series operator)
-template <int MODE>
-__global__ __launch_bounds__(kBlock) void k_chunk_pass(const double* __restrict__ E,
-                                                       const double* __restrict__ F,
+// T = float reads the fp32 copies of the cells (mixed-precision CG, modes 0 and 3); arithmetic is fp64.
+template <int MODE, typename T>
+__global__ __launch_bounds__(kBlock) void k_chunk_pass(const T* __restrict__ E,
+                                                       const T* __restrict__ F,
                                                        const int32_t* __restrict__ tile_row,
                                                        const int32_t* __restrict__ tile_pt,
                                                        const int32_t* __restrict__ pt_start,
@@ -269,10 +270,10 @@ __global__ __launch_bounds__(kBlock) void k_chunk_pass(const double* __restrict_
     const int p = p0;
     double s[3] = {0.0, 0.0, 0.0};
     for (int r = r0 + tid; r < r1; r += kBlock) {
-      const double* e = E + 6 * int64_t(r);
+      const T* e = E + 6 * int64_t(r);
       double t0 = 0.0, t1 = 0.0;
       if (MODE != 1) {
-        const double* f = F + 18 * int64_t(r);
+        const T* f = F + 18 * int64_t(r);
         const double* xc = xf + 9 * int64_t(row_cam[r]);
         for (int k = 0; k < 9; ++k) { t0 += f[k] * xc[k]; t1 += f[9 + k] * xc[k]; }
       }
@@ -294,10 +295,10 @@ __global__ __launch_bounds__(kBlock) void k_chunk_pass(const double* __restrict_
       if (tid == 0) { double* o = out + 3 * int64_t(p); o[0] = u0; o[1] = u1; o[2] = u2; }
     } else {
       for (int r = r0 + tid; r < r1; r += kBlock) {
-        const double* e = E + 6 * int64_t(r);
+        const T* e = E + 6 * int64_t(r);
         double t0 = 0.0, t1 = 0.0;
         if (MODE == 0) {
-          const double* f = F + 18 * int64_t(r);
+          const T* f = F + 18 * int64_t(r);
           const double* xc = xf + 9 * int64_t(row_cam[r]);
           for (int k = 0; k < 9; ++k) { t0 += f[k] * xc[k]; t1 += f[9 + k] * xc[k]; }
         } else if (MODE == 1) {
@@ -1142,15 +1143,23 @@ int cxs_compute_ete_inverse(cx_matrix* A, const double* D, const double* b, doub
 int cxs_chunk_pass(cx_matrix* A, int mode, const double* ete_inv, const double* xf, const double* b, double* out) {
   hipStream_t st = A->ctx->stream;
   if (A->num_tiles == 0) return CX_OK;
-  const double* E = A->d_values.p;
-  const double* F = A->d_values.p + 6 * A->O;
-#define CX_LAUNCH_PASS(M)                                                                                   \
-  hipLaunchKernelGGL(k_chunk_pass<M>, dim3(A->num_tiles), dim3(kBlock), 0, st, E, F, A->d_tile_row.p,       \
+#define CX_LAUNCH_PASS(M, T, EP, FP)                                                                           \
+  hipLaunchKernelGGL((k_chunk_pass<M, T>), dim3(A->num_tiles), dim3(kBlock), 0, st, EP, FP, A->d_tile_row.p,   \
                      A->d_tile_pt.p, A->d_pt_start.p, A->d_row_cam.p, A->d_row_pt.p, ete_inv, xf, b, out, A->stop, 0)
-  if (mode == 0) CX_LAUNCH_PASS(0);
-  else if (mode == 1) CX_LAUNCH_PASS(1);
-  else if (mode == 3) CX_LAUNCH_PASS(3);
-  else CX_LAUNCH_PASS(2);
+  if (A->use_f32 && (mode == 0 || mode == 3)) {
+    // products inside a mixed-precision CG: fp32 copies of the cells (cx_matrix_ensure_f32)
+    const float* E = A->d_vals32.p;
+    const float* F = A->d_vals32.p + 6 * A->O;
+    if (mode == 0) CX_LAUNCH_PASS(0, float, E, F);
+    else CX_LAUNCH_PASS(3, float, E, F);
+  } else {
+    const double* E = A->d_values.p;
+    const double* F = A->d_values.p + 6 * A->O;
+    if (mode == 0) CX_LAUNCH_PASS(0, double, E, F);
+    else if (mode == 1) CX_LAUNCH_PASS(1, double, E, F);
+    else if (mode == 3) CX_LAUNCH_PASS(3, double, E, F);
+    else CX_LAUNCH_PASS(2, double, E, F);
+  }
 #undef CX_LAUNCH_PASS
   CX_HIP(hipGetLastError());
   return CX_OK;

@@ -908,9 +908,16 @@ int SolveIterativeSchur239(cx_solver* S, cx_matrix* A, const double* b, const do
                                                                           : static_cast<LinOp&>(bd);
   CgDriver cg{S, ctx, st, nf, nf};
   CX_TRY(S->state.alloc(1));
+  // use_mixed_precision_solves: S x inside CG streams fp32 copies of the cells (fp64 accumulation, fp64
+  // vectors); set-up, right-hand side and back substitution stay on the fp64 values.  Not in the reference
+  // (its mixed precision is for Cholesky, solver.h:572-590); parity is stated against the fp64 path.
+  const bool mixed = o.use_mixed_precision_solves != 0;
+  if (mixed) CX_TRY(cx_matrix_ensure_f32(A));
+  A->use_f32 = mixed;
   A->stop = &S->state.p->flag;  // product kernels of a speculatively enqueued iteration exit early
   const int cg_rc = cg.run(lhs, pre, S->v_rhs.p, S->v_x.p, zero_initial, r_tol, q_tol, summary);
   A->stop = nullptr;
+  A->use_f32 = false;
   CX_TRY(cg_rc);
   CX_TRY(sw.stop(&S->timing.reduced_solve_ms));
 

@@ -559,3 +559,33 @@ def test_edge_structures(ctx, oracle, case):
         assert relerr(xs, ref) < 1e-8
     S.close()
     A0.close()
+
+
+@pytest.mark.parametrize("pre", ["JACOBI", "SCHUR_JACOBI"])
+def test_mixed_precision_iterative_schur(ctx, oracle, pre):
+    """use_mixed_precision_solves with ITERATIVE_SCHUR: S x inside CG streams fp32 copies of the cells (fp64
+    accumulation and vectors), everything else stays fp64.  Not in the reference; compared with the fp64 path:
+    the fp32 rounding of J (6e-8) shows up at the 1e-6 level after CG, iteration counts agree to one step."""
+    C, P, O = 30, 4000, 20000
+    prob, bs, order, vals, b, D = make(C, P, O, 9, "eval", oracle)
+    A = cx.Matrix(ctx, bs, P)
+    A.set_values(vals)
+    kw = dict(type=cx.ITERATIVE_SCHUR, preconditioner_type=getattr(cx, pre), num_eliminate_blocks=P, max_num_iterations=200)
+    S64 = cx.Solver(ctx, **kw)
+    Smix = cx.Solver(ctx, use_mixed_precision_solves=1, **kw)
+    for q in (0.1, 1e-3):
+        x64, s64 = S64.solve(A, b, D, r_tolerance=-1.0, q_tolerance=q)
+        xm, sm = Smix.solve(A, b, D, r_tolerance=-1.0, q_tolerance=q)
+        assert sm.termination_type == cx.SUCCESS
+        assert abs(sm.num_iterations - s64.num_iterations) <= 1, (sm.num_iterations, s64.num_iterations)
+        assert relerr(xm, x64) < (1e-5 if sm.num_iterations == s64.num_iterations else 1e-2)
+        assert relerr(xm, x64) > 0.0  # the fp32 copies really were used
+    # fresh values invalidate the fp32 copies
+    A.set_values(vals * 2.0)
+    xm2, _ = Smix.solve(A, b, D, r_tolerance=-1.0, q_tolerance=0.1)
+    x642, _ = S64.solve(A, b, D, r_tolerance=-1.0, q_tolerance=0.1)
+    assert relerr(xm2, x642) < 1e-5
+    S64.close()
+    Smix.close()
+    A.close()
+
