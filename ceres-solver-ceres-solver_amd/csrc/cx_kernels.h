@@ -118,6 +118,67 @@ __device__ __forceinline__ void stage_cells(const double* __restrict__ base, int
   exchange_cells<DPR>(v, lds, out);
 }
 
+// stage_cells with half the LDS (kBlock * DPR / 2 doubles): all loads are issued first, then the run goes
+// through the buffer in two rounds -- the first half of the bytes (the cells of threads 0..kBlock/2-1),
+// then the second.  Two more barriers, but an 18 KB instead of a 36 KB workgroup lets twice as many
+// wavefronts share a CU (the streaming kernels are bound by loads in flight).
+template <int DPR>
+__device__ __forceinline__ void stage_cells_halves(const double* __restrict__ base, int nvalid,
+                                                   double* __restrict__ lds, double (&out)[DPR]) {
+  constexpr int kPieces = DPR / 2;
+  constexpr int kHalf = kBlock * kPieces / 2;
+  static_assert((kBlock * kPieces) % 2 == 0, "the run splits into two equal halves");
+  const int tid = threadIdx.x;
+  double2 v[kPieces];
+  load_cells<DPR>(base, nvalid, v);
+  double2* l2 = reinterpret_cast<double2*>(lds);
+#pragma unroll
+  for (int i = 0; i < kPieces; ++i) {
+    const int idx = i * kBlock + tid;
+    if (idx < kHalf) l2[idx] = v[i];
+  }
+  __syncthreads();
+  if (tid < kBlock / 2) {
+#pragma unroll
+    for (int i = 0; i < kPieces; ++i) {
+      const double2 t = l2[tid * kPieces + i];
+      out[2 * i] = t.x;
+      out[2 * i + 1] = t.y;
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < kPieces; ++i) {
+    const int idx = i * kBlock + tid;
+    if (idx >= kHalf) l2[idx - kHalf] = v[i];
+  }
+  __syncthreads();
+  if (tid >= kBlock / 2) {
+#pragma unroll
+    for (int i = 0; i < kPieces; ++i) {
+      const double2 t = l2[(tid - kBlock / 2) * kPieces + i];
+      out[2 * i] = t.x;
+      out[2 * i + 1] = t.y;
+    }
+  }
+  __syncthreads();
+}
+
+// The F cells (18 values) of a tile: fp64 through the half-size buffer, fp32 through the plain one.
+template <typename T> struct FStage;
+template <> struct FStage<double> {
+  static constexpr int kLdsDoubles = kBlock * 9;
+  static __device__ __forceinline__ void run(const double* __restrict__ base, int nvalid, double* __restrict__ lds, double (&out)[18]) {
+    stage_cells_halves<18>(base, nvalid, lds, out);
+  }
+};
+template <> struct FStage<float> {
+  static constexpr int kLdsDoubles = kBlock * 18;
+  static __device__ __forceinline__ void run(const float* __restrict__ base, int nvalid, double* __restrict__ lds, double (&out)[18]) {
+    stage_cells<18>(base, nvalid, lds, out);
+  }
+};
+
 // reverse of stage_cells: every thread hands in its own cell, the workgroup stores
 // the nvalid cells as one contiguous run of 16-byte pieces
 template <int DPR>

@@ -26,7 +26,7 @@ __global__ __launch_bounds__(kBlock) void k_right_239(const T* __restrict__ E,
                                                       const double* __restrict__ xf,
                                                       double* __restrict__ y, int64_t O, int use_e,
                                                       int use_f, int accumulate, const int* __restrict__ stop) {
-  __shared__ double lds[kBlock * 18];
+  __shared__ double lds[FStage<T>::kLdsDoubles];  // 18 KB for fp64: 8 workgroups per CU
   if (stop && *stop) return;
   const int64_t r0 = int64_t(blockIdx.x) * kBlock;
   const int nvalid = int(min(int64_t(kBlock), O - r0));
@@ -38,7 +38,7 @@ __global__ __launch_bounds__(kBlock) void k_right_239(const T* __restrict__ E,
   double acc0 = 0.0, acc1 = 0.0;
   if (use_f) {
     double f[18];
-    stage_cells<18>(F + 18 * r0, nvalid, lds, f);
+    FStage<T>::run(F + 18 * r0, nvalid, lds, f);
     if (live) {
       const double* xc = xf + 9 * int64_t(row_cam[r]);
 #pragma unroll
