@@ -300,3 +300,47 @@ def perturb(prob, rotation_sigma, translation_sigma, point_sigma, seed=0):
     if translation_sigma > 0:
         cams[:, 3:6] += rng.normal(0.0, translation_sigma, (prob.num_cameras, 3))
     return dataclasses.replace(prob, cameras=cams, points=pts)
+
+
+# ----------------------------------------------------------------------------------------------
+# Quaternion cameras (BALProblem(filename, use_quaternions = true), bal_problem.cc:111-130):
+# [w x y z | translation 3 | focal k1 k2], conversions of include/ceres/rotation.h:315-388.
+# ----------------------------------------------------------------------------------------------
+def angle_axis_to_quaternion(aa):
+    """AngleAxisToQuaternion for an [n, 3] array -> [n, 4], w first."""
+    aa = np.asarray(aa, dtype=np.float64)
+    theta = np.sqrt((aa * aa).sum(axis=1))
+    nz = theta != 0.0
+    safe = np.where(nz, theta, 1.0)
+    k = np.where(nz, np.sin(0.5 * safe) / safe, 0.5)
+    w = np.where(nz, np.cos(0.5 * safe), 1.0)
+    return np.concatenate([w[:, None], aa * k[:, None]], axis=1)
+
+
+def quaternion_to_angle_axis(q):
+    """QuaternionToAngleAxis for an [n, 4] array -> [n, 3]."""
+    q = np.asarray(q, dtype=np.float64)
+    s = np.sqrt((q[:, 1:] ** 2).sum(axis=1))
+    nz = s != 0.0
+    c = q[:, 0]
+    two_theta = 2.0 * np.where(c < 0.0, np.arctan2(-s, -c), np.arctan2(s, c))
+    k = np.where(nz, two_theta / np.where(nz, s, 1.0), 2.0)
+    return q[:, 1:] * k[:, None]
+
+
+def quaternion_cameras(prob):
+    """[C, 10] camera array of the quaternion parameterisation."""
+    return np.concatenate([angle_axis_to_quaternion(prob.cameras[:, 0:3]), prob.cameras[:, 3:9]], axis=1)
+
+
+def state_quaternion(prob):
+    """Ambient parameter vector [points | 10-parameter cameras] for CX_CAMERA_QUATERNION_MANIFOLD."""
+    return np.concatenate([prob.points.ravel(), quaternion_cameras(prob).ravel()])
+
+
+def cameras_from_quaternion_state(prob, state):
+    """Back to a BalProblem with angle-axis cameras (BALProblem::WriteToFile converts the same way)."""
+    P, C = prob.num_points, prob.num_cameras
+    cams10 = np.asarray(state[3 * P:]).reshape(C, 10)
+    cams = np.concatenate([quaternion_to_angle_axis(cams10[:, 0:4]), cams10[:, 4:10]], axis=1)
+    return dataclasses.replace(prob, points=np.asarray(state[:3 * P]).reshape(P, 3).copy(), cameras=cams)

@@ -94,6 +94,14 @@ typedef enum {
   CX_LOSS_TUKEY = 6
 } cx_loss_type;
 
+/* Camera parameterisation of the bundle-adjustment evaluator (examples/bundle_adjuster.cc:316-346):
+ * CX_CAMERA_ANGLE_AXIS: 9 parameters (angle-axis 3, translation 3, focal, k1, k2), Euclidean --
+ *   SnavelyReprojectionError, snavely_reprojection_error.h:53-104;
+ * CX_CAMERA_QUATERNION_MANIFOLD: 10 parameters (quaternion w x y z, translation 3, focal, k1, k2) on
+ *   ProductManifold<QuaternionManifold, EuclideanManifold<6>> (--use_quaternions --use_manifolds):
+ *   SnavelyReprojectionErrorWithQuaternions :111-170; tangent size 9, so J keeps the <2,3,9> structure. */
+typedef enum { CX_CAMERA_ANGLE_AXIS = 0, CX_CAMERA_QUATERNION_MANIFOLD = 1 } cx_camera_model;
+
 /* Where b, D, x, state ... pointers of a call live. */
 typedef enum { CX_HOST = 0, CX_DEVICE = 1 } cx_memspace;
 

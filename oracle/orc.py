@@ -99,7 +99,8 @@ SOLVE_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, c_double_p, c_double_
 class orc_min_problem(ctypes.Structure):
     _fields_ = [("num_parameters", ctypes.c_int32), ("num_residuals", ctypes.c_int32), ("user", ctypes.c_void_p),
                 ("evaluate", EVALUATE_FN), ("squared_column_norm", VEC_OUT_FN), ("scale_columns", VEC_IN_FN),
-                ("right_multiply", MULT_FN), ("solve", SOLVE_FN)]
+                ("right_multiply", MULT_FN), ("solve", SOLVE_FN), ("num_effective_parameters", ctypes.c_int32),
+                ("plus", ctypes.c_void_p)]
 
 DENSE_SCHUR, SPARSE_SCHUR, ITERATIVE_SCHUR, CGNR = 0, 1, 2, 3
 IDENTITY, JACOBI, SCHUR_JACOBI, SCHUR_POWER_SERIES_EXPANSION = 0, 1, 2, 3
@@ -423,7 +424,7 @@ def minimize_dense(fun, x0, options=None):
         return SUCCESS
 
     cbs = (EVALUATE_FN(evaluate), VEC_OUT_FN(sqnorm), VEC_IN_FN(scale), MULT_FN(mult), SOLVE_FN(solve))
-    prob = orc_min_problem(n, m, None, *cbs)
+    prob = orc_min_problem(n, m, None, *cbs, n, None)
     options = options or minimizer_options()
     cap = options.max_num_iterations + 2
     its = (cx_iteration_summary * cap)()
@@ -433,8 +434,65 @@ def minimize_dense(fun, x0, options=None):
     return x0, _summary_dict(summ), [_summary_dict(its[i]) for i in range(k)]
 
 
+ANGLE_AXIS, QUATERNION_MANIFOLD = 0, 1
+
+
+def angle_axis_to_quaternion(aa):
+    q = np.zeros(4)
+    lib().orc_angle_axis_to_quaternion(_p(_f64(aa)), _p(q))
+    return q
+
+
+def quaternion_to_angle_axis(q):
+    aa = np.zeros(3)
+    lib().orc_quaternion_to_angle_axis(_p(_f64(q)), _p(aa))
+    return aa
+
+
+def quaternion_plus(x, delta):
+    out = np.zeros(4)
+    lib().orc_quaternion_plus(_p(_f64(x)), _p(_f64(delta)), _p(out))
+    return out
+
+
+def quaternion_plus_jacobian(x):
+    out = np.zeros(12)
+    lib().orc_quaternion_plus_jacobian(_p(_f64(x)), _p(out))
+    return out.reshape(4, 3)
+
+
+def snavely_quaternion(camera10, point, obs, want_jacobian=True):
+    res, jc, jp = np.zeros(2), np.zeros(18), np.zeros(6)
+    lib().orc_snavely_quaternion(_p(_f64(camera10)), _p(_f64(point)), _p(_f64(obs)), _p(res),
+                                 _p(jc) if want_jacobian else None, _p(jp) if want_jacobian else None)
+    return res, jc.reshape(2, 9), jp.reshape(2, 3)
+
+
+def bal_plus(num_cameras, num_points, camera_model, x, delta):
+    out = np.zeros_like(_f64(x))
+    lib().orc_bal_plus(int(num_cameras), int(num_points), int(camera_model), _p(_f64(x)), _p(_f64(delta)), _p(out))
+    return out
+
+
+def bal_evaluate_model(bs, num_cameras, num_points, camera_index, point_index, observations, order, state,
+                       camera_model, loss=None, want_jacobian=True):
+    O = int(camera_index.shape[0])
+    cost = ctypes.c_double()
+    res = np.zeros(2 * O)
+    grad = np.zeros(3 * num_points + 9 * num_cameras)
+    vals = np.zeros(24 * O) if want_jacobian else None
+    ltype, la, lb = loss if loss is not None else (0, 0.0, 0.0)
+    lib().orc_bal_evaluate_model(bs.c, int(num_cameras), int(num_points), ctypes.c_int64(O),
+                                 _p(np.ascontiguousarray(camera_index, dtype=np.int32)),
+                                 _p(np.ascontiguousarray(point_index, dtype=np.int32)), _p(_f64(observations)),
+                                 _p(np.ascontiguousarray(order, dtype=np.int64)), _p(_f64(state)), int(camera_model),
+                                 int(ltype), ctypes.c_double(la), ctypes.c_double(lb), ctypes.byref(cost), _p(res),
+                                 _p(grad), _p(vals))
+    return cost.value, res, grad, vals
+
+
 def minimize_bal(num_cameras, num_points, camera_index, point_index, observations, state, solver_options,
-                 options=None, loss=None):
+                 options=None, loss=None, camera_model=0):
     state = np.array(state, dtype=np.float64).copy()
     options = options or minimizer_options()
     cap = options.max_num_iterations + 2
@@ -445,7 +503,7 @@ def minimize_bal(num_cameras, num_points, camera_index, point_index, observation
     lib().orc_minimize_bal(int(num_cameras), int(num_points), ctypes.c_int64(O),
                            _p(np.ascontiguousarray(camera_index, dtype=np.int32)),
                            _p(np.ascontiguousarray(point_index, dtype=np.int32)), _p(_f64(observations)),
-                           int(ltype), ctypes.c_double(la), ctypes.c_double(lb), ctypes.byref(solver_options),
+                           int(camera_model), int(ltype), ctypes.c_double(la), ctypes.c_double(lb), ctypes.byref(solver_options),
                            ctypes.byref(options), _p(state), ctypes.byref(summ), its, cap)
     k = min(cap, summ.num_iterations)
     return state, _summary_dict(summ), [_summary_dict(its[i]) for i in range(k)]

@@ -121,6 +121,25 @@ void orc_bal_evaluate_robust(const cx_block_structure* bs, int num_cameras, int 
                              int loss_type, double loss_a, double loss_b, double* cost,
                              double* residuals, double* gradient, double* values);
 
+/* ---- quaternion cameras on a manifold (bundle_adjuster --use_quaternions --use_manifolds) ---- */
+/* AngleAxisToQuaternion / QuaternionToAngleAxis (rotation.h:315-388), w first */
+void orc_angle_axis_to_quaternion(const double* angle_axis, double* quaternion);
+void orc_quaternion_to_angle_axis(const double* quaternion, double* angle_axis);
+/* QuaternionManifold::Plus / PlusJacobian (manifold.cc:27-78, 4x3 row-major) */
+void orc_quaternion_plus(const double* x, const double* delta, double* x_plus_delta);
+void orc_quaternion_plus_jacobian(const double* x, double* jacobian);
+/* SnavelyReprojectionErrorWithQuaternions + PlusJacobian projection: residual[2], tangent jac_cam[2x9], jac_pt[2x3] */
+void orc_snavely_quaternion(const double* camera10, const double* point3, const double* obs2,
+                            double* residual, double* jac_cam, double* jac_pt);
+/* Evaluator::Plus of the BAL program for a cx_camera_model (state [points | cameras]) */
+void orc_bal_plus(int num_cameras, int num_points, int camera_model, const double* x, const double* delta, double* out);
+/* orc_bal_evaluate_robust for a cx_camera_model: state has 3P + (9 or 10)C entries, gradient 3P + 9C */
+void orc_bal_evaluate_model(const cx_block_structure* bs, int num_cameras, int num_points, int64_t num_obs,
+                            const int32_t* camera_index, const int32_t* point_index, const double* observations,
+                            const int64_t* order, const double* state, int camera_model, int loss_type,
+                            double loss_a, double loss_b, double* cost, double* residuals, double* gradient,
+                            double* values);
+
 /* ---- trust region minimizer ---- */
 /* The Evaluator / SparseMatrix / LinearSolver operations TrustRegionMinimizer and
  * LevenbergMarquardtStrategy call, as callbacks so that tests can drive the loop with the
@@ -139,13 +158,17 @@ typedef struct {
   /* LinearSolver::Solve: min |J x - b|^2 + |D x|^2; returns cx_termination */
   int (*solve)(void* user, const double* b, const double* D, double q_tolerance, double* x,
                int* num_iterations);
+  /* Evaluator::Plus and NumEffectiveParameters for programs with manifolds; plus == NULL: Euclidean,
+   * num_effective_parameters is then ignored (= num_parameters) */
+  int32_t num_effective_parameters;
+  void (*plus)(void* user, const double* x, const double* delta, double* x_plus_delta);
 } orc_min_problem;
 int orc_minimize(const orc_min_problem* problem, const cx_minimizer_options* options,
                  double* parameters, cx_minimizer_summary* summary,
                  cx_iteration_summary* iterations, int capacity);
 /* the same loop on the BAL program with orc_bal_evaluate_robust and orc_solve */
 int orc_minimize_bal(int num_cameras, int num_points, int64_t num_obs, const int32_t* camera_index,
-                     const int32_t* point_index, const double* observations, int loss_type,
+                     const int32_t* point_index, const double* observations, int camera_model, int loss_type,
                      double loss_a, double loss_b, const cx_solver_options* solver_options,
                      const cx_minimizer_options* options, double* state,
                      cx_minimizer_summary* summary, cx_iteration_summary* iterations, int capacity);

@@ -65,6 +65,14 @@ template <int N> inline Jet<N> hypot3(const Jet<N>& x, const Jet<N>& y, const Je
   return r;
 }
 inline double hypot3(double x, double y, double z) { return std::hypot(x, y, z); }
+// jet.h:483-487
+template <int N> inline Jet<N> sqrt(const Jet<N>& f) {
+  const double tmp = std::sqrt(f.a);
+  const double two_a_inverse = 1.0 / (2.0 * tmp);
+  Jet<N> r; r.a = tmp;
+  for (int i = 0; i < N; ++i) r.v[i] = f.v[i] * two_a_inverse;
+  return r;
+}
 inline double value_of(double x) { return x; }
 template <int N> inline double value_of(const Jet<N>& x) { return x.a; }
 inline double make(double, double s) { return s; }
@@ -132,6 +140,104 @@ static void SnavelyAutoDiff(const double* cam, const double* pt, const double* o
     res[k] = r[k].a;
     if (jc) for (int i = 0; i < 9; ++i) jc[k * 9 + i] = r[k].v[i];
     if (jp) for (int i = 0; i < 3; ++i) jp[k * 3 + i] = r[k].v[9 + i];
+  }
+}
+
+// rotation.h:722-760
+template <typename T>
+inline void UnitQuaternionRotatePoint(const T q[4], const T pt[3], T result[3]) {
+  T uv0 = q[2] * pt[2] - q[3] * pt[1];
+  T uv1 = q[3] * pt[0] - q[1] * pt[2];
+  T uv2 = q[1] * pt[1] - q[2] * pt[0];
+  uv0 = uv0 + uv0;
+  uv1 = uv1 + uv1;
+  uv2 = uv2 + uv2;
+  result[0] = pt[0] + q[0] * uv0;
+  result[1] = pt[1] + q[0] * uv1;
+  result[2] = pt[2] + q[0] * uv2;
+  result[0] = result[0] + (q[2] * uv2 - q[3] * uv1);
+  result[1] = result[1] + (q[3] * uv0 - q[1] * uv2);
+  result[2] = result[2] + (q[1] * uv1 - q[2] * uv0);
+}
+template <typename T>
+inline void QuaternionRotatePoint(const T q[4], const T pt[3], T result[3]) {
+  using std::sqrt;
+  const T scale = 1.0 / sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+  const T unit[4] = {scale * q[0], scale * q[1], scale * q[2], scale * q[3]};
+  UnitQuaternionRotatePoint(unit, pt, result);
+}
+template <int N> inline Jet<N> operator*(double s, const Jet<N>& f) { return f * s; }
+
+// examples/snavely_reprojection_error.h:111-170 (camera: quaternion 4, translation 3, focal, k1, k2)
+template <typename T>
+inline void SnavelyQuaternion(const T* camera, const T* point, double ox, double oy, T* residuals) {
+  T p[3];
+  QuaternionRotatePoint(camera, point, p);
+  p[0] = p[0] + camera[4];
+  p[1] = p[1] + camera[5];
+  p[2] = p[2] + camera[6];
+  const T xp = -p[0] / p[2];
+  const T yp = -p[1] / p[2];
+  const T& l1 = camera[8];
+  const T& l2 = camera[9];
+  const T r2 = xp * xp + yp * yp;
+  const T distortion = 1.0 + r2 * (l1 + l2 * r2);
+  const T& focal = camera[7];
+  const T predicted_x = focal * distortion * xp;
+  const T predicted_y = focal * distortion * yp;
+  residuals[0] = predicted_x - ox;
+  residuals[1] = predicted_y - oy;
+}
+
+// QuaternionManifold (manifold.cc:27-78), w first
+static void QuaternionPlus(const double* x, const double* delta, double* x_plus_delta) {
+  const double norm_delta = std::hypot(delta[0], delta[1], delta[2]);
+  if (std::fpclassify(norm_delta) == FP_ZERO) {
+    std::copy(x, x + 4, x_plus_delta);
+    return;
+  }
+  const double sin_delta_by_delta = std::sin(norm_delta) / norm_delta;
+  const double q[4] = {std::cos(norm_delta), sin_delta_by_delta * delta[0], sin_delta_by_delta * delta[1],
+                       sin_delta_by_delta * delta[2]};
+  x_plus_delta[0] = q[0] * x[0] - q[1] * x[1] - q[2] * x[2] - q[3] * x[3];
+  x_plus_delta[1] = q[0] * x[1] + q[1] * x[0] + q[2] * x[3] - q[3] * x[2];
+  x_plus_delta[2] = q[0] * x[2] - q[1] * x[3] + q[2] * x[0] + q[3] * x[1];
+  x_plus_delta[3] = q[0] * x[3] + q[1] * x[2] - q[2] * x[1] + q[3] * x[0];
+}
+static void QuaternionPlusJacobian(const double* x, double* j /* 4x3 row-major */) {
+  j[0] = -x[1]; j[1] = -x[2]; j[2] = -x[3];
+  j[3] = x[0];  j[4] = x[3];  j[5] = -x[2];
+  j[6] = -x[3]; j[7] = x[0];  j[8] = x[1];
+  j[9] = x[2];  j[10] = -x[1]; j[11] = x[0];
+}
+
+// AutoDiffCostFunction<SnavelyReprojectionErrorWithQuaternions, 2, 10, 3> followed by the projection with
+// the PlusJacobian of ProductManifold<QuaternionManifold, EuclideanManifold<6>> (residual_block.cc:136-159):
+// jc is the 2x9 tangent-space block
+static void SnavelyQuaternionAutoDiff(const double* cam, const double* pt, const double* obs, double* res, double* jc,
+                                      double* jp) {
+  if (!jc && !jp) {
+    SnavelyQuaternion<double>(cam, pt, obs[0], obs[1], res);
+    return;
+  }
+  using J = Jet<13>;
+  J c[10], p[3], r[2];
+  for (int i = 0; i < 10; ++i) c[i] = J(cam[i], i);
+  for (int i = 0; i < 3; ++i) p[i] = J(pt[i], 10 + i);
+  SnavelyQuaternion<J>(c, p, obs[0], obs[1], r);
+  double pj[12];
+  QuaternionPlusJacobian(cam, pj);
+  for (int k = 0; k < 2; ++k) {
+    res[k] = r[k].a;
+    if (jc) {
+      for (int t = 0; t < 3; ++t) {
+        double sum = 0.0;
+        for (int a = 0; a < 4; ++a) sum += r[k].v[a] * pj[a * 3 + t];
+        jc[k * 9 + t] = sum;
+      }
+      for (int i = 0; i < 6; ++i) jc[k * 9 + 3 + i] = r[k].v[4 + i];
+    }
+    if (jp) for (int i = 0; i < 3; ++i) jp[k * 3 + i] = r[k].v[10 + i];
   }
 }
 
@@ -319,11 +425,57 @@ void orc_corrector_apply(double sq_norm, const double* rho, int num_rows, int nu
   for (int r = 0; r < num_rows; ++r) residuals[r] *= residual_scaling;
 }
 
-void orc_bal_evaluate_robust(const cx_block_structure* s, int C, int P, int64_t O, const int32_t* cam,
-                             const int32_t* pt, const double* observations, const int64_t* order,
-                             const double* state, int loss_type, double loss_a, double loss_b,
-                             double* cost, double* residuals, double* gradient, double* values) {
+// rotation.h:315-388
+void orc_angle_axis_to_quaternion(const double* aa, double* q) {
+  const double theta = std::hypot(aa[0], aa[1], aa[2]);
+  if (std::fpclassify(theta) != FP_ZERO) {
+    const double half_theta = theta * 0.5;
+    const double k = std::sin(half_theta) / theta;
+    q[0] = std::cos(half_theta); q[1] = aa[0] * k; q[2] = aa[1] * k; q[3] = aa[2] * k;
+  } else {
+    q[0] = 1.0; q[1] = aa[0] * 0.5; q[2] = aa[1] * 0.5; q[3] = aa[2] * 0.5;
+  }
+}
+void orc_quaternion_to_angle_axis(const double* q, double* aa) {
+  const double sin_theta = std::hypot(q[1], q[2], q[3]);
+  if (std::fpclassify(sin_theta) != FP_ZERO) {
+    const double cos_theta = q[0];
+    const double two_theta = 2.0 * ((cos_theta < 0.0) ? std::atan2(-sin_theta, -cos_theta) : std::atan2(sin_theta, cos_theta));
+    const double k = two_theta / sin_theta;
+    aa[0] = q[1] * k; aa[1] = q[2] * k; aa[2] = q[3] * k;
+  } else {
+    aa[0] = q[1] * 2.0; aa[1] = q[2] * 2.0; aa[2] = q[3] * 2.0;
+  }
+}
+void orc_quaternion_plus(const double* x, const double* delta, double* x_plus_delta) { QuaternionPlus(x, delta, x_plus_delta); }
+void orc_quaternion_plus_jacobian(const double* x, double* jacobian) { QuaternionPlusJacobian(x, jacobian); }
+void orc_snavely_quaternion(const double* cam10, const double* pt, const double* obs, double* res, double* jc9, double* jp) {
+  SnavelyQuaternionAutoDiff(cam10, pt, obs, res, jc9, jp);
+}
+
+// Evaluator::Plus for the BAL program: points Euclidean; cameras Euclidean (camera_model 0: 9 parameters) or
+// ProductManifold<QuaternionManifold, EuclideanManifold<6>> (camera_model 1: 10 parameters, 9 tangent)
+void orc_bal_plus(int C, int P, int camera_model, const double* x, const double* delta, double* out) {
+  for (int i = 0; i < 3 * P; ++i) out[i] = x[i] + delta[i];
+  if (camera_model == CX_CAMERA_ANGLE_AXIS) {
+    for (int i = 0; i < 9 * C; ++i) out[3 * P + i] = x[3 * P + i] + delta[3 * P + i];
+    return;
+  }
+  for (int c = 0; c < C; ++c) {
+    const double* xc = x + 3 * P + 10 * c;
+    const double* dc = delta + 3 * P + 9 * c;
+    double* oc = out + 3 * P + 10 * c;
+    QuaternionPlus(xc, dc, oc);
+    for (int i = 0; i < 6; ++i) oc[4 + i] = xc[4 + i] + dc[3 + i];
+  }
+}
+
+void orc_bal_evaluate_model(const cx_block_structure* s, int C, int P, int64_t O, const int32_t* cam,
+                            const int32_t* pt, const double* observations, const int64_t* order,
+                            const double* state, int camera_model, int loss_type, double loss_a, double loss_b,
+                            double* cost, double* residuals, double* gradient, double* values) {
   (void)s;
+  const int cam_size = camera_model == CX_CAMERA_ANGLE_AXIS ? 9 : 10;
   const int threads = orc_get_num_threads();
   double total = 0.0;
   const int num_cols = 3 * P + 9 * C;
@@ -332,11 +484,14 @@ void orc_bal_evaluate_robust(const cx_block_structure* s, int C, int P, int64_t 
 #pragma omp parallel for schedule(static) num_threads(threads) reduction(+ : total)
   for (int64_t k = 0; k < O; ++k) {
     const int64_t i = order[k];
-    const double* camera = state + 3 * P + 9 * cam[i];
+    const double* camera = state + 3 * P + cam_size * cam[i];
     const double* point = state + 3 * pt[i];
     double r[2], jc[18], jp[6];
     const bool need_j = values || gradient;
-    SnavelyAutoDiff(camera, point, observations + 2 * i, r, need_j ? jc : nullptr, need_j ? jp : nullptr);
+    if (camera_model == CX_CAMERA_ANGLE_AXIS)
+      SnavelyAutoDiff(camera, point, observations + 2 * i, r, need_j ? jc : nullptr, need_j ? jp : nullptr);
+    else
+      SnavelyQuaternionAutoDiff(camera, point, observations + 2 * i, r, need_j ? jc : nullptr, need_j ? jp : nullptr);
     const double sq = r[0] * r[0] + r[1] * r[1];
     if (loss_type == CX_LOSS_NONE) {
       total += 0.5 * sq;                       // residual_block.cc:160-163
@@ -368,6 +523,14 @@ void orc_bal_evaluate_robust(const cx_block_structure* s, int C, int P, int64_t 
     std::fill(gradient, gradient + num_cols, 0.0);
     for (auto& g : grads) for (int i = 0; i < num_cols; ++i) gradient[i] += g[i];
   }
+}
+
+void orc_bal_evaluate_robust(const cx_block_structure* s, int C, int P, int64_t O, const int32_t* cam,
+                             const int32_t* pt, const double* observations, const int64_t* order,
+                             const double* state, int loss_type, double loss_a, double loss_b,
+                             double* cost, double* residuals, double* gradient, double* values) {
+  orc_bal_evaluate_model(s, C, P, O, cam, pt, observations, order, state, CX_CAMERA_ANGLE_AXIS, loss_type, loss_a, loss_b,
+                         cost, residuals, gradient, values);
 }
 
 void orc_bal_evaluate(const cx_block_structure* s, int C, int P, int64_t O, const int32_t* cam,

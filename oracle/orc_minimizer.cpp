@@ -22,6 +22,7 @@ namespace {
 // levenberg_marquardt_strategy.cc:50-175
 struct LmStrategy {
   const orc_min_problem* p;
+  int n = 0;  // tangent size (jacobian->num_cols())
   double radius, max_radius, min_diagonal, max_diagonal;
   double decrease_factor = 2.0;
   bool reuse_diagonal = false;
@@ -29,7 +30,6 @@ struct LmStrategy {
 
   // returns cx_termination
   int ComputeStep(double eta, const double* residuals, double* step, int* num_iterations) {
-    const int n = p->num_parameters;
     if (!reuse_diagonal) {
       diagonal.assign(n, 0.0);
       p->squared_column_norm(p->user, diagonal.data());
@@ -109,7 +109,7 @@ struct Minimizer {
   cx_minimizer_summary* out;
   cx_iteration_summary* iterations;
   int capacity;
-  int n, m;
+  int n, m, n_amb;  // n: tangent size (gradient, step), n_amb: ambient size (x)
   std::vector<double> x, candidate_x, residuals, gradient, step, delta, scaling, model_residuals;
   double x_cost = std::numeric_limits<double>::max(), minimum_cost = x_cost, candidate_cost = 0.0;
   double model_cost_change = 0.0;
@@ -120,6 +120,11 @@ struct Minimizer {
   int num_written = 0;
 
   void Message(const char* fmt, double a, double b) { std::snprintf(out->message, sizeof(out->message), fmt, a, b); }
+
+  void Plus(const double* xx, const double* dd, double* out) const {
+    if (p->plus) p->plus(p->user, xx, dd, out);
+    else for (int i = 0; i < n; ++i) out[i] = xx[i] + dd[i];
+  }
 
   // trust_region_minimizer.cc:228-299
   bool EvaluateGradientAndJacobian() {
@@ -136,11 +141,13 @@ struct Minimizer {
       }
       p->scale_columns(p->user, scaling.data());
     }
-    // |Plus(x, -gradient) - x| with Plus(x, d) = x + d
+    // |Plus(x, -gradient) - x| in the ambient space
+    std::vector<double> negative_gradient(n), projected(n_amb);
+    for (int i = 0; i < n; ++i) negative_gradient[i] = -gradient[i];
+    Plus(x.data(), negative_gradient.data(), projected.data());
     double max_norm = 0.0, sq = 0.0;
-    for (int i = 0; i < n; ++i) {
-      const double projected = x[i] + (-gradient[i]);
-      const double d = x[i] - projected;
+    for (int i = 0; i < n_amb; ++i) {
+      const double d = x[i] - projected[i];
       max_norm = std::max(max_norm, std::fabs(d));
       sq += d * d;
     }
@@ -237,10 +244,11 @@ struct Minimizer {
 
   void Run() {
     auto start = Clock::now();
-    n = p->num_parameters;
+    n_amb = p->num_parameters;
+    n = (p->plus && p->num_effective_parameters > 0) ? p->num_effective_parameters : n_amb;
     m = p->num_residuals;
-    x.assign(parameters, parameters + n);
-    candidate_x.resize(n); residuals.resize(m); gradient.resize(n); step.resize(n); delta.resize(n);
+    x.assign(parameters, parameters + n_amb);
+    candidate_x.resize(n_amb); residuals.resize(m); gradient.resize(n); step.resize(n); delta.resize(n);
     model_residuals.resize(m);
     scaling.assign(n, 1.0);
     out->termination_type = CX_MIN_NO_CONVERGENCE;
@@ -257,6 +265,7 @@ struct Minimizer {
       it.step_is_successful = 1;
       LmStrategy strategy;
       strategy.p = p;
+      strategy.n = n;
       strategy.radius = o.initial_trust_region_radius;
       strategy.max_radius = o.max_trust_region_radius;
       strategy.min_diagonal = o.min_lm_diagonal;
@@ -278,13 +287,13 @@ struct Minimizer {
           continue;
         }
         // ComputeCandidatePointAndEvaluateCost (trust_region_minimizer.cc:753-774)
-        for (int i = 0; i < n; ++i) candidate_x[i] = x[i] + delta[i];
+        Plus(x.data(), delta.data(), candidate_x.data());
         if (!p->evaluate(p->user, candidate_x.data(), &candidate_cost, nullptr, nullptr, 0))
           candidate_cost = std::numeric_limits<double>::max();
         if (atleast_one_successful_step) {
           // ParameterToleranceReached (trust_region_minimizer.cc:700-723)
           double x_sq = 0.0, d_sq = 0.0;
-          for (int i = 0; i < n; ++i) {
+          for (int i = 0; i < n_amb; ++i) {
             x_sq += x[i] * x[i];
             const double d = x[i] - candidate_x[i];
             d_sq += d * d;
@@ -333,6 +342,7 @@ struct Minimizer {
 
 // ------------------------------------------------------------------ BAL program
 struct BalProgram {
+  int camera_model = CX_CAMERA_ANGLE_AXIS;
   int C, P;
   int64_t O;
   const int32_t *cam, *pt;
@@ -349,8 +359,8 @@ struct BalProgram {
 };
 int BalEvaluate(void* u, const double* x, double* cost, double* residuals, double* gradient, int want_jacobian) {
   auto* b = static_cast<BalProgram*>(u);
-  orc_bal_evaluate_robust(&b->bs, b->C, b->P, b->O, b->cam, b->pt, b->obs, b->order.data(), x, b->loss_type, b->loss_a,
-                          b->loss_b, cost, residuals, gradient, want_jacobian ? b->values.data() : nullptr);
+  orc_bal_evaluate_model(&b->bs, b->C, b->P, b->O, b->cam, b->pt, b->obs, b->order.data(), x, b->camera_model, b->loss_type,
+                         b->loss_a, b->loss_b, cost, residuals, gradient, want_jacobian ? b->values.data() : nullptr);
   return std::isfinite(*cost) ? 1 : 0;
 }
 void BalSqNorm(void* u, double* out) {
@@ -364,6 +374,10 @@ void BalScale(void* u, const double* scale) {
 void BalRight(void* u, const double* x, double* y) {
   auto* b = static_cast<BalProgram*>(u);
   orc_right_multiply(&b->bs, b->values.data(), x, y);
+}
+void BalPlus(void* u, const double* x, const double* delta, double* out) {
+  auto* b = static_cast<BalProgram*>(u);
+  orc_bal_plus(b->C, b->P, b->camera_model, x, delta, out);
 }
 int BalSolve(void* u, const double* rhs, const double* D, double q_tolerance, double* x, int* num_iterations) {
   auto* b = static_cast<BalProgram*>(u);
@@ -391,12 +405,14 @@ int orc_minimize(const orc_min_problem* problem, const cx_minimizer_options* opt
   return 0;
 }
 
-int orc_minimize_bal(int C, int P, int64_t O, const int32_t* cam, const int32_t* pt, const double* obs, int loss_type,
+int orc_minimize_bal(int C, int P, int64_t O, const int32_t* cam, const int32_t* pt, const double* obs, int camera_model,
+                     int loss_type,
                      double loss_a, double loss_b, const cx_solver_options* solver_options,
                      const cx_minimizer_options* options, double* state, cx_minimizer_summary* summary,
                      cx_iteration_summary* iterations, int capacity) {
   orc::BalProgram b;
   b.C = C; b.P = P; b.O = O; b.cam = cam; b.pt = pt; b.obs = obs;
+  b.camera_model = camera_model;
   b.loss_type = loss_type; b.loss_a = loss_a; b.loss_b = loss_b;
   b.solver_options = *solver_options;
   b.order.resize(O);
@@ -405,8 +421,9 @@ int orc_minimize_bal(int C, int P, int64_t O, const int32_t* cam, const int32_t*
   orc_bal_structure(C, P, O, cam, pt, b.order.data(), b.rows.data(), b.cols.data(), b.rcb.data(), b.cells.data());
   b.bs = cx_block_structure{int32_t(O), P + C, b.rows.data(), b.cols.data(), b.rcb.data(), b.cells.data()};
   b.values.assign(size_t(24) * O, 0.0);
-  orc_min_problem p{3 * P + 9 * C, int32_t(2 * O), &b, orc::BalEvaluate, orc::BalSqNorm, orc::BalScale, orc::BalRight,
-                    orc::BalSolve};
+  const int cam_size = camera_model == CX_CAMERA_ANGLE_AXIS ? 9 : 10;
+  orc_min_problem p{3 * P + cam_size * C, int32_t(2 * O), &b, orc::BalEvaluate, orc::BalSqNorm, orc::BalScale, orc::BalRight,
+                    orc::BalSolve, 3 * P + 9 * C, orc::BalPlus};
   return orc_minimize(&p, options, state, summary, iterations, capacity);
 }
 
