@@ -18,6 +18,7 @@ _lib = None
 HOST, DEVICE = 0, 1
 DENSE_SCHUR, SPARSE_SCHUR, ITERATIVE_SCHUR, CGNR = 0, 1, 2, 3
 LOSS_NONE, LOSS_HUBER, LOSS_SOFT_L_ONE, LOSS_CAUCHY, LOSS_ARCTAN, LOSS_TOLERANT, LOSS_TUKEY = range(7)
+CAMERA_ANGLE_AXIS, CAMERA_QUATERNION_MANIFOLD = 0, 1
 IDENTITY, JACOBI, SCHUR_JACOBI, SCHUR_POWER_SERIES_EXPANSION = 0, 1, 2, 3
 SUCCESS, NO_CONVERGENCE, FAILURE, FATAL_ERROR = 0, 1, 2, 3
 
@@ -35,6 +36,7 @@ EXPORTED_SYMBOLS = [
     "cx_solver_solve", "cx_solver_last_timing", "cx_solver_kernel_stats", "cx_schur_eliminate_dense", "cx_schur_back_substitute",
     "cx_implicit_schur_multiply", "cx_dense_cholesky_solve", "cx_evaluator_create_bal", "cx_evaluator_destroy",
     "cx_evaluator_jacobian", "cx_evaluator_row_of_observation", "cx_evaluator_evaluate", "cx_evaluator_set_loss", "cx_minimizer_default_options", "cx_minimize", "cx_schur_sparse_structure",
+    "cx_evaluator_set_camera_model", "cx_evaluator_num_parameters", "cx_evaluator_num_effective_parameters", "cx_evaluator_plus",
     "cx_evaluator_last_kernel_ms", "cx_detect_structure", "cx_partition_points", "cx_stable_schur_ordering",
 ]
 
@@ -154,6 +156,8 @@ def load_library():
     lib.cx_matrix_device_values.restype = ctypes.c_void_p
     lib.cx_matrix_last_kernel_ms.restype = ctypes.c_double
     lib.cx_evaluator_last_kernel_ms.restype = ctypes.c_double
+    lib.cx_evaluator_num_parameters.restype = ctypes.c_int64
+    lib.cx_evaluator_num_effective_parameters.restype = ctypes.c_int64
     lib.cx_evaluator_jacobian.restype = ctypes.c_void_p
     lib.cx_context_stream.restype = ctypes.c_void_p
     for name in ("cx_matrix_destroy", "cx_solver_destroy", "cx_evaluator_destroy", "cx_context_destroy",
@@ -515,6 +519,25 @@ class Evaluator:
         return out
 
     last_kernel_ms = property(lambda s: s.lib.cx_evaluator_last_kernel_ms(s._h))
+
+    def set_camera_model(self, model):
+        """CAMERA_ANGLE_AXIS (9 parameters) or CAMERA_QUATERNION_MANIFOLD (10 parameters, 9 tangent)."""
+        _check(self.lib.cx_evaluator_set_camera_model(self._h, int(model)))
+
+    @property
+    def num_parameters(self):
+        return int(self.lib.cx_evaluator_num_parameters(self._h))
+
+    @property
+    def num_effective_parameters(self):
+        return int(self.lib.cx_evaluator_num_effective_parameters(self._h))
+
+    def plus(self, x, delta):
+        """Evaluator::Plus on host arrays: x ambient, delta tangent."""
+        x, delta = _f64(x), _f64(delta)
+        out = np.zeros(self.num_parameters)
+        _check(self.lib.cx_evaluator_plus(self._h, _ptr(x), _ptr(delta), _ptr(out), HOST))
+        return out
 
     def set_loss(self, loss_type, a=1.0, b=0.0):
         """loss_type: one of LOSS_* (cx_loss_type); a, b the LossFunction constructor arguments."""

@@ -223,7 +223,88 @@ __device__ __forceinline__ void snavely_jet(const double* camv, const double* pt
   for (int i = 0; i < 3; ++i) { jp[i] = px.v[9 + i]; jp[3 + i] = py.v[9 + i]; }
 }
 
-template <bool WITH_J>
+// jet.h:483-487
+template <int N> __device__ __forceinline__ Jet<N> jsqrt(const Jet<N>& f) {
+  const double t = sqrt(f.a);
+  const double m = 1.0 / (2.0 * t);
+  Jet<N> r; r.a = t;
+#pragma unroll
+  for (int i = 0; i < N; ++i) r.v[i] = f.v[i] * m;
+  return r;
+}
+template <int N> __device__ __forceinline__ Jet<N> operator*(double s, const Jet<N>& f) { Jet<N> r; r.a = s * f.a;
+#pragma unroll
+  for (int i = 0; i < N; ++i) r.v[i] = s * f.v[i]; return r; }
+
+// ---- quaternion cameras: SnavelyReprojectionErrorWithQuaternions (snavely_reprojection_error.h:111-170) with
+// QuaternionRotatePoint / UnitQuaternionRotatePoint (rotation.h:722-760).  T is double or Jet<13>.
+template <typename T>
+__device__ __forceinline__ void unit_quaternion_rotate(const T (&q)[4], const T (&pt)[3], T (&result)[3]) {
+  T uv0 = q[2] * pt[2] - q[3] * pt[1];
+  T uv1 = q[3] * pt[0] - q[1] * pt[2];
+  T uv2 = q[1] * pt[1] - q[2] * pt[0];
+  uv0 = uv0 + uv0;
+  uv1 = uv1 + uv1;
+  uv2 = uv2 + uv2;
+  result[0] = pt[0] + q[0] * uv0;
+  result[1] = pt[1] + q[0] * uv1;
+  result[2] = pt[2] + q[0] * uv2;
+  result[0] = result[0] + (q[2] * uv2 - q[3] * uv1);
+  result[1] = result[1] + (q[3] * uv0 - q[1] * uv2);
+  result[2] = result[2] + (q[1] * uv1 - q[2] * uv0);
+}
+
+__device__ __forceinline__ void snavely_value_quat(const double* cam, const double* ptv, double ox, double oy, double& r0, double& r1) {
+  const double scale = 1.0 / sqrt(cam[0] * cam[0] + cam[1] * cam[1] + cam[2] * cam[2] + cam[3] * cam[3]);
+  const double unit[4] = {scale * cam[0], scale * cam[1], scale * cam[2], scale * cam[3]};
+  const double pt[3] = {ptv[0], ptv[1], ptv[2]};
+  double p[3];
+  unit_quaternion_rotate(unit, pt, p);
+  p[0] += cam[4]; p[1] += cam[5]; p[2] += cam[6];
+  const double xp = -p[0] / p[2], yp = -p[1] / p[2];
+  const double r2 = xp * xp + yp * yp;
+  const double dist = 1.0 + r2 * (cam[8] + cam[9] * r2);
+  r0 = cam[7] * dist * xp - ox;
+  r1 = cam[7] * dist * yp - oy;
+}
+
+// Dual numbers over the 10 + 3 ambient parameters, then the projection with the PlusJacobian of
+// ProductManifold<QuaternionManifold, EuclideanManifold<6>> (residual_block.cc:136-159, manifold.cc:62-78):
+// jc is the 2x9 tangent-space cell the static <2,3,9> layout stores.
+__device__ __forceinline__ void snavely_jet_quat(const double* camv, const double* ptv, double ox, double oy, double& r0,
+                                                 double& r1, double (&jc)[18], double (&jp)[6]) {
+  using J = Jet<13>;
+  J c[10], x[3];
+#pragma unroll
+  for (int i = 0; i < 10; ++i) c[i] = jvar<13>(camv[i], i);
+#pragma unroll
+  for (int i = 0; i < 3; ++i) x[i] = jvar<13>(ptv[i], 10 + i);
+  const J scale = 1.0 / jsqrt(c[0] * c[0] + c[1] * c[1] + c[2] * c[2] + c[3] * c[3]);
+  const J unit[4] = {scale * c[0], scale * c[1], scale * c[2], scale * c[3]};
+  J p[3];
+  unit_quaternion_rotate(unit, x, p);
+  p[0] = p[0] + c[4]; p[1] = p[1] + c[5]; p[2] = p[2] + c[6];
+  const J xp = -p[0] / p[2], yp = -p[1] / p[2];
+  const J r2 = xp * xp + yp * yp;
+  const J dist = 1.0 + r2 * (c[8] + c[9] * r2);
+  const J px = c[7] * dist * xp, py = c[7] * dist * yp;
+  r0 = px.a - ox;
+  r1 = py.a - oy;
+  // 4x3 PlusJacobian of the quaternion (w x y z): rows {-x -y -z; w z -y; -z w x; y -x w}
+  const double w = camv[0], qx = camv[1], qy = camv[2], qz = camv[3];
+  jc[0] = -px.v[0] * qx + px.v[1] * w - px.v[2] * qz + px.v[3] * qy;
+  jc[1] = -px.v[0] * qy + px.v[1] * qz + px.v[2] * w - px.v[3] * qx;
+  jc[2] = -px.v[0] * qz - px.v[1] * qy + px.v[2] * qx + px.v[3] * w;
+  jc[9] = -py.v[0] * qx + py.v[1] * w - py.v[2] * qz + py.v[3] * qy;
+  jc[10] = -py.v[0] * qy + py.v[1] * qz + py.v[2] * w - py.v[3] * qx;
+  jc[11] = -py.v[0] * qz - py.v[1] * qy + py.v[2] * qx + py.v[3] * w;
+#pragma unroll
+  for (int i = 0; i < 6; ++i) { jc[3 + i] = px.v[4 + i]; jc[12 + i] = py.v[4 + i]; }
+#pragma unroll
+  for (int i = 0; i < 3; ++i) { jp[i] = px.v[10 + i]; jp[3 + i] = py.v[10 + i]; }
+}
+
+template <bool WITH_J, int MODEL>
 __global__ __launch_bounds__(kBlock) void k_bal_evaluate(const double* __restrict__ state,
                                                          const double* __restrict__ obs,
                                                          const int32_t* __restrict__ row_pt,
@@ -240,16 +321,22 @@ __global__ __launch_bounds__(kBlock) void k_bal_evaluate(const double* __restric
   double res0 = 0.0, res1 = 0.0, cost_term = 0.0;
   double jc[18], jp[6];
   if (tid < nvalid) {
-    double cam[9], pt[3];
-    const double* cp = state + cam_off + 9 * int64_t(row_cam[r]);
+    constexpr int kCam = (MODEL == CX_CAMERA_ANGLE_AXIS) ? 9 : 10;
+    double cam[kCam], pt[3];
+    const double* cp = state + cam_off + kCam * int64_t(row_cam[r]);
     const double* pp = state + 3 * int64_t(row_pt[r]);
 #pragma unroll
-    for (int i = 0; i < 9; ++i) cam[i] = cp[i];
+    for (int i = 0; i < kCam; ++i) cam[i] = cp[i];
 #pragma unroll
     for (int i = 0; i < 3; ++i) pt[i] = pp[i];
     const double2 o = reinterpret_cast<const double2*>(obs)[r];
-    if (WITH_J) snavely_jet(cam, pt, o.x, o.y, res0, res1, jc, jp);
-    else snavely_value(cam, pt, o.x, o.y, res0, res1);
+    if constexpr (MODEL == CX_CAMERA_ANGLE_AXIS) {
+      if (WITH_J) snavely_jet(cam, pt, o.x, o.y, res0, res1, jc, jp);
+      else snavely_value(cam, pt, o.x, o.y, res0, res1);
+    } else {
+      if (WITH_J) snavely_jet_quat(cam, pt, o.x, o.y, res0, res1, jc, jp);
+      else snavely_value_quat(cam, pt, o.x, o.y, res0, res1);
+    }
     const double sq = res0 * res0 + res1 * res1;
     cost_term = 0.5 * sq;
     if (loss.type != CX_LOSS_NONE) {
@@ -295,7 +382,55 @@ __global__ __launch_bounds__(256) void k_sum_partials(const double* __restrict__
   if (threadIdx.x == 0) *out = s[0];
 }
 
+// Evaluator::Plus (program_evaluator.h:306-320): out = x + sign * delta on Euclidean blocks ...
+__global__ __launch_bounds__(256) void k_plus_euclidean(const double* __restrict__ x, const double* __restrict__ delta, double sign,
+                                                        double* __restrict__ out, int64_t n) {
+  const int64_t i = int64_t(blockIdx.x) * 256 + threadIdx.x;
+  if (i < n) out[i] = x[i] + sign * delta[i];
+}
+
+// ... and ProductManifold<QuaternionManifold, EuclideanManifold<6>>::Plus per camera (manifold.cc:27-59):
+// 10 ambient values from 10 + 9 (tangent) values
+__global__ __launch_bounds__(256) void k_plus_quaternion_cameras(const double* __restrict__ x, const double* __restrict__ delta,
+                                                                 double sign, double* __restrict__ out, int C) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= C) return;
+  const double* xc = x + 10 * int64_t(c);
+  const double* dc = delta + 9 * int64_t(c);
+  double* oc = out + 10 * int64_t(c);
+  const double d0 = sign * dc[0], d1 = sign * dc[1], d2 = sign * dc[2];
+  const double norm_delta = norm3d(d0, d1, d2);
+  if (norm_delta == 0.0) {
+    oc[0] = xc[0]; oc[1] = xc[1]; oc[2] = xc[2]; oc[3] = xc[3];
+  } else {
+    const double s = sin(norm_delta) / norm_delta;
+    const double q0 = cos(norm_delta), q1 = s * d0, q2 = s * d1, q3 = s * d2;
+    oc[0] = q0 * xc[0] - q1 * xc[1] - q2 * xc[2] - q3 * xc[3];
+    oc[1] = q0 * xc[1] + q1 * xc[0] + q2 * xc[3] - q3 * xc[2];
+    oc[2] = q0 * xc[2] - q1 * xc[3] + q2 * xc[0] + q3 * xc[1];
+    oc[3] = q0 * xc[3] + q1 * xc[2] - q2 * xc[1] + q3 * xc[0];
+  }
+#pragma unroll
+  for (int i = 0; i < 6; ++i) oc[4 + i] = xc[4 + i] + sign * dc[3 + i];
+}
+
 }  // namespace
+
+int cxe_plus(cx_evaluator* e, const double* x, const double* delta, double sign, double* out) {
+  hipStream_t st = e->ctx->stream;
+  const int64_t np = 3 * int64_t(e->P);
+  if (e->camera_model == CX_CAMERA_ANGLE_AXIS) {
+    const int64_t n = np + 9 * int64_t(e->C);
+    hipLaunchKernelGGL(k_plus_euclidean, dim3(unsigned((n + 255) / 256)), dim3(256), 0, st, x, delta, sign, out, n);
+  } else {
+    if (np > 0) hipLaunchKernelGGL(k_plus_euclidean, dim3(unsigned((np + 255) / 256)), dim3(256), 0, st, x, delta, sign, out, np);
+    if (e->C > 0)
+      hipLaunchKernelGGL(k_plus_quaternion_cameras, dim3(unsigned((e->C + 255) / 256)), dim3(256), 0, st, x + np, delta + np, sign,
+                         out + np, e->C);
+  }
+  CX_HIP(hipGetLastError());
+  return CX_OK;
+}
 
 extern "C" {
 
@@ -372,7 +507,8 @@ int cx_evaluator_evaluate(cx_evaluator* e, const double* state, double* cost, do
   CX_HIP(hipSetDevice(ctx->device));
   const int64_t ncols = A->num_cols, nrows = A->num_rows;
   HostOrDevice hs(ctx), hr(ctx), hg(ctx);
-  CX_TRY(hs.in(state, size_t(ncols), memspace));
+  const int64_t nstate = 3 * int64_t(e->P) + (e->camera_model == CX_CAMERA_ANGLE_AXIS ? 9 : 10) * int64_t(e->C);
+  CX_TRY(hs.in(state, size_t(nstate), memspace));
   CX_TRY(hr.inout(residuals, size_t(nrows), memspace, false));
   CX_TRY(hg.inout(gradient, size_t(ncols), memspace, false));
   const bool with_j = evaluate_jacobian != 0 || gradient != nullptr;
@@ -386,14 +522,18 @@ int cx_evaluator_evaluate(cx_evaluator* e, const double* state, double* cost, do
   double* F = A->d_values.p + 6 * e->O;
   const LossParams loss{e->loss_type, e->loss_a, e->loss_b};
   CX_HIP(hipEventRecord(ctx->ev[6], st));
-  if (with_j)
-    hipLaunchKernelGGL(k_bal_evaluate<true>, dim3(grid), dim3(kBlock), 0, st, (const double*)hs.dptr, (const double*)e->d_obs.p,
-                       (const int32_t*)A->d_row_pt.p, (const int32_t*)A->d_row_cam.p, e->O, 3 * int64_t(e->P), res_dev, E, F,
-                       cost ? e->d_partial.p : nullptr, loss);
-  else
-    hipLaunchKernelGGL(k_bal_evaluate<false>, dim3(grid), dim3(kBlock), 0, st, (const double*)hs.dptr, (const double*)e->d_obs.p,
-                       (const int32_t*)A->d_row_pt.p, (const int32_t*)A->d_row_cam.p, e->O, 3 * int64_t(e->P), res_dev, E, F,
-                       cost ? e->d_partial.p : nullptr, loss);
+#define CX_LAUNCH_EVAL(WJ, MODEL)                                                                                      \
+  hipLaunchKernelGGL((k_bal_evaluate<WJ, MODEL>), dim3(grid), dim3(kBlock), 0, st, (const double*)hs.dptr,              \
+                     (const double*)e->d_obs.p, (const int32_t*)A->d_row_pt.p, (const int32_t*)A->d_row_cam.p, e->O,    \
+                     3 * int64_t(e->P), res_dev, E, F, cost ? e->d_partial.p : nullptr, loss)
+  if (e->camera_model == CX_CAMERA_ANGLE_AXIS) {
+    if (with_j) CX_LAUNCH_EVAL(true, CX_CAMERA_ANGLE_AXIS);
+    else CX_LAUNCH_EVAL(false, CX_CAMERA_ANGLE_AXIS);
+  } else {
+    if (with_j) CX_LAUNCH_EVAL(true, CX_CAMERA_QUATERNION_MANIFOLD);
+    else CX_LAUNCH_EVAL(false, CX_CAMERA_QUATERNION_MANIFOLD);
+  }
+#undef CX_LAUNCH_EVAL
   if (cost) hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(256), 0, st, (const double*)e->d_partial.p, int64_t(grid), e->d_partial.p + grid);
   CX_HIP(hipGetLastError());
   CX_HIP(hipEventRecord(ctx->ev[7], st));
@@ -413,6 +553,33 @@ int cx_evaluator_evaluate(cx_evaluator* e, const double* state, double* cost, do
   CX_TRY(hr.out());
   CX_TRY(hg.out());
   CX_HIP(hipStreamSynchronize(st));
+  return CX_OK;
+}
+
+int cx_evaluator_set_camera_model(cx_evaluator* e, int32_t camera_model) {
+  CX_CHECK_ARG(e != nullptr && (camera_model == CX_CAMERA_ANGLE_AXIS || camera_model == CX_CAMERA_QUATERNION_MANIFOLD));
+  e->camera_model = camera_model;
+  return CX_OK;
+}
+
+int64_t cx_evaluator_num_parameters(const cx_evaluator* e) {
+  if (!e) return 0;
+  return 3 * int64_t(e->P) + (e->camera_model == CX_CAMERA_ANGLE_AXIS ? 9 : 10) * int64_t(e->C);
+}
+
+int64_t cx_evaluator_num_effective_parameters(const cx_evaluator* e) { return e ? 3 * int64_t(e->P) + 9 * int64_t(e->C) : 0; }
+
+int cx_evaluator_plus(cx_evaluator* e, const double* x, const double* delta, double* x_plus_delta, int32_t memspace) {
+  CX_CHECK_ARG(e && x && delta && x_plus_delta);
+  cx_context* ctx = e->ctx;
+  CX_HIP(hipSetDevice(ctx->device));
+  HostOrDevice hx(ctx), hd(ctx), ho(ctx);
+  CX_TRY(hx.in(x, size_t(cx_evaluator_num_parameters(e)), memspace));
+  CX_TRY(hd.in(delta, size_t(cx_evaluator_num_effective_parameters(e)), memspace));
+  CX_TRY(ho.inout(x_plus_delta, size_t(cx_evaluator_num_parameters(e)), memspace, false));
+  CX_TRY(cxe_plus(e, hx.dptr, hd.dptr, 1.0, ho.dptr));
+  CX_TRY(ho.out());
+  CX_HIP(hipStreamSynchronize(ctx->stream));
   return CX_OK;
 }
 

@@ -211,6 +211,9 @@ struct cx_evaluator {
   float last_ms = 0.f;
   int32_t loss_type = CX_LOSS_NONE;
   double loss_a = 0.0, loss_b = 0.0;
+  int32_t camera_model = CX_CAMERA_ANGLE_AXIS;
 };
+// out = Plus(x, sign * delta) on device pointers (Evaluator::Plus), enqueued on the context stream
+int cxe_plus(cx_evaluator* e, const double* x, const double* delta, double sign, double* out);
 
 #endif

@@ -19,7 +19,7 @@ namespace {
 constexpr int kMinRedBlocks = 512;
 
 enum RedMode {
-  RED_GRADIENT = 0,    // a = x, b = gradient: v0 = sum d^2, v1 = max |d|, d = x - (x + (-g))
+  RED_GRADIENT = 0,    // a = x, b = Plus(x, -gradient): v0 = sum d^2, v1 = max |d|, d = a - b
   RED_MODEL_COST = 1,  // a = model residuals, b = residuals: v0 = sum m (r + m / 2)
   RED_STEP = 2         // a = x, b = candidate: v0 = sum x^2, v1 = sum (x - c)^2
 };
@@ -27,8 +27,7 @@ enum RedMode {
 template <int MODE>
 __device__ __forceinline__ void red_term(double a, double b, double& v0, double& v1) {
   if (MODE == RED_GRADIENT) {
-    const double projected = a + (-b);  // Plus(x, -gradient), trust_region_minimizer.cc:283-298
-    const double d = a - projected;
+    const double d = a - b;  // x - Plus(x, -gradient), trust_region_minimizer.cc:283-298
     v0 += d * d;
     v1 = fmax(v1, fabs(d));
   } else if (MODE == RED_MODEL_COST) {
@@ -135,13 +134,6 @@ __global__ __launch_bounds__(kBlock) void k_negate_and_unscale(double* __restric
   delta[i] = s * scaling[i];
 }
 
-// Evaluator::Plus on Euclidean manifolds (program_evaluator.h:306-320)
-__global__ __launch_bounds__(kBlock) void k_plus(const double* __restrict__ x, const double* __restrict__ delta,
-                                                 double* __restrict__ out, int64_t n) {
-  const int64_t i = int64_t(blockIdx.x) * kBlock + threadIdx.x;
-  if (i < n) out[i] = x[i] + delta[i];
-}
-
 __global__ __launch_bounds__(kBlock) void k_fill(double* __restrict__ p, int64_t n, double v) {
   const int64_t i = int64_t(blockIdx.x) * kBlock + threadIdx.x;
   if (i < n) p[i] = v;
@@ -218,7 +210,9 @@ struct Minimizer {
   cx_minimizer_summary* out;
   cx_iteration_summary* iterations;
   int capacity;
-  int64_t n, m, n_local;  // n_local: leading entries owned by this rank (points); the rest is replicated
+  // n: tangent size (gradient, step, J columns); n_amb: ambient size of the state (> n for cameras on a
+  // manifold); n_local: leading entries owned by this rank (the points); the rest is replicated
+  int64_t n, n_amb, m, n_local;
   DevBuf<double> x, candidate_x, residuals, gradient, step, delta, scaling, diagonal, lm_diagonal, model_residuals;
   DevBuf<double> partial, red_out, slots;
   double* parameters = nullptr;  // device: the minimum-cost iterate
@@ -292,8 +286,10 @@ struct Minimizer {
       }
       CX_TRY(cx_matrix_scale_columns(J, scaling.p, CX_DEVICE));
     }
+    // |x - Plus(x, -gradient)| in the ambient space; candidate_x is free at this point and serves as scratch
+    CX_TRY(cxe_plus(e, x.p, gradient.p, -1.0, candidate_x.p));
     double sq = 0.0, mx = 0.0;
-    CX_TRY(Reduce<RED_GRADIENT>(x.p, gradient.p, n, n_local, sq, mx));
+    CX_TRY(Reduce<RED_GRADIENT>(x.p, candidate_x.p, n_amb, n_local, sq, mx));
     it.gradient_max_norm = mx;
     it.gradient_norm = std::sqrt(sq);
     *ok = true;
@@ -306,7 +302,7 @@ struct Minimizer {
       ++out->num_successful_steps;
       if (x_cost < minimum_cost) {
         minimum_cost = x_cost;
-        CX_HIP(hipMemcpyAsync(parameters, x.p, size_t(n) * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+        CX_HIP(hipMemcpyAsync(parameters, x.p, size_t(n_amb) * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
         it.step_is_nonmonotonic = 0;
       } else {
         it.step_is_nonmonotonic = 1;
@@ -391,10 +387,12 @@ struct Minimizer {
     hipStream_t st = ctx->stream;
     auto start = Clock::now();
     J = e->J;
-    n = 3 * int64_t(e->P) + 9 * int64_t(e->C);
+    n = cx_evaluator_num_effective_parameters(e);
+    n_amb = cx_evaluator_num_parameters(e);
     m = 2 * e->O;
     n_local = 3 * int64_t(e->P);
-    for (DevBuf<double>* b : {&x, &candidate_x, &gradient, &step, &delta, &scaling, &diagonal, &lm_diagonal}) CX_TRY(b->alloc(size_t(n)));
+    for (DevBuf<double>* b : {&gradient, &step, &delta, &scaling, &diagonal, &lm_diagonal}) CX_TRY(b->alloc(size_t(n)));
+    for (DevBuf<double>* b : {&x, &candidate_x}) CX_TRY(b->alloc(size_t(n_amb)));
     CX_TRY(residuals.alloc(size_t(m)));
     CX_TRY(model_residuals.alloc(size_t(m)));
     CX_TRY(partial.alloc(2 * kMinRedBlocks));
@@ -402,13 +400,13 @@ struct Minimizer {
     CX_TRY(slots.alloc(size_t(1 + ctx->nranks)));
     DevBuf<double> best;
     if (memspace == CX_HOST) {
-      CX_TRY(best.alloc(size_t(n)));
+      CX_TRY(best.alloc(size_t(n_amb)));
       parameters = best.p;
-      CX_HIP(hipMemcpyAsync(x.p, state, size_t(n) * sizeof(double), hipMemcpyHostToDevice, st));
-      CX_HIP(hipMemcpyAsync(best.p, x.p, size_t(n) * sizeof(double), hipMemcpyDeviceToDevice, st));
+      CX_HIP(hipMemcpyAsync(x.p, state, size_t(n_amb) * sizeof(double), hipMemcpyHostToDevice, st));
+      CX_HIP(hipMemcpyAsync(best.p, x.p, size_t(n_amb) * sizeof(double), hipMemcpyDeviceToDevice, st));
     } else {
       parameters = state;
-      CX_HIP(hipMemcpyAsync(x.p, state, size_t(n) * sizeof(double), hipMemcpyDeviceToDevice, st));
+      CX_HIP(hipMemcpyAsync(x.p, state, size_t(n_amb) * sizeof(double), hipMemcpyDeviceToDevice, st));
     }
     hipLaunchKernelGGL(k_fill, dim3(grid_for(n)), dim3(kBlock), 0, st, scaling.p, n, 1.0);
     out->termination_type = CX_MIN_NO_CONVERGENCE;
@@ -465,14 +463,14 @@ struct Minimizer {
           continue;
         }
         // ComputeCandidatePointAndEvaluateCost (trust_region_minimizer.cc:753-774)
-        hipLaunchKernelGGL(k_plus, dim3(grid_for(n)), dim3(kBlock), 0, st, (const double*)x.p, (const double*)delta.p, candidate_x.p, n);
+        CX_TRY(cxe_plus(e, x.p, delta.p, 1.0, candidate_x.p));
         CX_TRY(cx_evaluator_evaluate(e, candidate_x.p, &candidate_cost, nullptr, nullptr, 0, CX_DEVICE));
         it.residual_ms = cx_evaluator_last_kernel_ms(e);
         if (!std::isfinite(candidate_cost)) candidate_cost = std::numeric_limits<double>::max();
         if (atleast_one_successful_step) {
           // ParameterToleranceReached (trust_region_minimizer.cc:700-723)
           double x_sq = 0.0, d_sq = 0.0;
-          CX_TRY(Reduce<RED_STEP>(x.p, candidate_x.p, n, n_local, x_sq, d_sq));
+          CX_TRY(Reduce<RED_STEP>(x.p, candidate_x.p, n_amb, n_local, x_sq, d_sq));
           const double x_norm = std::sqrt(x_sq);
           it.step_norm = std::sqrt(d_sq);
           if (it.step_norm <= o.parameter_tolerance * (x_norm + o.parameter_tolerance)) {
@@ -515,7 +513,7 @@ struct Minimizer {
     }
     out->num_iterations = num_written;
     out->final_cost = minimum_cost;
-    if (memspace == CX_HOST) CX_HIP(hipMemcpyAsync(state, parameters, size_t(n) * sizeof(double), hipMemcpyDeviceToHost, st));
+    if (memspace == CX_HOST) CX_HIP(hipMemcpyAsync(state, parameters, size_t(n_amb) * sizeof(double), hipMemcpyDeviceToHost, st));
     CX_HIP(hipStreamSynchronize(st));
     out->total_ms = MsSince(start);
     return CX_OK;

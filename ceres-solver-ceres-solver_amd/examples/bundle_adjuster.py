@@ -46,6 +46,9 @@ def main(argv=None):
     ap.add_argument("--max_linear_solver_iterations", type=int, default=500)
     ap.add_argument("--eta", type=float, default=1e-2)
     ap.add_argument("--robustify", action="store_true", help="HuberLoss(1.0) on every residual block")
+    ap.add_argument("--use_quaternions", action="store_true",
+                    help="quaternion cameras on ProductManifold<QuaternionManifold, EuclideanManifold<6>> "
+                         "(the reference's --use_quaternions --use_manifolds)")
     ap.add_argument("--nonmonotonic_steps", action="store_true")
     ap.add_argument("--rotation_sigma", type=float, default=0.0)
     ap.add_argument("--translation_sigma", type=float, default=0.0)
@@ -78,6 +81,8 @@ def main(argv=None):
     ev = cx.Evaluator(ctx, prob)
     if args.robustify:
         ev.set_loss(cx.binding.LOSS_HUBER, 1.0)  # bundle_adjuster.cc:327-328
+    if args.use_quaternions:
+        ev.set_camera_model(cx.binding.CAMERA_QUATERNION_MANIFOLD)  # bundle_adjuster.cc:316-346
     stype = getattr(cx.binding, args.linear_solver.upper())
     solver = cx.Solver(ctx, type=stype, preconditioner_type=getattr(cx.binding, args.preconditioner.upper()),
                        num_eliminate_blocks=0 if stype == cx.binding.CGNR else prob.num_points,
@@ -86,7 +91,8 @@ def main(argv=None):
     preprocess_s = time.time() - t0
     opts = cx.binding.minimizer_options(max_num_iterations=args.num_iterations, eta=args.eta,
                                         use_nonmonotonic_steps=int(args.nonmonotonic_steps))
-    state, summary, iterations = cx.binding.minimize(ev, solver, prob.state(), opts)
+    start = bal.state_quaternion(prob) if args.use_quaternions else prob.state()
+    state, summary, iterations = cx.binding.minimize(ev, solver, start, opts)
 
     # LoggingCallback's table (callbacks.cc:97-118)
     print("iter      cost      cost_change  |gradient|   |step|    tr_ratio  tr_radius  ls_iter  iter_time  total_time")
@@ -110,8 +116,11 @@ def main(argv=None):
     print("Termination: %s (%s)" % (term, summary["message"]))
     if args.final_bal:
         P = prob.num_points
-        out = bal.dataclasses.replace(prob, points=state[:3 * P].reshape(P, 3).copy(),
-                                      cameras=state[3 * P:].reshape(prob.num_cameras, 9).copy())
+        if args.use_quaternions:
+            out = bal.cameras_from_quaternion_state(prob, state)
+        else:
+            out = bal.dataclasses.replace(prob, points=state[:3 * P].reshape(P, 3).copy(),
+                                          cameras=state[3 * P:].reshape(prob.num_cameras, 9).copy())
         bal.write_bal(args.final_bal, out)
     solver.close()
     ev.close()

@@ -320,6 +320,15 @@ int cx_evaluator_evaluate(cx_evaluator* e, const double* state, double* cost,
  * CX_LOSS_NONE restores the plain squared loss (also what Evaluate does with
  * apply_loss_function = false, evaluator.h:84-92). */
 int cx_evaluator_set_loss(cx_evaluator* e, int32_t loss_type, double a, double b);
+/* Camera parameterisation (cx_camera_model; default CX_CAMERA_ANGLE_AXIS).  With
+ * CX_CAMERA_QUATERNION_MANIFOLD the state of evaluate / minimize has 3P + 10C entries ([points | cameras as
+ * w x y z, translation, focal, k1, k2]) while gradient, step and J stay in the 3P + 9C tangent space: the
+ * kernel multiplies the ambient 2x10 camera Jacobian by the manifold's PlusJacobian (residual_block.cc:136-159). */
+int cx_evaluator_set_camera_model(cx_evaluator* e, int32_t camera_model);
+int64_t cx_evaluator_num_parameters(const cx_evaluator* e);            /* Evaluator::NumParameters (ambient) */
+int64_t cx_evaluator_num_effective_parameters(const cx_evaluator* e);  /* Evaluator::NumEffectiveParameters (tangent) */
+/* Evaluator::Plus (evaluator.h:152-158): x_plus_delta = x [+] delta; x, x_plus_delta ambient, delta tangent */
+int cx_evaluator_plus(cx_evaluator* e, const double* x, const double* delta, double* x_plus_delta, int32_t memspace);
 double cx_evaluator_last_kernel_ms(const cx_evaluator* e);
 
 /* -------------------------------------------------------------- minimizer */

@@ -122,3 +122,57 @@ def test_minimize_device_state_and_limits(ctx, oracle):
     assert abs(summ["final_cost"] - summ_h["final_cost"]) <= 1e-12 * summ_h["final_cost"]
     solver.close()
     ev.close()
+
+
+def test_quaternion_cameras_on_manifold(ctx, oracle):
+    """bundle_adjuster --use_quaternions --use_manifolds: 10-parameter cameras on ProductManifold<QuaternionManifold,
+    EuclideanManifold<6>>; the kernel projects the ambient Jacobian with the PlusJacobian so J keeps the <2,3,9>
+    layout (residual_block.cc:136-159).  Evaluation, Plus and the whole trust-region loop against the oracle."""
+    C, P, O = 12, 300, 2400
+    prob = cx.bal.make_bal_like(C, P, O, 3)
+    bs, order = cx.bal.build_structure(prob)
+    state = cx.bal.state_quaternion(prob)
+    ev = cx.Evaluator(ctx, prob)
+    ev.set_camera_model(cx.binding.CAMERA_QUATERNION_MANIFOLD)
+    assert ev.num_parameters == 3 * P + 10 * C and ev.num_effective_parameters == 3 * P + 9 * C
+    cost, res, grad = ev.evaluate(state)
+    cost_r, res_r, grad_r, vals_r = oracle.bal_evaluate_model(bs, C, P, prob.camera_index, prob.point_index,
+                                                              prob.observations, order, state, oracle.QUATERNION_MANIFOLD)
+    vals = ev.jacobian(bs).get_values()
+    assert relerr(res, res_r) < 1e-11 and relerr(vals, vals_r) < 1e-11 and relerr(grad, grad_r) < 1e-10
+    assert abs(cost - cost_r) <= 1e-11 * cost_r
+    cost2, res2, _ = ev.evaluate(state, want_gradient=False, want_jacobian=False)       # value-only kernel
+    assert relerr(res2, res_r) < 1e-11
+    # same residuals as the angle-axis parameterisation of the same cameras
+    ev_aa = cx.Evaluator(ctx, prob)
+    _, res_aa, _ = ev_aa.evaluate(prob.state(), want_gradient=False, want_jacobian=False)
+    assert relerr(res, res_aa) < 1e-10
+    # Evaluator::Plus
+    delta = np.random.default_rng(1).standard_normal(3 * P + 9 * C) * 0.05
+    xp = ev.plus(state, delta)
+    xp_r = oracle.bal_plus(C, P, oracle.QUATERNION_MANIFOLD, state, delta)
+    assert relerr(xp, xp_r) < 1e-14
+    assert np.array_equal(ev.plus(state, np.zeros_like(delta)), state)
+    # the trust-region loop
+    mo = cx.binding.minimizer_options(max_num_iterations=8)
+    solver = cx.Solver(ctx, type=cx.binding.DENSE_SCHUR, num_eliminate_blocks=P)
+    x, summ, its = cx.binding.minimize(ev, solver, state, mo)
+    so = oracle.make_options(type=oracle.DENSE_SCHUR, num_eliminate_blocks=P)
+    x_r, summ_r, its_r = oracle.minimize_bal(C, P, prob.camera_index, prob.point_index, prob.observations, state, so,
+                                             oracle.minimizer_options(max_num_iterations=8),
+                                             camera_model=oracle.QUATERNION_MANIFOLD)
+    assert len(its) == len(its_r) and summ["termination_type"] == summ_r["termination_type"]
+    for a, b in zip(its, its_r):
+        assert a["step_is_successful"] == b["step_is_successful"]
+        assert abs(a["cost"] - b["cost"]) <= 1e-9 * abs(b["cost"])
+        assert abs(a["gradient_max_norm"] - b["gradient_max_norm"]) <= 1e-6 * its_r[0]["gradient_max_norm"]
+        assert abs(a["step_norm"] - b["step_norm"]) <= 1e-7 * max(1.0, b["step_norm"])
+    assert relerr(x, x_r) < 1e-8
+    q = x[3 * P:].reshape(C, 10)[:, 0:4]
+    assert np.allclose(np.linalg.norm(q, axis=1), 1.0, atol=1e-12)
+    # and the same optimum as the angle-axis run
+    x_aa, summ_aa, _ = cx.binding.minimize(ev_aa, solver, prob.state(), mo)
+    assert abs(summ["final_cost"] - summ_aa["final_cost"]) <= 1e-6 * summ_aa["final_cost"]
+    solver.close()
+    ev_aa.close()
+    ev.close()
