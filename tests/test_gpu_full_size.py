@@ -1,0 +1,81 @@
+"""BASELINE.json's full size (Final-13682 shape: 13 682 cameras, 4.46 M points, 29.0 M residual blocks), where no
+CPU oracle finishes in test time: size-independent properties of the domain instead -- adjointness and linearity
+of the J products, a checksum of the evaluator, the normal equations satisfied by a converged solve, and two
+independent implementations of S x (implicit chunk / camera passes vs explicitly assembled block-sparse S)
+driving CG to the same solution."""
+import numpy as np
+import pytest
+
+from conftest import cx
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def final():
+    ctx = cx.Context(0)
+    prob = cx.bal.make_preset("final13682")
+    ev = cx.Evaluator(ctx, prob)
+    state = ctx.to_device(prob.state())
+    res = ctx.empty(2 * prob.num_observations)
+    cost, _, _ = ev.evaluate(state, residuals=res, gradient=None, want_jacobian=True)
+    yield ctx, prob, ev, ev.jacobian(), res, cost
+    ev.close()
+    ctx.close()
+
+
+def test_evaluator_checksum(final):
+    ctx, prob, ev, A, res, cost = final
+    r = res.to_host()
+    assert np.all(np.isfinite(r))
+    assert abs(cost - 0.5 * float(r @ r)) <= 1e-12 * cost            # cost is the checksum of the residuals
+    cost2, _, _ = ev.evaluate(ctx.to_device(prob.state()), residuals=None, gradient=None, want_jacobian=False)
+    assert abs(cost2 - cost) <= 1e-12 * cost                          # value-only kernel agrees with the Jet kernel
+
+
+def test_products_adjoint_and_linear(final):
+    ctx, prob, ev, A, res, cost = final
+    rng = np.random.default_rng(0)
+    n_c, n_r = A.num_cols, A.num_rows
+    x1, x2 = rng.standard_normal(n_c), rng.standard_normal(n_c)
+    y = rng.standard_normal(n_r)
+    jx1 = A.right_multiply(x1)
+    jty = A.left_multiply(y)
+    lhs, rhs = float(jx1 @ y), float(x1 @ jty)
+    assert abs(lhs - rhs) <= 1e-11 * (np.linalg.norm(jx1) * np.linalg.norm(y))      # <J x, y> = <x, J' y>
+    jx2 = A.right_multiply(x2)
+    comb = A.right_multiply(2.5 * x1 + x2)
+    assert np.abs(comb - (2.5 * jx1 + jx2)).max() <= 1e-12 * np.abs(comb).max()       # linearity
+    # column norms are the diagonal of J'J: e_j' J' J e_j for a few columns
+    sq = A.squared_column_norm()
+    for j in (0, 17, 3 * prob.num_points + 5, n_c - 1):
+        e = np.zeros(n_c)
+        e[j] = 1.0
+        col = A.right_multiply(e)
+        assert abs(float(col @ col) - sq[j]) <= 1e-12 * max(sq[j], 1e-300)
+
+
+def test_two_implementations_of_schur_cg_agree_and_solve_the_normal_equations(final):
+    ctx, prob, ev, A, res, cost = final
+    P, C = prob.num_points, prob.num_cameras
+    b = res.to_host()
+    sq = A.squared_column_norm()
+    D = np.sqrt(np.clip(sq, 1e-6, 1e32) / 1e2)          # a well-regularised LM system (radius 100)
+    kw = dict(type=cx.ITERATIVE_SCHUR, preconditioner_type=cx.SCHUR_JACOBI, num_eliminate_blocks=P, max_num_iterations=500)
+    S_impl = cx.Solver(ctx, **kw)
+    S_expl = cx.Solver(ctx, use_explicit_schur_complement=1, **kw)
+    x1, s1 = S_impl.solve(A, b, D, r_tolerance=1e-11, q_tolerance=0.0)
+    x2, s2 = S_expl.solve(A, b, D, r_tolerance=1e-11, q_tolerance=0.0)
+    assert s1.termination_type == cx.SUCCESS and s2.termination_type == cx.SUCCESS, (s1.message, s2.message)
+    assert abs(s1.num_iterations - s2.num_iterations) <= 2
+    scale = np.abs(x1).max()
+    assert np.abs(x1 - x2).max() <= 1e-7 * scale
+    # normal equations (J'J + D^2) x = J'b through the plain products (a third code path)
+    g = A.left_multiply(A.right_multiply(x1) - b) + D * D * x1
+    jtb = A.left_multiply(b)
+    assert np.linalg.norm(g) <= 1e-8 * np.linalg.norm(jtb)
+    # determinism at full size: same solve, same bits
+    x1b, _ = S_impl.solve(A, b, D, r_tolerance=1e-11, q_tolerance=0.0)
+    assert np.array_equal(x1, x1b)
+    S_impl.close()
+    S_expl.close()
