@@ -126,7 +126,7 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default="final13682", choices=sorted(load_cx().bal.PRESETS))
-    ap.add_argument("--solver", default="iterative_schur", choices=["iterative_schur", "dense_schur", "cgnr"],
+    ap.add_argument("--solver", default="iterative_schur", choices=["iterative_schur", "dense_schur", "sparse_schur", "cgnr"],
                     help="linear solver of the step (the headline metric uses iterative_schur)")
     ap.add_argument("--preconditioner", default="jacobi", choices=["jacobi", "schur_jacobi", "identity"])
     ap.add_argument("--mixed", action="store_true", help="CG products on fp32 copies of the J values: CGNR (BASELINE config 5) or ITERATIVE_SCHUR; "
@@ -184,7 +184,8 @@ def main():
     t_gen = time.time() - t_gen
 
     ev, A, b, D, cost, eval_ms = lm_prepare_device(cx, ctx, prob)
-    stype = {"iterative_schur": cx.ITERATIVE_SCHUR, "dense_schur": cx.DENSE_SCHUR, "cgnr": cx.CGNR}[args.solver]
+    stype = {"iterative_schur": cx.ITERATIVE_SCHUR, "dense_schur": cx.DENSE_SCHUR, "sparse_schur": cx.SPARSE_SCHUR,
+             "cgnr": cx.CGNR}[args.solver]
     ptype = {"jacobi": cx.JACOBI, "schur_jacobi": cx.SCHUR_JACOBI, "identity": cx.IDENTITY}[args.preconditioner]
     solver_kw = dict(type=stype, preconditioner_type=ptype, num_eliminate_blocks=prob.num_points,
                      max_num_iterations=500, min_num_iterations=0, residual_reset_period=10,
@@ -222,7 +223,7 @@ def main():
     # ---- the same solve at bundle_adjuster's tighter default (eta = 1e-2, bundle_adjuster.cc:114): many more
     # CG iterations, so this is the per-iteration cost of S x; informational, outside the timed region
     tight = None
-    if args.solver != "dense_schur" and args.eta != 0.01:
+    if args.solver not in ("dense_schur", "sparse_schur") and args.eta != 0.01:
         S.solve(A, b, D, r_tolerance=-1.0, q_tolerance=0.01, x=x)
         barrier()
         t1 = time.perf_counter()

@@ -1,0 +1,123 @@
+// Wave-level building blocks of the blocked Cholesky factorisations (dense: cx_cholesky.hip, tile-sparse:
+// cx_sparse_chol.hip): the 32x32 diagonal factor + inverse by one wavefront, and the panel solve
+// X = U_kk^-T W(k, .) as an fp64 MFMA product whose result registers are the operands of the trailing update.
+#ifndef CX_CHOL_BLOCKS_H_
+#define CX_CHOL_BLOCKS_H_
+
+#include "cx_internal.h"
+
+namespace cxchol {
+
+constexpr int NB = 32;  // panel width: the wave-level diagonal factorisation keeps a 32x32 block in registers
+
+typedef double double4_t __attribute__((ext_vector_type(4)));
+
+// v at lane `l` (compile-time constant), as a wave-uniform value: two v_readlane_b32
+__device__ __forceinline__ double readlane_f64(double v, int l) {
+  const unsigned long long u = __double_as_longlong(v);
+  const unsigned lo = __builtin_amdgcn_readlane(unsigned(u), l);
+  const unsigned hi = __builtin_amdgcn_readlane(unsigned(u >> 32), l);
+  return __longlong_as_double((static_cast<unsigned long long>(hi) << 32) | lo);
+}
+
+// One wavefront: factor the kb x kb diagonal block of W at k0 (upper, U'U), store U_kk into the factor
+// F (ld n) and U_kk^-1 (NB x NB row-major, identity-padded) into uinv.  Lane c owns column c of the block
+// in NB registers; right-looking, fully unrolled, pivot row broadcast by v_readlane (no LDS round trip
+// or barrier in the 32-step chain).  The inverse is then formed column by column from an LDS copy of U
+// (broadcast reads), lds: NB * NB + NB doubles.
+// Pointer form: Wblk / Fblk address the block's (0, 0) entry, ldw / ldf are the row strides.
+__device__ __forceinline__ void potrf_inverse_block(const double* __restrict__ Wblk, int ldw, double* __restrict__ Fblk, int ldf,
+                                                    int kb, double* __restrict__ uinv, int* __restrict__ not_pd,
+                                                    double* __restrict__ lds) {
+  const int lane = threadIdx.x & 63;
+  double T[NB];
+  {
+    // branch-free: every lane loads from a clamped (always valid) address, padding is selected afterwards
+    const int cc = min(lane, kb - 1);
+    const double* __restrict__ base = Wblk + cc;
+#pragma unroll
+    for (int r = 0; r < NB; ++r) {
+      const double v = base[size_t(min(r, kb - 1)) * ldw];
+      const bool in = r < kb && lane < kb && lane >= r;
+      T[r] = in ? v : ((r == lane) ? 1.0 : 0.0);
+    }
+  }
+  bool ok = true;
+#pragma unroll
+  for (int j = 0; j < NB; ++j) {
+    const double d = readlane_f64(T[j], j);
+    ok = ok && (d > 0.0);
+    // 1 / sqrt(d) from the hardware estimate and two Newton steps (a correctly rounded sqrt and a
+    // division cost ~45 instructions of this single wavefront's 32-step serial chain)
+    double rs = __builtin_amdgcn_rsq(d);
+    rs = rs * (1.5 - 0.5 * d * rs * rs);
+    rs = rs * (1.5 - 0.5 * d * rs * rs);
+    const double sq = d * rs;
+    T[j] = (lane == j) ? sq : T[j] * rs;
+    if (lane == 0) lds[NB * NB + j] = rs;  // 1 / U(j, j) for the inverse below
+    const double uj = T[j];
+#pragma unroll
+    for (int i = j + 1; i < NB; ++i) {
+      // entries below the diagonal (lane < i) are updated too; they are never read
+      T[i] -= readlane_f64(T[j], i) * uj;
+    }
+    __builtin_amdgcn_sched_barrier(0);  // keep the broadcasts of step j + 1 out of step j (SGPR pressure)
+  }
+  if (!ok && lane == 0) *not_pd = 1;
+#pragma unroll
+  for (int r = 0; r < NB; ++r) {
+    if (r < kb && lane < kb && lane >= r) Fblk[size_t(r) * ldf + lane] = T[r];
+    if (lane < NB) lds[r * NB + lane] = (lane >= r) ? T[r] : 0.0;  // U(r, lane)
+  }
+  // (single wavefront: its LDS writes are ordered before its LDS reads, no barrier needed)
+  // V = U^-1, column `lane`: U V = I by back substitution
+  double V[NB];
+#pragma unroll
+  for (int r = NB - 1; r >= 0; --r) {
+    double sum = (r == lane) ? 1.0 : 0.0;
+#pragma unroll
+    for (int k = r + 1; k < NB; ++k) sum -= lds[r * NB + k] * V[k];
+    V[r] = (lane >= r) ? sum * lds[NB * NB + r] : 0.0;
+  }
+  if (lane < NB) {
+#pragma unroll
+    for (int r = 0; r < NB; ++r) uinv[r * NB + lane] = V[r];
+  }
+}
+
+// X = U_kk^-T W(k-rows, c0 .. c0 + 32) by MFMA: X[m][c] = sum_r Uinv[r][m] W[k0 + r][c], m, r < NB.
+// Pointer form: Wrow addresses W(k0, c0); local columns >= ncols and rows >= kb read as zero.
+// Result tile (mt, nt) register g of lane l is X[16 mt + (l >> 4) + 4 g][c0 + 16 nt + (l & 15)] -- which is
+// exactly the operand layout of the trailing update (K index m = 4 (4 mt + g) + (l >> 4)), so X feeds
+// the next MFMA without leaving the registers.
+__device__ __forceinline__ void panel_x(const double* __restrict__ Wrow, int ldw, const double* __restrict__ uinv, int kb,
+                                        int ncols, double4_t (&X)[2][2]) {
+  const int lane = threadIdx.x & 63;
+  const int li = lane & 15, lk = lane >> 4;
+  double bop[8][2], aop[8][2];
+#pragma unroll
+  for (int s = 0; s < 8; ++s) {
+    const int r = 4 * s + lk;
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+      const int c = 16 * nt + li;
+      bop[s][nt] = (r < kb && c < ncols) ? Wrow[size_t(r) * ldw + c] : 0.0;
+    }
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) aop[s][mt] = uinv[r * NB + 16 * mt + li];  // A(m, r) = Uinv[r][m]
+  }
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) X[mt][nt] = double4_t{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+  for (int s = 0; s < 8; ++s)
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt) X[mt][nt] = __builtin_amdgcn_mfma_f64_16x16x4f64(aop[s][mt], bop[s][nt], X[mt][nt], 0, 0, 0);
+}
+
+}  // namespace cxchol
+
+#endif

@@ -22,117 +22,25 @@
 // barrier's L2 invalidation); this file 4.6 ms (3.3 ms factor + 1.2 ms backward substitution).
 #include <cstdlib>
 
+#include "cx_chol_blocks.h"
 #include "cx_internal.h"
 #include "cx_schur.h"
 
 namespace {
 
-constexpr int NB = 32;  // panel width: the wave-level diagonal factorisation keeps a 32x32 block in registers
+using cxchol::NB;
+using cxchol::double4_t;
+using cxchol::readlane_f64;
 
-typedef double double4_t __attribute__((ext_vector_type(4)));
-
-// v at lane `l` (compile-time constant), as a wave-uniform value: two v_readlane_b32
-__device__ __forceinline__ double readlane_f64(double v, int l) {
-  const unsigned long long u = __double_as_longlong(v);
-  const unsigned lo = __builtin_amdgcn_readlane(unsigned(u), l);
-  const unsigned hi = __builtin_amdgcn_readlane(unsigned(u >> 32), l);
-  return __longlong_as_double((static_cast<unsigned long long>(hi) << 32) | lo);
-}
-
-// One wavefront: factor the kb x kb diagonal block of W at k0 (upper, U'U), store U_kk into the factor
-// F (ld n) and U_kk^-1 (NB x NB row-major, identity-padded) into uinv.  Lane c owns column c of the block
-// in NB registers; right-looking, fully unrolled, pivot row broadcast by v_readlane (no LDS round trip
-// or barrier in the 32-step chain).  The inverse is then formed column by column from an LDS copy of U
-// (broadcast reads), lds: NB * NB + NB doubles.
+// absolute-index wrappers of the shared blocks (cx_chol_blocks.h) for the dense working copy W (ld ldw) and factor F (ld n)
 __device__ __forceinline__ void potrf_inverse_block(const double* __restrict__ W, int ldw, double* __restrict__ F, int n,
                                                     int k0, int kb, double* __restrict__ uinv, int* __restrict__ not_pd,
                                                     double* __restrict__ lds) {
-  const int lane = threadIdx.x & 63;
-  double T[NB];
-  {
-    // branch-free: every lane loads from a clamped (always valid) address, padding is selected afterwards
-    const int cc = min(lane, kb - 1);
-    const double* __restrict__ base = W + size_t(k0) * ldw + k0 + cc;
-#pragma unroll
-    for (int r = 0; r < NB; ++r) {
-      const double v = base[size_t(min(r, kb - 1)) * ldw];
-      const bool in = r < kb && lane < kb && lane >= r;
-      T[r] = in ? v : ((r == lane) ? 1.0 : 0.0);
-    }
-  }
-  bool ok = true;
-#pragma unroll
-  for (int j = 0; j < NB; ++j) {
-    const double d = readlane_f64(T[j], j);
-    ok = ok && (d > 0.0);
-    // 1 / sqrt(d) from the hardware estimate and two Newton steps (a correctly rounded sqrt and a
-    // division cost ~45 instructions of this single wavefront's 32-step serial chain)
-    double rs = __builtin_amdgcn_rsq(d);
-    rs = rs * (1.5 - 0.5 * d * rs * rs);
-    rs = rs * (1.5 - 0.5 * d * rs * rs);
-    const double sq = d * rs;
-    T[j] = (lane == j) ? sq : T[j] * rs;
-    if (lane == 0) lds[NB * NB + j] = rs;  // 1 / U(j, j) for the inverse below
-    const double uj = T[j];
-#pragma unroll
-    for (int i = j + 1; i < NB; ++i) {
-      // entries below the diagonal (lane < i) are updated too; they are never read
-      T[i] -= readlane_f64(T[j], i) * uj;
-    }
-    __builtin_amdgcn_sched_barrier(0);  // keep the broadcasts of step j + 1 out of step j (SGPR pressure)
-  }
-  if (!ok && lane == 0) *not_pd = 1;
-#pragma unroll
-  for (int r = 0; r < NB; ++r) {
-    if (r < kb && lane < kb && lane >= r) F[size_t(k0 + r) * n + k0 + lane] = T[r];
-    if (lane < NB) lds[r * NB + lane] = (lane >= r) ? T[r] : 0.0;  // U(r, lane)
-  }
-  // (single wavefront: its LDS writes are ordered before its LDS reads, no barrier needed)
-  // V = U^-1, column `lane`: U V = I by back substitution
-  double V[NB];
-#pragma unroll
-  for (int r = NB - 1; r >= 0; --r) {
-    double sum = (r == lane) ? 1.0 : 0.0;
-#pragma unroll
-    for (int k = r + 1; k < NB; ++k) sum -= lds[r * NB + k] * V[k];
-    V[r] = (lane >= r) ? sum * lds[NB * NB + r] : 0.0;
-  }
-  if (lane < NB) {
-#pragma unroll
-    for (int r = 0; r < NB; ++r) uinv[r * NB + lane] = V[r];
-  }
+  cxchol::potrf_inverse_block(W + size_t(k0) * ldw + k0, ldw, F + size_t(k0) * n + k0, n, kb, uinv, not_pd, lds);
 }
-
-// X = U_kk^-T W(k-rows, c0 .. c0 + 32) by MFMA: X[m][c] = sum_r Uinv[r][m] W[k0 + r][c], m, r < NB.
-// Result tile (mt, nt) register g of lane l is X[16 mt + (l >> 4) + 4 g][c0 + 16 nt + (l & 15)] -- which is
-// exactly the operand layout of the trailing update (K index m = 4 (4 mt + g) + (l >> 4)), so X feeds
-// the next MFMA without leaving the registers.  Columns > cmax and rows >= kb read as zero.
 __device__ __forceinline__ void panel_x(const double* __restrict__ W, int ldw, const double* __restrict__ uinv, int k0, int kb,
                                         int c0, int cmax, double4_t (&X)[2][2]) {
-  const int lane = threadIdx.x & 63;
-  const int li = lane & 15, lk = lane >> 4;
-  double bop[8][2], aop[8][2];
-#pragma unroll
-  for (int s = 0; s < 8; ++s) {
-    const int r = 4 * s + lk;
-#pragma unroll
-    for (int nt = 0; nt < 2; ++nt) {
-      const int c = c0 + 16 * nt + li;
-      bop[s][nt] = (r < kb && c <= cmax) ? W[size_t(k0 + r) * ldw + c] : 0.0;
-    }
-#pragma unroll
-    for (int mt = 0; mt < 2; ++mt) aop[s][mt] = uinv[r * NB + 16 * mt + li];  // A(m, r) = Uinv[r][m]
-  }
-#pragma unroll
-  for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-    for (int nt = 0; nt < 2; ++nt) X[mt][nt] = double4_t{0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-  for (int s = 0; s < 8; ++s)
-#pragma unroll
-    for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-      for (int nt = 0; nt < 2; ++nt) X[mt][nt] = __builtin_amdgcn_mfma_f64_16x16x4f64(aop[s][mt], bop[s][nt], X[mt][nt], 0, 0, 0);
+  cxchol::panel_x(W + size_t(k0) * ldw + c0, ldw, uinv, kb, cmax - c0 + 1, X);
 }
 
 // store X (see panel_x) as rows k0.. of the factor: columns < n into F, column n (the right-hand side) into y

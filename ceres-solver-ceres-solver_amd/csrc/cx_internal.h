@@ -157,6 +157,13 @@ struct cx_matrix {
   int64_t num_items = 0;
   int64_t num_cells = 0;
   DevBuf<double> d_elim_bg0, d_elim_bg1, d_elim_bg2;  // per row B = E'F (3x9) and G = (E'E)^-1 B, 3 x 18 doubles
+  // tile-sparse Cholesky of S (cx_sparse_chol.hip): plan (0 not built, 1 ready, 2 not available) and pools
+  int sp_state = 0;
+  int sp_T = 0;
+  int64_t sp_num_tiles = 0;
+  std::vector<int32_t> h_sp_row_start, h_sp_col_start;
+  DevBuf<int32_t> d_sp_cam_pos, d_sp_row_start, d_sp_row_tiles, d_sp_col_start, d_sp_col_pool, d_sp_col_row;
+  DevBuf<double> d_sp_W, d_sp_F, d_sp_x;
   int pairs_state = 0;                   // 0 not built, 1 ready, 2 too many pairs (atomic path)
   int64_t num_pairs = 0;
 

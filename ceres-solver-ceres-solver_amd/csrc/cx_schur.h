@@ -22,6 +22,13 @@ int cxs_eliminate_dense(cx_matrix* A, const double* b, const double* D, bool add
 // D_f^2 NOT added, see k_pair_cells); CX_ERR_UNSUPPORTED when the pair list is too large to build
 int cxs_build_pair_lists(cx_matrix* A);
 int cxs_eliminate_sparse(cx_matrix* A, const double* b, const double* D, double* rhs);
+// the two halves of the gather elimination on their own (tile-sparse SPARSE_SCHUR): per-item pair sums, F'F
+// diagonal blocks and (E'E + D^2)^-1 into the matrix' scratch; rhs = F'(b - E (E'E)^-1 E'b)
+int cxs_assemble_pair_items(cx_matrix* A, const double* D);
+int cxs_eliminate_rhs(cx_matrix* A, const double* b, double* rhs);
+// tile-sparse Cholesky of the explicit S (cx_sparse_chol.hip)
+int cxsp_build_plan(cx_matrix* A);
+int cxsp_factor_and_solve(cx_matrix* A, const double* Df, const double* rhs, double* z, int* d_flag);
 // y = S x with that storage (BlockRandomAccessSparseMatrix::SymmetricRightMultiplyAndAccumulate); blocks[c] = S(c,c)
 int cxs_sparse_multiply(cx_matrix* A, const double* x, double* y);
 int cxs_sparse_diagonal(cx_matrix* A, double* blocks);

@@ -1187,7 +1187,7 @@ int cxs_block9_add_diag_invert(cx_context* ctx, double* blocks, const double* Df
 
 // Gather assembly shared by the dense and the block-sparse explicit S: (E'E + D_e^2)^-1 (closed-form inverse
 // of InvertPSDMatrix<3>), B / G of every row, F'F diagonal blocks, per-item pair sums.
-static int AssemblePairItems(cx_matrix* A, const double* D) {
+int cxs_assemble_pair_items(cx_matrix* A, const double* D) {
   hipStream_t st = A->ctx->stream;
   CX_TRY(A->d_elim_ete.alloc(size_t(std::max<int64_t>(9 * int64_t(A->P), 1))));
   CX_TRY(A->d_elim_diag.alloc(size_t(std::max<int64_t>(81 * int64_t(A->C), 1))));
@@ -1211,7 +1211,7 @@ static int AssemblePairItems(cx_matrix* A, const double* D) {
 }
 
 // rhs = F'(b - E (E'E)^-1 E'b)  (UpdateRhs, schur_eliminator_impl.h:379-420); A->d_elim_ete must be current
-static int EliminateRhs(cx_matrix* A, const double* b, double* rhs) {
+int cxs_eliminate_rhs(cx_matrix* A, const double* b, double* rhs) {
   if (!rhs) return CX_OK;
   if (!b) {
     CX_HIP(hipMemsetAsync(rhs, 0, size_t(9) * A->C * sizeof(double), A->ctx->stream));
@@ -1229,7 +1229,7 @@ int cxs_eliminate_dense(cx_matrix* A, const double* b, const double* D, bool add
   const double* Df = (D && add_df) ? D + 3 * int64_t(A->P) : nullptr;
   CX_TRY(cxs_build_pair_lists(A));
   if (A->pairs_state == 1) {
-    CX_TRY(AssemblePairItems(A, D));
+    CX_TRY(cxs_assemble_pair_items(A, D));
     if (n > 0) CX_HIP(hipMemsetAsync(lhs, 0, size_t(n) * n * sizeof(double), st));
     if (A->num_cells > 0)
       hipLaunchKernelGGL(k_pair_cells, dim3(unsigned((A->num_cells + 2) / 3)), dim3(3 * 81), 0, st,
@@ -1259,7 +1259,7 @@ int cxs_eliminate_dense(cx_matrix* A, const double* b, const double* D, bool add
                          (const double*)A->d_elim_diag.p, Df, lhs, C);
   }
   CX_HIP(hipGetLastError());
-  return EliminateRhs(A, b, rhs);
+  return cxs_eliminate_rhs(A, b, rhs);
 }
 
 int cxs_eliminate_sparse(cx_matrix* A, const double* b, const double* D, double* rhs) {
@@ -1269,14 +1269,14 @@ int cxs_eliminate_sparse(cx_matrix* A, const double* b, const double* D, double*
     return CX_ERR_UNSUPPORTED;
   }
   CX_TRY(A->d_S.alloc(size_t(std::max<int64_t>(A->num_cells, 1)) * 81));
-  CX_TRY(AssemblePairItems(A, D));
+  CX_TRY(cxs_assemble_pair_items(A, D));
   if (A->num_cells > 0)
     hipLaunchKernelGGL(k_pair_cells, dim3(unsigned((A->num_cells + 2) / 3)), dim3(3 * 81), 0, A->ctx->stream,
                        (const int32_t*)A->d_cell_c1.p, (const int32_t*)A->d_cell_c2.p, (const int32_t*)A->d_cell_item_start.p,
                        (const double*)A->d_item_partial.p, (const double*)A->d_elim_diag.p, (const double*)nullptr,
                        (double*)nullptr, A->d_S.p, A->C, A->num_cells);
   CX_HIP(hipGetLastError());
-  return EliminateRhs(A, b, rhs);
+  return cxs_eliminate_rhs(A, b, rhs);
 }
 
 int cxs_sparse_multiply(cx_matrix* A, const double* x, double* y) {

@@ -12,6 +12,8 @@
 #include <cmath>
 #include <memory>
 
+#include <cstdlib>
+
 #include "cx_internal.h"
 #include "cx_kernels.h"
 #include "cx_schur.h"
@@ -1066,10 +1068,48 @@ int SolveCgnr239(cx_solver* S, cx_matrix* A, const double* b, const double* D, d
   return CX_OK;
 }
 
+// SPARSE_SCHUR beyond the size a dense S is sensible for: the block-sparse S goes into 64x64 tiles and is
+// factored by the tile-sparse Cholesky (cx_sparse_chol.hip) -- SparseSchurComplementSolver with a sparse direct
+// reduced solve (schur_complement_solver.cc:101-159, 292-335).
+constexpr int kSparseCholeskyMinCameras = 2048;  // below: the dense path (fewer, fatter steps)
+
+int SolveSparseSchur239(cx_solver* S, cx_matrix* A, const double* b, const double* D, double* x, cx_summary* summary) {
+  cx_context* ctx = S->ctx;
+  hipStream_t st = ctx->stream;
+  const int64_t nf = 9 * int64_t(A->C), ne = 3 * int64_t(A->P);
+  Stopwatch sw{st, ctx->ev[2], ctx->ev[3]};
+  CX_TRY(S->v_rhs.alloc(nf));
+  CX_TRY(S->flag.alloc(1));
+  CX_HIP(hipMemsetAsync(S->flag.p, 0, sizeof(int), st));
+  CX_TRY(sw.start());
+  CX_TRY(cxs_assemble_pair_items(A, D));
+  CX_TRY(cxs_eliminate_rhs(A, b, S->v_rhs.p));
+  CX_TRY(sw.stop(&S->timing.eliminate_ms));
+  CX_TRY(sw.start());
+  double* z = x + ne;
+  summary->num_iterations = 1;
+  summary->termination_type = CX_SUCCESS;
+  std::snprintf(summary->message, sizeof(summary->message), "Success.");
+  CX_TRY(cxsp_factor_and_solve(A, D ? D + ne : nullptr, S->v_rhs.p, z, S->flag.p));
+  bool failed = false;
+  CX_TRY(CheckFlag(S, "Sparse Cholesky factorization failed: the reduced camera matrix is not positive definite.", summary, &failed));
+  if (failed) summary->num_iterations = 1;
+  CX_TRY(sw.stop(&S->timing.reduced_solve_ms));
+  CX_TRY(sw.start());
+  if (summary->termination_type == CX_SUCCESS) CX_TRY(cxs_chunk_pass(A, 2, A->d_elim_ete.p, z, b, x));
+  CX_TRY(sw.stop(&S->timing.back_substitute_ms));
+  return CX_OK;
+}
+
 int SolveDenseSchur239(cx_solver* S, cx_matrix* A, const double* b, const double* D, double* x, cx_summary* summary) {
   cx_context* ctx = S->ctx;
   hipStream_t st = ctx->stream;
   const int64_t nf = 9 * int64_t(A->C), ne = 3 * int64_t(A->P);
+  if (S->opt.type == CX_SPARSE_SCHUR && ctx->nranks == 1 &&
+      (A->C >= kSparseCholeskyMinCameras || std::getenv("CX_SPARSE_CHOLESKY"))) {
+    CX_TRY(cxsp_build_plan(A));
+    if (A->sp_state == 1) return SolveSparseSchur239(S, A, b, D, x, summary);
+  }
   Stopwatch sw{st, ctx->ev[2], ctx->ev[3]};
   CX_TRY(S->lhs.alloc(size_t(nf) * nf));
   CX_TRY(S->v_rhs.alloc(nf));

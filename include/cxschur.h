@@ -69,7 +69,7 @@ typedef enum {
  * members exist here. */
 typedef enum {
   CX_DENSE_SCHUR = 0,      /* explicit S, dense storage, dense Cholesky          */
-  CX_SPARSE_SCHUR = 1,     /* explicit S; stored dense on device while 9C fits   */
+  CX_SPARSE_SCHUR = 1,     /* explicit S; dense below 2048 cameras, tile-sparse Cholesky above */
   CX_ITERATIVE_SCHUR = 2,  /* implicit S + PCG                                   */
   CX_CGNR = 3              /* PCG on J'J + D'D                                   */
 } cx_linear_solver_type;

@@ -589,3 +589,45 @@ def test_mixed_precision_iterative_schur(ctx, oracle, pre):
     Smix.close()
     A.close()
 
+
+@pytest.mark.parametrize("C,P,O,seed", [(12, 300, 1500, 1), (30, 800, 4000, 2), (100, 3000, 14000, 3), (400, 9000, 40000, 4)])
+def test_sparse_schur_tile_cholesky(ctx, oracle, C, P, O, seed):
+    """SPARSE_SCHUR through the tile-sparse Cholesky (forced with CX_SPARSE_CHOLESKY; by default it takes over
+    from 2048 cameras): same step as the dense reduced solve and as the oracle (schur_complement_solver_test.cc
+    bound 1e-10 on |dx| / n).  The camera ordering is this library's own (reverse Cuthill-McKee): parity
+    unpinned for CHOLMOD's AMD / CAMD, pinned on the solution."""
+    prob, bs, order, vals, b, D = make(C, P, O, seed, "eval", oracle)
+    A = cx.Matrix(ctx, bs, P)
+    A.set_values(vals)
+    Sd = cx.Solver(ctx, type=cx.DENSE_SCHUR, num_eliminate_blocks=P)
+    xd, sd = Sd.solve(A, b, D)
+    os.environ["CX_SPARSE_CHOLESKY"] = "1"
+    try:
+        Ss = cx.Solver(ctx, type=cx.SPARSE_SCHUR, num_eliminate_blocks=P)
+        xs, ss = Ss.solve(A, b, D)
+        xs2, _ = Ss.solve(A, b, D)
+    finally:
+        del os.environ["CX_SPARSE_CHOLESKY"]
+    assert ss.termination_type == cx.SUCCESS and ss.num_iterations == 1
+    assert np.all(np.isfinite(xs))
+    assert np.linalg.norm(xs - xd) / xs.size < 1e-10 and relerr(xs, xd) < 1e-8
+    oo = oracle.make_options(type=oracle.SPARSE_SCHUR, num_eliminate_blocks=P)
+    xr, sr = oracle.solve(bs, vals, b, D, oo)
+    assert np.linalg.norm(xs - xr) / xs.size < 1e-10
+    assert np.array_equal(xs, xs2)   # fixed order of every sum
+    # not positive definite -> FAILURE, like the dense path
+    Dneg = D.copy()
+    vals_bad = vals.copy()
+    vals_bad[6 * O:] = 0.0           # F = 0 and D_f = 0: S is singular
+    Dneg[3 * P:] = 0.0
+    A.set_values(vals_bad)
+    os.environ["CX_SPARSE_CHOLESKY"] = "1"
+    try:
+        _, sbad = Ss.solve(A, b, Dneg)
+    finally:
+        del os.environ["CX_SPARSE_CHOLESKY"]
+    assert sbad.termination_type == cx.FAILURE
+    Sd.close()
+    Ss.close()
+    A.close()
+
