@@ -1071,7 +1071,8 @@ int SolveCgnr239(cx_solver* S, cx_matrix* A, const double* b, const double* D, d
 // SPARSE_SCHUR beyond the size a dense S is sensible for: the block-sparse S goes into 64x64 tiles and is
 // factored by the tile-sparse Cholesky (cx_sparse_chol.hip) -- SparseSchurComplementSolver with a sparse direct
 // reduced solve (schur_complement_solver.cc:101-159, 292-335).
-constexpr int kSparseCholeskyMinCameras = 2048;  // below: the dense path (fewer, fatter steps)
+constexpr int kSparseCholeskyMinCameras = 512;  // below: always the dense path (few, fat steps)
+constexpr int kDenseSchurMaxCameras = 6144;     // above: a dense S and its working copy pass 48 GB
 
 int SolveSparseSchur239(cx_solver* S, cx_matrix* A, const double* b, const double* D, double* x, cx_summary* summary) {
   cx_context* ctx = S->ctx;
@@ -1105,10 +1106,18 @@ int SolveDenseSchur239(cx_solver* S, cx_matrix* A, const double* b, const double
   cx_context* ctx = S->ctx;
   hipStream_t st = ctx->stream;
   const int64_t nf = 9 * int64_t(A->C), ne = 3 * int64_t(A->P);
-  if (S->opt.type == CX_SPARSE_SCHUR && ctx->nranks == 1 &&
-      (A->C >= kSparseCholeskyMinCameras || std::getenv("CX_SPARSE_CHOLESKY"))) {
-    CX_TRY(cxsp_build_plan(A));
-    if (A->sp_state == 1) return SolveSparseSchur239(S, A, b, D, x, summary);
+  if (S->opt.type == CX_SPARSE_SCHUR && ctx->nranks == 1) {
+    // tile-sparse factorisation when it stores less than half of the dense upper triangle, or when the dense
+    // matrix (and its working copy) would not be reasonable any more; small problems stay dense (fewer steps)
+    const bool forced = std::getenv("CX_SPARSE_CHOLESKY") != nullptr;
+    if (forced || A->C >= kSparseCholeskyMinCameras) {
+      CX_TRY(cxsp_build_plan(A));
+      if (A->sp_state == 1) {
+        const int64_t T = A->sp_T, dense_tiles = T * (T + 1) / 2 + T;
+        if (forced || 2 * A->sp_num_tiles <= dense_tiles || A->C >= kDenseSchurMaxCameras)
+          return SolveSparseSchur239(S, A, b, D, x, summary);
+      }
+    }
   }
   Stopwatch sw{st, ctx->ev[2], ctx->ev[3]};
   CX_TRY(S->lhs.alloc(size_t(nf) * nf));

@@ -7,7 +7,8 @@
 // library's own and parity is stated on the solution (it must equal the dense solve), not on the ordering
 // ("parity unpinned" for CAMD / AMD).
 //
-//   ordering   reverse Cuthill-McKee on the camera graph of S (host, once per structure)
+//   ordering   reverse Cuthill-McKee on the camera graph of S, optionally followed by minimum degree on groups
+//              of 64 cameras -- whichever leaves fewer tiles after fill (host, once per structure)
 //   structure  S in 64x64 tiles (upper triangle), symbolic fill at tile level; every tile row ends with one
 //              extra tile that carries the right-hand side as its column 0, so the forward substitution
 //              is part of the factorisation (as in the dense solver)
@@ -301,23 +302,47 @@ std::vector<int32_t> ReverseCuthillMcKee(int C, const std::vector<std::vector<in
   return pos;
 }
 
-}  // namespace
-
-int cxsp_build_plan(cx_matrix* A) {
-  if (A->sp_state != 0) return CX_OK;
-  CX_TRY(cxs_build_pair_lists(A));
-  if (A->pairs_state != 1) { A->sp_state = 2; return CX_OK; }
-  const int C = A->C;
-  const int n = 9 * C;
-  const int T = (n + kTile - 1) / kTile;
-  std::vector<std::vector<int32_t>> adj(static_cast<size_t>(C));
-  for (int64_t k = 0; k < A->num_cells; ++k) {
-    const int c1 = A->h_cell_c1[size_t(k)], c2 = A->h_cell_c2[size_t(k)];
-    if (c1 != c2) { adj[size_t(c1)].push_back(c2); adj[size_t(c2)].push_back(c1); }
+// Minimum degree on the quotient graph of groups of 64 consecutive cameras of a locality-preserving order
+// (64 cameras = 576 rows = 9 whole tiles, so the groups stay tile-aligned): hub groups that see everything move to
+// the end, where their fill is unavoidable, instead of sitting wherever the breadth-first order met them.
+std::vector<int32_t> GroupMinimumDegree(int C, const std::vector<std::vector<int32_t>>& adj, const std::vector<int32_t>& pos) {
+  const int G = (C + 63) / 64;
+  std::vector<std::vector<char>> g(static_cast<size_t>(G), std::vector<char>(static_cast<size_t>(G), 0));
+  for (int c = 0; c < C; ++c)
+    for (int32_t d : adj[size_t(c)]) g[size_t(pos[size_t(c)] / 64)][size_t(pos[size_t(d)] / 64)] = 1;
+  std::vector<char> done(static_cast<size_t>(G), 0);
+  std::vector<int32_t> rank(static_cast<size_t>(G), 0);
+  for (int step = 0; step < G; ++step) {
+    int best = -1, best_deg = 1 << 30;
+    for (int u = 0; u < G; ++u) {
+      if (done[size_t(u)]) continue;
+      int deg = 0;
+      for (int v = 0; v < G; ++v) deg += (!done[size_t(v)] && v != u && g[size_t(u)][size_t(v)]) ? 1 : 0;
+      if (deg < best_deg) { best_deg = deg; best = u; }
+    }
+    done[size_t(best)] = 1;
+    rank[size_t(best)] = step;
+    for (int v = 0; v < G; ++v) {
+      if (done[size_t(v)] || !g[size_t(best)][size_t(v)]) continue;
+      for (int w = 0; w < G; ++w)
+        if (!done[size_t(w)] && g[size_t(best)][size_t(w)]) g[size_t(v)][size_t(w)] = 1;
+    }
   }
-  std::vector<int32_t> pos = ReverseCuthillMcKee(C, adj);
-  // tile-level structure of the permuted S (upper), then symbolic fill: eliminating tile row k connects every
-  // pair of its later column tiles
+  // new position = start of the group's slot + old offset inside the group
+  std::vector<int32_t> size(static_cast<size_t>(G), 0), start(static_cast<size_t>(G), 0), by_rank(static_cast<size_t>(G), 0);
+  for (int c = 0; c < C; ++c) size[size_t(pos[size_t(c)] / 64)]++;
+  for (int u = 0; u < G; ++u) by_rank[size_t(rank[size_t(u)])] = u;
+  int32_t acc = 0;
+  for (int r = 0; r < G; ++r) { start[size_t(by_rank[size_t(r)])] = acc; acc += size[size_t(by_rank[size_t(r)])]; }
+  std::vector<int32_t> out(static_cast<size_t>(C));
+  for (int c = 0; c < C; ++c) out[size_t(c)] = start[size_t(pos[size_t(c)] / 64)] + pos[size_t(c)] % 64;
+  return out;
+}
+
+// tile-level structure of the permuted S (upper) and its symbolic fill (eliminating tile row k connects every pair
+// of its later column tiles); rows as sorted lists, each closed by the right-hand-side tile T
+void TileStructure(const cx_matrix* A, const std::vector<int32_t>& pos, int T, std::vector<int32_t>* row_start,
+                   std::vector<int32_t>* row_tiles) {
   std::vector<std::vector<char>> nz(static_cast<size_t>(T), std::vector<char>(static_cast<size_t>(T), 0));
   auto mark = [&](int p1, int p2) {  // camera positions p1 <= p2
     for (int rt = (9 * p1) >> 6; rt <= (9 * p1 + 8) >> 6; ++rt)
@@ -335,13 +360,43 @@ int cxsp_build_plan(cx_matrix* A) {
     for (size_t x = 0; x < later.size(); ++x)
       for (size_t y = x; y < later.size(); ++y) nz[size_t(later[x])][size_t(later[y])] = 1;
   }
-  std::vector<int32_t> row_start(size_t(T) + 1, 0), row_tiles;
+  row_start->assign(size_t(T) + 1, 0);
+  row_tiles->clear();
   for (int I = 0; I < T; ++I) {
-    row_start[size_t(I)] = int32_t(row_tiles.size());
-    for (int J = I; J < T; ++J) if (nz[size_t(I)][size_t(J)]) row_tiles.push_back(J);
-    row_tiles.push_back(T);  // the right-hand side rides along
+    (*row_start)[size_t(I)] = int32_t(row_tiles->size());
+    for (int J = I; J < T; ++J) if (nz[size_t(I)][size_t(J)]) row_tiles->push_back(J);
+    row_tiles->push_back(T);  // the right-hand side rides along
   }
-  row_start[size_t(T)] = int32_t(row_tiles.size());
+  (*row_start)[size_t(T)] = int32_t(row_tiles->size());
+}
+
+}  // namespace
+
+int cxsp_build_plan(cx_matrix* A) {
+  if (A->sp_state != 0) return CX_OK;
+  CX_TRY(cxs_build_pair_lists(A));
+  if (A->pairs_state != 1) { A->sp_state = 2; return CX_OK; }
+  const int C = A->C;
+  const int n = 9 * C;
+  const int T = (n + kTile - 1) / kTile;
+  std::vector<std::vector<int32_t>> adj(static_cast<size_t>(C));
+  for (int64_t k = 0; k < A->num_cells; ++k) {
+    const int c1 = A->h_cell_c1[size_t(k)], c2 = A->h_cell_c2[size_t(k)];
+    if (c1 != c2) { adj[size_t(c1)].push_back(c2); adj[size_t(c2)].push_back(c1); }
+  }
+  // two candidate orderings, the one with fewer tiles after fill wins
+  std::vector<int32_t> pos = ReverseCuthillMcKee(C, adj);
+  std::vector<int32_t> row_start, row_tiles;
+  TileStructure(A, pos, T, &row_start, &row_tiles);
+  {
+    std::vector<int32_t> pos2 = GroupMinimumDegree(C, adj, pos), rs2, rt2;
+    TileStructure(A, pos2, T, &rs2, &rt2);
+    if (rt2.size() < row_tiles.size()) {
+      pos.swap(pos2);
+      row_start.swap(rs2);
+      row_tiles.swap(rt2);
+    }
+  }
   const int64_t num_tiles = int64_t(row_tiles.size());
   // transposed index: the tiles (Ii <= I, I) of tile column I, ascending Ii, with their pool positions
   std::vector<int32_t> col_start(size_t(T) + 1, 0), col_pool, col_row;

@@ -631,3 +631,40 @@ def test_sparse_schur_tile_cholesky(ctx, oracle, C, P, O, seed):
     Ss.close()
     A.close()
 
+
+def test_sparse_schur_with_hub_cameras(ctx, oracle):
+    """A ring of cameras plus two hub cameras that see points everywhere: the group-minimum-degree ordering has to
+    move the hubs' group to the end; whatever ordering wins, the step equals the dense solve's."""
+    C, P = 330, 3000
+    rng = np.random.default_rng(8)
+    lists = []
+    for j in range(P):
+        c0 = int(j * (C - 2) / P)
+        cams = {2 + (c0 + d) % (C - 2) for d in (0, 1, 2)}
+        if j % 4 == 0:
+            cams.add(0)
+        if j % 7 == 0:
+            cams.add(1)
+        lists.append(sorted(cams))
+    prob = _custom_problem(C, lists, 5)
+    bs, order = cx.bal.build_structure(prob)
+    O = prob.num_observations
+    vals = cx.bal.random_jacobian_values(O, 3)
+    b = rng.standard_normal(2 * O)
+    D = rng.uniform(0.5, 2.0, bs.num_cols)
+    A = cx.Matrix(ctx, bs, P)
+    A.set_values(vals)
+    Sd = cx.Solver(ctx, type=cx.DENSE_SCHUR, num_eliminate_blocks=P)
+    xd, _ = Sd.solve(A, b, D)
+    os.environ["CX_SPARSE_CHOLESKY"] = "1"
+    try:
+        Ss = cx.Solver(ctx, type=cx.SPARSE_SCHUR, num_eliminate_blocks=P)
+        xs, ss = Ss.solve(A, b, D)
+    finally:
+        del os.environ["CX_SPARSE_CHOLESKY"]
+    assert ss.termination_type == cx.SUCCESS
+    assert np.linalg.norm(xs - xd) / xs.size < 1e-10 and relerr(xs, xd) < 1e-8
+    Sd.close()
+    Ss.close()
+    A.close()
+
