@@ -162,7 +162,13 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(backend="gloo", rank=rank, world_size=world)   # control plane only
     ctx = cx.Context(local_rank)
-    if world > 1:
+    if world > 1 and os.environ.get("CX_BENCH_TRANSPORT") == "gloo":
+        # rehearsal only (several ranks sharing one GPU, where RCCL refuses to form a communicator): the
+        # exchange step goes through the library's callback transport and a host-staged gloo all-reduce
+        def _allreduce(a):
+            dist.all_reduce(torch.from_numpy(a), op=dist.ReduceOp.SUM)
+        ctx.set_comm_callback(rank, world, _allreduce)
+    elif world > 1:
         ids = [cx.Context.unique_id() if rank == 0 else None]
         dist.broadcast_object_list(ids, src=0)
         ctx.set_comm(rank, world, ids[0])                                     # data plane: RCCL over xGMI

@@ -67,8 +67,11 @@ int RcclCheck(int rc, const char* what) {
 }
 }  // namespace
 
-int cx_allreduce_device(cx_context* ctx, double* p, int64_t n) {
-  if (ctx->nranks <= 1 || n == 0) return CX_OK;
+static int AllReduce(cx_context* ctx, double* p, int64_t n, bool even_single_rank) {
+  if (n == 0) return CX_OK;
+  // with one rank the sum is the identity: skipped inside the solvers, but cx_allreduce_sum still goes through
+  // RCCL when a communicator exists, so that the call path can be exercised on a one-GPU box
+  if (ctx->nranks <= 1 && !(even_single_rank && ctx->comm)) return CX_OK;
   if (ctx->allreduce_cb) {
     CX_HIP(hipStreamSynchronize(ctx->stream));
     if (ctx->allreduce_cb(p, n, ctx->allreduce_cb_user) != 0) {
@@ -86,6 +89,8 @@ int cx_allreduce_device(cx_context* ctx, double* p, int64_t n) {
   ctx->allreduce_host_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
   return RcclCheck(rc, "ncclAllReduce");
 }
+
+int cx_allreduce_device(cx_context* ctx, double* p, int64_t n) { return AllReduce(ctx, p, n, false); }
 
 extern "C" {
 
@@ -172,7 +177,7 @@ int cx_context_num_ranks(const cx_context* ctx) { return ctx ? ctx->nranks : 1; 
 
 int cx_allreduce_sum(cx_context* ctx, double* device_ptr, int64_t n) {
   CX_CHECK_ARG(ctx != nullptr && (device_ptr != nullptr || n == 0));
-  return cx_allreduce_device(ctx, device_ptr, n);
+  return AllReduce(ctx, device_ptr, n, true);
 }
 
 int cx_malloc(cx_context* ctx, size_t bytes, void** device_ptr) {

@@ -359,8 +359,9 @@ def test_host_adapter_cpp():
 
 
 def test_rccl_single_rank_communicator(ctx):
-    """librccl is resolved with dlopen and a 1-rank communicator all-reduces in place
-    (the N > 1 data path; more ranks need more GPUs than the test box has)."""
+    """librccl is resolved with dlopen, ncclCommInitRank forms a 1-rank communicator and cx_allreduce_sum really
+    calls ncclAllReduce(sum, fp64) on the context's stream (the N > 1 data path; more ranks need more GPUs than
+    the test box has -- the sharded logic itself runs with two ranks in tests/test_gpu_sharded.py)."""
     c2 = cx.Context(0)
     uid = cx.Context.unique_id()
     assert len(uid) == 128
