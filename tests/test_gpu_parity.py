@@ -669,3 +669,30 @@ def test_sparse_schur_with_hub_cameras(ctx, oracle):
     Ss.close()
     A.close()
 
+
+def test_sparse_schur_selected_by_fill(ctx, oracle):
+    """From 512 cameras on SPARSE_SCHUR looks at the tile fill: a banded camera graph (every point seen by a few
+    consecutive cameras) goes through the tile-sparse Cholesky without being forced, and must reproduce the dense
+    reduced solve."""
+    C, P = 640, 6000
+    lists = [sorted({(int(j * C / P) + d) % C for d in (0, 1, 2, 3)}) for j in range(P)]
+    prob = _custom_problem(C, lists, 9)
+    bs, order = cx.bal.build_structure(prob)
+    O = prob.num_observations
+    rng = np.random.default_rng(10)
+    vals = cx.bal.random_jacobian_values(O, 4)
+    b = rng.standard_normal(2 * O)
+    D = rng.uniform(0.5, 2.0, bs.num_cols)
+    A = cx.Matrix(ctx, bs, P)
+    A.set_values(vals)
+    Sd = cx.Solver(ctx, type=cx.DENSE_SCHUR, num_eliminate_blocks=P)
+    xd, _ = Sd.solve(A, b, D)
+    Ss = cx.Solver(ctx, type=cx.SPARSE_SCHUR, num_eliminate_blocks=P)
+    xs, ss = Ss.solve(A, b, D)
+    assert ss.termination_type == cx.SUCCESS
+    assert np.linalg.norm(xs - xd) / xs.size < 1e-10 and relerr(xs, xd) < 1e-8
+    assert not np.array_equal(xs, xd)        # another elimination order: not the dense code path
+    Sd.close()
+    Ss.close()
+    A.close()
+
