@@ -24,7 +24,8 @@ def short(name):
         depth += ch == "<"
         depth -= ch == ">"
         out.append(ch)
-    return "".join(out).strip()
+    # the fp64 instantiations keep the names the library reports (k_chunk_pass<0>, not k_chunk_pass<0, double>)
+    return "".join(out).strip().replace(", double>", ">")
 
 
 def read(path, counter):
