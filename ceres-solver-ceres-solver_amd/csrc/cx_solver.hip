@@ -1119,6 +1119,13 @@ int SolveDenseSchur239(cx_solver* S, cx_matrix* A, const double* b, const double
       }
     }
   }
+  if (A->C >= 2 * kDenseSchurMaxCameras) {
+    // a dense S of this size (> 190 GB with its working copy) cannot be meant: several ranks, or a structure whose
+    // tile-sparse plan could not be built
+    cx_set_error("%s with %d cameras: the dense reduced matrix does not fit and the tile-sparse Cholesky is not available "
+                 "here (sharded context or too much fill); use ITERATIVE_SCHUR", S->opt.type == CX_SPARSE_SCHUR ? "SPARSE_SCHUR" : "DENSE_SCHUR", A->C);
+    return CX_ERR_UNSUPPORTED;
+  }
   Stopwatch sw{st, ctx->ev[2], ctx->ev[3]};
   CX_TRY(S->lhs.alloc(size_t(nf) * nf));
   CX_TRY(S->v_rhs.alloc(nf));
