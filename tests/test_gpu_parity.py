@@ -696,3 +696,48 @@ def test_sparse_schur_selected_by_fill(ctx, oracle):
     Ss.close()
     A.close()
 
+
+@pytest.mark.parametrize("seed", range(24))
+def test_random_structures_all_solvers(ctx, oracle, seed):
+    """Randomly drawn visibility structures (1..C observations per point, cameras nobody sees, single-camera
+    problems, chunks of very different length) through every solver family, solved to convergence so that the
+    comparison with the oracle does not depend on where a truncated CG stops: |dx| / n < 1e-9, same termination."""
+    rng = np.random.default_rng(1000 + seed)
+    C = int(rng.integers(1, 40))
+    P = int(rng.integers(1, 80))
+    lists = []
+    for j in range(P):
+        k = int(rng.integers(1, min(C, 9) + 1))
+        if rng.random() < 0.1:
+            k = C                                   # a point every camera sees
+        lists.append(sorted(rng.choice(C, size=k, replace=False).tolist()))
+    prob = _custom_problem(C, lists, seed)
+    bs, order = cx.bal.build_structure(prob)
+    O = prob.num_observations
+    vals = cx.bal.random_jacobian_values(O, seed + 1)
+    b = rng.standard_normal(2 * O)
+    D = rng.uniform(0.3, 2.0, bs.num_cols)           # regularised: every block is positive definite
+    cases = [("DENSE_SCHUR", "IDENTITY", 0, False), ("SPARSE_SCHUR", "IDENTITY", 0, True),
+             ("ITERATIVE_SCHUR", "JACOBI", 0, False), ("ITERATIVE_SCHUR", "SCHUR_JACOBI", 1, False),
+             ("ITERATIVE_SCHUR", "SCHUR_POWER_SERIES_EXPANSION", 0, False), ("CGNR", "JACOBI", 0, False)]
+    for stype, pre, explicit, force_sparse in cases:
+        nelim = 0 if stype == "CGNR" else P
+        A = cx.Matrix(ctx, bs, nelim)
+        A.set_values(vals)
+        if force_sparse:
+            os.environ["CX_SPARSE_CHOLESKY"] = "1"
+        try:
+            S = cx.Solver(ctx, type=getattr(cx, stype), preconditioner_type=getattr(cx, pre), num_eliminate_blocks=nelim,
+                          max_num_iterations=4 * bs.num_cols + 50, use_explicit_schur_complement=explicit)
+            x, s = S.solve(A, b, D, r_tolerance=1e-13, q_tolerance=0.0)
+        finally:
+            os.environ.pop("CX_SPARSE_CHOLESKY", None)
+        oo = oracle.make_options(type=getattr(oracle, stype), preconditioner_type=getattr(oracle, pre), num_eliminate_blocks=P,
+                                 max_num_iterations=4 * bs.num_cols + 50, use_explicit_schur_complement=explicit)
+        xr, sr = oracle.solve(bs, vals, b, D, oo, r_tolerance=1e-13, q_tolerance=0.0)
+        assert s.termination_type == sr.termination_type == cx.SUCCESS, (stype, pre, s.message, sr.message)
+        assert np.all(np.isfinite(x))
+        assert np.linalg.norm(x - xr) / x.size < 1e-9, (stype, pre, C, P, O)
+        S.close()
+        A.close()
+
