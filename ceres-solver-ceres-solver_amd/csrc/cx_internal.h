@@ -73,7 +73,7 @@ struct DevBuf {
 struct cx_context {
   int device = 0;
   hipStream_t stream = nullptr;
-  hipEvent_t ev[8] = {};
+  hipEvent_t ev[16] = {};  // 0-7 general purpose pairs, 8-15 the solver's phase stopwatch
   // RCCL (resolved at run time from librccl.so.1; see cx_context.cpp)
   void* comm = nullptr;
   int (*allreduce_cb)(double*, int64_t, void*) = nullptr;  // rehearsal transport (cx_context_set_comm_callback)

@@ -818,15 +818,19 @@ struct CgnrJacobiOp : LinOp {
   }
 };
 
+// Phase timer: an event pair per phase on the context's stream; the elapsed times are read in cx_solver_solve
+// after the solve's final synchronisation, so a phase boundary costs two event records and no host wait.
 struct Stopwatch {
+  cx_solver* S;
   hipStream_t st;
-  hipEvent_t a, b;
-  int start() { return hipEventRecord(a, st) == hipSuccess ? CX_OK : CX_ERR_HIP; }
+  int start() {
+    if (S->num_pending >= 4) return CX_OK;
+    return hipEventRecord(S->ctx->ev[8 + 2 * S->num_pending], st) == hipSuccess ? CX_OK : CX_ERR_HIP;
+  }
   int stop(double* ms) {
-    if (hipEventRecord(b, st) != hipSuccess || hipEventSynchronize(b) != hipSuccess) return CX_ERR_HIP;
-    float f = 0.f;
-    if (hipEventElapsedTime(&f, a, b) != hipSuccess) return CX_ERR_HIP;
-    *ms = f;
+    if (S->num_pending >= 4) return CX_OK;
+    if (hipEventRecord(S->ctx->ev[9 + 2 * S->num_pending], st) != hipSuccess) return CX_ERR_HIP;
+    S->pending_ms[S->num_pending++] = ms;
     return CX_OK;
   }
 };
@@ -851,7 +855,7 @@ int SolveIterativeSchur239(cx_solver* S, cx_matrix* A, const double* b, const do
   hipStream_t st = ctx->stream;
   const cx_solver_options& o = S->opt;
   const int64_t nf = 9 * int64_t(A->C), ne = 3 * int64_t(A->P);
-  Stopwatch sw{st, ctx->ev[2], ctx->ev[3]};
+  Stopwatch sw{S, st};
   CX_TRY(S->ete_inv.alloc(9 * size_t(A->P)));
   CX_TRY(S->v_rows.alloc(size_t(A->num_rows)));
   CX_TRY(S->v_rhs.alloc(nf));
@@ -941,7 +945,7 @@ int SolveExplicitSchur239(cx_solver* S, cx_matrix* A, const double* b, const dou
   cx_context* ctx = S->ctx;
   hipStream_t st = ctx->stream;
   const int64_t nf = 9 * int64_t(A->C), ne = 3 * int64_t(A->P);
-  Stopwatch sw{st, ctx->ev[2], ctx->ev[3]};
+  Stopwatch sw{S, st};
   CX_TRY(S->ete_inv.alloc(9 * size_t(A->P)));
   CX_TRY(S->v_rhs.alloc(nf));
   CX_TRY(S->v_x.alloc(nf));
@@ -992,7 +996,7 @@ int SolveCgnr239(cx_solver* S, cx_matrix* A, const double* b, const double* D, d
   hipStream_t st = ctx->stream;
   const cx_solver_options& o = S->opt;
   const int64_t n = A->num_cols, ne = 3 * int64_t(A->P);
-  Stopwatch sw{st, ctx->ev[2], ctx->ev[3]};
+  Stopwatch sw{S, st};
   CX_TRY(S->v_rows.alloc(size_t(A->num_rows)));
   CX_TRY(S->v_rhs.alloc(n));
   CX_TRY(S->flag.alloc(1));
@@ -1078,7 +1082,7 @@ int SolveSparseSchur239(cx_solver* S, cx_matrix* A, const double* b, const doubl
   cx_context* ctx = S->ctx;
   hipStream_t st = ctx->stream;
   const int64_t nf = 9 * int64_t(A->C), ne = 3 * int64_t(A->P);
-  Stopwatch sw{st, ctx->ev[2], ctx->ev[3]};
+  Stopwatch sw{S, st};
   CX_TRY(S->v_rhs.alloc(nf));
   CX_TRY(S->flag.alloc(1));
   CX_HIP(hipMemsetAsync(S->flag.p, 0, sizeof(int), st));
@@ -1126,7 +1130,7 @@ int SolveDenseSchur239(cx_solver* S, cx_matrix* A, const double* b, const double
                  "here (sharded context or too much fill); use ITERATIVE_SCHUR", S->opt.type == CX_SPARSE_SCHUR ? "SPARSE_SCHUR" : "DENSE_SCHUR", A->C);
     return CX_ERR_UNSUPPORTED;
   }
-  Stopwatch sw{st, ctx->ev[2], ctx->ev[3]};
+  Stopwatch sw{S, st};
   CX_TRY(S->lhs.alloc(size_t(nf) * nf));
   CX_TRY(S->v_rhs.alloc(nf));
   CX_TRY(S->ete_inv.alloc(9 * size_t(A->P)));
@@ -1264,6 +1268,7 @@ int cx_solver_solve(cx_solver* S, cx_matrix* A, const double* b, const cx_per_so
   if (o.type != CX_CGNR) CX_CHECK_ARG(o.num_eliminate_blocks == A->nelim);
   std::memset(summary, 0, sizeof(*summary));
   S->timing = cx_solve_timing{};
+  S->num_pending = 0;
   S->ktimer.reset();
   ctx->allreduce_host_ms = 0.0;
   HostOrDevice hb(ctx), hD(ctx), hx(ctx);
@@ -1298,6 +1303,11 @@ int cx_solver_solve(cx_solver* S, cx_matrix* A, const double* b, const cx_per_so
   float ms = 0.f;
   CX_HIP(hipEventElapsedTime(&ms, ctx->ev[4], ctx->ev[5]));
   S->timing.total_ms = ms;
+  for (int i = 0; i < S->num_pending; ++i) {
+    float f = 0.f;
+    CX_HIP(hipEventElapsedTime(&f, ctx->ev[8 + 2 * i], ctx->ev[9 + 2 * i]));
+    *S->pending_ms[i] = f;
+  }
   S->timing.allreduce_ms = ctx->allreduce_host_ms;
   CX_TRY(S->ktimer.collect());
   return hx.out();

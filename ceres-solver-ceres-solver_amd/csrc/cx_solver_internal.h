@@ -102,6 +102,9 @@ struct cx_solver {
   CgState* ring_d = nullptr;
   DevBuf<int> flag;
   DevBuf<unsigned> ticket;  // arrival counter of the fused reductions (zero between kernels)
+  // phase timings are read back once, at the end of the solve (no synchronisation between the phases)
+  double* pending_ms[4] = {};
+  int num_pending = 0;
 };
 
 // ConjugateGradientsSolver (conjugate_gradients_solver.h:107-305) on device vectors of
