@@ -113,6 +113,33 @@ __global__ __launch_bounds__(256) void k_dot2_final(const double* __restrict__ p
   cg_scalar_step(s[0], s[1], op, iter, add_prev, st, ring, ring_slots);
 }
 
+// Prologue of a CG run that starts from x = 0 (conjugate_gradients_solver.h:139-160), on the device so that the
+// host does not have to wait for |rhs|: st->s0 = rhs.rhs on entry, st->tol_r holds the relative tolerance.
+// Sets tol_r = r_tolerance |rhs|, |r| = |rhs|, and raises a flag when there is nothing to iterate on (zero
+// right-hand side, converged at the start, or a preconditioner that could not be formed); a raised flag is
+// published as "iteration 1" so that the host's pipeline reads it where it expects the first outcome.
+__global__ void k_cg_prologue(CgState* __restrict__ st, CgState* __restrict__ ring, int ring_slots,
+                              const int* __restrict__ preconditioner_failed) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  const double norm_rhs = sqrt(st->s0);
+  st->norm_r = norm_rhs;
+  if (preconditioner_failed && *preconditioner_failed) {
+    st->flag = CG_FAIL_PRECONDITIONER;
+  } else if (norm_rhs == 0.0) {
+    st->flag = CG_ZERO_RHS;
+  } else {
+    st->tol_r = st->tol_r * norm_rhs;
+    if (st->min_iter == 0 && norm_rhs <= st->tol_r) st->flag = CG_CONVERGED_AT_START;
+  }
+  if (st->flag != CG_RUNNING) {
+    st->iter = 0;
+    CgState* slot = ring + (1 % ring_slots);
+    *slot = *st;
+    __threadfence_system();
+    __hip_atomic_store(&slot->seq, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+}
+
 // ---------------------------------------------------------------- fused reductions
 // One-kernel form of partial + final: every workgroup stores its two sums, takes a ticket, and
 // the workgroup that draws the last ticket adds the partials up in index order (so the result
@@ -357,6 +384,9 @@ struct CgDriver {
   // sharded CGNR: entries [shared0, n) are replicated over the ranks
   int64_t shared0;
   static constexpr int kRingSlots = 16;
+  // set by solvers whose set-up raises a device flag when the preconditioner cannot be formed: the prologue then
+  // ends the run before the first iteration (no host check, no synchronisation, in between)
+  const int* preconditioner_failed = nullptr;
 
   // vectors replicated on every rank (or a single rank): dot products need no exchange
   bool fused() const { return !(ctx->nranks > 1 && shared0 < n); }
@@ -497,49 +527,67 @@ struct CgDriver {
     summary->num_iterations = 0;
 
     CgState h{};
-    CX_HIP(hipMemcpyAsync(ds, &h, sizeof(h), hipMemcpyHostToDevice, st));
-    CX_TRY(dot2(rhs, rhs, nullptr, nullptr, FIN_STORE, 0, ds));
-    CX_TRY(read_state(&h));
-    const double norm_rhs = std::sqrt(h.s0);
-    if (norm_rhs == 0.0) {
-      CX_HIP(hipMemsetAsync(x, 0, n * sizeof(double), st));
-      summary->termination_type = CX_SUCCESS;
-      std::snprintf(summary->message, sizeof(summary->message), "Convergence. |b| = 0.");
-      return CX_OK;
-    }
-    const double tol_r = r_tol * norm_rhs;
-    double norm_r, Q0;
+    CgState* init = S->ring_h + kRingSlots;  // pinned staging slot of the initial device state
+    double tol_r = 0.0;
     if (zero_initial) {
-      // x = 0: r = rhs, |r| = |rhs|, Q0 = -x.(rhs + r) = 0 -- nothing to compute or to wait for
+      // x = 0: r = rhs, Q0 = 0; |rhs|, the absolute tolerance and the "nothing to do" cases are the device
+      // prologue's business -- the host goes straight on to enqueue the first iteration
+      *init = CgState{};
+      init->rho = 1.0;
+      init->Q0 = 0.0;
+      init->tol_r = r_tol;  // relative; k_cg_prologue scales it by |rhs|
+      init->q_tol = q_tol;
+      init->min_iter = o.min_num_iterations;
+      init->max_iter = o.max_num_iterations;
+      init->flag = CG_RUNNING;
+      init->seq = -1;
+      CX_HIP(hipMemcpyAsync(ds, init, sizeof(CgState), hipMemcpyHostToDevice, st));
+      CX_TRY(dot2(rhs, rhs, nullptr, nullptr, FIN_STORE, 0, ds));
+      hipLaunchKernelGGL(k_cg_prologue, dim3(1), dim3(1), 0, st, ds, S->ring_d, kRingSlots, preconditioner_failed);
       CX_HIP(hipMemcpyAsync(r, rhs, n * sizeof(double), hipMemcpyDeviceToDevice, st));
-      norm_r = norm_rhs;
-      Q0 = 0.0;
     } else {
+      CX_HIP(hipMemcpyAsync(ds, &h, sizeof(h), hipMemcpyHostToDevice, st));
+      CX_TRY(dot2(rhs, rhs, nullptr, nullptr, FIN_STORE, 0, ds));
+      int precond_flag = 0;
+      if (preconditioner_failed)
+        CX_HIP(hipMemcpyAsync(&precond_flag, preconditioner_failed, sizeof(int), hipMemcpyDeviceToHost, st));
+      CX_TRY(read_state(&h));  // this path waits for the device anyway
+      if (precond_flag) {
+        summary->termination_type = CX_FAILURE;
+        std::snprintf(summary->message, sizeof(summary->message), "Preconditioner update failed.");
+        return CX_OK;
+      }
+      const double norm_rhs = std::sqrt(h.s0);
+      if (norm_rhs == 0.0) {
+        CX_HIP(hipMemsetAsync(x, 0, n * sizeof(double), st));
+        summary->termination_type = CX_SUCCESS;
+        std::snprintf(summary->message, sizeof(summary->message), "Convergence. |b| = 0.");
+        return CX_OK;
+      }
+      tol_r = r_tol * norm_rhs;
       CX_TRY(lhs.apply(x, tmp));
       hipLaunchKernelGGL(k_residual, dim3(g), dim3(256), 0, st, rhs, (const double*)tmp, r, tmp, n, (const CgState*)nullptr);
       // tmp = rhs + r now;  s0 = x.tmp, s1 = r.r
       CX_TRY(dot2(x, tmp, r, r, FIN_STORE, 0, ds));
       CX_TRY(read_state(&h));
-      norm_r = std::sqrt(h.s1);
-      Q0 = -h.s0;  // Q0 = -x.(rhs + r)   (conjugate_gradients_solver.h:155-158)
+      const double norm_r = std::sqrt(h.s1);
+      const double Q0 = -h.s0;  // Q0 = -x.(rhs + r)   (conjugate_gradients_solver.h:155-158)
+      if (o.min_num_iterations == 0 && norm_r <= tol_r) {
+        summary->termination_type = CX_SUCCESS;
+        std::snprintf(summary->message, sizeof(summary->message), "Convergence. |r| = %e <= %e.", norm_r, tol_r);
+        return CX_OK;
+      }
+      *init = CgState{};
+      init->rho = 1.0;
+      init->Q0 = Q0;
+      init->tol_r = tol_r;
+      init->q_tol = q_tol;
+      init->min_iter = o.min_num_iterations;
+      init->max_iter = o.max_num_iterations;
+      init->flag = CG_RUNNING;
+      init->seq = -1;
+      CX_HIP(hipMemcpyAsync(ds, init, sizeof(CgState), hipMemcpyHostToDevice, st));
     }
-    if (o.min_num_iterations == 0 && norm_r <= tol_r) {
-      summary->termination_type = CX_SUCCESS;
-      std::snprintf(summary->message, sizeof(summary->message), "Convergence. |r| = %e <= %e.", norm_r, tol_r);
-      return CX_OK;
-    }
-    // initial device state, staged through the pinned ring's spare slot (no stack buffer, no sync)
-    CgState* init = S->ring_h + kRingSlots;
-    *init = CgState{};
-    init->rho = 1.0;
-    init->Q0 = Q0;
-    init->tol_r = tol_r;
-    init->q_tol = q_tol;
-    init->min_iter = o.min_num_iterations;
-    init->max_iter = o.max_num_iterations;
-    init->flag = CG_RUNNING;
-    init->seq = -1;
-    CX_HIP(hipMemcpyAsync(ds, init, sizeof(CgState), hipMemcpyHostToDevice, st));
 
     // Software pipeline: while the device runs the tail of iteration i the host has already
     // enqueued the head of iteration i+1; it then learns the outcome of iteration i from the
@@ -564,7 +612,7 @@ struct CgDriver {
       case CG_CONVERGED_R:
         summary->termination_type = CX_SUCCESS;
         std::snprintf(summary->message, sizeof(summary->message), "Iteration: %d Convergence. |r| = %e <= %e.",
-                      summary->num_iterations, h.norm_r, tol_r);
+                      summary->num_iterations, h.norm_r, h.tol_r);
         break;
       case CG_FAIL_RHO:
         summary->termination_type = CX_FAILURE;
@@ -584,6 +632,18 @@ struct CgDriver {
         summary->termination_type = CX_FAILURE;
         std::snprintf(summary->message, sizeof(summary->message),
                       "Numerical failure. alpha = rho / pq = %e, rho = %e, pq = %e.", h.alpha, h.rho, h.pq);
+        break;
+      case CG_ZERO_RHS:
+        summary->termination_type = CX_SUCCESS;
+        std::snprintf(summary->message, sizeof(summary->message), "Convergence. |b| = 0.");
+        break;
+      case CG_CONVERGED_AT_START:
+        summary->termination_type = CX_SUCCESS;
+        std::snprintf(summary->message, sizeof(summary->message), "Convergence. |r| = %e <= %e.", h.norm_r, h.tol_r);
+        break;
+      case CG_FAIL_PRECONDITIONER:
+        summary->termination_type = CX_FAILURE;
+        std::snprintf(summary->message, sizeof(summary->message), "Preconditioner update failed.");
         break;
       default: break;  // CG_MAX_ITER keeps NO_CONVERGENCE
     }
@@ -886,9 +946,8 @@ int SolveIterativeSchur239(cx_solver* S, cx_matrix* A, const double* b, const do
   }
   if (ctx->nranks > 1) CX_TRY(cx_allreduce_device(ctx, S->v_rhs.p, nf));
   CX_TRY(sw.stop(&S->timing.eliminate_ms));
-  bool failed = false;
-  CX_TRY(CheckFlag(S, "Preconditioner update failed.", summary, &failed));
-  if (failed) return CX_OK;
+  // a block that could not be inverted raises S->flag on the device; the CG prologue reads it there and ends
+  // the run before the first iteration ("Preconditioner update failed.") -- no host check in between
 
   CX_TRY(sw.start());
   CX_HIP(hipMemsetAsync(S->v_x.p, 0, nf * sizeof(double), st));
@@ -913,6 +972,7 @@ int SolveIterativeSchur239(cx_solver* S, cx_matrix* A, const double* b, const do
                : (o.preconditioner_type == CX_SCHUR_POWER_SERIES_EXPANSION) ? static_cast<LinOp&>(spse_pre)
                                                                           : static_cast<LinOp&>(bd);
   CgDriver cg{S, ctx, st, nf, nf};
+  cg.preconditioner_failed = S->flag.p;
   CX_TRY(S->state.alloc(1));
   // use_mixed_precision_solves: S x inside CG streams fp32 copies of the cells (fp64 accumulation, fp64
   // vectors); set-up, right-hand side and back substitution stay on the fp64 values.  Not in the reference
@@ -962,9 +1022,6 @@ int SolveExplicitSchur239(cx_solver* S, cx_matrix* A, const double* b, const dou
   // preconditioner_->Invert() on S(c,c) + D_f^2 (schur_complement_solver.cc:360-383)
   CX_TRY(cxs_block9_add_diag_invert(ctx, S->cam_blocks.p, D ? D + ne : nullptr, A->C, S->flag.p));
   CX_TRY(sw.stop(&S->timing.eliminate_ms));
-  bool failed = false;
-  CX_TRY(CheckFlag(S, "Preconditioner update failed.", summary, &failed));
-  if (failed) return CX_OK;
 
   CX_TRY(sw.start());
   CX_HIP(hipMemsetAsync(S->v_x.p, 0, nf * sizeof(double), st));
@@ -973,6 +1030,7 @@ int SolveExplicitSchur239(cx_solver* S, cx_matrix* A, const double* b, const dou
   BlockDiag9Op bd;
   bd.ctx = ctx; bd.blocks = S->cam_blocks.p; bd.nblocks = A->C;
   CgDriver cg{S, ctx, st, nf, nf};
+  cg.preconditioner_failed = S->flag.p;
   CX_TRY(S->state.alloc(1));
   A->stop = &S->state.p->flag;
   const int cg_rc = cg.run(lhs, bd, S->v_rhs.p, S->v_x.p, true, r_tol, q_tol, summary);

@@ -12,7 +12,11 @@ enum CgFlag : int {
   CG_FAIL_RHO = 4,
   CG_FAIL_BETA = 5,
   CG_INDEFINITE = 6,
-  CG_FAIL_ALPHA = 7
+  CG_FAIL_ALPHA = 7,
+  // outcomes of the device prologue (before the first iteration)
+  CG_ZERO_RHS = 8,
+  CG_CONVERGED_AT_START = 9,
+  CG_FAIL_PRECONDITIONER = 10
 };
 
 struct CgState {

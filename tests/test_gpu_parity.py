@@ -741,3 +741,33 @@ def test_random_structures_all_solvers(ctx, oracle, seed):
         S.close()
         A.close()
 
+
+@pytest.mark.parametrize("explicit", [0, 1])
+def test_preconditioner_failure_is_reported(ctx, oracle, explicit):
+    """A camera block that cannot be inverted (F = 0 and D_f = 0 for one camera): the device raises the flag during
+    set-up, the CG prologue ends the run before the first iteration and the solve returns FAILURE, as
+    IterativeSchurComplementSolver does when the preconditioner update fails (iterative_schur_complement_solver.cc:
+    118-125) -- LM then shrinks the trust region.  No iteration is spent on the broken system."""
+    C, P, O = 6, 80, 320
+    prob, bs, order, vals, b, D = make(C, P, O, 5, "random")
+    vals = vals.copy()
+    D = D.copy()
+    rows = np.nonzero(prob.camera_index[order] == 2)[0]
+    for r in rows:
+        vals[6 * O + 18 * r: 6 * O + 18 * r + 18] = 0.0
+    D[3 * P + 18: 3 * P + 27] = 0.0
+    A = cx.Matrix(ctx, bs, P)
+    A.set_values(vals)
+    S = cx.Solver(ctx, type=cx.ITERATIVE_SCHUR, preconditioner_type=cx.SCHUR_JACOBI, num_eliminate_blocks=P,
+                  use_explicit_schur_complement=explicit)
+    x, s = S.solve(A, b, D, q_tolerance=0.1)
+    assert s.termination_type == cx.FAILURE and s.num_iterations == 0
+    assert "Preconditioner update failed" in s.message.decode()
+    # the same solver object recovers on a healthy system
+    prob2, bs2, order2, vals2, b2, D2 = make(C, P, O, 5, "random")
+    A.set_values(vals2)
+    x2, s2 = S.solve(A, b2, D2, q_tolerance=0.1)
+    assert s2.termination_type == cx.SUCCESS and s2.num_iterations > 0
+    S.close()
+    A.close()
+
