@@ -19,7 +19,8 @@ HOST, DEVICE = 0, 1
 DENSE_SCHUR, SPARSE_SCHUR, ITERATIVE_SCHUR, CGNR = 0, 1, 2, 3
 LOSS_NONE, LOSS_HUBER, LOSS_SOFT_L_ONE, LOSS_CAUCHY, LOSS_ARCTAN, LOSS_TOLERANT, LOSS_TUKEY = range(7)
 CAMERA_ANGLE_AXIS, CAMERA_QUATERNION_MANIFOLD = 0, 1
-IDENTITY, JACOBI, SCHUR_JACOBI, SCHUR_POWER_SERIES_EXPANSION = 0, 1, 2, 3
+IDENTITY, JACOBI, SCHUR_JACOBI, SCHUR_POWER_SERIES_EXPANSION, CLUSTER_JACOBI, CLUSTER_TRIDIAGONAL = 0, 1, 2, 3, 4, 5
+CANONICAL_VIEWS, SINGLE_LINKAGE = 0, 1
 SUCCESS, NO_CONVERGENCE, FAILURE, FATAL_ERROR = 0, 1, 2, 3
 
 # every symbol include/cxschur.h declares (tests check that the library exports them all)
@@ -60,6 +61,8 @@ class cx_solver_options(ctypes.Structure):
         ("spse_tolerance", ctypes.c_double),
         ("deterministic", ctypes.c_int32),
         ("use_explicit_schur_complement", ctypes.c_int32),
+        ("visibility_clustering_type", ctypes.c_int32),
+        ("reserved", ctypes.c_int32),
     ]
 
 

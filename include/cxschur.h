@@ -79,8 +79,17 @@ typedef enum {
   CX_IDENTITY = 0,
   CX_JACOBI = 1,
   CX_SCHUR_JACOBI = 2,
-  CX_SCHUR_POWER_SERIES_EXPANSION = 3
+  CX_SCHUR_POWER_SERIES_EXPANSION = 3,
+  /* VisibilityBasedPreconditioner (visibility_based_preconditioner.cc:68-577): the cells of S whose cameras share
+   * a visibility cluster (CLUSTER_JACOBI), plus the cells between clusters joined by an edge of the degree-2
+   * maximum spanning forest of the cluster graph (CLUSTER_TRIDIAGONAL), factored by Cholesky.  ITERATIVE_SCHUR
+   * on the implicit S only, as in the reference. */
+  CX_CLUSTER_JACOBI = 4,
+  CX_CLUSTER_TRIDIAGONAL = 5
 } cx_preconditioner_type;
+
+/* include/ceres/types.h:143-173 (VisibilityClusteringType) */
+typedef enum { CX_CANONICAL_VIEWS = 0, CX_SINGLE_LINKAGE = 1 } cx_visibility_clustering_type;
 
 /* Built-in LossFunction of a residual block (include/ceres/loss_function.h:171-292); a, b are
  * the constructor arguments (b only for TOLERANT). */
@@ -120,6 +129,8 @@ typedef struct {
   double spse_tolerance;              /* default 0.1 */
   int32_t deterministic;              /* 1: camera-space sums in fixed order (bitwise reproducible) */
   int32_t use_explicit_schur_complement; /* ITERATIVE_SCHUR on an explicitly computed block-sparse S (solver.h:518-540) */
+  int32_t visibility_clustering_type; /* cx_visibility_clustering_type, CLUSTER_* preconditioners (solver.h:337-338) */
+  int32_t reserved;
 } cx_solver_options;
 
 /* LinearSolver::PerSolveOptions (linear_solver.h:232-318) */

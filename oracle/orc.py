@@ -31,6 +31,8 @@ class cx_solver_options(ctypes.Structure):
         ("spse_tolerance", ctypes.c_double),
         ("deterministic", ctypes.c_int32),
         ("use_explicit_schur_complement", ctypes.c_int32),
+        ("visibility_clustering_type", ctypes.c_int32),
+        ("reserved", ctypes.c_int32),
     ]
 
 
@@ -103,7 +105,8 @@ class orc_min_problem(ctypes.Structure):
                 ("plus", ctypes.c_void_p)]
 
 DENSE_SCHUR, SPARSE_SCHUR, ITERATIVE_SCHUR, CGNR = 0, 1, 2, 3
-IDENTITY, JACOBI, SCHUR_JACOBI, SCHUR_POWER_SERIES_EXPANSION = 0, 1, 2, 3
+IDENTITY, JACOBI, SCHUR_JACOBI, SCHUR_POWER_SERIES_EXPANSION, CLUSTER_JACOBI, CLUSTER_TRIDIAGONAL = 0, 1, 2, 3, 4, 5
+CANONICAL_VIEWS, SINGLE_LINKAGE = 0, 1
 SUCCESS, NO_CONVERGENCE, FAILURE, FATAL_ERROR = 0, 1, 2, 3
 
 ALLREDUCE_FN = ctypes.CFUNCTYPE(None, c_double_p, ctypes.c_int64, ctypes.c_void_p)
@@ -124,6 +127,7 @@ def lib():
         _LIB.orc_stable_schur_ordering.restype = ctypes.c_int
         _LIB.orc_last_solve_seconds.restype = ctypes.c_double
         _LIB.orc_schur_sparse_structure.restype = ctypes.c_int64
+        _LIB.orc_visibility_structure.restype = ctypes.c_int64
     return _LIB
 
 
@@ -150,10 +154,73 @@ def schur_sparse_structure(bs, num_eliminate_blocks):
     return r, c
 
 
+def _edges(edges):
+    u = np.ascontiguousarray([e[0] for e in edges], dtype=np.int32)
+    v = np.ascontiguousarray([e[1] for e in edges], dtype=np.int32)
+    w = np.ascontiguousarray([e[2] for e in edges], dtype=np.float64)
+    return u, v, w
+
+
+def schur_complement_graph(bs, num_eliminate_blocks):
+    """CreateSchurComplementGraph: list of (u, v, weight), u <= v, self edges included."""
+    n = lib().orc_schur_complement_graph(bs.c, int(num_eliminate_blocks), None, None, None, 0)
+    u = np.zeros(n, dtype=np.int32)
+    v = np.zeros(n, dtype=np.int32)
+    w = np.zeros(n)
+    lib().orc_schur_complement_graph(bs.c, int(num_eliminate_blocks), _p(u), _p(v), _p(w), n)
+    return list(zip(u.tolist(), v.tolist(), w.tolist()))
+
+
+def canonical_views(n, vertex_weights, edges, min_views=3, size_penalty_weight=5.75, similarity_penalty_weight=100.0,
+                    view_score_weight=0.0):
+    u, v, w = _edges(edges)
+    vw = _f64(vertex_weights)
+    centers = np.zeros(n, dtype=np.int32)
+    membership = np.zeros(n, dtype=np.int32)
+    k = lib().orc_canonical_views(int(n), _p(vw), len(u), _p(u), _p(v), _p(w), int(min_views),
+                                  ctypes.c_double(size_penalty_weight), ctypes.c_double(similarity_penalty_weight),
+                                  ctypes.c_double(view_score_weight), _p(centers), _p(membership))
+    return centers[:k].tolist(), membership.tolist()
+
+
+def single_linkage(n, edges, min_similarity=0.99):
+    u, v, w = _edges(edges)
+    membership = np.zeros(n, dtype=np.int32)
+    k = lib().orc_single_linkage(int(n), len(u), _p(u), _p(v), _p(w), ctypes.c_double(min_similarity), _p(membership))
+    return k, membership.tolist()
+
+
+def degree2_forest(n, edges):
+    u, v, w = _edges(edges)
+    fu = np.zeros(max(n, 1), dtype=np.int32)
+    fv = np.zeros(max(n, 1), dtype=np.int32)
+    k = lib().orc_degree2_forest(int(n), len(u), _p(u), _p(v), _p(w), _p(fu), _p(fv))
+    return list(zip(fu[:k].tolist(), fv[:k].tolist()))
+
+
+def visibility_structure(bs, num_eliminate_blocks, preconditioner_type, clustering_type=0):
+    """membership, num_clusters, cluster pairs, block pairs of the CLUSTER_* preconditioner."""
+    nf = bs.num_col_blocks - num_eliminate_blocks
+    membership = np.zeros(nf, dtype=np.int32)
+    nc = ctypes.c_int32(0)
+    ncp = ctypes.c_int32(0)
+    nbp = lib().orc_visibility_structure(bs.c, int(num_eliminate_blocks), int(preconditioner_type), int(clustering_type),
+                                         _p(membership), ctypes.byref(nc), ctypes.byref(ncp), None, None, 0, None, None,
+                                         ctypes.c_int64(0))
+    cp1 = np.zeros(ncp.value, dtype=np.int32)
+    cp2 = np.zeros(ncp.value, dtype=np.int32)
+    bp1 = np.zeros(nbp, dtype=np.int32)
+    bp2 = np.zeros(nbp, dtype=np.int32)
+    lib().orc_visibility_structure(bs.c, int(num_eliminate_blocks), int(preconditioner_type), int(clustering_type),
+                                   _p(membership), ctypes.byref(nc), ctypes.byref(ncp), _p(cp1), _p(cp2), ncp.value,
+                                   _p(bp1), _p(bp2), ctypes.c_int64(nbp))
+    return membership, nc.value, np.stack([cp1, cp2], 1), np.stack([bp1, bp2], 1)
+
+
 def make_options(type=ITERATIVE_SCHUR, preconditioner_type=JACOBI, num_eliminate_blocks=0,
                  min_num_iterations=0, max_num_iterations=500, residual_reset_period=10,
                  max_num_spse_iterations=5, use_spse_initialization=0, spse_tolerance=0.1,
-                 use_explicit_schur_complement=0):
+                 use_explicit_schur_complement=0, visibility_clustering_type=0):
     o = cx_solver_options()
     o.type = type
     o.preconditioner_type = preconditioner_type
@@ -165,6 +232,7 @@ def make_options(type=ITERATIVE_SCHUR, preconditioner_type=JACOBI, num_eliminate
     o.use_spse_initialization = use_spse_initialization
     o.spse_tolerance = spse_tolerance
     o.use_explicit_schur_complement = use_explicit_schur_complement
+    o.visibility_clustering_type = visibility_clustering_type
     return o
 
 

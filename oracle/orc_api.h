@@ -55,6 +55,28 @@ int orc_solve(const cx_block_structure* bs, const double* values, const double* 
               const cx_solver_options* options, double r_tolerance, double q_tolerance, double* x,
               cx_summary* summary);
 
+/* Visibility based preconditioning (orc_visibility.cpp).  Graphs are edge lists (u, v, w) over vertices 0..n-1.
+ * CreateSchurComplementGraph (visibility.cc:77-146): edges u <= v incl. the self edges; returns their number. */
+int orc_schur_complement_graph(const cx_block_structure* bs, int num_eliminate_blocks, int32_t* u, int32_t* v, double* w,
+                               int capacity);
+/* ComputeCanonicalViewsClustering (canonical_views_clustering.cc:81-222): centers[<= n], membership[n] = index of
+ * the vertex' centre or -1; returns the number of centres */
+int orc_canonical_views(int n, const double* vertex_weights, int num_edges, const int32_t* u, const int32_t* v,
+                        const double* w, int min_views, double size_penalty_weight, double similarity_penalty_weight,
+                        double view_score_weight, int32_t* centers, int32_t* membership);
+/* ComputeSingleLinkageClustering (single_linkage_clustering.cc:42-92): membership[n] = cluster representative;
+ * returns the number of clusters */
+int orc_single_linkage(int n, int num_edges, const int32_t* u, const int32_t* v, const double* w, double min_similarity,
+                       int32_t* membership);
+/* Degree2MaximumSpanningForest (graph_algorithms.h:259-339): forest edges (fu < fv), at most n - 1; returns their number */
+int orc_degree2_forest(int n, int num_edges, const int32_t* u, const int32_t* v, const double* w, int32_t* fu, int32_t* fv);
+/* VisibilityBasedPreconditioner's structure (visibility_based_preconditioner.cc:121-302): membership[num f-blocks],
+ * cluster pairs and the f-block pairs of the preconditioner matrix (lexicographic); returns the number of block pairs */
+int64_t orc_visibility_structure(const cx_block_structure* bs, int num_eliminate_blocks, int preconditioner_type,
+                                 int clustering_type, int32_t* membership, int32_t* num_clusters, int32_t* num_cluster_pairs,
+                                 int32_t* cluster_pair_1, int32_t* cluster_pair_2, int32_t cluster_pair_capacity,
+                                 int32_t* block_pair_1, int32_t* block_pair_2, int64_t block_pair_capacity);
+
 /* SparseSchurComplementSolver::InitStorage (schur_complement_solver.cc:224-290): the (row, column) f-block
  * ids of the cells of the block-sparse reduced matrix in creation order; returns their number */
 int64_t orc_schur_sparse_structure(const cx_block_structure* bs, int num_eliminate_blocks, int32_t* cell_row,

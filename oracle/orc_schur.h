@@ -40,6 +40,20 @@ struct DenseBRAM : BRAM {
   int num_rows() const override { return n; }
 };
 
+// block_random_access_sparse_matrix.cc:48-122 as the eliminator sees it: only the cells of a given set of block
+// pairs exist (GetCell is null for the others); kept in dense storage so the cell arithmetic is the same.
+struct SubsetBRAM : DenseBRAM {
+  std::vector<std::pair<int, int>> pairs;  // sorted
+  SubsetBRAM(double* v, const std::vector<int>& block_sizes, const std::vector<std::pair<int, int>>& block_pairs)
+      : DenseBRAM(v, block_sizes), pairs(block_pairs) {
+    std::sort(pairs.begin(), pairs.end());
+  }
+  double* GetCell(int i, int j, int* r, int* c, int* rs, int* cs) override {
+    if (!std::binary_search(pairs.begin(), pairs.end(), std::make_pair(i, j))) return nullptr;
+    return DenseBRAM::GetCell(i, j, r, c, rs, cs);
+  }
+};
+
 // block_random_access_diagonal_matrix.cc:50-85
 struct DiagonalBRAM : BRAM {
   double* values;

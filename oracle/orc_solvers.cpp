@@ -16,6 +16,7 @@
 #include <functional>
 
 #include "orc_schur.h"
+#include "orc_visibility.h"
 
 namespace orc {
 
@@ -549,8 +550,69 @@ static cx_summary SolveIterativeSchur(const cx_block_structure* s, const double*
       InvertPSD(sj[i].data(), sizes[i]);
     }
   }
+  // VisibilityBasedPreconditioner (visibility_based_preconditioner.cc:68-434): the eliminator runs on a storage
+  // that only has the block pairs of the preconditioner (GetCell of any other cell is null), then a Cholesky
+  // factorisation; CLUSTER_TRIDIAGONAL retries once with the cells between different clusters halved (:354-393).
+  // The reference factors with a sparse Cholesky (SuiteSparse & co, not in the tree); dense here.
+  Vec vis_factor;
+  if (o.preconditioner_type == CX_CLUSTER_JACOBI || o.preconditioner_type == CX_CLUSTER_TRIDIAGONAL) {
+    const VisibilityStructure vs = ComputeVisibilityStructure(s, nelim, o.preconditioner_type, o.visibility_clustering_type);
+    Eliminator el(s, values, nelim);
+    auto sizes = el.FBlockSizes();
+    Vec m_values(size_t(n) * n, 0.0);
+    SubsetBRAM m(m_values.data(), sizes, vs.block_pairs);
+    if (!comm.active()) {
+      el.Eliminate(nullptr, D, &m, nullptr, threads);
+    } else {
+      Vec Dmod;
+      const double* Duse = nullptr;
+      if (D) {
+        Dmod.assign(D, D + isc.A.num_cols_e + n);
+        std::fill(Dmod.begin() + isc.A.num_cols_e, Dmod.end(), 0.0);
+        Duse = Dmod.data();
+      }
+      el.Eliminate(nullptr, Duse, &m, nullptr, threads);
+      comm.Sum(m_values.data(), int64_t(m_values.size()));
+      if (D) for (int i = 0; i < n; ++i) m_values[size_t(i) * n + i] += D[isc.A.num_cols_e + i] * D[isc.A.num_cols_e + i];
+    }
+    vis_factor = m_values;
+    bool ok = CholeskyUpper(vis_factor.data(), n, threads);
+    if (!ok && o.preconditioner_type == CX_CLUSTER_TRIDIAGONAL) {
+      // ScaleOffDiagonalCells :371-393
+      for (const auto& bp : vs.block_pairs) {
+        if (vs.membership[size_t(bp.first)] == vs.membership[size_t(bp.second)]) continue;
+        for (int a = 0; a < sizes[size_t(bp.first)]; ++a)
+          for (int c = 0; c < sizes[size_t(bp.second)]; ++c) m_values[size_t(m.layout[size_t(bp.first)] + a) * n + m.layout[size_t(bp.second)] + c] *= 0.5;
+      }
+      vis_factor = m_values;
+      ok = CholeskyUpper(vis_factor.data(), n, threads);
+    }
+    if (!ok) {
+      // IterativeSchurComplementSolver::SolveImpl :115-121
+      summary.termination_type = CX_FAILURE;
+      SetMessage(&summary, "Preconditioner update failed.");
+      return summary;
+    }
+  }
   Op precond = [&](const Vec& r, Vec& z) {
     switch (o.preconditioner_type) {
+      case CX_CLUSTER_JACOBI:
+      case CX_CLUSTER_TRIDIAGONAL: {
+        // SparseCholesky::Solve: U' y = r, U x = y (the operator overwrites, visibility_based_preconditioner.cc:427-434)
+        Vec y(n);
+        for (int i = 0; i < n; ++i) {
+          double sum = r[i];
+          for (int k = 0; k < i; ++k) sum -= vis_factor[size_t(k) * n + i] * y[k];
+          y[i] = sum / vis_factor[size_t(i) * n + i];
+        }
+        for (int i = n - 1; i >= 0; --i) {
+          double sum = y[i];
+          const double* Ui = vis_factor.data() + size_t(i) * n;
+          for (int k = i + 1; k < n; ++k) sum -= Ui[k] * z[k];
+          z[i] = sum / Ui[i];
+        }
+        break;
+      }
       case CX_JACOBI: isc.FtFInvMultiply(r.data(), z.data()); break;
       case CX_SCHUR_JACOBI: BlockDiagMultiply(sj, isc.A.bs.cols, nelim, isc.A.num_cols_e, r.data(), z.data()); break;
       case CX_SCHUR_POWER_SERIES_EXPANSION: {
