@@ -128,7 +128,8 @@ def main():
     ap.add_argument("--workload", default="final13682", choices=sorted(load_cx().bal.PRESETS))
     ap.add_argument("--solver", default="iterative_schur", choices=["iterative_schur", "dense_schur", "sparse_schur", "cgnr"],
                     help="linear solver of the step (the headline metric uses iterative_schur)")
-    ap.add_argument("--preconditioner", default="jacobi", choices=["jacobi", "schur_jacobi", "identity"])
+    ap.add_argument("--preconditioner", default="jacobi",
+                    choices=["jacobi", "schur_jacobi", "identity", "cluster_jacobi", "cluster_tridiagonal"])
     ap.add_argument("--mixed", action="store_true", help="CG products on fp32 copies of the J values: CGNR (BASELINE config 5) or ITERATIVE_SCHUR; "
                                                      "fp64 accumulation, vectors, set-up and back substitution")
     ap.add_argument("--explicit-schur", action="store_true",
@@ -192,7 +193,8 @@ def main():
     ev, A, b, D, cost, eval_ms = lm_prepare_device(cx, ctx, prob)
     stype = {"iterative_schur": cx.ITERATIVE_SCHUR, "dense_schur": cx.DENSE_SCHUR, "sparse_schur": cx.SPARSE_SCHUR,
              "cgnr": cx.CGNR}[args.solver]
-    ptype = {"jacobi": cx.JACOBI, "schur_jacobi": cx.SCHUR_JACOBI, "identity": cx.IDENTITY}[args.preconditioner]
+    ptype = {"jacobi": cx.JACOBI, "schur_jacobi": cx.SCHUR_JACOBI, "identity": cx.IDENTITY, "cluster_jacobi": cx.CLUSTER_JACOBI,
+             "cluster_tridiagonal": cx.CLUSTER_TRIDIAGONAL}[args.preconditioner]
     solver_kw = dict(type=stype, preconditioner_type=ptype, num_eliminate_blocks=prob.num_points,
                      max_num_iterations=500, min_num_iterations=0, residual_reset_period=10,
                      use_mixed_precision_solves=1 if args.mixed else 0,

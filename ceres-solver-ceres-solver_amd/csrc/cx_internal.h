@@ -9,6 +9,7 @@
 #include <cstdio>
 #include <cstring>
 #include <string>
+#include <memory>
 #include <vector>
 
 #include "../../include/cxschur.h"
@@ -145,6 +146,7 @@ struct cx_matrix {
   // the order SparseSchurComplementSolver::InitStorage lists them (every (c,c), then co-visible c1 < c2,
   // lexicographic -- schur_complement_solver.cc:224-290) and per cell the co-observing row pairs in chunk order
   std::vector<int32_t> h_cell_c1, h_cell_c2;  // host copy of the cell list (parity tests, sparse consumers)
+  std::vector<int32_t> h_cell_item_start;     // host copy of d_cell_item_start
   DevBuf<int32_t> d_cell_c1, d_cell_c2;  // [num_cells]
   DevBuf<int32_t> d_cell_row_start;      // [C + 1] cells of block row c1 (contiguous, sorted by c2)
   DevBuf<int32_t> d_col_cell_start;      // [C + 1] off-diagonal cells of block column c2 ...
@@ -165,6 +167,8 @@ struct cx_matrix {
   DevBuf<int32_t> d_sp_cam_pos, d_sp_row_start, d_sp_row_tiles, d_sp_col_start, d_sp_col_pool, d_sp_col_row;
   DevBuf<double> d_sp_W, d_sp_F, d_sp_x;
   int pairs_state = 0;                   // 0 not built, 1 ready, 2 too many pairs (atomic path)
+  // visibility based preconditioner of this structure (cx_visibility.h), built on first use
+  std::shared_ptr<struct cx_vis_plan> vis;
   int64_t num_pairs = 0;
 
   // scratch for host-pointer calls

@@ -24,7 +24,8 @@ int cxs_build_pair_lists(cx_matrix* A);
 int cxs_eliminate_sparse(cx_matrix* A, const double* b, const double* D, double* rhs);
 // the two halves of the gather elimination on their own (tile-sparse SPARSE_SCHUR): per-item pair sums, F'F
 // diagonal blocks and (E'E + D^2)^-1 into the matrix' scratch; rhs = F'(b - E (E'E)^-1 E'b)
-int cxs_assemble_pair_items(cx_matrix* A, const double* D);
+// item_ids (device, optional): only these work items are summed (the cells a visibility preconditioner keeps)
+int cxs_assemble_pair_items(cx_matrix* A, const double* D, const int32_t* item_ids = nullptr, int64_t num_selected = 0);
 int cxs_eliminate_rhs(cx_matrix* A, const double* b, double* rhs);
 // tile-sparse Cholesky of the explicit S (cx_sparse_chol.hip)
 int cxsp_build_plan(cx_matrix* A);

@@ -923,6 +923,7 @@ int cxs_build_pair_lists(cx_matrix* A) {
   CX_TRY(A->d_pair_rows.upload(pairs, st));
   CX_TRY(A->d_item_begin.upload(item_begin, st));
   CX_TRY(A->d_cell_item_start.upload(cell_item_start, st));
+  A->h_cell_item_start = cell_item_start;
   CX_TRY(A->d_cell_c1.upload(A->h_cell_c1, st));
   CX_TRY(A->d_cell_c2.upload(A->h_cell_c2, st));
   CX_TRY(A->d_cell_row_start.upload(row_cells, st));
@@ -981,11 +982,13 @@ __global__ __launch_bounds__(kBlock) void k_row_bg(const double* __restrict__ E,
 // sums are added in group order.
 __global__ __launch_bounds__(kBlock) void k_pair_items(const int32_t* __restrict__ pair_rows,
                                                        const int64_t* __restrict__ item_begin,
+                                                       const int32_t* __restrict__ item_ids,
                                                        const double* __restrict__ bg0, const double* __restrict__ bg1,
                                                        const double* __restrict__ bg2, double* __restrict__ item_partial) {
   __shared__ double part[kPairGroups * 81];
   const int tid = threadIdx.x;
-  const int64_t p0 = item_begin[blockIdx.x], p1 = item_begin[blockIdx.x + 1];
+  const int64_t item = item_ids ? int64_t(item_ids[blockIdx.x]) : int64_t(blockIdx.x);  // a selection, or all items
+  const int64_t p0 = item_begin[item], p1 = item_begin[item + 1];
   const int g = tid / 9, sub = tid - g * 9;
   const int a0 = 3 * (sub / 3), c0 = 3 * (sub - 3 * (sub / 3));
   if (g < kPairGroups) {
@@ -1019,7 +1022,7 @@ __global__ __launch_bounds__(kBlock) void k_pair_items(const int32_t* __restrict
     double v = 0.0;
 #pragma unroll 4
     for (int q = 0; q < kPairGroups; ++q) v += part[q * 81 + tid];
-    item_partial[int64_t(blockIdx.x) * 81 + tid] = v;
+    item_partial[item * 81 + tid] = v;
   }
 }
 
@@ -1187,7 +1190,7 @@ int cxs_block9_add_diag_invert(cx_context* ctx, double* blocks, const double* Df
 
 // Gather assembly shared by the dense and the block-sparse explicit S: (E'E + D_e^2)^-1 (closed-form inverse
 // of InvertPSDMatrix<3>), B / G of every row, F'F diagonal blocks, per-item pair sums.
-int cxs_assemble_pair_items(cx_matrix* A, const double* D) {
+int cxs_assemble_pair_items(cx_matrix* A, const double* D, const int32_t* item_ids, int64_t num_selected) {
   hipStream_t st = A->ctx->stream;
   CX_TRY(A->d_elim_ete.alloc(size_t(std::max<int64_t>(9 * int64_t(A->P), 1))));
   CX_TRY(A->d_elim_diag.alloc(size_t(std::max<int64_t>(81 * int64_t(A->C), 1))));
@@ -1202,9 +1205,10 @@ int cxs_assemble_pair_items(cx_matrix* A, const double* D) {
                        (const double*)(A->d_values.p + 6 * A->O), (const int32_t*)A->d_row_pt.p,
                        (const double*)A->d_elim_ete.p, A->O, A->d_elim_bg0.p, A->d_elim_bg1.p, A->d_elim_bg2.p);
   CX_TRY(cxs_camera_block_diagonal(A, A->d_elim_diag.p));
-  if (A->num_items > 0)
-    hipLaunchKernelGGL(k_pair_items, dim3(unsigned(A->num_items)), dim3(kBlock), 0, st, (const int32_t*)A->d_pair_rows.p,
-                       (const int64_t*)A->d_item_begin.p, (const double*)A->d_elim_bg0.p, (const double*)A->d_elim_bg1.p,
+  const int64_t launch_items = item_ids ? num_selected : A->num_items;
+  if (launch_items > 0)
+    hipLaunchKernelGGL(k_pair_items, dim3(unsigned(launch_items)), dim3(kBlock), 0, st, (const int32_t*)A->d_pair_rows.p,
+                       (const int64_t*)A->d_item_begin.p, item_ids, (const double*)A->d_elim_bg0.p, (const double*)A->d_elim_bg1.p,
                        (const double*)A->d_elim_bg2.p, A->d_item_partial.p);
   CX_HIP(hipGetLastError());
   return CX_OK;

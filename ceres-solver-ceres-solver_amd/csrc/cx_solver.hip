@@ -18,6 +18,7 @@
 #include "cx_kernels.h"
 #include "cx_schur.h"
 #include "cx_solver_internal.h"
+#include "cx_visibility.h"
 
 static int grid_for(int64_t n, int block) { return int((n + block - 1) / block); }
 
@@ -830,6 +831,15 @@ struct BlockDiag9Op : LinOp {
   }
 };
 
+// VisibilityBasedPreconditioner::RightMultiplyAndAccumulate (visibility_based_preconditioner.cc:427-434): the
+// banded Cholesky solve of cx_band_chol.hip
+struct VisibilityOp : LinOp {
+  cx_matrix* A = nullptr;
+  cx_vis_plan* plan = nullptr;
+  int64_t size() const override { return 9 * int64_t(A->C); }
+  int apply(const double* x, double* y) override { return cxv_solve(A, plan, x, y); }
+};
+
 struct IdentityOp : LinOp {
   cx_context* ctx;
   int64_t n;
@@ -933,7 +943,10 @@ int SolveIterativeSchur239(cx_solver* S, cx_matrix* A, const double* b, const do
     return CX_ERR_UNSUPPORTED;
   }
   const bool want_blocks = need_ftf || o.preconditioner_type == CX_SCHUR_JACOBI;
-  if (!want_blocks && o.preconditioner_type != CX_IDENTITY) {
+  const bool visibility = o.preconditioner_type == CX_CLUSTER_JACOBI || o.preconditioner_type == CX_CLUSTER_TRIDIAGONAL;
+  cx_vis_plan* vis_plan = nullptr;
+  if (visibility) CX_TRY(cxv_get_plan(A, o.preconditioner_type, o.visibility_clustering_type, &vis_plan));
+  if (!want_blocks && !visibility && o.preconditioner_type != CX_IDENTITY) {
     cx_set_error("preconditioner %d is not available for ITERATIVE_SCHUR on the device", o.preconditioner_type);
     return CX_ERR_UNSUPPORTED;
   }
@@ -945,6 +958,21 @@ int SolveIterativeSchur239(cx_solver* S, cx_matrix* A, const double* b, const do
     CX_TRY(cxs_block9_add_diag_invert(ctx, S->cam_blocks.p, D ? D + ne : nullptr, A->C, S->flag.p));
   }
   if (ctx->nranks > 1) CX_TRY(cx_allreduce_device(ctx, S->v_rhs.p, nf));
+  if (visibility) {
+    // VisibilityBasedPreconditioner::UpdateImpl (visibility_based_preconditioner.cc:321-364)
+    CX_TRY(cxv_factor(A, vis_plan, D, false, S->flag.p));
+    if (o.preconditioner_type == CX_CLUSTER_TRIDIAGONAL) {
+      // "If it works, great, otherwise we scale all the cells in the preconditioner corresponding to the edges
+      // in the degree-2 forest and that guarantees positive definiteness" (:331-360) -- the one host check
+      bool failed = false;
+      cx_summary unused{};
+      CX_TRY(CheckFlag(S, "", &unused, &failed));
+      if (failed) {
+        CX_HIP(hipMemsetAsync(S->flag.p, 0, sizeof(int), st));
+        CX_TRY(cxv_factor(A, vis_plan, D, true, S->flag.p));
+      }
+    }
+  }
   CX_TRY(sw.stop(&S->timing.eliminate_ms));
   // a block that could not be inverted raises S->flag on the device; the CG prologue reads it there and ends
   // the run before the first iteration ("Preconditioner update failed.") -- no host check in between
@@ -968,9 +996,12 @@ int SolveIterativeSchur239(cx_solver* S, cx_matrix* A, const double* b, const do
     CX_TRY(init.apply(S->v_rhs.p, S->v_x.p));
     zero_initial = false;
   }
+  VisibilityOp vis_pre;
+  vis_pre.A = A; vis_pre.plan = vis_plan;
   LinOp& pre = (o.preconditioner_type == CX_IDENTITY) ? static_cast<LinOp&>(id)
                : (o.preconditioner_type == CX_SCHUR_POWER_SERIES_EXPANSION) ? static_cast<LinOp&>(spse_pre)
-                                                                          : static_cast<LinOp&>(bd);
+               : visibility ? static_cast<LinOp&>(vis_pre)
+                            : static_cast<LinOp&>(bd);
   CgDriver cg{S, ctx, st, nf, nf};
   cg.preconditioner_failed = S->flag.p;
   CX_TRY(S->state.alloc(1));
@@ -1268,6 +1299,16 @@ int cx_solver_create(cx_context* ctx, const cx_solver_options* options, cx_solve
   CX_CHECK_ARG(options->type >= CX_DENSE_SCHUR && options->type <= CX_CGNR);
   CX_CHECK_ARG(options->residual_reset_period > 0 && options->max_num_iterations >= 0);
   if (options->type != CX_CGNR) CX_CHECK_ARG(options->num_eliminate_blocks > 0);
+  const bool cluster_pre = options->preconditioner_type == CX_CLUSTER_JACOBI || options->preconditioner_type == CX_CLUSTER_TRIDIAGONAL;
+  if (cluster_pre && options->type == CX_CGNR) {
+    // solver.cc:237-260 / solver_test.cc:1082-1092
+    cx_set_error("Can only use CLUSTER_JACOBI / CLUSTER_TRIDIAGONAL with ITERATIVE_SCHUR, not with CGNR.");
+    return CX_ERR_INVALID_ARGUMENT;
+  }
+  if (cluster_pre && options->visibility_clustering_type != CX_CANONICAL_VIEWS && options->visibility_clustering_type != CX_SINGLE_LINKAGE) {
+    cx_set_error("Unknown visibility clustering algorithm.");
+    return CX_ERR_INVALID_ARGUMENT;
+  }
   if (options->type == CX_ITERATIVE_SCHUR && options->use_explicit_schur_complement) {
     // the reference's option validation (solver.cc:277-290)
     if (options->preconditioner_type != CX_SCHUR_JACOBI) {

@@ -286,6 +286,15 @@ int cx_schur_eliminate_dense(cx_context* ctx, cx_matrix* A, const double* b, con
  * Static <2,3,9> matrices only.  *num_cells is always set; the arrays (may be NULL) receive up to
  * capacity entries of the (row block, column block) ids. */
 int cx_schur_sparse_structure(cx_matrix* A, int64_t* num_cells, int32_t* cell_row, int32_t* cell_col, int64_t capacity);
+/* The structure of a CLUSTER_JACOBI / CLUSTER_TRIDIAGONAL preconditioner as VisibilityBasedPreconditioner holds it
+ * (visibility_based_preconditioner.h:130-199): cluster_membership_[num cameras], num_clusters_, cluster_pairs_
+ * (c1 <= c2, lexicographic) and block_pairs_ (f-block pairs b1 <= b2 of the preconditioner matrix, lexicographic).
+ * Counts are always set; arrays (may be NULL) receive up to their capacity.  Static <2,3,9> matrices only.
+ * Ties the reference leaves to hash-table iteration order are broken by ascending id. */
+int cx_visibility_structure(cx_matrix* A, int32_t preconditioner_type, int32_t clustering_type, int32_t* membership,
+                            int32_t* num_clusters, int32_t* num_cluster_pairs, int32_t* cluster_pair_1,
+                            int32_t* cluster_pair_2, int32_t cluster_pair_capacity, int64_t* num_block_pairs,
+                            int32_t* block_pair_1, int32_t* block_pair_2, int64_t block_pair_capacity);
 int cx_schur_back_substitute(cx_context* ctx, cx_matrix* A, const double* b, const double* D,
                              const double* z, double* x, int32_t memspace);
 /* ImplicitSchurComplement: Init + RightMultiplyAndAccumulate

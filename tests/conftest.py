@@ -70,3 +70,40 @@ def lls_problem(pid):
     bs = cx.BlockStructure.from_rows(raw["col_sizes"], rows)
     return (bs, np.array(raw["values"], dtype=np.float64), np.array(raw["b"], dtype=np.float64),
             np.array(raw["D"], dtype=np.float64), raw["num_eliminate_blocks"], raw)
+
+
+def crafted_indefinite_tridiagonal(seed, shared=12, private=4, de=1e-3, df=0.05):
+    """Three cameras in three visibility clusters (SINGLE_LINKAGE: similarity 0.75 < 0.9) whose CLUSTER_TRIDIAGONAL
+    matrix is NOT positive definite until its off-diagonal cells are halved (visibility_based_preconditioner.cc:
+    331-393): every shared point has E blocks A, B, -(A + B) and the same F block in all three cameras, so its
+    contribution to S is ~ ones(3, 3) (x) G'G / 3, and dropping the (0, 1) cell leaves an indefinite matrix.
+    Returns (problem, block structure, values, b, D, num points)."""
+    rng = np.random.default_rng(seed)
+    C = 3
+    lists = [[0, 1, 2]] * shared + [[c] for c in range(3) for _ in range(private)]
+    cam, pt = [], []
+    for j, cams in enumerate(lists):
+        cam.extend(sorted(cams))
+        pt.extend([j] * len(cams))
+    cam, pt = np.array(cam, dtype=np.int32), np.array(pt, dtype=np.int32)
+    O, P = cam.size, len(lists)
+    prob = cx.bal.BalProblem(C, P, cam, pt, np.zeros((O, 2)), np.zeros((C, 9)), np.zeros((P, 3)))
+    bs, _ = cx.bal.build_structure(prob)
+    vals = np.zeros(24 * O)
+    E, F = vals[:6 * O].reshape(O, 2, 3), vals[6 * O:].reshape(O, 2, 9)
+    row_pt, row_cam = bs.cells["block_id"][0::2], bs.cells["block_id"][1::2] - P
+    drawn = {}
+    for r in range(O):
+        p, c = int(row_pt[r]), int(row_cam[r])
+        if p < shared:
+            if p not in drawn:
+                drawn[p] = (rng.standard_normal((2, 3)), rng.standard_normal((2, 3)), rng.standard_normal((2, 9)))
+            a, b_, g = drawn[p]
+            E[r] = a if c == 0 else (b_ if c == 1 else -a - b_)
+            F[r] = g
+        else:
+            E[r] = rng.standard_normal((2, 3))
+            F[r] = rng.standard_normal((2, 9))
+    b = rng.standard_normal(2 * O)
+    D = np.concatenate([np.full(3 * P, de), np.full(9 * C, df)])
+    return prob, bs, vals, b, D, P

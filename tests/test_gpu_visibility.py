@@ -1,0 +1,207 @@
+"""CLUSTER_JACOBI / CLUSTER_TRIDIAGONAL on the device (cx_visibility.cpp, cx_band_chol.hip) against the oracle:
+the integer structure (clusters, cluster pairs, block pairs) exactly, the preconditioned CG path by iteration
+count and solution (fp64, tolerances in the tests)."""
+import numpy as np
+import pytest
+
+from conftest import cx, crafted_indefinite_tridiagonal
+
+pytestmark = pytest.mark.gpu
+
+PRE = ["CLUSTER_JACOBI", "CLUSTER_TRIDIAGONAL"]
+CLUSTERING = ["CANONICAL_VIEWS", "SINGLE_LINKAGE"]
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    c = cx.Context(0)
+    yield c
+    c.close()
+
+
+def make(oracle, C, P, O, seed):
+    prob = cx.bal.make_bal_like(C, P, O, seed)
+    bs, order = cx.bal.build_structure(prob)
+    _, b, _, vals = oracle.bal_evaluate(bs, C, P, prob.camera_index, prob.point_index, prob.observations, order,
+                                        prob.state(), want_gradient=False)
+    rng = np.random.default_rng(seed + 1000)
+    D = rng.uniform(0.5, 2.0, bs.num_cols) * 1e-2 * np.sqrt(np.abs(vals).mean())
+    return prob, bs, vals, b, D
+
+
+def relerr(a, b):
+    return np.abs(a - b).max() / max(np.abs(b).max(), 1e-300)
+
+
+PROBLEMS = [(6, 40, 130, 1), (16, 700, 2800, 2), (49, 7776, 31843, 49), (100, 3000, 14000, 3), (400, 9000, 40000, 4)]
+
+
+@pytest.mark.parametrize("clustering", CLUSTERING)
+@pytest.mark.parametrize("pre", PRE)
+@pytest.mark.parametrize("C,P,O,seed", PROBLEMS)
+def test_structure_is_bit_exact(ctx, oracle, C, P, O, seed, pre, clustering):
+    """cluster_membership_, num_clusters_, cluster_pairs_, block_pairs_: integers, compared exactly."""
+    prob = cx.bal.make_bal_like(C, P, O, seed)
+    bs, _ = cx.bal.build_structure(prob)
+    A = cx.Matrix(ctx, bs, P)
+    m, k, cp, bp = cx.binding.visibility_structure(A, getattr(cx, pre), getattr(cx, clustering))
+    mr, kr, cpr, bpr = oracle.visibility_structure(bs, P, getattr(oracle, pre), getattr(oracle, clustering))
+    assert k == kr
+    assert np.array_equal(m, mr)
+    assert np.array_equal(cp, cpr)
+    assert np.array_equal(bp, bpr)
+    A.close()
+
+
+@pytest.mark.parametrize("clustering", CLUSTERING)
+@pytest.mark.parametrize("pre", PRE)
+@pytest.mark.parametrize("C,P,O,seed", PROBLEMS[:4])
+def test_solve_matches_oracle(ctx, oracle, C, P, O, seed, pre, clustering):
+    """The LM call (q_tolerance = eta = 0.1, r_tolerance = -1): same iteration count, solution to 1e-8 relative
+    (CG amplifies summation-order differences by the condition number)."""
+    prob, bs, vals, b, D = make(oracle, C, P, O, seed)
+    A = cx.Matrix(ctx, bs, P)
+    A.set_values(vals)
+    S = cx.Solver(ctx, type=cx.ITERATIVE_SCHUR, preconditioner_type=getattr(cx, pre), num_eliminate_blocks=P,
+                  visibility_clustering_type=getattr(cx, clustering), max_num_iterations=200)
+    x, s = S.solve(A, b, D, r_tolerance=-1.0, q_tolerance=0.1)
+    oo = oracle.make_options(type=oracle.ITERATIVE_SCHUR, preconditioner_type=getattr(oracle, pre), num_eliminate_blocks=P,
+                             visibility_clustering_type=getattr(oracle, clustering), max_num_iterations=200)
+    xr, sr = oracle.solve(bs, vals, b, D, oo, r_tolerance=-1.0, q_tolerance=0.1)
+    assert s.termination_type == sr.termination_type, (s.message, sr.message)
+    assert s.num_iterations == sr.num_iterations, (s.message, sr.message)
+    assert np.all(np.isfinite(x))
+    assert relerr(x, xr) < 1e-8
+    # a second solve reuses the plan and gives the same bits (fixed summation order everywhere)
+    x2, s2 = S.solve(A, b, D, r_tolerance=-1.0, q_tolerance=0.1)
+    assert s2.num_iterations == s.num_iterations and np.array_equal(x, x2)
+    S.close()
+    A.close()
+
+
+@pytest.mark.parametrize("pre", PRE)
+def test_tight_solve_and_fewer_iterations_than_schur_jacobi(ctx, oracle, pre):
+    """eta = 1e-3 on 400 cameras (26 clusters, one forest path): iteration count equals the oracle's and is
+    lower than SCHUR_JACOBI's -- the reason the preconditioner exists."""
+    C, P, O, seed = 400, 9000, 40000, 4
+    prob, bs, vals, b, D = make(oracle, C, P, O, seed)
+    A = cx.Matrix(ctx, bs, P)
+    A.set_values(vals)
+    S = cx.Solver(ctx, type=cx.ITERATIVE_SCHUR, preconditioner_type=getattr(cx, pre), num_eliminate_blocks=P, max_num_iterations=500)
+    x, s = S.solve(A, b, D, r_tolerance=-1.0, q_tolerance=1e-3)
+    oo = oracle.make_options(type=oracle.ITERATIVE_SCHUR, preconditioner_type=getattr(oracle, pre), num_eliminate_blocks=P,
+                             max_num_iterations=500)
+    xr, sr = oracle.solve(bs, vals, b, D, oo, r_tolerance=-1.0, q_tolerance=1e-3)
+    assert s.termination_type == sr.termination_type == 0, (s.message, sr.message)
+    assert s.num_iterations == sr.num_iterations, (s.message, sr.message)
+    assert relerr(x, xr) < 1e-7
+    J = cx.Solver(ctx, type=cx.ITERATIVE_SCHUR, preconditioner_type=cx.SCHUR_JACOBI, num_eliminate_blocks=P, max_num_iterations=500)
+    _, sj = J.solve(A, b, D, r_tolerance=-1.0, q_tolerance=1e-3)
+    assert s.num_iterations < sj.num_iterations, (s.num_iterations, sj.num_iterations)
+    J.close()
+    S.close()
+    A.close()
+
+
+def test_tridiagonal_retry_with_halved_off_diagonal_cells(ctx, oracle):
+    """The unscaled CLUSTER_TRIDIAGONAL matrix of this problem is indefinite (tests/test_oracle_visibility.py shows
+    it): the device must notice, halve the cells between clusters, factor again and follow the oracle."""
+    prob, bs, vals, b, D, P = crafted_indefinite_tridiagonal(0)
+    A = cx.Matrix(ctx, bs, P)
+    A.set_values(vals)
+    S = cx.Solver(ctx, type=cx.ITERATIVE_SCHUR, preconditioner_type=cx.CLUSTER_TRIDIAGONAL, num_eliminate_blocks=P,
+                  visibility_clustering_type=cx.SINGLE_LINKAGE, max_num_iterations=100)
+    x, s = S.solve(A, b, D, r_tolerance=-1.0, q_tolerance=0.01)
+    oo = oracle.make_options(type=oracle.ITERATIVE_SCHUR, preconditioner_type=oracle.CLUSTER_TRIDIAGONAL, num_eliminate_blocks=P,
+                             visibility_clustering_type=oracle.SINGLE_LINKAGE, max_num_iterations=100)
+    xr, sr = oracle.solve(bs, vals, b, D, oo, r_tolerance=-1.0, q_tolerance=0.01)
+    assert s.termination_type == sr.termination_type == 0, (s.message, sr.message)
+    assert s.num_iterations == sr.num_iterations, (s.message, sr.message)
+    assert relerr(x, xr) < 1e-6
+    # CLUSTER_JACOBI on the same problem needs no retry
+    Sj = cx.Solver(ctx, type=cx.ITERATIVE_SCHUR, preconditioner_type=cx.CLUSTER_JACOBI, num_eliminate_blocks=P,
+                   visibility_clustering_type=cx.SINGLE_LINKAGE, max_num_iterations=100)
+    xj, sj = Sj.solve(A, b, D, r_tolerance=-1.0, q_tolerance=0.01)
+    oo.preconditioner_type = oracle.CLUSTER_JACOBI
+    xjr, sjr = oracle.solve(bs, vals, b, D, oo, r_tolerance=-1.0, q_tolerance=0.01)
+    assert sj.num_iterations == sjr.num_iterations and relerr(xj, xjr) < 1e-6
+    Sj.close()
+    S.close()
+    A.close()
+
+
+def test_one_cluster_is_the_exact_inverse(ctx, oracle):
+    """All cameras see all points: one cluster, the preconditioner is S, CG converges at once."""
+    C, P = 5, 60
+    cam = np.tile(np.arange(C, dtype=np.int32), P)
+    pt = np.repeat(np.arange(P, dtype=np.int32), C)
+    O = C * P
+    prob = cx.bal.BalProblem(C, P, cam, pt, np.zeros((O, 2)), np.zeros((C, 9)), np.zeros((P, 3)))
+    bs, _ = cx.bal.build_structure(prob)
+    vals = cx.bal.random_jacobian_values(O, 3)
+    b = np.random.default_rng(3).standard_normal(2 * O)
+    D = np.full(bs.num_cols, 0.1)
+    A = cx.Matrix(ctx, bs, P)
+    A.set_values(vals)
+    m, k, cp, bp = cx.binding.visibility_structure(A, cx.CLUSTER_JACOBI, cx.SINGLE_LINKAGE)
+    assert k == 1 and len(bp) == C * (C + 1) // 2
+    S = cx.Solver(ctx, type=cx.ITERATIVE_SCHUR, preconditioner_type=cx.CLUSTER_JACOBI, num_eliminate_blocks=P,
+                  visibility_clustering_type=cx.SINGLE_LINKAGE, max_num_iterations=50)
+    x, s = S.solve(A, b, D, r_tolerance=1e-10, q_tolerance=0.0)
+    assert s.termination_type == 0 and s.num_iterations <= 2, s.message
+    od = oracle.make_options(type=oracle.DENSE_SCHUR, num_eliminate_blocks=P)
+    xd, _ = oracle.solve(bs, vals, b, D, od)
+    assert relerr(x, xd) < 1e-9
+    S.close()
+    A.close()
+
+
+def test_failure_and_option_validation(ctx, oracle):
+    """A camera whose S block is singular (F = 0, D_f = 0): "Preconditioner update failed." as in
+    IterativeSchurComplementSolver::SolveImpl (:115-121); CLUSTER_* with CGNR or an explicit S is refused
+    (solver.cc option validation, solver_test.cc:1082-1157)."""
+    C, P, O, seed = 16, 700, 2800, 2
+    prob, bs, vals, b, D = make(oracle, C, P, O, seed)
+    row_cam = bs.cells["block_id"][1::2] - P
+    vals = vals.copy()
+    F = vals[6 * O:].reshape(O, 18)
+    F[row_cam == 2] = 0.0
+    D = D.copy()
+    D[3 * P + 18:3 * P + 27] = 0.0
+    A = cx.Matrix(ctx, bs, P)
+    A.set_values(vals)
+    for pre in PRE:
+        S = cx.Solver(ctx, type=cx.ITERATIVE_SCHUR, preconditioner_type=getattr(cx, pre), num_eliminate_blocks=P, max_num_iterations=50)
+        x, s = S.solve(A, b, D, r_tolerance=-1.0, q_tolerance=0.1)
+        assert s.termination_type == cx.FAILURE and s.num_iterations == 0
+        assert b"Preconditioner update failed" in s.message
+        S.close()
+    with pytest.raises(cx.CxError):
+        cx.Solver(ctx, type=cx.CGNR, preconditioner_type=cx.CLUSTER_JACOBI)
+    with pytest.raises(cx.CxError):
+        cx.Solver(ctx, type=cx.ITERATIVE_SCHUR, preconditioner_type=cx.CLUSTER_TRIDIAGONAL, num_eliminate_blocks=P,
+                  use_explicit_schur_complement=1)
+    with pytest.raises(cx.CxError):
+        cx.Solver(ctx, type=cx.ITERATIVE_SCHUR, preconditioner_type=cx.CLUSTER_JACOBI, num_eliminate_blocks=P,
+                  visibility_clustering_type=7)
+    A.close()
+
+
+def test_lm_loop_with_cluster_jacobi(ctx, oracle):
+    """cx_minimize with CLUSTER_JACOBI inside: the iterations follow the oracle's TrustRegionMinimizer."""
+    C, P, O = 12, 300, 2400
+    prob = cx.bal.make_bal_like(C, P, O, 3)
+    ev = cx.Evaluator(ctx, prob)
+    solver = cx.Solver(ctx, type=cx.ITERATIVE_SCHUR, preconditioner_type=cx.CLUSTER_JACOBI, num_eliminate_blocks=P,
+                       max_num_iterations=500)
+    x, summ, its = cx.binding.minimize(ev, solver, prob.state(), cx.binding.minimizer_options(max_num_iterations=8))
+    so = oracle.make_options(type=oracle.ITERATIVE_SCHUR, preconditioner_type=oracle.CLUSTER_JACOBI, num_eliminate_blocks=P,
+                             max_num_iterations=500)
+    x_r, summ_r, its_r = oracle.minimize_bal(C, P, prob.camera_index, prob.point_index, prob.observations, prob.state(), so,
+                                             oracle.minimizer_options(max_num_iterations=8))
+    assert summ["termination_type"] == summ_r["termination_type"] and len(its) == len(its_r)
+    for a, b in zip(its, its_r):
+        assert a["step_is_successful"] == b["step_is_successful"]
+        assert abs(a["cost"] - b["cost"]) <= 1e-5 * abs(b["cost"])
+    solver.close()
+    ev.close()

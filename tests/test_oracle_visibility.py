@@ -229,3 +229,43 @@ def test_one_cluster_is_the_exact_inverse(oracle):
                              visibility_clustering_type=oracle.SINGLE_LINKAGE, max_num_iterations=50)
     xo, so = oracle.solve(bs, vals, b, D, oo, r_tolerance=1e-10, q_tolerance=0.0)
     assert so.termination_type == 0 and so.num_iterations <= 2, so.message
+
+
+def test_tridiagonal_retry_with_halved_off_diagonal_cells(oracle):
+    """ScaleOffDiagonalCells (visibility_based_preconditioner.cc:331-393): the unscaled matrix is indefinite, the
+    solve still succeeds and takes the path of PCG with the halved matrix."""
+    from conftest import crafted_indefinite_tridiagonal
+    prob, bs, vals, b, D, P = crafted_indefinite_tridiagonal(0)
+    membership, k, _, block_pairs = oracle.visibility_structure(bs, P, oracle.CLUSTER_TRIDIAGONAL, oracle.SINGLE_LINKAGE)
+    assert k == 3 and len(block_pairs) == 5
+    S, rhs = oracle.schur_eliminate_dense(bs, vals, b, D, P)
+    S = np.triu(S) + np.triu(S, 1).T
+    M = np.zeros_like(S)
+    for i, j in block_pairs.tolist():
+        M[9 * i:9 * i + 9, 9 * j:9 * j + 9] = S[9 * i:9 * i + 9, 9 * j:9 * j + 9]
+        M[9 * j:9 * j + 9, 9 * i:9 * i + 9] = S[9 * j:9 * j + 9, 9 * i:9 * i + 9]
+    assert np.linalg.eigvalsh(M).min() < -1.0
+    for i, j in block_pairs.tolist():
+        if membership[i] != membership[j]:
+            M[9 * i:9 * i + 9, 9 * j:9 * j + 9] *= 0.5
+            M[9 * j:9 * j + 9, 9 * i:9 * i + 9] *= 0.5
+    assert np.linalg.eigvalsh(M).min() > 0.1
+    oo = oracle.make_options(type=oracle.ITERATIVE_SCHUR, preconditioner_type=oracle.CLUSTER_TRIDIAGONAL, num_eliminate_blocks=P,
+                             visibility_clustering_type=oracle.SINGLE_LINKAGE, max_num_iterations=100)
+    x, s = oracle.solve(bs, vals, b, D, oo, r_tolerance=1e-12, q_tolerance=0.0)
+    assert s.termination_type == 0, s.message
+    assert np.abs(S @ x[3 * P:] - rhs).max() < 1e-5 * np.abs(rhs).max()   # (E'E + 1e-6 I)^-1 of the private points
+    # same iterates as PCG preconditioned with the halved matrix
+    Minv = np.linalg.inv(M)
+    xs = np.zeros(27)
+    r = rhs.copy()
+    rho = 1.0
+    for it in range(1, s.num_iterations + 1):
+        z = Minv @ r
+        last_rho, rho = rho, r @ z
+        p = z.copy() if it == 1 else z + (rho / last_rho) * p
+        q = S @ p
+        alpha = rho / (p @ q)
+        xs += alpha * p
+        r = rhs - S @ xs if it % 10 == 0 else r - alpha * q
+    assert np.abs(xs - x[3 * P:]).max() < 1e-4 * np.abs(xs).max()
