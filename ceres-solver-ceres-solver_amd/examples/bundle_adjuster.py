@@ -39,7 +39,9 @@ def main(argv=None):
     ap.add_argument("--linear_solver", default="iterative_schur",
                     choices=["dense_schur", "sparse_schur", "iterative_schur", "cgnr"])
     ap.add_argument("--preconditioner", default="jacobi",
-                    choices=["identity", "jacobi", "schur_jacobi", "schur_power_series_expansion"])
+                    choices=["identity", "jacobi", "schur_jacobi", "schur_power_series_expansion", "cluster_jacobi",
+                             "cluster_tridiagonal"])
+    ap.add_argument("--visibility_clustering", default="canonical_views", choices=["canonical_views", "single_linkage"])
     ap.add_argument("--explicit_schur_complement", action="store_true",
                     help="ITERATIVE_SCHUR on the explicitly computed block-sparse S (needs schur_jacobi)")
     ap.add_argument("--num_iterations", type=int, default=5)
@@ -87,7 +89,8 @@ def main(argv=None):
     solver = cx.Solver(ctx, type=stype, preconditioner_type=getattr(cx.binding, args.preconditioner.upper()),
                        num_eliminate_blocks=0 if stype == cx.binding.CGNR else prob.num_points,
                        max_num_iterations=args.max_linear_solver_iterations,
-                       use_explicit_schur_complement=int(args.explicit_schur_complement))
+                       use_explicit_schur_complement=int(args.explicit_schur_complement),
+                       visibility_clustering_type=getattr(cx.binding, args.visibility_clustering.upper()))
     preprocess_s = time.time() - t0
     opts = cx.binding.minimizer_options(max_num_iterations=args.num_iterations, eta=args.eta,
                                         use_nonmonotonic_steps=int(args.nonmonotonic_steps))

@@ -26,6 +26,7 @@ namespace ceres {
 
 enum LinearSolverType { DENSE_NORMAL_CHOLESKY, DENSE_QR, SPARSE_NORMAL_CHOLESKY, DENSE_SCHUR, SPARSE_SCHUR, ITERATIVE_SCHUR, CGNR };
 enum PreconditionerType { IDENTITY, JACOBI, SCHUR_JACOBI, SCHUR_POWER_SERIES_EXPANSION, CLUSTER_JACOBI, CLUSTER_TRIDIAGONAL, SUBSET };
+enum VisibilityClusteringType { CANONICAL_VIEWS, SINGLE_LINKAGE };  // types.h:143-173
 
 namespace internal {
 
@@ -102,6 +103,7 @@ class LinearSolver {
     int residual_reset_period = 10;
     std::vector<int> elimination_groups;
     int row_block_size = -1, e_block_size = -1, f_block_size = -1;
+    VisibilityClusteringType visibility_clustering_type = CANONICAL_VIEWS;  // linear_solver.h:153
     bool use_explicit_schur_complement = false;  // linear_solver.h:161
     bool use_mixed_precision_solves = false;
     int max_num_refinement_iterations = 0;

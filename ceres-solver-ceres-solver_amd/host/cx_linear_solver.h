@@ -94,6 +94,8 @@ class CxLinearSolver final : public BlockSparseMatrixSolver {
         case JACOBI: o.preconditioner_type = CX_JACOBI; break;
         case SCHUR_JACOBI: o.preconditioner_type = CX_SCHUR_JACOBI; break;
         case SCHUR_POWER_SERIES_EXPANSION: o.preconditioner_type = CX_SCHUR_POWER_SERIES_EXPANSION; break;
+        case CLUSTER_JACOBI: o.preconditioner_type = CX_CLUSTER_JACOBI; break;
+        case CLUSTER_TRIDIAGONAL: o.preconditioner_type = CX_CLUSTER_TRIDIAGONAL; break;
         default:
           summary.termination_type = LinearSolverTerminationType::FATAL_ERROR;
           summary.message = "Preconditioner not available in cxschur.";
@@ -109,6 +111,7 @@ class CxLinearSolver final : public BlockSparseMatrixSolver {
       o.use_spse_initialization = options_.use_spse_initialization;
       o.spse_tolerance = options_.spse_tolerance;
       o.use_explicit_schur_complement = options_.use_explicit_schur_complement;
+      o.visibility_clustering_type = options_.visibility_clustering_type == SINGLE_LINKAGE ? CX_SINGLE_LINKAGE : CX_CANONICAL_VIEWS;
       if (cx_solver_create(ctx, &o, &solver_) != CX_OK) return Fatal(&summary);
     }
     // Values change every LM iteration: upload them verbatim (same cell layout).
