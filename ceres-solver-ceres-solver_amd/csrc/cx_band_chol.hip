@@ -200,7 +200,7 @@ __global__ __launch_bounds__(256) void k_band_solve(const double* __restrict__ F
       const double* __restrict__ col = F + size_t(k0) * ld + c;
       double acc = 0.0;
 #pragma unroll 8
-      for (int m = 0; m < NB; ++m) acc += col[size_t(m) * ld] * yb[m];
+      for (int m = 0; m < NB; ++m) acc = fma(col[size_t(m) * ld], yb[m], acc);
       y[c] -= acc;
     }
     __syncthreads();
@@ -212,7 +212,7 @@ __global__ __launch_bounds__(256) void k_band_solve(const double* __restrict__ F
       const int m = tid >> 3, part = tid & 7;
       const double* __restrict__ row = F + size_t(k0 + m) * ld;
       double acc = 0.0;
-      for (int c = rest + part; c < cend; c += 8) acc += row[c] * y[c];
+      for (int c = rest + part; c < cend; c += 8) acc = fma(row[c], y[c], acc);
       acc += __shfl_xor(acc, 1, 64);
       acc += __shfl_xor(acc, 2, 64);
       acc += __shfl_xor(acc, 4, 64);
@@ -226,6 +226,168 @@ __global__ __launch_bounds__(256) void k_band_solve(const double* __restrict__ F
       for (int q = 0; q < 16; ++q) sum += ui[m * kUiStride + 16 * half + q] * tb[16 * half + q];
       sum += __shfl_xor(sum, 32, 64);
       if (half == 0) y[k0 + m] = sum;
+    }
+    __syncthreads();
+  }
+  for (int r = r0 + tid; r < r1; r += 256) {
+    const int src = row_src[r];
+    if (src >= 0) z_out[src] = y[r];
+  }
+}
+
+// The same walk with the active part of the vector in LDS: at block step b only y(c), c in [k0, column end of b),
+// is live, a ring of kWin doubles indexed by c mod kWin.  The dependency chain then runs through LDS only; what
+// comes from HBM in a step (the block row of the factor, the next inverse, the columns that enter the window) does
+// not depend on it, and the inverse and the new columns are fetched one step ahead.  Two barriers per step instead
+// of three and no global read-after-write inside the chain: 6.5 -> see DESIGN.md us per step on the long path of
+// the Final shape.  Needs band + 64 <= kWin (otherwise k_band_solve).
+constexpr int kWin = 4096;
+
+__global__ __launch_bounds__(256) void k_band_solve_lds(const double* __restrict__ F, int ld, const double* __restrict__ uinv,
+                                                        const int32_t* __restrict__ path_first_blk, const int32_t* __restrict__ path_num_blk,
+                                                        const int32_t* __restrict__ blk_cend, const int32_t* __restrict__ row_src,
+                                                        const double* __restrict__ r_in, double* __restrict__ y, double* __restrict__ z_out) {
+  __shared__ double yw[kWin];
+  __shared__ double ui[2][NB * kUiStride];
+  __shared__ double tb[NB], yb[NB];
+  const int tid = threadIdx.x;
+  const int b0 = path_first_blk[blockIdx.x], nb = path_num_blk[blockIdx.x];
+  const int r0 = NB * b0, r1 = NB * (b0 + nb);
+  // r in band order
+  for (int r = r0 + tid; r < r1; r += 256) {
+    const int src = row_src[r];
+    y[r] = src >= 0 ? r_in[src] : 0.0;
+  }
+  __syncthreads();
+  {
+    const int hi = blk_cend[b0];
+    for (int c = r0 + tid; c < hi; c += 256) yw[c & (kWin - 1)] = y[c];
+    for (int i = tid; i < NB * NB; i += 256) ui[0][(i / NB) * kUiStride + (i % NB)] = uinv[size_t(b0) * NB * NB + i];
+  }
+  __syncthreads();
+  // ---- forward: U' y = r
+  for (int s = 0; s < nb; ++s) {
+    const int b = b0 + s, k0 = NB * b, rest = k0 + NB, cend = blk_cend[b];
+    const bool more = s + 1 < nb;
+    const int next_cend = more ? blk_cend[b + 1] : cend;
+    double pu[4], pn[2];
+    if (more) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) pu[q] = uinv[size_t(b + 1) * NB * NB + tid + 256 * q];
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        const int c = cend + tid + 256 * q;
+        pn[q] = c < next_cend ? y[c] : 0.0;
+      }
+    }
+    // this step's block row of the factor: all loads in flight at once, before the barrier (they do not depend
+    // on y_b); 2 x 256 columns per pass cover bands up to 544, wider windows take the loop below
+    double f0[NB], f1[NB];
+    {
+      const int c0 = rest + tid, c1 = c0 + 256;
+      const double* __restrict__ col = F + size_t(k0) * ld;
+#pragma unroll
+      for (int m = 0; m < NB; ++m) f0[m] = c0 < cend ? col[size_t(m) * ld + c0] : 0.0;
+#pragma unroll
+      for (int m = 0; m < NB; ++m) f1[m] = c1 < cend ? col[size_t(m) * ld + c1] : 0.0;
+    }
+    if (tid < 64) {
+      const int m = tid & 31, half = tid >> 5;
+      const double* __restrict__ u = ui[s & 1];
+      double sum = 0.0;
+#pragma unroll
+      for (int q = 0; q < 16; ++q) sum += u[(16 * half + q) * kUiStride + m] * yw[(k0 + 16 * half + q) & (kWin - 1)];
+      sum += __shfl_xor(sum, 32, 64);
+      if (half == 0) {
+        yb[m] = sum;
+        y[k0 + m] = sum;
+      }
+    }
+    __syncthreads();
+    {
+      const int c0 = rest + tid, c1 = c0 + 256;
+      double a0 = 0.0, a1 = 0.0;
+#pragma unroll
+      for (int m = 0; m < NB; ++m) {
+        a0 = fma(f0[m], yb[m], a0);
+        a1 = fma(f1[m], yb[m], a1);
+      }
+      if (c0 < cend) yw[c0 & (kWin - 1)] -= a0;
+      if (c1 < cend) yw[c1 & (kWin - 1)] -= a1;
+    }
+    for (int c = rest + 512 + tid; c < cend; c += 256) {
+      const double* __restrict__ col = F + size_t(k0) * ld + c;
+      double acc = 0.0;
+#pragma unroll
+      for (int m = 0; m < NB; ++m) acc = fma(col[size_t(m) * ld], yb[m], acc);
+      yw[c & (kWin - 1)] -= acc;
+    }
+    if (more) {
+      double* __restrict__ un = ui[(s + 1) & 1];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int i = tid + 256 * q;
+        un[(i / NB) * kUiStride + (i % NB)] = pu[q];
+      }
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        const int c = cend + tid + 256 * q;
+        if (c < next_cend) yw[c & (kWin - 1)] = pn[q];
+      }
+      for (int c = cend + 512 + tid; c < next_cend; c += 256) yw[c & (kWin - 1)] = y[c];
+    }
+    __syncthreads();
+  }
+  // ---- backward: U x = y.  The window now holds x(c), c in [rest, column end); ui[(nb - 1) & 1] is still staged.
+  if (tid < NB) tb[tid] = y[r1 - NB + tid];  // y of the last block (tb doubles as the "current y block")
+  __syncthreads();
+  for (int s = nb - 1; s >= 0; --s) {
+    const int b = b0 + s, k0 = NB * b, rest = k0 + NB, cend = blk_cend[b];
+    const bool more = s > 0;
+    double pu[4], py = 0.0;
+    if (more) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) pu[q] = uinv[size_t(b - 1) * NB * NB + tid + 256 * q];
+      if (tid < NB) py = y[k0 - NB + tid];
+    }
+    {
+      const int m = tid >> 3, part = tid & 7;
+      const double* __restrict__ row = F + size_t(k0 + m) * ld;
+      double acc = 0.0;
+      // 64 loads in flight per pass (512 columns of the row)
+      for (int base = rest + part; base < cend; base += 512) {
+        double fr[64];
+#pragma unroll
+        for (int j = 0; j < 64; ++j) fr[j] = base + 8 * j < cend ? row[base + 8 * j] : 0.0;
+#pragma unroll
+        for (int j = 0; j < 64; ++j) acc = base + 8 * j < cend ? fma(fr[j], yw[(base + 8 * j) & (kWin - 1)], acc) : acc;  // (stale slots may hold NaN)
+      }
+      acc += __shfl_xor(acc, 1, 64);
+      acc += __shfl_xor(acc, 2, 64);
+      acc += __shfl_xor(acc, 4, 64);
+      if (part == 0) yb[m] = tb[m] - acc;
+    }
+    __syncthreads();
+    if (tid < 64) {
+      const int m = tid & 31, half = tid >> 5;
+      const double* __restrict__ u = ui[s & 1];
+      double sum = 0.0;
+#pragma unroll
+      for (int q = 0; q < 16; ++q) sum += u[m * kUiStride + 16 * half + q] * yb[16 * half + q];
+      sum += __shfl_xor(sum, 32, 64);
+      if (half == 0) {
+        yw[(k0 + m) & (kWin - 1)] = sum;
+        y[k0 + m] = sum;
+      }
+    }
+    if (more) {
+      double* __restrict__ un = ui[(s - 1) & 1];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int i = tid + 256 * q;
+        un[(i / NB) * kUiStride + (i % NB)] = pu[q];
+      }
+      if (tid < NB) tb[tid] = py;
     }
     __syncthreads();
   }
@@ -265,9 +427,15 @@ int cxv_factor(cx_matrix* A, cx_vis_plan* plan, const double* D, bool halve_offd
 }
 
 int cxv_solve(cx_matrix* A, cx_vis_plan* plan, const double* r, double* z) {
-  hipLaunchKernelGGL(k_band_solve, dim3(unsigned(plan->num_paths)), dim3(256), 0, A->ctx->stream, (const double*)plan->d_F.p, plan->ld,
-                     (const double*)plan->d_uinv.p, (const int32_t*)plan->d_path_first_blk.p, (const int32_t*)plan->d_path_num_blk.p,
-                     (const int32_t*)plan->d_blk_cend.p, (const int32_t*)plan->d_row_src.p, r, plan->d_y.p, z);
+  const bool force_global = std::getenv("CX_BAND_SOLVE_GLOBAL") != nullptr;  // A/B switch, read per call so tests can flip it
+  if (plan->ld + 64 <= kWin && !force_global)
+    hipLaunchKernelGGL(k_band_solve_lds, dim3(unsigned(plan->num_paths)), dim3(256), 0, A->ctx->stream, (const double*)plan->d_F.p, plan->ld,
+                       (const double*)plan->d_uinv.p, (const int32_t*)plan->d_path_first_blk.p, (const int32_t*)plan->d_path_num_blk.p,
+                       (const int32_t*)plan->d_blk_cend.p, (const int32_t*)plan->d_row_src.p, r, plan->d_y.p, z);
+  else
+    hipLaunchKernelGGL(k_band_solve, dim3(unsigned(plan->num_paths)), dim3(256), 0, A->ctx->stream, (const double*)plan->d_F.p, plan->ld,
+                       (const double*)plan->d_uinv.p, (const int32_t*)plan->d_path_first_blk.p, (const int32_t*)plan->d_path_num_blk.p,
+                       (const int32_t*)plan->d_blk_cend.p, (const int32_t*)plan->d_row_src.p, r, plan->d_y.p, z);
   CX_HIP(hipGetLastError());
   return CX_OK;
 }

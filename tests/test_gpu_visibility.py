@@ -79,6 +79,25 @@ def test_solve_matches_oracle(ctx, oracle, C, P, O, seed, pre, clustering):
     A.close()
 
 
+def test_global_memory_walk_gives_the_same_bits(ctx, oracle, monkeypatch):
+    """k_band_solve (vector in global memory, used when the band does not fit the LDS window) and
+    k_band_solve_lds do the same arithmetic in the same order."""
+    C, P, O, seed = 100, 3000, 14000, 3
+    prob, bs, vals, b, D = make(oracle, C, P, O, seed)
+    A = cx.Matrix(ctx, bs, P)
+    A.set_values(vals)
+    out = []
+    for force in (False, True):
+        if force:
+            monkeypatch.setenv("CX_BAND_SOLVE_GLOBAL", "1")
+        S = cx.Solver(ctx, type=cx.ITERATIVE_SCHUR, preconditioner_type=cx.CLUSTER_TRIDIAGONAL, num_eliminate_blocks=P, max_num_iterations=200)
+        out.append(S.solve(A, b, D, r_tolerance=-1.0, q_tolerance=1e-3))
+        S.close()
+    assert out[0][1].num_iterations == out[1][1].num_iterations
+    assert np.array_equal(out[0][0], out[1][0])
+    A.close()
+
+
 @pytest.mark.parametrize("pre", PRE)
 def test_tight_solve_and_fewer_iterations_than_schur_jacobi(ctx, oracle, pre):
     """eta = 1e-3 on 400 cameras (26 clusters, one forest path): iteration count equals the oracle's and is
