@@ -410,11 +410,15 @@ int cxv_factor(cx_matrix* A, cx_vis_plan* plan, const double* D, bool halve_offd
   CX_HIP(hipMemsetAsync(plan->d_W.p, 0, band * sizeof(double), st));
   CX_TRY(cxs_assemble_pair_items(A, D, plan->d_sel_items.p, plan->num_sel_items));
   const int64_t num_sel = int64_t(plan->sel_cells.size());
-  const double* Df = D ? D + 3 * int64_t(A->P) : nullptr;
+  // sharded matrix: every rank assembles the contributions of its points into the same band layout, the band is
+  // summed over the ranks, D_f^2 enters once (rank 0) and the unit diagonal of the padding rows after the sum
+  const bool sharded = A->ctx->nranks > 1;
+  const double* Df = (D && (!sharded || A->ctx->rank == 0)) ? D + 3 * int64_t(A->P) : nullptr;
   hipLaunchKernelGGL(k_band_assemble, dim3(unsigned((num_sel + 2) / 3)), dim3(3 * 81), 0, st, (const int32_t*)plan->d_sel_cells.p,
                      (const int32_t*)plan->d_sel_offdiag.p, (const int32_t*)A->d_cell_c1.p, (const int32_t*)A->d_cell_c2.p,
                      (const int32_t*)A->d_cell_item_start.p, (const double*)A->d_item_partial.p, (const double*)A->d_elim_diag.p, Df,
                      (const int32_t*)plan->d_cam_row.p, plan->d_W.p, ld, num_sel, halve_offdiag ? 0.5 : 1.0);
+  if (sharded) CX_TRY(cx_allreduce_device(A->ctx, plan->d_W.p, int64_t(band)));
   hipLaunchKernelGGL(k_band_pad, dim3((N + 255) / 256), dim3(256), 0, st, (const int32_t*)plan->d_row_src.p, plan->d_W.p, ld, N);
   hipLaunchKernelGGL(k_band_first, dim3(unsigned(plan->num_paths)), dim3(64), 0, st, (const double*)plan->d_W.p, plan->d_F.p, ld,
                      (const int32_t*)plan->d_path_first_blk.p, plan->d_uinv.p, d_flag);

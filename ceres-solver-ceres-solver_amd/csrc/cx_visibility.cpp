@@ -75,9 +75,11 @@ void Visibility(const cx_matrix* A, Csr* cam_pts, Csr* pt_cams) {
       cam_pts->idx[size_t(fill[size_t(pt_cams->idx[size_t(k)])]++)] = p;
 }
 
-// CreateSchurComplementGraph: edge (c1, c2) weighs |V1 n V2| / sqrt(|V1| |V2|)
-Graph SchurComplementGraph(int C, const Csr& cam_pts, const Csr& pt_cams) {
-  std::vector<std::vector<std::pair<int32_t, int32_t>>> upper(static_cast<size_t>(C));  // (c2 > c1, shared points)
+using PairCounts = std::vector<std::vector<std::pair<int32_t, int32_t>>>;  // per camera c1: (c2 > c1, shared points), ascending c2
+
+// points shared by every pair of cameras
+PairCounts SharedPointCounts(int C, const Csr& cam_pts, const Csr& pt_cams) {
+  PairCounts upper(static_cast<size_t>(C));
   const unsigned hw = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
   std::vector<std::thread> workers;
   for (unsigned t = 0; t < hw; ++t)
@@ -100,6 +102,42 @@ Graph SchurComplementGraph(int C, const Csr& cam_pts, const Csr& pt_cams) {
       }
     });
   for (auto& w : workers) w.join();
+  return upper;
+}
+
+// in-place sum of a host array over the ranks of a sharded matrix (through the context's transport)
+int SumOverRanks(cx_context* ctx, std::vector<double>* host) {
+  DevBuf<double> tmp;
+  CX_TRY(tmp.upload(*host, ctx->stream));
+  CX_TRY(cx_allreduce_device(ctx, tmp.p, int64_t(host->size())));
+  CX_HIP(hipMemcpyAsync(host->data(), tmp.p, host->size() * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  CX_HIP(hipStreamSynchronize(ctx->stream));
+  return CX_OK;
+}
+
+// Sharded matrix: a rank sees the points of its shard only; every point lives in exactly one shard, so the number
+// of points a camera sees and the number two cameras share are sums over the ranks (dense, once per structure).
+int SumCountsOverRanks(cx_context* ctx, int C, PairCounts* upper, std::vector<size_t>* sizes) {
+  if (int64_t(C) > 16384) {
+    cx_set_error("visibility based preconditioners on a sharded matrix are limited to 16384 cameras (dense count exchange)");
+    return CX_ERR_UNSUPPORTED;
+  }
+  std::vector<double> dense(size_t(C) * C + size_t(C), 0.0);
+  for (int c1 = 0; c1 < C; ++c1)
+    for (const auto& e : (*upper)[size_t(c1)]) dense[size_t(c1) * C + e.first] = double(e.second);
+  for (int c = 0; c < C; ++c) dense[size_t(C) * C + c] = double((*sizes)[size_t(c)]);
+  CX_TRY(SumOverRanks(ctx, &dense));
+  for (int c1 = 0; c1 < C; ++c1) {
+    (*upper)[size_t(c1)].clear();
+    (*sizes)[size_t(c1)] = size_t(dense[size_t(C) * C + c1]);
+    for (int c2 = c1 + 1; c2 < C; ++c2)
+      if (dense[size_t(c1) * C + c2] > 0.0) (*upper)[size_t(c1)].push_back({c2, int32_t(dense[size_t(c1) * C + c2])});
+  }
+  return CX_OK;
+}
+
+// CreateSchurComplementGraph: edge (c1, c2) weighs |V1 n V2| / sqrt(|V1| |V2|)
+Graph SchurComplementGraph(int C, const PairCounts& upper, const std::vector<size_t>& sizes) {
   Graph g;
   g.n = C;
   g.start.assign(size_t(C) + 1, 0);
@@ -111,7 +149,6 @@ Graph SchurComplementGraph(int C, const Csr& cam_pts, const Csr& pt_cams) {
   g.nb.resize(size_t(g.start[size_t(C)]));
   g.w.resize(size_t(g.start[size_t(C)]));
   std::vector<int64_t> fill(g.start.begin(), g.start.end() - 1);
-  auto size_of = [&](int c) { return size_t(cam_pts.start[size_t(c) + 1] - cam_pts.start[size_t(c)]); };
   // lower neighbours arrive in ascending c1, then the self edge, then the upper neighbours in ascending c2
   for (int c1 = 0; c1 < C; ++c1) {
     {
@@ -120,7 +157,7 @@ Graph SchurComplementGraph(int C, const Csr& cam_pts, const Csr& pt_cams) {
       g.w[size_t(slot)] = 1.0;  // kSelfEdgeWeight
     }
     for (const auto& e : upper[size_t(c1)]) {
-      const double weight = static_cast<double>(e.second) / (std::sqrt(static_cast<double>(size_of(c1) * size_of(e.first))));
+      const double weight = static_cast<double>(e.second) / (std::sqrt(static_cast<double>(sizes[size_t(c1)] * sizes[size_t(e.first)])));
       int64_t slot = fill[size_t(c1)]++;
       g.nb[size_t(slot)] = e.first;
       g.w[size_t(slot)] = weight;
@@ -223,11 +260,16 @@ struct WeightedEdge {
 };
 
 // CreateClusterGraph + Degree2MaximumSpanningForest: edge weight = points seen from both clusters
-std::vector<std::pair<int32_t, int32_t>> ClusterForest(int K, const std::vector<int32_t>& membership, const Csr& pt_cams) {
+int ClusterForest(cx_context* ctx, int K, const std::vector<int32_t>& membership, const Csr& pt_cams,
+                  std::vector<std::pair<int32_t, int32_t>>* forest_out) {
   const int P = int(pt_cams.start.size()) - 1;
   std::vector<WeightedEdge> edges;
   std::vector<int32_t> ks;
   const bool dense = int64_t(K) * K <= (int64_t(1) << 26);
+  if (!dense && ctx->nranks > 1) {
+    cx_set_error("CLUSTER_TRIDIAGONAL on a sharded matrix is limited to 8192 clusters (dense count exchange)");
+    return CX_ERR_UNSUPPORTED;
+  }
   std::vector<int32_t> counts;
   std::unordered_map<uint64_t, int32_t> sparse_counts;
   if (dense) counts.assign(size_t(K) * K, 0);
@@ -241,6 +283,11 @@ std::vector<std::pair<int32_t, int32_t>> ClusterForest(int K, const std::vector<
         if (dense) counts[size_t(ks[i]) * K + ks[j]]++;
         else sparse_counts[(uint64_t(uint32_t(ks[i])) << 32) | uint32_t(ks[j])]++;
       }
+  }
+  if (dense && ctx->nranks > 1) {  // the other shards' points
+    std::vector<double> sum(counts.begin(), counts.end());
+    CX_TRY(SumOverRanks(ctx, &sum));
+    for (size_t i = 0; i < sum.size(); ++i) counts[i] = int32_t(sum[i]);
   }
   if (dense) {
     for (int a = 0; a < K; ++a)
@@ -257,7 +304,8 @@ std::vector<std::pair<int32_t, int32_t>> ClusterForest(int K, const std::vector<
   });
   std::vector<int32_t> component(static_cast<size_t>(K)), degree(size_t(K), 0);
   std::iota(component.begin(), component.end(), 0);
-  std::vector<std::pair<int32_t, int32_t>> forest;
+  std::vector<std::pair<int32_t, int32_t>>& forest = *forest_out;
+  forest.clear();
   for (const WeightedEdge& e : edges) {
     if (degree[size_t(e.a)] == 2 || degree[size_t(e.b)] == 2) continue;
     int32_t r1 = Find(component, e.a), r2 = Find(component, e.b);
@@ -268,7 +316,7 @@ std::vector<std::pair<int32_t, int32_t>> ClusterForest(int K, const std::vector<
     if (r2 < r1) std::swap(r1, r2);
     component[size_t(r2)] = r1;
   }
-  return forest;
+  return CX_OK;
 }
 
 int BuildPlan(cx_matrix* A, int preconditioner_type, int clustering_type, cx_vis_plan* plan) {
@@ -277,7 +325,12 @@ int BuildPlan(cx_matrix* A, int preconditioner_type, int clustering_type, cx_vis
   plan->clustering_type = clustering_type;
   Csr cam_pts, pt_cams;
   Visibility(A, &cam_pts, &pt_cams);
-  const Graph graph = SchurComplementGraph(C, cam_pts, pt_cams);
+  PairCounts upper = SharedPointCounts(C, cam_pts, pt_cams);
+  std::vector<size_t> sizes(static_cast<size_t>(C));
+  for (int c = 0; c < C; ++c) sizes[size_t(c)] = size_t(cam_pts.start[size_t(c) + 1] - cam_pts.start[size_t(c)]);
+  if (A->ctx->nranks > 1) CX_TRY(SumCountsOverRanks(A->ctx, C, &upper, &sizes));
+  const Graph graph = SchurComplementGraph(C, upper, sizes);
+  PairCounts().swap(upper);
   // ClusterCameras
   std::vector<int32_t> raw;
   int K = 0;
@@ -304,7 +357,7 @@ int BuildPlan(cx_matrix* A, int preconditioner_type, int clustering_type, cx_vis
   }
   // cluster pairs; partner[k] = the (at most two) forest neighbours of cluster k
   std::vector<std::pair<int32_t, int32_t>> forest;
-  if (preconditioner_type == CX_CLUSTER_TRIDIAGONAL) forest = ClusterForest(K, plan->membership, pt_cams);
+  if (preconditioner_type == CX_CLUSTER_TRIDIAGONAL) CX_TRY(ClusterForest(A->ctx, K, plan->membership, pt_cams, &forest));
   std::vector<std::array<int32_t, 2>> partner(size_t(K), std::array<int32_t, 2>{-1, -1});
   for (const auto& e : forest) {
     for (int side = 0; side < 2; ++side) {
@@ -456,10 +509,6 @@ int cxv_get_plan(cx_matrix* A, int preconditioner_type, int clustering_type, cx_
   if (A->C == 0) {
     cx_set_error("Jacobian should have at least 1 f_block for visibility based preconditioning.");
     return CX_ERR_INVALID_ARGUMENT;
-  }
-  if (A->ctx->nranks > 1) {
-    cx_set_error("the visibility based preconditioners are not available for a matrix sharded over several ranks");
-    return CX_ERR_UNSUPPORTED;
   }
   if (!A->vis || A->vis->preconditioner_type != preconditioner_type || A->vis->clustering_type != clustering_type) {
     auto plan = std::make_shared<cx_vis_plan>();

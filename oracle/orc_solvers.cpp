@@ -556,7 +556,9 @@ static cx_summary SolveIterativeSchur(const cx_block_structure* s, const double*
   // The reference factors with a sparse Cholesky (SuiteSparse & co, not in the tree); dense here.
   Vec vis_factor;
   if (o.preconditioner_type == CX_CLUSTER_JACOBI || o.preconditioner_type == CX_CLUSTER_TRIDIAGONAL) {
-    const VisibilityStructure vs = ComputeVisibilityStructure(s, nelim, o.preconditioner_type, o.visibility_clustering_type);
+    const SumFn shard_sum = [&](double* buf, int64_t count) { comm.Sum(buf, count); };
+    const VisibilityStructure vs =
+        ComputeVisibilityStructure(s, nelim, o.preconditioner_type, o.visibility_clustering_type, comm.active() ? &shard_sum : nullptr);
     Eliminator el(s, values, nelim);
     auto sizes = el.FBlockSizes();
     Vec m_values(size_t(n) * n, 0.0);

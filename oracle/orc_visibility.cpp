@@ -48,8 +48,11 @@ double WGraph::EdgeWeight(int u, int v) const {
   return it == adj[size_t(u)].end() ? 0.0 : it->second;
 }
 
-// visibility.cc:77-146
-WGraph SchurComplementGraph(const std::vector<std::vector<int>>& visibility) {
+// visibility.cc:77-146.  sum (optional): the rows of the structure are one shard of the points; the number of
+// points a camera sees and the number two cameras share are then sums over the shards (every point lives in
+// exactly one), taken on dense arrays before the weights are formed.
+WGraph SchurComplementGraph(const std::vector<std::vector<int>>& visibility, const SumFn* sum) {
+  const int n = int(visibility.size());
   int num_points = 0;
   for (const auto& v : visibility)
     if (!v.empty()) num_points = std::max(num_points, v.back() + 1);
@@ -60,12 +63,25 @@ WGraph SchurComplementGraph(const std::vector<std::vector<int>>& visibility) {
   for (const auto& cams : inverse)
     for (size_t a = 0; a < cams.size(); ++a)
       for (size_t b = a + 1; b < cams.size(); ++b) ++camera_pairs[{cams[a], cams[b]}];
-  WGraph g(int(visibility.size()));
+  std::vector<size_t> size(static_cast<size_t>(n));
+  for (int i = 0; i < n; ++i) size[size_t(i)] = visibility[size_t(i)].size();
+  if (sum) {
+    std::vector<double> dense(size_t(n) * n + size_t(n), 0.0);
+    for (const auto& pc : camera_pairs) dense[size_t(pc.first.first) * n + pc.first.second] = double(pc.second);
+    for (int i = 0; i < n; ++i) dense[size_t(n) * n + i] = double(size[size_t(i)]);
+    (*sum)(dense.data(), int64_t(dense.size()));
+    camera_pairs.clear();
+    for (int i = 0; i < n; ++i) {
+      size[size_t(i)] = size_t(dense[size_t(n) * n + i]);
+      for (int j = i + 1; j < n; ++j)
+        if (dense[size_t(i) * n + j] > 0.0) camera_pairs[{i, j}] = int(dense[size_t(i) * n + j]);
+    }
+  }
+  WGraph g(n);
   for (int i = 0; i < g.n; ++i) g.AddEdge(i, i, 1.0);  // kSelfEdgeWeight
   for (const auto& pc : camera_pairs) {
     const int c1 = pc.first.first, c2 = pc.first.second;
-    const double weight =
-        static_cast<double>(pc.second) / (std::sqrt(static_cast<double>(visibility[size_t(c1)].size() * visibility[size_t(c2)].size())));
+    const double weight = static_cast<double>(pc.second) / (std::sqrt(static_cast<double>(size[size_t(c1)] * size[size_t(c2)])));
     g.AddEdge(c1, c2, weight);
   }
   return g;
@@ -171,12 +187,12 @@ std::vector<std::pair<int, int>> Degree2MaximumSpanningForest(const WGraph& grap
 
 // visibility_based_preconditioner.cc:121-201, 482-575
 VisibilityStructure ComputeVisibilityStructure(const cx_block_structure* s, int num_eliminate_blocks, int preconditioner_type,
-                                               int clustering_type) {
+                                               int clustering_type, const SumFn* sum) {
   BS bs(s);
   VisibilityStructure out;
   const auto visibility = ComputeVisibility(bs, num_eliminate_blocks);
   const int num_blocks = int(visibility.size());
-  const WGraph graph = SchurComplementGraph(visibility);
+  const WGraph graph = SchurComplementGraph(visibility, sum);
   // ClusterCameras :173-201
   std::vector<int> raw;
   int num_clusters = 0;
@@ -209,14 +225,19 @@ VisibilityStructure ComputeVisibilityStructure(const cx_block_structure* s, int 
     for (int i = 0; i < num_blocks; ++i)
       cluster_visibility[size_t(out.membership[size_t(i)])].insert(visibility[size_t(i)].begin(), visibility[size_t(i)].end());
     WGraph cluster_graph(num_clusters);
+    std::vector<double> shared(size_t(num_clusters) * num_clusters, 0.0);
     for (int i = 0; i < num_clusters; ++i)
       for (int j = i + 1; j < num_clusters; ++j) {
         std::vector<int> intersection;
         std::set_intersection(cluster_visibility[size_t(i)].begin(), cluster_visibility[size_t(i)].end(),
                               cluster_visibility[size_t(j)].begin(), cluster_visibility[size_t(j)].end(),
                               std::back_inserter(intersection));
-        if (!intersection.empty()) cluster_graph.AddEdge(i, j, double(intersection.size()));
+        shared[size_t(i) * num_clusters + j] = double(intersection.size());
       }
+    if (sum) (*sum)(shared.data(), int64_t(shared.size()));  // points of the other shards
+    for (int i = 0; i < num_clusters; ++i)
+      for (int j = i + 1; j < num_clusters; ++j)
+        if (shared[size_t(i) * num_clusters + j] > 0.0) cluster_graph.AddEdge(i, j, shared[size_t(i) * num_clusters + j]);
     // ForestToClusterPairs :458-477
     for (const auto& e : Degree2MaximumSpanningForest(cluster_graph)) cluster_pairs.emplace(e.first, e.second);
   }
@@ -272,7 +293,7 @@ extern "C" {
 int orc_schur_complement_graph(const cx_block_structure* bs, int num_eliminate_blocks, int32_t* u, int32_t* v, double* w,
                                int capacity) {
   BS b(bs);
-  const WGraph g = SchurComplementGraph(ComputeVisibility(b, num_eliminate_blocks));
+  const WGraph g = SchurComplementGraph(ComputeVisibility(b, num_eliminate_blocks), nullptr);
   int count = 0;
   for (int i = 0; i < g.n; ++i)
     for (const auto& nb : g.adj[size_t(i)]) {
@@ -316,7 +337,7 @@ int64_t orc_visibility_structure(const cx_block_structure* bs, int num_eliminate
                                  int clustering_type, int32_t* membership, int32_t* num_clusters, int32_t* num_cluster_pairs,
                                  int32_t* cluster_pair_1, int32_t* cluster_pair_2, int32_t cluster_pair_capacity,
                                  int32_t* block_pair_1, int32_t* block_pair_2, int64_t block_pair_capacity) {
-  const VisibilityStructure vs = ComputeVisibilityStructure(bs, num_eliminate_blocks, preconditioner_type, clustering_type);
+  const VisibilityStructure vs = ComputeVisibilityStructure(bs, num_eliminate_blocks, preconditioner_type, clustering_type, nullptr);
   if (membership) std::copy(vs.membership.begin(), vs.membership.end(), membership);
   if (num_clusters) *num_clusters = vs.num_clusters;
   if (num_cluster_pairs) *num_cluster_pairs = int32_t(vs.cluster_pairs.size());

@@ -4,6 +4,7 @@
 #ifndef ORC_VISIBILITY_H_
 #define ORC_VISIBILITY_H_
 
+#include <functional>
 #include <map>
 #include <utility>
 #include <vector>
@@ -31,7 +32,8 @@ struct CanonicalViewsOptions {  // canonical_views_clustering.h:104-121
 };
 
 std::vector<std::vector<int>> ComputeVisibility(const BS& bs, int num_eliminate_blocks);
-WGraph SchurComplementGraph(const std::vector<std::vector<int>>& visibility);
+using SumFn = std::function<void(double*, int64_t)>;  // in-place sum over the shards of a sharded solve
+WGraph SchurComplementGraph(const std::vector<std::vector<int>>& visibility, const SumFn* sum);
 void CanonicalViews(const CanonicalViewsOptions& options, const WGraph& graph, std::vector<int>* centers,
                     std::vector<int>* membership);
 int SingleLinkage(double min_similarity, const WGraph& graph, std::vector<int>* membership);
@@ -44,7 +46,7 @@ struct VisibilityStructure {
   std::vector<std::pair<int, int>> block_pairs;     // f-block pairs (b1 <= b2) of the preconditioner, lexicographic
 };
 VisibilityStructure ComputeVisibilityStructure(const cx_block_structure* s, int num_eliminate_blocks, int preconditioner_type,
-                                               int clustering_type);
+                                               int clustering_type, const SumFn* sum);
 
 }  // namespace orc
 #endif

@@ -61,7 +61,8 @@ def _worker(rank, port, results_dir):
     A = ev.jacobian()
     for stype, pre, explicit in (("ITERATIVE_SCHUR", "JACOBI", 0), ("ITERATIVE_SCHUR", "SCHUR_JACOBI", 0),
                                  ("ITERATIVE_SCHUR", "SCHUR_POWER_SERIES_EXPANSION", 0), ("CGNR", "JACOBI", 0),
-                                 ("DENSE_SCHUR", "IDENTITY", 0), ("ITERATIVE_SCHUR", "SCHUR_JACOBI", 1)):
+                                 ("DENSE_SCHUR", "IDENTITY", 0), ("ITERATIVE_SCHUR", "SCHUR_JACOBI", 1),
+                                 ("ITERATIVE_SCHUR", "CLUSTER_JACOBI", 0), ("ITERATIVE_SCHUR", "CLUSTER_TRIDIAGONAL", 0)):
         o_full = orc.make_options(type=getattr(orc, stype), preconditioner_type=getattr(orc, pre),
                                   num_eliminate_blocks=P, max_num_iterations=300, use_explicit_schur_complement=explicit)
         x_full, s_full = orc.solve(bs_full, vals_f, res_f, D_full, o_full, r_tolerance=-1.0, q_tolerance=0.1)
@@ -105,7 +106,7 @@ def test_two_ranks_one_gpu(tmp_path, oracle):
     mp.spawn(_worker, args=(port, str(tmp_path)), nprocs=WORLD, join=True)
     for rank in range(WORLD):
         lines = open(tmp_path / ("rank%d.txt" % rank)).read().strip().splitlines()
-        assert len(lines) == 9
+        assert len(lines) == 11
         for line in lines:
             rec = eval(line)
             assert rec[1], line

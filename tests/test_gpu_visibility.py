@@ -224,3 +224,62 @@ def test_lm_loop_with_cluster_jacobi(ctx, oracle):
         assert abs(a["cost"] - b["cost"]) <= 1e-5 * abs(b["cost"])
     solver.close()
     ev.close()
+
+
+def _custom_problem(C, cam_lists):
+    cam, pt = [], []
+    for j, cams in enumerate(cam_lists):
+        cam.extend(sorted(int(c) for c in cams))
+        pt.extend([j] * len(cams))
+    cam, pt = np.array(cam, dtype=np.int32), np.array(pt, dtype=np.int32)
+    O = cam.size
+    return cx.bal.BalProblem(C, len(cam_lists), cam, pt, np.zeros((O, 2)), np.zeros((C, 9)), np.zeros((len(cam_lists), 3)))
+
+
+@pytest.mark.parametrize("clustering", CLUSTERING)
+@pytest.mark.parametrize("pre", PRE)
+@pytest.mark.parametrize("case", ["unseen_camera", "one_camera", "two_components", "identical_views", "big_cluster"])
+def test_edge_structures(ctx, oracle, case, pre, clustering):
+    """A camera nobody observes (no edges, its block is D^2), a single camera, two groups of cameras that share
+    no point (forest with two paths), groups of cameras with identical visibility (similarity exactly 1: exact
+    ties between candidate views), and one cluster of 120 cameras (band 1080+: more than two 256-column passes of
+    the solve kernel's window).  Structure exact, solve against the oracle."""
+    rng = np.random.default_rng({"unseen_camera": 1, "one_camera": 2, "two_components": 3, "identical_views": 4, "big_cluster": 5}[case])
+    if case == "unseen_camera":
+        C, lists = 6, [list(rng.choice([0, 1, 2, 4, 5], size=int(rng.integers(2, 5)), replace=False)) for _ in range(60)]
+    elif case == "one_camera":
+        C, lists = 1, [[0] for _ in range(40)]
+    elif case == "two_components":
+        C = 24
+        lists = [list(rng.choice(12, size=4, replace=False) + (12 if j % 2 else 0)) for j in range(300)]
+    elif case == "identical_views":
+        C = 12
+        groups = [[0, 1, 2], [3, 4, 5], [6, 7, 8], [9, 10, 11]]
+        lists = [groups[j % 4] + ([groups[(j + 1) % 4][0]] if j % 5 == 0 else []) for j in range(120)]
+    else:
+        C = 120
+        lists = [list(range(C)) for _ in range(40)] + [list(rng.choice(C, size=3, replace=False)) for _ in range(200)]
+    prob = _custom_problem(C, lists)
+    P, O = prob.num_points, prob.num_observations
+    bs, _ = cx.bal.build_structure(prob)
+    vals = cx.bal.random_jacobian_values(O, 3)
+    b = rng.standard_normal(2 * O)
+    D = rng.uniform(0.5, 2.0, bs.num_cols)
+    A = cx.Matrix(ctx, bs, P)
+    A.set_values(vals)
+    got = cx.binding.visibility_structure(A, getattr(cx, pre), getattr(cx, clustering))
+    ref = oracle.visibility_structure(bs, P, getattr(oracle, pre), getattr(oracle, clustering))
+    assert got[1] == ref[1]
+    for a, r in zip((got[0], got[2], got[3]), (ref[0], ref[2], ref[3])):
+        assert np.array_equal(a, r)
+    S = cx.Solver(ctx, type=cx.ITERATIVE_SCHUR, preconditioner_type=getattr(cx, pre), num_eliminate_blocks=P,
+                  visibility_clustering_type=getattr(cx, clustering), max_num_iterations=300)
+    x, s = S.solve(A, b, D, r_tolerance=-1.0, q_tolerance=1e-4)
+    oo = oracle.make_options(type=oracle.ITERATIVE_SCHUR, preconditioner_type=getattr(oracle, pre), num_eliminate_blocks=P,
+                             visibility_clustering_type=getattr(oracle, clustering), max_num_iterations=300)
+    xr, sr = oracle.solve(bs, vals, b, D, oo, r_tolerance=-1.0, q_tolerance=1e-4)
+    assert s.termination_type == sr.termination_type == 0, (s.message, sr.message)
+    assert s.num_iterations == sr.num_iterations, (s.message, sr.message)
+    assert relerr(x, xr) < 1e-8
+    S.close()
+    A.close()
