@@ -167,8 +167,9 @@ struct cx_matrix {
   DevBuf<int32_t> d_sp_cam_pos, d_sp_row_start, d_sp_row_tiles, d_sp_col_start, d_sp_col_pool, d_sp_col_row;
   DevBuf<double> d_sp_W, d_sp_F, d_sp_x;
   int pairs_state = 0;                   // 0 not built, 1 ready, 2 too many pairs (atomic path)
-  // visibility based preconditioner of this structure (cx_visibility.h), built on first use
-  std::shared_ptr<struct cx_vis_plan> vis;
+  // visibility based preconditioners of this structure (cx_visibility.h), one plan per (preconditioner type,
+  // clustering type), built on first use
+  std::vector<std::shared_ptr<struct cx_vis_plan>> vis_plans;
   int64_t num_pairs = 0;
 
   // scratch for host-pointer calls

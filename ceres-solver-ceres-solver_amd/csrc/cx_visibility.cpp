@@ -18,6 +18,7 @@
 #include "cx_visibility.h"
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <limits>
 #include <numeric>
@@ -510,12 +511,19 @@ int cxv_get_plan(cx_matrix* A, int preconditioner_type, int clustering_type, cx_
     cx_set_error("Jacobian should have at least 1 f_block for visibility based preconditioning.");
     return CX_ERR_INVALID_ARGUMENT;
   }
-  if (!A->vis || A->vis->preconditioner_type != preconditioner_type || A->vis->clustering_type != clustering_type) {
-    auto plan = std::make_shared<cx_vis_plan>();
-    CX_TRY(BuildPlan(A, preconditioner_type, clustering_type, plan.get()));
-    A->vis = plan;
-  }
-  *out = A->vis.get();
+  for (const auto& plan : A->vis_plans)
+    if (plan->preconditioner_type == preconditioner_type && plan->clustering_type == clustering_type) {
+      *out = plan.get();
+      return CX_OK;
+    }
+  auto plan = std::make_shared<cx_vis_plan>();
+  const auto t0 = std::chrono::steady_clock::now();
+  CX_TRY(BuildPlan(A, preconditioner_type, clustering_type, plan.get()));
+  if (std::getenv("CX_VISIBILITY_VERBOSE"))
+    std::fprintf(stderr, "[cxschur] visibility plan built in %.2f s\n",
+                 std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
+  A->vis_plans.push_back(plan);
+  *out = plan.get();
   return CX_OK;
 }
 

@@ -107,3 +107,24 @@ def crafted_indefinite_tridiagonal(seed, shared=12, private=4, de=1e-3, df=0.05)
     b = rng.standard_normal(2 * O)
     D = np.concatenate([np.full(3 * P, de), np.full(9 * C, df)])
     return prob, bs, vals, b, D, P
+
+
+def one_f_block_problem(seed=0, num_e_blocks=5):
+    """The structure of schur_eliminator_test.cc:221-278 (SchurEliminatorForOneFBlock<2,3,6>): e-blocks of size 3, ONE
+    f-block of size 6; per e-block a 2-row block with (e, f) cells and a 2-row block with the e cell only; a last
+    3-row block with the f cell only.  Values ~ N(0,1), D = 1 as in the reference test."""
+    rng = np.random.default_rng(seed)
+    col_sizes = [3] * num_e_blocks + [6]
+    rows, pos = [], 0
+    for i in range(num_e_blocks):
+        rows.append((2, [(i, pos), (num_e_blocks, pos + 6)]))
+        pos += 6 + 12
+        rows.append((2, [(i, pos)]))
+        pos += 6
+    rows.append((3, [(num_e_blocks, pos)]))
+    pos += 18
+    bs = cx.BlockStructure.from_rows(col_sizes, rows)
+    values = rng.standard_normal(pos)
+    b = rng.uniform(-1.0, 1.0, bs.num_rows)
+    D = np.ones(bs.num_cols)
+    return bs, values, b, D, num_e_blocks

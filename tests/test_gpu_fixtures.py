@@ -195,3 +195,31 @@ def test_generic_path_on_random_block_problem(ctx, oracle):
         assert np.abs(x - xo).max() <= 1e-9 * np.abs(xo).max()
         Sv.close()
     A.close()
+
+
+def test_one_f_block_2_3_6(ctx, oracle):
+    """The reference specialises the eliminator for problems with a single f-block (SchurEliminatorForOneFBlock<2,3,6>,
+    schur_eliminator.h:383-625) and checks it against the general one (schur_eliminator_test.cc:221-372).  The device
+    has one eliminator for dynamic block sizes; same procedure: lhs, rhs, back substitution, and the solvers."""
+    from conftest import one_f_block_problem
+    bs, values, b, D, nelim = one_f_block_problem()
+    A = cx.Matrix(ctx, bs, nelim)
+    assert not A.is_static_239
+    A.set_values(values)
+    lhs, rhs = cx.eliminate_dense(ctx, A, b, D, 6)
+    lhs_o, rhs_o = oracle.schur_eliminate_dense(bs, values, b, D, nelim)
+    assert np.abs(lhs - lhs_o).max() <= 1e-13 * np.abs(lhs_o).max()
+    assert np.abs(rhs - rhs_o).max() <= 1e-13 * np.abs(rhs_o).max()
+    f_sol = np.random.default_rng(1).uniform(-1, 1, 6)
+    x = cx.back_substitute(ctx, A, b, D, f_sol)
+    xo = oracle.schur_back_substitute(bs, values, b, D, nelim, f_sol)
+    assert np.abs(x[:3 * nelim] - xo[:3 * nelim]).max() <= 1e-12 * np.abs(xo).max()
+    H, g, S, rhs_ref, sol, ne = dense(bs, values, b, D, nelim)
+    for stype, pre in (("DENSE_SCHUR", "IDENTITY"), ("ITERATIVE_SCHUR", "SCHUR_JACOBI"), ("ITERATIVE_SCHUR", "JACOBI")):
+        Sv = cx.Solver(ctx, type=getattr(cx, stype), preconditioner_type=getattr(cx, pre), num_eliminate_blocks=nelim,
+                       max_num_iterations=50)
+        xs, s = Sv.solve(A, b, D, r_tolerance=1e-13, q_tolerance=0.0)
+        assert s.termination_type == cx.SUCCESS, s.message
+        assert np.abs(xs - sol).max() <= 1e-10 * np.abs(sol).max()
+        Sv.close()
+    A.close()

@@ -253,3 +253,20 @@ def test_detect_structure(oracle):
     assert oracle.detect_structure(bs, nelim) == (2, 2, 2)
     bs, values, b, D, nelim, raw = lls_problem(6)
     assert oracle.detect_structure(bs, nelim) == (2, 2, 2)
+
+
+def test_one_f_block_2_3_6(oracle):
+    """schur_eliminator_test.cc:221-372 (SchurEliminatorForOneFBlock, MatchesSchurEliminator): lhs, rhs and the
+    back-substituted e-part on the <2,3,6> single-f-block structure, here against dense algebra."""
+    from conftest import one_f_block_problem
+    bs, values, b, D, nelim = one_f_block_problem()
+    J, H, g, S, rhs_ref, sol = dense_reference(bs, values, b, D, nelim)
+    lhs, rhs = oracle.schur_eliminate_dense(bs, values, b, D, nelim)
+    assert lhs.shape == (6, 6)
+    assert np.abs(np.triu(lhs) - np.triu(S)).max() < 1e-13 * np.abs(S).max()
+    assert np.abs(rhs - rhs_ref).max() < 1e-13 * np.abs(rhs_ref).max()
+    f_sol = np.random.default_rng(1).uniform(-1, 1, 6)
+    x = oracle.schur_back_substitute(bs, values, b, D, nelim, f_sol)
+    ne = 3 * nelim
+    e_ref = np.linalg.solve(H[:ne, :ne], g[:ne] - H[:ne, ne:] @ f_sol)
+    assert np.abs(x[:ne] - e_ref).max() < 1e-12 * np.abs(e_ref).max()
