@@ -68,7 +68,7 @@ __global__ void k_band_pad(const int32_t* __restrict__ row_src, double* __restri
 __global__ __launch_bounds__(64) void k_band_first(const double* __restrict__ W, double* __restrict__ F, int ld,
                                                    const int32_t* __restrict__ path_first_blk, double* __restrict__ uinv,
                                                    int* __restrict__ not_pd) {
-  __shared__ double lds[NB * NB + NB];
+  __shared__ double lds[cxchol::kPotrfLds];
   const int b = path_first_blk[blockIdx.x];
   const size_t off = size_t(NB * b) * ld + NB * b;
   cxchol::potrf_inverse_block(W + off, ld, F + off, ld, NB, uinv + size_t(b) * NB * NB, not_pd, lds);
@@ -82,7 +82,7 @@ __global__ __launch_bounds__(256) void k_band_step(double* __restrict__ W, doubl
                                                    const int32_t* __restrict__ path_first_blk, const int32_t* __restrict__ path_num_blk,
                                                    const int32_t* __restrict__ blk_cend, double* __restrict__ uinv, int s,
                                                    int* __restrict__ not_pd) {
-  __shared__ double lds[NB * NB + NB];
+  __shared__ double lds[cxchol::kPotrfLds];
   const int path = blockIdx.y;
   const int nblk = path_num_blk[path];
   if (s >= nblk) return;
@@ -147,13 +147,11 @@ __global__ __launch_bounds__(256) void k_band_step(double* __restrict__ W, doubl
           if (i < cend && j < cend && j >= i) W[size_t(i) * ld + j] -= acc[x][y][g];
         }
   }
-  if (t == 0 && s + 1 < nblk) {
-    __threadfence();
-    __syncthreads();
-    if (threadIdx.x < 64) {
-      const size_t off = size_t(rest) * ld + rest;
-      cxchol::potrf_inverse_block(W + off, ld, F + off, ld, NB, uinv + size_t(b + 1) * NB * NB, not_pd, lds);
-    }
+  if (t == 0 && s + 1 < nblk && threadIdx.x < 64) {
+    // the next diagonal block is the quadrant this wavefront has just updated (see k_chol_step)
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+    const size_t off = size_t(rest) * ld + rest;
+    cxchol::potrf_inverse_block(W + off, ld, F + off, ld, NB, uinv + size_t(b + 1) * NB * NB, not_pd, lds);
   }
 }
 

@@ -12,6 +12,8 @@ constexpr int NB = 32;  // panel width: the wave-level diagonal factorisation ke
 
 typedef double double4_t __attribute__((ext_vector_type(4)));
 
+constexpr int kPotrfLds = NB * NB + NB;  // LDS doubles potrf_inverse_block needs: a copy of U and 1 / diag(U)
+
 // v at lane `l` (compile-time constant), as a wave-uniform value: two v_readlane_b32
 __device__ __forceinline__ double readlane_f64(double v, int l) {
   const unsigned long long u = __double_as_longlong(v);
@@ -24,7 +26,13 @@ __device__ __forceinline__ double readlane_f64(double v, int l) {
 // F (ld n) and U_kk^-1 (NB x NB row-major, identity-padded) into uinv.  Lane c owns column c of the block
 // in NB registers; right-looking, fully unrolled, pivot row broadcast by v_readlane (no LDS round trip
 // or barrier in the 32-step chain).  The inverse is then formed column by column from an LDS copy of U
-// (broadcast reads), lds: NB * NB + NB doubles.
+// (broadcast reads), lds: kPotrfLds doubles.
+// Measured, MI355X: 14.4 us per call warm (tools/potrf_bench.hip; 20 k of its 31 k cycles in the 496 broadcast + fp64
+// FMA pairs of the factorisation -- an fp64 FMA costs a lone wavefront 8 cycles --, 6 k in its 64 narrow stores,
+// 5 k in the inverse), ~22 us cold inside a step kernel.  A/B: the same routine blocked by 16 (two 16-column
+// factorisations and inverses on the vector ALU, the four 16x16x16 products of U12, the Schur update and V12 on
+// v_mfma_f64_16x16x4_f64, a third of the instructions) ran 9.3 us warm but LOST in place on the same box:
+// Dubrovnik-356 reduced solve 4.18 -> 4.29 ms, tile-sparse Final 175 -> 186 ms; it is not kept.
 // Pointer form: Wblk / Fblk address the block's (0, 0) entry, ldw / ldf are the row strides.
 __device__ __forceinline__ void potrf_inverse_block(const double* __restrict__ Wblk, int ldw, double* __restrict__ Fblk, int ldf,
                                                     int kb, double* __restrict__ uinv, int* __restrict__ not_pd,

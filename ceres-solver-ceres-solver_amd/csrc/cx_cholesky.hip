@@ -19,7 +19,8 @@
 // Measured alternatives (n = 3204, Dubrovnik-356): five kernels per step (potrf, per-column trsm,
 // syrk, blocked forward/backward substitution) 8.2 ms; the whole solve as one cooperative kernel with
 // grid barriers 10.2 ms (one workgroup per CU cannot hide the memory latency of its tiles after every
-// barrier's L2 invalidation); this file 4.6 ms (3.3 ms factor + 1.2 ms backward substitution).
+// barrier's L2 invalidation); this file 4.2 ms (2.9 ms factor + 1.2 ms backward substitution; 4.6 ms while an
+// agent-scope fence and a barrier stood in front of the look-ahead).
 #include <cstdlib>
 
 #include "cx_chol_blocks.h"
@@ -126,7 +127,7 @@ __global__ __launch_bounds__(256) void k_chol_augment(const double* __restrict__
 // first diagonal block
 __global__ __launch_bounds__(64) void k_chol_first(const double* __restrict__ W, int ldw, double* __restrict__ F, int n,
                                                    double* __restrict__ uinv, int* __restrict__ not_pd) {
-  __shared__ double lds[NB * NB + NB];
+  __shared__ double lds[cxchol::kPotrfLds];
   potrf_inverse_block(W, ldw, F, n, 0, min(NB, n), uinv, not_pd, lds);
 }
 
@@ -136,7 +137,7 @@ __global__ __launch_bounds__(64) void k_chol_first(const double* __restrict__ W,
 __global__ __launch_bounds__(256) void k_chol_step(double* __restrict__ W, int ldw, double* __restrict__ F, int n,
                                                    double* __restrict__ y, double* __restrict__ uinv, int k0, int parity,
                                                    int* __restrict__ not_pd) {
-  __shared__ double lds[NB * NB + NB];
+  __shared__ double lds[cxchol::kPotrfLds];
   const int kb = min(NB, n - k0);
   const int rest = k0 + kb;
   const int rem = n - rest;
@@ -151,10 +152,12 @@ __global__ __launch_bounds__(256) void k_chol_step(double* __restrict__ W, int l
   const int t = blockIdx.x;
   while (t >= first + (Tc - ti)) { first += Tc - ti; ++ti; }
   fused_tile(W, ldw, F, n, y, ui, k0, kb, ti, ti + (t - first), true);
-  if (t == 0) {
-    __threadfence();
-    __syncthreads();
-    if (threadIdx.x < 64) potrf_inverse_block(W, ldw, F, n, rest, min(NB, n - rest), uinv + (parity ^ 1) * NB * NB, not_pd, lds);
+  if (t == 0 && threadIdx.x < 64) {
+    // look-ahead: the next diagonal block is the quadrant this very wavefront has just updated, so its own program
+    // order is all the ordering needed (a workgroup-scope fence = wait for its stores; the agent-scope
+    // __threadfence + barrier that stood here cost several us per step for nothing)
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+    potrf_inverse_block(W, ldw, F, n, rest, min(NB, n - rest), uinv + (parity ^ 1) * NB * NB, not_pd, lds);
   }
 }
 

@@ -98,7 +98,7 @@ __global__ void k_sp_rhs(const double* __restrict__ rhs, const int32_t* __restri
 
 __global__ __launch_bounds__(64) void k_sp_first(const double* __restrict__ W, double* __restrict__ F, int n, double* __restrict__ uinv,
                                                  int* __restrict__ not_pd) {
-  __shared__ double lds[NB * NB + NB];
+  __shared__ double lds[cxchol::kPotrfLds];
   cxchol::potrf_inverse_block(W, kTile, F, kTile, min(NB, n), uinv, not_pd, lds);
 }
 
@@ -108,7 +108,7 @@ __global__ __launch_bounds__(64) void k_sp_first(const double* __restrict__ W, d
 __global__ __launch_bounds__(256) void k_sp_step(double* __restrict__ W, double* __restrict__ F, const int32_t* __restrict__ row_start,
                                                  const int32_t* __restrict__ row_tiles, int n, int T, double* __restrict__ uinv,
                                                  int k0, int parity, int* __restrict__ not_pd) {
-  __shared__ double lds[NB * NB + NB];
+  __shared__ double lds[cxchol::kPotrfLds];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int li = lane & 15, lk = lane >> 4;
   const int kb = min(NB, n - k0), rest = k0 + kb;
@@ -184,9 +184,11 @@ __global__ __launch_bounds__(256) void k_sp_step(double* __restrict__ W, double*
   if (blockIdx.x == 0 && rest < n) {
     // look-ahead: the next diagonal block lies in the tile this workgroup has just updated, or in a
     // tile this step does not touch
-    __threadfence();
-    __syncthreads();
-    if (tid < 64) {
+    // owner of the next diagonal block: an upper-half step updates it as quadrant (1, 1) of the diagonal tile
+    // (wavefront 3), a lower-half step as quadrant (0, 0) of the next diagonal tile (wavefront 0) or not at all --
+    // either way one wavefront's own program order suffices (see k_chol_step)
+    if (wave == (half ? 0 : 3)) {
+      __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
       const int In = rest >> 6, hn = (rest >> 5) & 1;
       const size_t off = size_t(row_start[In]) * kTileDoubles + size_t(32 * hn) * kTile + 32 * hn;
       cxchol::potrf_inverse_block(W + off, kTile, F + off, kTile, min(NB, n - rest), uinv + (parity ^ 1) * NB * NB, not_pd, lds);
