@@ -290,7 +290,9 @@ int cx_schur_sparse_structure(cx_matrix* A, int64_t* num_cells, int32_t* cell_ro
  * (visibility_based_preconditioner.h:130-199): cluster_membership_[num cameras], num_clusters_, cluster_pairs_
  * (c1 <= c2, lexicographic) and block_pairs_ (f-block pairs b1 <= b2 of the preconditioner matrix, lexicographic).
  * Counts are always set; arrays (may be NULL) receive up to their capacity.  Static <2,3,9> matrices only.
- * Ties the reference leaves to hash-table iteration order are broken by ascending id. */
+ * Ties the reference leaves to hash-table iteration order are broken by ascending id.  On a sharded
+ * matrix membership and cluster pairs are global (the visibility counts are summed over the ranks), block pairs are
+ * the rank's own. */
 int cx_visibility_structure(cx_matrix* A, int32_t preconditioner_type, int32_t clustering_type, int32_t* membership,
                             int32_t* num_clusters, int32_t* num_cluster_pairs, int32_t* cluster_pair_1,
                             int32_t* cluster_pair_2, int32_t cluster_pair_capacity, int64_t* num_block_pairs,
