@@ -135,13 +135,13 @@ __global__ __launch_bounds__(64) void k_chol_first(const double* __restrict__ W,
 // the trailing matrix (row ti has Tc - ti tiles; the last column tile holds the right-hand side); block
 // 0 owns tile (0,0) and the look-ahead.  Tr == 0 (last block step): only the right-hand side is left.
 __global__ __launch_bounds__(256) void k_chol_step(double* __restrict__ W, int ldw, double* __restrict__ F, int n,
-                                                   double* __restrict__ y, double* __restrict__ uinv, int k0, int parity,
+                                                   double* __restrict__ y, double* __restrict__ uinv, int k0,
                                                    int* __restrict__ not_pd) {
   __shared__ double lds[cxchol::kPotrfLds];
   const int kb = min(NB, n - k0);
   const int rest = k0 + kb;
   const int rem = n - rest;
-  const double* ui = uinv + parity * NB * NB;
+  const double* ui = uinv + size_t(k0 / NB) * NB * NB;  // every block's inverse is kept: the backward substitution uses them
   const int Tr = (rem + 63) / 64;
   const int Tc = (rem + 1 + 63) / 64;
   if (Tr == 0) {
@@ -157,46 +157,72 @@ __global__ __launch_bounds__(256) void k_chol_step(double* __restrict__ W, int l
     // order is all the ordering needed (a workgroup-scope fence = wait for its stores; the agent-scope
     // __threadfence + barrier that stood here cost several us per step for nothing)
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
-    potrf_inverse_block(W, ldw, F, n, rest, min(NB, n - rest), uinv + (parity ^ 1) * NB * NB, not_pd, lds);
+    potrf_inverse_block(W, ldw, F, n, rest, min(NB, n - rest), uinv + size_t(rest / NB) * NB * NB, not_pd, lds);
   }
 }
 
-// Backward substitution, same scheme: U_kk x_blk = x_blk (lane t owns row t of U_kk), then
-// x(i) -= U(i, blk) x_blk for the rows above the block.
-__global__ __launch_bounds__(256) void k_trsv_bwd(const double* __restrict__ A, int n, int k0, int kb,
-                                                  double* __restrict__ x, double* __restrict__ sol) {
-  __shared__ double Us[NB * (NB + 1)];
-  __shared__ double xs[NB];
+// Backward substitution, two blocks (64 rows k0 .. k0 + 63) per launch, right-looking: every workgroup first solves
+// the 64 x 64 triangular system of the group with the stored inverses of its two diagonal blocks,
+//   x2 = U22^-1 y2,  x1 = U11^-1 (y1 - U12 x2)
+// (three 32 x 32 matrix-vector products; workgroup 0 stores x), then workgroup w subtracts U(i, group) x from the
+// 64 rows i = 64 w .. above the group.  Half as many dependent launches as one block per launch (a launch of this
+// size is ~10 us of dispatch and drain around ~5 us of work) and no 32-step substitution chain.
+__device__ __forceinline__ void gemv32(const double* __restrict__ M, int ldm, bool upper_only, const double* __restrict__ v,
+                                       double* __restrict__ out, int rows_valid, int cols_valid) {
+  // out[m] = sum_c M[m][c] v[c]; 8 threads per row, 4 columns each
+  const int t = threadIdx.x, m = t >> 3, part = t & 7;
+  double s = 0.0;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int c = 4 * part + q;
+    const bool in = m < rows_valid && c < cols_valid && (!upper_only || c >= m);
+    s += in ? M[size_t(m) * ldm + c] * v[c] : 0.0;
+  }
+  s += __shfl_xor(s, 1, 64);
+  s += __shfl_xor(s, 2, 64);
+  s += __shfl_xor(s, 4, 64);
+  if (part == 0) out[m] = s;
+}
+
+__global__ __launch_bounds__(256) void k_trsv_bwd64(const double* __restrict__ A, int n, int k0, const double* __restrict__ uinv,
+                                                    double* __restrict__ x, double* __restrict__ sol) {
+  __shared__ double y1[NB], y2[NB], x1[NB], x2[NB], tmp[NB];
   const int t = threadIdx.x;
-  if (t < NB)
-    for (int i = 0; i < NB; ++i) Us[i * (NB + 1) + t] = (i < kb && t < kb && t >= i) ? A[size_t(k0 + i) * n + k0 + t] : ((i == t) ? 1.0 : 0.0);
-  __syncthreads();
-  if (t < 64) {
-    double Urow[NB];  // Urow[c] = U(t, c)
-#pragma unroll
-    for (int c = 0; c < NB; ++c) Urow[c] = (t < NB) ? Us[t * (NB + 1) + c] : ((c == t) ? 1.0 : 0.0);
-    double diag = 1.0;
-#pragma unroll
-    for (int c = 0; c < NB; ++c) if (c == t) diag = Urow[c];
-    const double rdiag = 1.0 / diag;
-    double xt = (t < kb) ? x[k0 + t] : 0.0;
-#pragma unroll
-    for (int i = NB - 1; i >= 0; --i) {
-      const double xi = readlane_f64(xt * rdiag, i);
-      if (t == i) xt = xi;
-      if (t < i) xt -= Urow[i] * xi;
-    }
-    if (t < NB) xs[t] = xt;
-    if (blockIdx.x == 0 && t < kb) sol[k0 + t] = xt;
+  const int kb1 = min(NB, n - k0), kb2 = max(0, min(NB, n - k0 - NB));
+  if (t < NB) {
+    y1[t] = t < kb1 ? x[k0 + t] : 0.0;
+    y2[t] = t < kb2 ? x[k0 + NB + t] : 0.0;
   }
   __syncthreads();
-  // 4 threads per row above the block, 8 columns each
+  const double* __restrict__ ui1 = uinv + size_t(k0 / NB) * NB * NB;
+  if (kb2 > 0) {
+    gemv32(ui1 + NB * NB, NB, true, y2, x2, NB, NB);                       // x2 = U22^-1 y2 (identity-padded inverse)
+    __syncthreads();
+    gemv32(A + size_t(k0) * n + k0 + NB, n, false, x2, tmp, kb1, kb2);     // U12 x2
+    __syncthreads();
+    if (t < NB) y1[t] -= tmp[t];
+  } else if (t < NB) {
+    x2[t] = 0.0;
+  }
+  __syncthreads();
+  gemv32(ui1, NB, true, y1, x1, NB, NB);                                    // x1 = U11^-1 (y1 - U12 x2)
+  __syncthreads();
+  if (blockIdx.x == 0 && t < 64) {
+    const double v = t < NB ? x1[t] : x2[t - NB];
+    if (t < kb1 + kb2) sol[k0 + t] = v;   // not into x: other workgroups still read the group's y
+  }
+  // 4 threads per row above the group, 16 columns of the group each
   const int gi = blockIdx.x * 64 + (t >> 2);
   const int part = t & 3;
   double s = 0.0;
   if (gi < k0) {
-    const double* row = A + size_t(gi) * n + k0;
-    for (int c = part * (NB / 4); c < min(kb, (part + 1) * (NB / 4)); ++c) s += row[c] * xs[c];
+    const double* __restrict__ row = A + size_t(gi) * n + k0;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      const int c = 16 * part + q;
+      const double xv = c < NB ? x1[c] : x2[c - NB];
+      s += c < kb1 + kb2 ? row[c] * xv : 0.0;
+    }
   }
   s += __shfl_xor(s, 1, 64);
   s += __shfl_xor(s, 2, 64);
@@ -210,25 +236,22 @@ int cxd_cholesky_solve(cx_context* ctx, int n, double* a, const double* rhs, dou
   hipStream_t st = ctx->stream;
   const int ldw = ((n + 1 + 15) / 16) * 16;
   const size_t wsize = size_t(n) * ldw;
-  CX_TRY(ctx->chol_scratch.alloc(wsize + size_t(n) + 2 * NB * NB));
+  CX_TRY(ctx->chol_scratch.alloc(wsize + size_t(n) + size_t((n + NB - 1) / NB) * NB * NB));
   double* W = ctx->chol_scratch.p;
   double* y = W + wsize;  // U^-T rhs, then updated in place by the backward substitution
-  double* uinv = y + n;
+  double* uinv = y + n;  // one inverted diagonal block per 32 rows
   hipLaunchKernelGGL(k_chol_augment, dim3((n + 1 + 255) / 256, n), dim3(256), 0, st, (const double*)a, rhs, n, ldw, W);
   hipLaunchKernelGGL(k_chol_first, dim3(1), dim3(64), 0, st, (const double*)W, ldw, a, n, uinv, d_flag);
-  int parity = 0;
-  for (int k0 = 0; k0 < n; k0 += NB, parity ^= 1) {
+  for (int k0 = 0; k0 < n; k0 += NB) {
     const int rem = n - std::min(n, k0 + NB);
     const int Tr = (rem + 63) / 64, Tc = (rem + 1 + 63) / 64;
     const int NT = Tr == 0 ? 1 : Tr * Tc - Tr * (Tr - 1) / 2;
-    hipLaunchKernelGGL(k_chol_step, dim3(NT), dim3(256), 0, st, W, ldw, a, n, y, uinv, k0, parity, d_flag);
+    hipLaunchKernelGGL(k_chol_step, dim3(NT), dim3(256), 0, st, W, ldw, a, n, y, uinv, k0, d_flag);
   }
   CX_HIP(hipGetLastError());
-  const int last = ((n - 1) / NB) * NB;
-  for (int k0 = last; k0 >= 0; k0 -= NB) {
-    const int kb = std::min(NB, n - k0);
-    hipLaunchKernelGGL(k_trsv_bwd, dim3(std::max(1, (k0 + 63) / 64)), dim3(256), 0, st, (const double*)a, n, k0, kb, y, x);
-  }
+  const int last = ((n - 1) / 64) * 64;
+  for (int k0 = last; k0 >= 0; k0 -= 64)
+    hipLaunchKernelGGL(k_trsv_bwd64, dim3(std::max(1, (k0 + 63) / 64)), dim3(256), 0, st, (const double*)a, n, k0, (const double*)uinv, y, x);
   CX_HIP(hipGetLastError());
   return CX_OK;
 }
