@@ -14,13 +14,14 @@
 //     dense, MFMA-bound piece;
 //   * tiles of the first tile row store X: together they write rows k.. of the factor;
 //   * the workgroup of tile (0,0) goes on to factor and invert the next diagonal block (look-ahead).
-// Backward substitution follows, one launch per block (k_trsv_bwd).
+// Backward substitution follows, one launch per two blocks (k_trsv_bwd64).
 //
 // Measured alternatives (n = 3204, Dubrovnik-356): five kernels per step (potrf, per-column trsm,
 // syrk, blocked forward/backward substitution) 8.2 ms; the whole solve as one cooperative kernel with
 // grid barriers 10.2 ms (one workgroup per CU cannot hide the memory latency of its tiles after every
-// barrier's L2 invalidation); this file 4.2 ms (2.9 ms factor + 1.2 ms backward substitution; 4.6 ms while an
-// agent-scope fence and a barrier stood in front of the look-ahead).
+// barrier's L2 invalidation); this file 3.3 ms (2.9 ms factor + 0.4 ms backward substitution; 4.6 ms while an
+// agent-scope fence and a barrier stood in front of the look-ahead and the backward substitution took one launch
+// per 32-row block).
 #include <cstdlib>
 
 #include "cx_chol_blocks.h"

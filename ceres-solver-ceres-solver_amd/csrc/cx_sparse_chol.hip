@@ -17,7 +17,8 @@
 //   numeric    the dense solver's step kernel with tile indirection: one launch per 32-column block step,
 //              a workgroup per pair of non-zero tiles of the step's tile row, panel solve and trailing
 //              update on fp64 MFMA, look-ahead factorisation of the next diagonal block
-//   solve      one launch per block for the backward substitution, then the inverse permutation
+//   solve      one launch per tile row (64 rows) for the backward substitution, with the kept inverses of the
+//              diagonal blocks, then the inverse permutation
 // The factorisation is bound by the ~25 us a dependent launch + diagonal block cost on this part
 // (n / 32 steps), not by flops or bytes.
 #include <algorithm>
@@ -107,13 +108,13 @@ __global__ __launch_bounds__(64) void k_sp_first(const double* __restrict__ W, d
 // pair (a <= b) number t of that list: target tile (L[a], L[b]), panel pieces from tiles (I, L[a]), (I, L[b]).
 __global__ __launch_bounds__(256) void k_sp_step(double* __restrict__ W, double* __restrict__ F, const int32_t* __restrict__ row_start,
                                                  const int32_t* __restrict__ row_tiles, int n, int T, double* __restrict__ uinv,
-                                                 int k0, int parity, int* __restrict__ not_pd) {
+                                                 int k0, int* __restrict__ not_pd) {
   __shared__ double lds[cxchol::kPotrfLds];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int li = lane & 15, lk = lane >> 4;
   const int kb = min(NB, n - k0), rest = k0 + kb;
   const int I = k0 >> 6, half = (k0 >> 5) & 1;
-  const double* ui = uinv + parity * NB * NB;
+  const double* ui = uinv + size_t(k0 / NB) * NB * NB;  // all block inverses are kept (backward substitution)
   const int rs = row_start[I] + half;  // a lower-half step has left the diagonal tile behind
   const int m = row_start[I + 1] - rs;
   int a, b;
@@ -191,7 +192,7 @@ __global__ __launch_bounds__(256) void k_sp_step(double* __restrict__ W, double*
       __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
       const int In = rest >> 6, hn = (rest >> 5) & 1;
       const size_t off = size_t(row_start[In]) * kTileDoubles + size_t(32 * hn) * kTile + 32 * hn;
-      cxchol::potrf_inverse_block(W + off, kTile, F + off, kTile, min(NB, n - rest), uinv + (parity ^ 1) * NB * NB, not_pd, lds);
+      cxchol::potrf_inverse_block(W + off, kTile, F + off, kTile, min(NB, n - rest), uinv + size_t(rest / NB) * NB * NB, not_pd, lds);
     }
   }
 }
@@ -203,53 +204,72 @@ __global__ void k_sp_gather_y(const double* __restrict__ F, const int32_t* __res
   y[i] = F[size_t(row_start[(i >> 6) + 1] - 1) * kTileDoubles + size_t(i & 63) * kTile];
 }
 
-// Backward substitution for block k0, right-looking like the dense solver's k_trsv_bwd: every workgroup solves
-// U_kk x_blk = y_blk itself (first wavefront; workgroup 0 stores it), then workgroup w subtracts U(i, blk) x_blk
-// from the 64 rows of the w-th tile of tile column I (transposed tile index; the diagonal tile contributes its
-// upper rows in a lower-half step).  One short, wide launch per block instead of one long, narrow one.
-__global__ __launch_bounds__(256) void k_sp_bwd(const double* __restrict__ F, const int32_t* __restrict__ row_start,
-                                                const int32_t* __restrict__ col_start, const int32_t* __restrict__ col_pool,
-                                                const int32_t* __restrict__ col_row, int n, int k0, double* __restrict__ y,
-                                                double* __restrict__ x) {
-  __shared__ double xs[NB];
-  const int t = threadIdx.x;
-  const int kb = min(NB, n - k0);
-  const int I = k0 >> 6, half = (k0 >> 5) & 1;
-  if (t < 64) {
-    const double* __restrict__ Ukk = F + size_t(row_start[I]) * kTileDoubles + size_t(32 * half) * kTile + 32 * half;
-    double Urow[NB];  // Urow[c] = U(t, c)
-#pragma unroll
-    for (int c = 0; c < NB; ++c) Urow[c] = (t < kb && c < kb && c >= t) ? Ukk[size_t(t) * kTile + c] : ((c == t) ? 1.0 : 0.0);
-    double diag = 1.0;
-#pragma unroll
-    for (int c = 0; c < NB; ++c) if (c == t) diag = Urow[c];
-    const double rdiag = 1.0 / diag;
-    double xt = (t < kb) ? y[k0 + t] : 0.0;
-#pragma unroll
-    for (int i = NB - 1; i >= 0; --i) {
-      const double xi = readlane_f64(xt * rdiag, i);
-      if (t == i) xt = xi;
-      if (t < i) xt -= Urow[i] * xi;
-    }
-    if (t < NB) xs[t] = xt;
-    if (blockIdx.x == 0 && t < kb) x[k0 + t] = xt;  // not into y: other workgroups still read y_blk
-  }
-  __syncthreads();
-  const int p = col_start[I] + blockIdx.x;
-  if (p >= col_start[I + 1]) return;
-  const int Ii = col_row[p];
-  // 4 threads per row of the tile, 8 columns of the block each
-  const int il = t >> 2, part = t & 3;
-  const int i = kTile * Ii + il;
+// out[m] = sum_c M[m][c] v[c] for a 32 x 32 block, 8 threads per row
+__device__ __forceinline__ void sp_gemv32(const double* __restrict__ M, int ldm, const double* __restrict__ v, double* __restrict__ out,
+                                          int rows_valid, int cols_valid) {
+  const int t = threadIdx.x, m = t >> 3, part = t & 7;
   double s = 0.0;
-  if (i < k0) {
-    const double* __restrict__ row = F + size_t(col_pool[p]) * kTileDoubles + size_t(il) * kTile + 32 * half + 8 * part;
 #pragma unroll
-    for (int c = 0; c < 8; ++c) s += (8 * part + c < kb) ? row[c] * xs[8 * part + c] : 0.0;
+  for (int q = 0; q < 4; ++q) {
+    const int c = 4 * part + q;
+    s += (m < rows_valid && c < cols_valid) ? M[size_t(m) * ldm + c] * v[c] : 0.0;
   }
   s += __shfl_xor(s, 1, 64);
   s += __shfl_xor(s, 2, 64);
-  if (i < k0 && part == 0) y[i] -= s;
+  s += __shfl_xor(s, 4, 64);
+  if (part == 0) out[m] = s;
+}
+
+// Backward substitution, one tile row (64 rows) per launch, as the dense solver's k_trsv_bwd64: every workgroup solves
+// the tile row's 64 x 64 triangular system with the stored inverses of its two diagonal blocks (x2 = U22^-1 y2,
+// x1 = U11^-1 (y1 - U12 x2)), then workgroup w subtracts (tile w of tile column I) x from that tile's 64 rows.
+__global__ __launch_bounds__(256) void k_sp_bwd64(const double* __restrict__ F, const int32_t* __restrict__ row_start,
+                                                  const int32_t* __restrict__ col_start, const int32_t* __restrict__ col_pool,
+                                                  const int32_t* __restrict__ col_row, int n, int I, const double* __restrict__ uinv,
+                                                  double* __restrict__ y, double* __restrict__ x) {
+  __shared__ double y1[NB], y2[NB], x1[NB], x2[NB], tmp[NB];
+  const int t = threadIdx.x;
+  const int k0 = kTile * I;
+  const int kb1 = min(NB, n - k0), kb2 = max(0, min(NB, n - k0 - NB));
+  if (t < NB) {
+    y1[t] = t < kb1 ? y[k0 + t] : 0.0;
+    y2[t] = t < kb2 ? y[k0 + NB + t] : 0.0;
+  }
+  __syncthreads();
+  const double* __restrict__ D = F + size_t(row_start[I]) * kTileDoubles;  // the diagonal tile
+  const double* __restrict__ ui1 = uinv + size_t(2 * I) * NB * NB;
+  if (kb2 > 0) {
+    sp_gemv32(ui1 + NB * NB, NB, y2, x2, NB, NB);
+    __syncthreads();
+    sp_gemv32(D + NB, kTile, x2, tmp, kb1, kb2);  // U12 x2
+    __syncthreads();
+    if (t < NB) y1[t] -= tmp[t];
+  } else if (t < NB) {
+    x2[t] = 0.0;
+  }
+  __syncthreads();
+  sp_gemv32(ui1, NB, y1, x1, NB, NB);
+  __syncthreads();
+  if (blockIdx.x == 0 && t < 64) {
+    const double v = t < NB ? x1[t] : x2[t - NB];
+    if (t < kb1 + kb2) x[k0 + t] = v;  // not into y: other workgroups still read the tile row's y
+  }
+  const int p = col_start[I] + blockIdx.x;
+  if (p >= col_start[I + 1]) return;
+  const int Ii = col_row[p];
+  if (Ii >= I) return;  // the diagonal tile's part (U12) is inside the group solve
+  const int il = t >> 2, part = t & 3;
+  const double* __restrict__ row = F + size_t(col_pool[p]) * kTileDoubles + size_t(il) * kTile + 16 * part;
+  double s = 0.0;
+#pragma unroll
+  for (int q = 0; q < 16; ++q) {
+    const int c = 16 * part + q;
+    const double xv = c < NB ? x1[c] : x2[c - NB];
+    s += c < kb1 + kb2 ? row[q] * xv : 0.0;
+  }
+  s += __shfl_xor(s, 1, 64);
+  s += __shfl_xor(s, 2, 64);
+  if (part == 0) y[kTile * Ii + il] -= s;
 }
 
 __global__ void k_sp_unpermute(const double* __restrict__ xp, const int32_t* __restrict__ cam_pos, double* __restrict__ x, int C) {
@@ -443,7 +463,7 @@ int cxsp_factor_and_solve(cx_matrix* A, const double* Df, const double* rhs, dou
   const size_t pool = size_t(A->sp_num_tiles) * kTileDoubles;
   CX_TRY(A->d_sp_W.alloc(pool));
   CX_TRY(A->d_sp_F.alloc(pool));
-  CX_TRY(A->d_sp_x.alloc(2 * size_t(n) + 2 * NB * NB));
+  CX_TRY(A->d_sp_x.alloc(2 * size_t(n) + size_t((n + NB - 1) / NB) * NB * NB));
   double* W = A->d_sp_W.p;
   double* F = A->d_sp_F.p;
   double* xp = A->d_sp_x.p;
@@ -459,22 +479,19 @@ int cxsp_factor_and_solve(cx_matrix* A, const double* Df, const double* rhs, dou
   hipLaunchKernelGGL(k_sp_rhs, dim3((n + 255) / 256), dim3(256), 0, st, rhs, (const int32_t*)A->d_sp_cam_pos.p,
                      (const int32_t*)A->d_sp_row_start.p, W, C);
   hipLaunchKernelGGL(k_sp_first, dim3(1), dim3(64), 0, st, (const double*)W, F, n, uinv, d_flag);
-  int parity = 0;
-  for (int k0 = 0; k0 < n; k0 += NB, parity ^= 1) {
+  for (int k0 = 0; k0 < n; k0 += NB) {
     const int I = k0 >> 6, half = (k0 >> 5) & 1;
     const int m = A->h_sp_row_start[size_t(I) + 1] - A->h_sp_row_start[size_t(I)] - half;
     hipLaunchKernelGGL(k_sp_step, dim3(unsigned(m * (m + 1) / 2)), dim3(256), 0, st, W, F, (const int32_t*)A->d_sp_row_start.p,
-                       (const int32_t*)A->d_sp_row_tiles.p, n, T, uinv, k0, parity, d_flag);
+                       (const int32_t*)A->d_sp_row_tiles.p, n, T, uinv, k0, d_flag);
   }
   CX_HIP(hipGetLastError());
   hipLaunchKernelGGL(k_sp_gather_y, dim3((n + 255) / 256), dim3(256), 0, st, (const double*)F, (const int32_t*)A->d_sp_row_start.p, yv, n);
-  const int last = ((n - 1) / NB) * NB;
-  for (int k0 = last; k0 >= 0; k0 -= NB) {
-    const int I = k0 >> 6;
-    const int tiles_above = A->h_sp_col_start[size_t(I) + 1] - A->h_sp_col_start[size_t(I)];
-    hipLaunchKernelGGL(k_sp_bwd, dim3(unsigned(std::max(1, tiles_above))), dim3(256), 0, st, (const double*)F,
+  for (int I = T - 1; I >= 0; --I) {
+    const int tiles = A->h_sp_col_start[size_t(I) + 1] - A->h_sp_col_start[size_t(I)];
+    hipLaunchKernelGGL(k_sp_bwd64, dim3(unsigned(std::max(1, tiles))), dim3(256), 0, st, (const double*)F,
                        (const int32_t*)A->d_sp_row_start.p, (const int32_t*)A->d_sp_col_start.p, (const int32_t*)A->d_sp_col_pool.p,
-                       (const int32_t*)A->d_sp_col_row.p, n, k0, yv, xp);
+                       (const int32_t*)A->d_sp_col_row.p, n, I, (const double*)uinv, yv, xp);
   }
   hipLaunchKernelGGL(k_sp_unpermute, dim3((n + 255) / 256), dim3(256), 0, st, (const double*)xp, (const int32_t*)A->d_sp_cam_pos.p, z, C);
   CX_HIP(hipGetLastError());
