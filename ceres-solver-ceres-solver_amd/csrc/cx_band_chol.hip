@@ -241,10 +241,17 @@ __global__ __launch_bounds__(256) void k_band_solve(const double* __restrict__ F
 // the Final shape.  Needs band + 64 <= kWin (otherwise k_band_solve).
 constexpr int kWin = 4096;
 
-__global__ __launch_bounds__(256) void k_band_solve_lds(const double* __restrict__ F, int ld, const double* __restrict__ uinv,
-                                                        const int32_t* __restrict__ path_first_blk, const int32_t* __restrict__ path_num_blk,
-                                                        const int32_t* __restrict__ blk_cend, const int32_t* __restrict__ row_src,
-                                                        const double* __restrict__ r_in, double* __restrict__ y, double* __restrict__ z_out) {
+// NT threads per workgroup: the walk is bound by the instruction issue of its one workgroup (per step ~100 KB of the
+// factor as 8-byte loads plus as many FMAs), so more wavefronts per path mean fewer instructions per wavefront.
+template <int NT>
+__global__ __launch_bounds__(NT) void k_band_solve_lds(const double* __restrict__ F, int ld, const double* __restrict__ uinv,
+                                                       const int32_t* __restrict__ path_first_blk, const int32_t* __restrict__ path_num_blk,
+                                                       const int32_t* __restrict__ blk_cend, const int32_t* __restrict__ row_src,
+                                                       const double* __restrict__ r_in, double* __restrict__ y, double* __restrict__ z_out) {
+  constexpr int KCF = NT >= 512 ? 1 : 512 / NT;       // column chunks of the forward update fetched before the barrier
+  constexpr int PU = NB * NB / NT;                    // pieces of the next inverse per thread
+  constexpr int PART = NT / NB;                       // threads per row in the backward dot products
+  constexpr int JB = 512 / PART;                      // loads in flight per thread and pass (512 columns of the row)
   __shared__ double yw[kWin];
   __shared__ double ui[2][NB * kUiStride];
   __shared__ double tb[NB], yb[NB];
@@ -252,15 +259,15 @@ __global__ __launch_bounds__(256) void k_band_solve_lds(const double* __restrict
   const int b0 = path_first_blk[blockIdx.x], nb = path_num_blk[blockIdx.x];
   const int r0 = NB * b0, r1 = NB * (b0 + nb);
   // r in band order
-  for (int r = r0 + tid; r < r1; r += 256) {
+  for (int r = r0 + tid; r < r1; r += NT) {
     const int src = row_src[r];
     y[r] = src >= 0 ? r_in[src] : 0.0;
   }
   __syncthreads();
   {
     const int hi = blk_cend[b0];
-    for (int c = r0 + tid; c < hi; c += 256) yw[c & (kWin - 1)] = y[c];
-    for (int i = tid; i < NB * NB; i += 256) ui[0][(i / NB) * kUiStride + (i % NB)] = uinv[size_t(b0) * NB * NB + i];
+    for (int c = r0 + tid; c < hi; c += NT) yw[c & (kWin - 1)] = y[c];
+    for (int i = tid; i < NB * NB; i += NT) ui[0][(i / NB) * kUiStride + (i % NB)] = uinv[size_t(b0) * NB * NB + i];
   }
   __syncthreads();
   // ---- forward: U' y = r
@@ -268,26 +275,27 @@ __global__ __launch_bounds__(256) void k_band_solve_lds(const double* __restrict
     const int b = b0 + s, k0 = NB * b, rest = k0 + NB, cend = blk_cend[b];
     const bool more = s + 1 < nb;
     const int next_cend = more ? blk_cend[b + 1] : cend;
-    double pu[4], pn[2];
+    double pu[PU], pn[KCF];
     if (more) {
 #pragma unroll
-      for (int q = 0; q < 4; ++q) pu[q] = uinv[size_t(b + 1) * NB * NB + tid + 256 * q];
+      for (int q = 0; q < PU; ++q) pu[q] = uinv[size_t(b + 1) * NB * NB + tid + NT * q];
 #pragma unroll
-      for (int q = 0; q < 2; ++q) {
-        const int c = cend + tid + 256 * q;
+      for (int q = 0; q < KCF; ++q) {
+        const int c = cend + tid + NT * q;
         pn[q] = c < next_cend ? y[c] : 0.0;
       }
     }
     // this step's block row of the factor: all loads in flight at once, before the barrier (they do not depend
-    // on y_b); 2 x 256 columns per pass cover bands up to 544, wider windows take the loop below
-    double f0[NB], f1[NB];
+    // on y_b); the first NT * KCF (>= 512) columns of the window, wider windows take the loop below
+    double f[KCF][NB];
     {
-      const int c0 = rest + tid, c1 = c0 + 256;
       const double* __restrict__ col = F + size_t(k0) * ld;
 #pragma unroll
-      for (int m = 0; m < NB; ++m) f0[m] = c0 < cend ? col[size_t(m) * ld + c0] : 0.0;
+      for (int q = 0; q < KCF; ++q) {
+        const int c = rest + tid + NT * q;
 #pragma unroll
-      for (int m = 0; m < NB; ++m) f1[m] = c1 < cend ? col[size_t(m) * ld + c1] : 0.0;
+        for (int m = 0; m < NB; ++m) f[q][m] = c < cend ? col[size_t(m) * ld + c] : 0.0;
+      }
     }
     if (tid < 64) {
       const int m = tid & 31, half = tid >> 5;
@@ -302,18 +310,15 @@ __global__ __launch_bounds__(256) void k_band_solve_lds(const double* __restrict
       }
     }
     __syncthreads();
-    {
-      const int c0 = rest + tid, c1 = c0 + 256;
-      double a0 = 0.0, a1 = 0.0;
 #pragma unroll
-      for (int m = 0; m < NB; ++m) {
-        a0 = fma(f0[m], yb[m], a0);
-        a1 = fma(f1[m], yb[m], a1);
-      }
-      if (c0 < cend) yw[c0 & (kWin - 1)] -= a0;
-      if (c1 < cend) yw[c1 & (kWin - 1)] -= a1;
+    for (int q = 0; q < KCF; ++q) {
+      const int c = rest + tid + NT * q;
+      double a = 0.0;
+#pragma unroll
+      for (int m = 0; m < NB; ++m) a = fma(f[q][m], yb[m], a);
+      if (c < cend) yw[c & (kWin - 1)] -= a;
     }
-    for (int c = rest + 512 + tid; c < cend; c += 256) {
+    for (int c = rest + NT * KCF + tid; c < cend; c += NT) {
       const double* __restrict__ col = F + size_t(k0) * ld + c;
       double acc = 0.0;
 #pragma unroll
@@ -323,16 +328,16 @@ __global__ __launch_bounds__(256) void k_band_solve_lds(const double* __restrict
     if (more) {
       double* __restrict__ un = ui[(s + 1) & 1];
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int i = tid + 256 * q;
+      for (int q = 0; q < PU; ++q) {
+        const int i = tid + NT * q;
         un[(i / NB) * kUiStride + (i % NB)] = pu[q];
       }
 #pragma unroll
-      for (int q = 0; q < 2; ++q) {
-        const int c = cend + tid + 256 * q;
+      for (int q = 0; q < KCF; ++q) {
+        const int c = cend + tid + NT * q;
         if (c < next_cend) yw[c & (kWin - 1)] = pn[q];
       }
-      for (int c = cend + 512 + tid; c < next_cend; c += 256) yw[c & (kWin - 1)] = y[c];
+      for (int c = cend + NT * KCF + tid; c < next_cend; c += NT) yw[c & (kWin - 1)] = y[c];
     }
     __syncthreads();
   }
@@ -342,27 +347,25 @@ __global__ __launch_bounds__(256) void k_band_solve_lds(const double* __restrict
   for (int s = nb - 1; s >= 0; --s) {
     const int b = b0 + s, k0 = NB * b, rest = k0 + NB, cend = blk_cend[b];
     const bool more = s > 0;
-    double pu[4], py = 0.0;
+    double pu[PU], py = 0.0;
     if (more) {
 #pragma unroll
-      for (int q = 0; q < 4; ++q) pu[q] = uinv[size_t(b - 1) * NB * NB + tid + 256 * q];
+      for (int q = 0; q < PU; ++q) pu[q] = uinv[size_t(b - 1) * NB * NB + tid + NT * q];
       if (tid < NB) py = y[k0 - NB + tid];
     }
     {
-      const int m = tid >> 3, part = tid & 7;
+      const int m = tid / PART, part = tid % PART;
       const double* __restrict__ row = F + size_t(k0 + m) * ld;
       double acc = 0.0;
-      // 64 loads in flight per pass (512 columns of the row)
       for (int base = rest + part; base < cend; base += 512) {
-        double fr[64];
+        double fr[JB];
 #pragma unroll
-        for (int j = 0; j < 64; ++j) fr[j] = base + 8 * j < cend ? row[base + 8 * j] : 0.0;
+        for (int j = 0; j < JB; ++j) fr[j] = base + PART * j < cend ? row[base + PART * j] : 0.0;
 #pragma unroll
-        for (int j = 0; j < 64; ++j) acc = base + 8 * j < cend ? fma(fr[j], yw[(base + 8 * j) & (kWin - 1)], acc) : acc;  // (stale slots may hold NaN)
+        for (int j = 0; j < JB; ++j) acc = base + PART * j < cend ? fma(fr[j], yw[(base + PART * j) & (kWin - 1)], acc) : acc;  // (stale slots may hold NaN)
       }
-      acc += __shfl_xor(acc, 1, 64);
-      acc += __shfl_xor(acc, 2, 64);
-      acc += __shfl_xor(acc, 4, 64);
+#pragma unroll
+      for (int d = 1; d < PART; d <<= 1) acc += __shfl_xor(acc, d, 64);
       if (part == 0) yb[m] = tb[m] - acc;
     }
     __syncthreads();
@@ -381,15 +384,15 @@ __global__ __launch_bounds__(256) void k_band_solve_lds(const double* __restrict
     if (more) {
       double* __restrict__ un = ui[(s - 1) & 1];
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int i = tid + 256 * q;
+      for (int q = 0; q < PU; ++q) {
+        const int i = tid + NT * q;
         un[(i / NB) * kUiStride + (i % NB)] = pu[q];
       }
       if (tid < NB) tb[tid] = py;
     }
     __syncthreads();
   }
-  for (int r = r0 + tid; r < r1; r += 256) {
+  for (int r = r0 + tid; r < r1; r += NT) {
     const int src = row_src[r];
     if (src >= 0) z_out[src] = y[r];
   }
@@ -430,10 +433,18 @@ int cxv_factor(cx_matrix* A, cx_vis_plan* plan, const double* D, bool halve_offd
 
 int cxv_solve(cx_matrix* A, cx_vis_plan* plan, const double* r, double* z) {
   const bool force_global = std::getenv("CX_BAND_SOLVE_GLOBAL") != nullptr;  // A/B switch, read per call so tests can flip it
-  if (plan->ld + 64 <= kWin && !force_global)
-    hipLaunchKernelGGL(k_band_solve_lds, dim3(unsigned(plan->num_paths)), dim3(256), 0, A->ctx->stream, (const double*)plan->d_F.p, plan->ld,
-                       (const double*)plan->d_uinv.p, (const int32_t*)plan->d_path_first_blk.p, (const int32_t*)plan->d_path_num_blk.p,
-                       (const int32_t*)plan->d_blk_cend.p, (const int32_t*)plan->d_row_src.p, r, plan->d_y.p, z);
+  static const int threads = std::getenv("CX_BAND_SOLVE_THREADS") ? std::atoi(std::getenv("CX_BAND_SOLVE_THREADS")) : 512;
+  if (plan->ld + 64 <= kWin && !force_global) {
+#define CX_LAUNCH_BAND_SOLVE(NT)                                                                                                   \
+  hipLaunchKernelGGL(k_band_solve_lds<NT>, dim3(unsigned(plan->num_paths)), dim3(NT), 0, A->ctx->stream, (const double*)plan->d_F.p, \
+                     plan->ld, (const double*)plan->d_uinv.p, (const int32_t*)plan->d_path_first_blk.p,                              \
+                     (const int32_t*)plan->d_path_num_blk.p, (const int32_t*)plan->d_blk_cend.p, (const int32_t*)plan->d_row_src.p, \
+                     r, plan->d_y.p, z)
+    if (threads == 256) CX_LAUNCH_BAND_SOLVE(256);
+    else if (threads == 1024) CX_LAUNCH_BAND_SOLVE(1024);
+    else CX_LAUNCH_BAND_SOLVE(512);
+#undef CX_LAUNCH_BAND_SOLVE
+  }
   else
     hipLaunchKernelGGL(k_band_solve, dim3(unsigned(plan->num_paths)), dim3(256), 0, A->ctx->stream, (const double*)plan->d_F.p, plan->ld,
                        (const double*)plan->d_uinv.p, (const int32_t*)plan->d_path_first_blk.p, (const int32_t*)plan->d_path_num_blk.p,

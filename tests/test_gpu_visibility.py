@@ -79,9 +79,9 @@ def test_solve_matches_oracle(ctx, oracle, C, P, O, seed, pre, clustering):
     A.close()
 
 
-def test_global_memory_walk_gives_the_same_bits(ctx, oracle, monkeypatch):
+def test_global_memory_walk_agrees(ctx, oracle, monkeypatch):
     """k_band_solve (vector in global memory, used when the band does not fit the LDS window) and
-    k_band_solve_lds do the same arithmetic in the same order."""
+    k_band_solve_lds do the same arithmetic (the backward dot products are grouped differently: 1e-12)."""
     C, P, O, seed = 100, 3000, 14000, 3
     prob, bs, vals, b, D = make(oracle, C, P, O, seed)
     A = cx.Matrix(ctx, bs, P)
@@ -94,7 +94,7 @@ def test_global_memory_walk_gives_the_same_bits(ctx, oracle, monkeypatch):
         out.append(S.solve(A, b, D, r_tolerance=-1.0, q_tolerance=1e-3))
         S.close()
     assert out[0][1].num_iterations == out[1][1].num_iterations
-    assert np.array_equal(out[0][0], out[1][0])
+    assert relerr(out[0][0], out[1][0]) < 1e-12
     A.close()
 
 
