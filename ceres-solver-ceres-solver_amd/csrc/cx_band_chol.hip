@@ -248,7 +248,7 @@ __global__ __launch_bounds__(NT) void k_band_solve_lds(const double* __restrict_
                                                        const int32_t* __restrict__ path_first_blk, const int32_t* __restrict__ path_num_blk,
                                                        const int32_t* __restrict__ blk_cend, const int32_t* __restrict__ row_src,
                                                        const double* __restrict__ r_in, double* __restrict__ y, double* __restrict__ z_out) {
-  constexpr int KCF = NT >= 512 ? 1 : 512 / NT;       // column chunks of the forward update fetched before the barrier
+  constexpr int KCF = NT >= 512 ? 1 : 512 / NT;       // chunks of new window columns fetched a step ahead
   constexpr int PU = NB * NB / NT;                    // pieces of the next inverse per thread
   constexpr int PART = NT / NB;                       // threads per row in the backward dot products
   constexpr int JB = 512 / PART;                      // loads in flight per thread and pass (512 columns of the row)
@@ -286,16 +286,14 @@ __global__ __launch_bounds__(NT) void k_band_solve_lds(const double* __restrict_
       }
     }
     // this step's block row of the factor: all loads in flight at once, before the barrier (they do not depend
-    // on y_b); the first NT * KCF (>= 512) columns of the window, wider windows take the loop below
-    double f[KCF][NB];
+    // on y_b).  A thread owns two adjacent columns (16-byte loads: rows start at multiples of 16 doubles and the
+    // window at a multiple of 32); the first 2 NT columns of the window, wider windows take the loop below
+    double2 f[NB];
     {
       const double* __restrict__ col = F + size_t(k0) * ld;
+      const int c = rest + 2 * tid;
 #pragma unroll
-      for (int q = 0; q < KCF; ++q) {
-        const int c = rest + tid + NT * q;
-#pragma unroll
-        for (int m = 0; m < NB; ++m) f[q][m] = c < cend ? col[size_t(m) * ld + c] : 0.0;
-      }
+      for (int m = 0; m < NB; ++m) f[m] = c < cend ? *reinterpret_cast<const double2*>(col + size_t(m) * ld + c) : double2{0.0, 0.0};
     }
     if (tid < 64) {
       const int m = tid & 31, half = tid >> 5;
@@ -310,15 +308,19 @@ __global__ __launch_bounds__(NT) void k_band_solve_lds(const double* __restrict_
       }
     }
     __syncthreads();
+    {
+      const int c = rest + 2 * tid;
+      double a0 = 0.0, a1 = 0.0;
 #pragma unroll
-    for (int q = 0; q < KCF; ++q) {
-      const int c = rest + tid + NT * q;
-      double a = 0.0;
-#pragma unroll
-      for (int m = 0; m < NB; ++m) a = fma(f[q][m], yb[m], a);
-      if (c < cend) yw[c & (kWin - 1)] -= a;
+      for (int m = 0; m < NB; ++m) {
+        a0 = fma(f[m].x, yb[m], a0);
+        a1 = fma(f[m].y, yb[m], a1);
+      }
+      // (the column end is even only when the band's last row block is: guard the odd column separately)
+      if (c < cend) yw[c & (kWin - 1)] -= a0;
+      if (c + 1 < cend) yw[(c + 1) & (kWin - 1)] -= a1;
     }
-    for (int c = rest + NT * KCF + tid; c < cend; c += NT) {
+    for (int c = rest + 2 * NT + tid; c < cend; c += NT) {
       const double* __restrict__ col = F + size_t(k0) * ld + c;
       double acc = 0.0;
 #pragma unroll
@@ -357,12 +359,18 @@ __global__ __launch_bounds__(NT) void k_band_solve_lds(const double* __restrict_
       const int m = tid / PART, part = tid % PART;
       const double* __restrict__ row = F + size_t(k0 + m) * ld;
       double acc = 0.0;
-      for (int base = rest + part; base < cend; base += 512) {
-        double fr[JB];
+      // pairs of adjacent columns (16-byte loads), JB / 2 loads in flight per pass over 512 columns of the row
+      for (int base = rest + 2 * part; base < cend; base += 512) {
+        double2 fr[JB / 2];
 #pragma unroll
-        for (int j = 0; j < JB; ++j) fr[j] = base + PART * j < cend ? row[base + PART * j] : 0.0;
+        for (int j = 0; j < JB / 2; ++j) fr[j] = base + 2 * PART * j < cend ? *reinterpret_cast<const double2*>(row + base + 2 * PART * j) : double2{0.0, 0.0};
 #pragma unroll
-        for (int j = 0; j < JB; ++j) acc = base + PART * j < cend ? fma(fr[j], yw[(base + PART * j) & (kWin - 1)], acc) : acc;  // (stale slots may hold NaN)
+        for (int j = 0; j < JB / 2; ++j) {
+          const int c = base + 2 * PART * j;
+          // (stale slots of the ring may hold NaN: no multiplication by zero instead of the guards)
+          acc = c < cend ? fma(fr[j].x, yw[c & (kWin - 1)], acc) : acc;
+          acc = c + 1 < cend ? fma(fr[j].y, yw[(c + 1) & (kWin - 1)], acc) : acc;
+        }
       }
 #pragma unroll
       for (int d = 1; d < PART; d <<= 1) acc += __shfl_xor(acc, d, 64);
@@ -441,8 +449,7 @@ int cxv_solve(cx_matrix* A, cx_vis_plan* plan, const double* r, double* z) {
                      (const int32_t*)plan->d_path_num_blk.p, (const int32_t*)plan->d_blk_cend.p, (const int32_t*)plan->d_row_src.p, \
                      r, plan->d_y.p, z)
     if (threads == 256) CX_LAUNCH_BAND_SOLVE(256);
-    else if (threads == 1024) CX_LAUNCH_BAND_SOLVE(1024);
-    else CX_LAUNCH_BAND_SOLVE(512);
+    else CX_LAUNCH_BAND_SOLVE(512);  // 1 024 threads leave 128 registers per thread: the row block spills (6 s per solve)
 #undef CX_LAUNCH_BAND_SOLVE
   }
   else
