@@ -32,7 +32,9 @@ __device__ __forceinline__ double readlane_f64(double v, int l) {
 // 5 k in the inverse), ~22 us cold inside a step kernel.  A/B: the same routine blocked by 16 (two 16-column
 // factorisations and inverses on the vector ALU, the four 16x16x16 products of U12, the Schur update and V12 on
 // v_mfma_f64_16x16x4_f64, a third of the instructions) ran 9.3 us warm but LOST in place on the same box:
-// Dubrovnik-356 reduced solve 4.18 -> 4.29 ms, tile-sparse Final 175 -> 186 ms; it is not kept.
+// Dubrovnik-356 reduced solve 4.18 -> 4.29 ms, tile-sparse Final 175 -> 186 ms; it is not kept.  Broadcasting the pivot
+// row through LDS (one ds_read per row instead of two v_readlane) was slower both ways: 20.1 us warm, Dubrovnik-356
+// 3.29 -> 3.82 ms.
 // Pointer form: Wblk / Fblk address the block's (0, 0) entry, ldw / ldf are the row strides.
 __device__ __forceinline__ void potrf_inverse_block(const double* __restrict__ Wblk, int ldw, double* __restrict__ Fblk, int ldf,
                                                     int kb, double* __restrict__ uinv, int* __restrict__ not_pd,
