@@ -918,6 +918,35 @@ int CheckFlag(cx_solver* S, const char* what, cx_summary* summary, bool* failed)
   return CX_OK;
 }
 
+// Sharded set-up: the per-camera 9x9 blocks are symmetric, so their 45 distinct values and the 9 entries of the
+// reduced right-hand side travel together -- ONE all-reduce of 54 C doubles instead of 81 C and then 9 C.
+__global__ void k_pack_blocks_rhs(const double* __restrict__ blocks, const double* __restrict__ rhs, double* __restrict__ packed, int C,
+                                  int with_blocks) {
+  const int per = with_blocks ? 54 : 9;
+  const int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i >= int64_t(C) * per) return;
+  const int c = int(i / per), k = int(i - int64_t(c) * per);
+  const int kr = with_blocks ? k - 45 : k;
+  if (kr >= 0) { packed[i] = rhs[9 * int64_t(c) + kr]; return; }
+  int a = 0, rem = k;
+  while (rem >= 9 - a) { rem -= 9 - a; ++a; }
+  packed[i] = blocks[81 * int64_t(c) + a * 9 + a + rem];
+}
+__global__ void k_unpack_blocks_rhs(const double* __restrict__ packed, double* __restrict__ blocks, double* __restrict__ rhs, int C,
+                                    int with_blocks) {
+  const int per = with_blocks ? 54 : 9;
+  const int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i >= int64_t(C) * per) return;
+  const int c = int(i / per), k = int(i - int64_t(c) * per);
+  const int kr = with_blocks ? k - 45 : k;
+  if (kr >= 0) { rhs[9 * int64_t(c) + kr] = packed[i]; return; }
+  int a = 0, rem = k;
+  while (rem >= 9 - a) { rem -= 9 - a; ++a; }
+  const int bcol = a + rem;
+  blocks[81 * int64_t(c) + a * 9 + bcol] = packed[i];
+  blocks[81 * int64_t(c) + bcol * 9 + a] = packed[i];
+}
+
 // ------------------------------------------------------------------- solvers
 int SolveIterativeSchur239(cx_solver* S, cx_matrix* A, const double* b, const double* D, double r_tol,
                            double q_tol, double* x, cx_summary* summary) {
@@ -953,11 +982,18 @@ int SolveIterativeSchur239(cx_solver* S, cx_matrix* A, const double* b, const do
   CX_TRY(S->cam_blocks.alloc(81 * size_t(std::max(A->C, 1))));
   CX_TRY(cxs_implicit_init(A, D, b, want_blocks, o.preconditioner_type == CX_SCHUR_JACOBI, S->ete_inv.p, S->v_rows.p,
                            S->cam_blocks.p, S->v_rhs.p, S->flag.p));
-  if (want_blocks) {
-    if (ctx->nranks > 1) CX_TRY(cx_allreduce_device(ctx, S->cam_blocks.p, 81 * int64_t(A->C)));
-    CX_TRY(cxs_block9_add_diag_invert(ctx, S->cam_blocks.p, D ? D + ne : nullptr, A->C, S->flag.p));
+  if (ctx->nranks > 1 && A->C > 0) {
+    const int per = want_blocks ? 54 : 9;
+    const int64_t count = int64_t(A->C) * per;
+    CX_TRY(S->v_pack.alloc(size_t(count)));
+    hipLaunchKernelGGL(k_pack_blocks_rhs, dim3(grid_for(count, 256)), dim3(256), 0, st, (const double*)S->cam_blocks.p,
+                       (const double*)S->v_rhs.p, S->v_pack.p, A->C, want_blocks ? 1 : 0);
+    CX_TRY(cx_allreduce_device(ctx, S->v_pack.p, count));
+    hipLaunchKernelGGL(k_unpack_blocks_rhs, dim3(grid_for(count, 256)), dim3(256), 0, st, (const double*)S->v_pack.p, S->cam_blocks.p,
+                       S->v_rhs.p, A->C, want_blocks ? 1 : 0);
+    CX_HIP(hipGetLastError());
   }
-  if (ctx->nranks > 1) CX_TRY(cx_allreduce_device(ctx, S->v_rhs.p, nf));
+  if (want_blocks) CX_TRY(cxs_block9_add_diag_invert(ctx, S->cam_blocks.p, D ? D + ne : nullptr, A->C, S->flag.p));
   if (visibility) {
     // VisibilityBasedPreconditioner::UpdateImpl (visibility_based_preconditioner.cc:321-364)
     CX_TRY(cxv_factor(A, vis_plan, D, false, S->flag.p));

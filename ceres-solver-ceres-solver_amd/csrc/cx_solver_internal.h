@@ -99,7 +99,7 @@ struct cx_solver {
   KernelTimer ktimer;
   // persistent device scratch
   DevBuf<double> v_p, v_r, v_z, v_tmp, v_x, v_rhs, v_rows, v_rows2, v_cols;
-  DevBuf<double> ete_inv, cam_blocks, pt_blocks, g_e, lhs, partial;
+  DevBuf<double> ete_inv, cam_blocks, pt_blocks, g_e, lhs, partial, v_pack;
   DevBuf<CgState> state, spse_state;
   DevBuf<double> v_spse;
   CgState* ring_h = nullptr;  // host-pinned, device-visible ring of published CG states
