@@ -36,7 +36,7 @@ EXPORTED_SYMBOLS = [
     "cx_matrix_last_kernel_ms", "cx_solver_create", "cx_solver_destroy", "cx_solver_default_options",
     "cx_solver_solve", "cx_solver_last_timing", "cx_solver_kernel_stats", "cx_schur_eliminate_dense", "cx_schur_back_substitute",
     "cx_implicit_schur_multiply", "cx_dense_cholesky_solve", "cx_evaluator_create_bal", "cx_evaluator_destroy",
-    "cx_evaluator_jacobian", "cx_evaluator_row_of_observation", "cx_evaluator_evaluate", "cx_evaluator_set_loss", "cx_minimizer_default_options", "cx_minimize", "cx_schur_sparse_structure", "cx_visibility_structure",
+    "cx_evaluator_jacobian", "cx_evaluator_row_of_observation", "cx_evaluator_evaluate", "cx_evaluator_set_loss", "cx_minimizer_default_options", "cx_minimize", "cx_schur_sparse_structure", "cx_visibility_structure", "cx_visibility_clusters_host",
     "cx_evaluator_set_camera_model", "cx_evaluator_num_parameters", "cx_evaluator_num_effective_parameters", "cx_evaluator_plus",
     "cx_evaluator_last_kernel_ms", "cx_detect_structure", "cx_partition_points", "cx_stable_schur_ordering",
 ]
@@ -612,6 +612,20 @@ def visibility_structure(A, preconditioner_type, clustering_type=CANONICAL_VIEWS
                                        ctypes.byref(ncp), _ptr(cp1), _ptr(cp2), ncp.value, ctypes.byref(nbp), _ptr(bp1),
                                        _ptr(bp2), ctypes.c_int64(nbp.value)))
     return membership, nc.value, np.stack([cp1, cp2], 1), np.stack([bp1, bp2], 1)
+
+
+def visibility_clusters_host(bs, num_eliminate_blocks, preconditioner_type, clustering_type=CANONICAL_VIEWS):
+    """(membership, num_clusters, cluster pairs [k, 2]) from the block structure alone -- runs without a GPU."""
+    lib = load_library()
+    membership = np.zeros(bs.num_col_blocks - int(num_eliminate_blocks), dtype=np.int32)
+    nc, ncp = ctypes.c_int32(), ctypes.c_int32()
+    _check(lib.cx_visibility_clusters_host(bs.c, int(num_eliminate_blocks), int(preconditioner_type), int(clustering_type),
+                                           _ptr(membership), ctypes.byref(nc), ctypes.byref(ncp), None, None, 0))
+    cp1 = np.zeros(ncp.value, dtype=np.int32)
+    cp2 = np.zeros(ncp.value, dtype=np.int32)
+    _check(lib.cx_visibility_clusters_host(bs.c, int(num_eliminate_blocks), int(preconditioner_type), int(clustering_type),
+                                           _ptr(membership), ctypes.byref(nc), ctypes.byref(ncp), _ptr(cp1), _ptr(cp2), ncp.value))
+    return membership, nc.value, np.stack([cp1, cp2], 1)
 
 
 def detect_structure(bs, num_eliminate_blocks):

@@ -47,9 +47,8 @@ struct Graph {
 };
 
 // ComputeVisibility: points of every camera and cameras of every point, both ascending and distinct
-void Visibility(const cx_matrix* A, Csr* cam_pts, Csr* pt_cams) {
-  const int C = A->C, P = A->P;
-  const int64_t O = A->O;
+// (cells: two per row block, point cell then camera cell, rows sorted by point -- the static <2,3,9> layout)
+void Visibility(const cx_cell* cells, int C, int P, int64_t O, Csr* cam_pts, Csr* pt_cams) {
   pt_cams->start.assign(size_t(P) + 1, 0);
   pt_cams->idx.clear();
   pt_cams->idx.reserve(size_t(O));
@@ -57,8 +56,8 @@ void Visibility(const cx_matrix* A, Csr* cam_pts, Csr* pt_cams) {
   int64_t r = 0;
   for (int p = 0; p < P; ++p) {
     tmp.clear();
-    while (r < O && A->cells[size_t(2 * r)].block_id == p) {
-      tmp.push_back(A->cells[size_t(2 * r + 1)].block_id - P);
+    while (r < O && cells[size_t(2 * r)].block_id == p) {
+      tmp.push_back(cells[size_t(2 * r + 1)].block_id - P);
       ++r;
     }
     std::sort(tmp.begin(), tmp.end());
@@ -267,7 +266,7 @@ int ClusterForest(cx_context* ctx, int K, const std::vector<int32_t>& membership
   std::vector<WeightedEdge> edges;
   std::vector<int32_t> ks;
   const bool dense = int64_t(K) * K <= (int64_t(1) << 26);
-  if (!dense && ctx->nranks > 1) {
+  if (!dense && ctx != nullptr) {
     cx_set_error("CLUSTER_TRIDIAGONAL on a sharded matrix is limited to 8192 clusters (dense count exchange)");
     return CX_ERR_UNSUPPORTED;
   }
@@ -285,7 +284,7 @@ int ClusterForest(cx_context* ctx, int K, const std::vector<int32_t>& membership
         else sparse_counts[(uint64_t(uint32_t(ks[i])) << 32) | uint32_t(ks[j])]++;
       }
   }
-  if (dense && ctx->nranks > 1) {  // the other shards' points
+  if (dense && ctx != nullptr) {  // the other shards' points
     std::vector<double> sum(counts.begin(), counts.end());
     CX_TRY(SumOverRanks(ctx, &sum));
     for (size_t i = 0; i < sum.size(); ++i) counts[i] = int32_t(sum[i]);
@@ -320,16 +319,19 @@ int ClusterForest(cx_context* ctx, int K, const std::vector<int32_t>& membership
   return CX_OK;
 }
 
-int BuildPlan(cx_matrix* A, int preconditioner_type, int clustering_type, cx_vis_plan* plan) {
-  const int C = A->C;
+// Clusters and cluster pairs (everything VisibilityBasedPreconditioner derives from the structure alone).  ctx is the
+// context of a sharded matrix (the counts are then summed over its ranks) or null: no device is touched without it.
+int ComputeClusters(const cx_cell* cells, int C, int P, int64_t O, cx_context* ctx, int preconditioner_type, int clustering_type,
+                    cx_vis_plan* plan, std::vector<std::array<int32_t, 2>>* partner_out) {
   plan->preconditioner_type = preconditioner_type;
   plan->clustering_type = clustering_type;
+  const bool sharded = ctx != nullptr && ctx->nranks > 1;
   Csr cam_pts, pt_cams;
-  Visibility(A, &cam_pts, &pt_cams);
+  Visibility(cells, C, P, O, &cam_pts, &pt_cams);
   PairCounts upper = SharedPointCounts(C, cam_pts, pt_cams);
   std::vector<size_t> sizes(static_cast<size_t>(C));
   for (int c = 0; c < C; ++c) sizes[size_t(c)] = size_t(cam_pts.start[size_t(c) + 1] - cam_pts.start[size_t(c)]);
-  if (A->ctx->nranks > 1) CX_TRY(SumCountsOverRanks(A->ctx, C, &upper, &sizes));
+  if (sharded) CX_TRY(SumCountsOverRanks(ctx, C, &upper, &sizes));
   const Graph graph = SchurComplementGraph(C, upper, sizes);
   PairCounts().swap(upper);
   // ClusterCameras
@@ -358,8 +360,9 @@ int BuildPlan(cx_matrix* A, int preconditioner_type, int clustering_type, cx_vis
   }
   // cluster pairs; partner[k] = the (at most two) forest neighbours of cluster k
   std::vector<std::pair<int32_t, int32_t>> forest;
-  if (preconditioner_type == CX_CLUSTER_TRIDIAGONAL) CX_TRY(ClusterForest(A->ctx, K, plan->membership, pt_cams, &forest));
-  std::vector<std::array<int32_t, 2>> partner(size_t(K), std::array<int32_t, 2>{-1, -1});
+  if (preconditioner_type == CX_CLUSTER_TRIDIAGONAL) CX_TRY(ClusterForest(sharded ? ctx : nullptr, K, plan->membership, pt_cams, &forest));
+  std::vector<std::array<int32_t, 2>>& partner = *partner_out;
+  partner.assign(size_t(K), std::array<int32_t, 2>{-1, -1});
   for (const auto& e : forest) {
     for (int side = 0; side < 2; ++side) {
       const int32_t k = side ? e.second : e.first, other = side ? e.first : e.second;
@@ -370,6 +373,14 @@ int BuildPlan(cx_matrix* A, int preconditioner_type, int clustering_type, cx_vis
   for (int k = 0; k < K; ++k) plan->cluster_pairs.push_back({k, k});
   for (const auto& e : forest) plan->cluster_pairs.push_back({std::min(e.first, e.second), std::max(e.first, e.second)});
   std::sort(plan->cluster_pairs.begin(), plan->cluster_pairs.end());
+  return CX_OK;
+}
+
+int BuildPlan(cx_matrix* A, int preconditioner_type, int clustering_type, cx_vis_plan* plan) {
+  const int C = A->C;
+  std::vector<std::array<int32_t, 2>> partner;
+  CX_TRY(ComputeClusters(A->cells.data(), C, A->P, A->O, A->ctx, preconditioner_type, clustering_type, plan, &partner));
+  const int K = plan->num_clusters;
   // block pairs: the S cells (all diagonal cells + co-visible pairs, lexicographic: cxs_build_pair_lists) whose
   // cluster pair is in the preconditioner
   CX_TRY(cxs_build_pair_lists(A));
@@ -546,6 +557,41 @@ extern "C" int cx_visibility_structure(cx_matrix* A, int32_t preconditioner_type
   for (size_t k = 0; k < plan->sel_cells.size() && int64_t(k) < block_pair_capacity; ++k) {
     block_pair_1[k] = A->h_cell_c1[size_t(plan->sel_cells[k])];
     block_pair_2[k] = A->h_cell_c2[size_t(plan->sel_cells[k])];
+  }
+  return CX_OK;
+}
+
+// The same clustering without a device or a cx_matrix: straight from the flat block structure (static <2,3,9> layout:
+// two cells per row block, e-block first, rows sorted by e-block).  Used by the CPU tests of the host logic.
+extern "C" int cx_visibility_clusters_host(const cx_block_structure* bs, int32_t num_eliminate_blocks, int32_t preconditioner_type,
+                                           int32_t clustering_type, int32_t* membership, int32_t* num_clusters,
+                                           int32_t* num_cluster_pairs, int32_t* cluster_pair_1, int32_t* cluster_pair_2,
+                                           int32_t cluster_pair_capacity) {
+  CX_CHECK_ARG(bs != nullptr && num_eliminate_blocks > 0 && num_eliminate_blocks < bs->num_col_blocks);
+  CX_CHECK_ARG(preconditioner_type == CX_CLUSTER_JACOBI || preconditioner_type == CX_CLUSTER_TRIDIAGONAL);
+  CX_CHECK_ARG(clustering_type == CX_CANONICAL_VIEWS || clustering_type == CX_SINGLE_LINKAGE);
+  const int P = num_eliminate_blocks, C = bs->num_col_blocks - num_eliminate_blocks;
+  const int64_t O = bs->num_row_blocks;
+  int32_t last = -1;
+  for (int64_t r = 0; r < O; ++r) {
+    const int32_t first = bs->row_cell_begin[r];
+    const bool ok = bs->row_cell_begin[r + 1] - first == 2 && bs->cells[first].block_id < P && bs->cells[first].block_id >= last &&
+                    bs->cells[first + 1].block_id >= P && first == 2 * r;
+    if (!ok) {
+      cx_set_error("cx_visibility_clusters_host: static <2,3,9> layout expected (row block %lld)", (long long)r);
+      return CX_ERR_UNSUPPORTED;
+    }
+    last = bs->cells[first].block_id;
+  }
+  cx_vis_plan plan;
+  std::vector<std::array<int32_t, 2>> partner;
+  CX_TRY(ComputeClusters(bs->cells, C, P, O, nullptr, preconditioner_type, clustering_type, &plan, &partner));
+  if (membership) std::copy(plan.membership.begin(), plan.membership.end(), membership);
+  if (num_clusters) *num_clusters = plan.num_clusters;
+  if (num_cluster_pairs) *num_cluster_pairs = int32_t(plan.cluster_pairs.size());
+  for (size_t k = 0; k < plan.cluster_pairs.size() && int64_t(k) < cluster_pair_capacity; ++k) {
+    cluster_pair_1[k] = plan.cluster_pairs[k].first;
+    cluster_pair_2[k] = plan.cluster_pairs[k].second;
   }
   return CX_OK;
 }

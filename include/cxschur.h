@@ -297,6 +297,13 @@ int cx_visibility_structure(cx_matrix* A, int32_t preconditioner_type, int32_t c
                             int32_t* num_clusters, int32_t* num_cluster_pairs, int32_t* cluster_pair_1,
                             int32_t* cluster_pair_2, int32_t cluster_pair_capacity, int64_t* num_block_pairs,
                             int32_t* block_pair_1, int32_t* block_pair_2, int64_t block_pair_capacity);
+/* The clusters and cluster pairs of the same preconditioner computed from the flat block structure alone: no device,
+ * no matrix object: the host part of the structure analysis.  Static <2,3,9> layout as the device path requires,
+ * two cells per row block, e-block first, rows sorted by e-block. */
+int cx_visibility_clusters_host(const cx_block_structure* bs, int32_t num_eliminate_blocks, int32_t preconditioner_type,
+                                int32_t clustering_type, int32_t* membership, int32_t* num_clusters,
+                                int32_t* num_cluster_pairs, int32_t* cluster_pair_1, int32_t* cluster_pair_2,
+                                int32_t cluster_pair_capacity);
 int cx_schur_back_substitute(cx_context* ctx, cx_matrix* A, const double* b, const double* D,
                              const double* z, double* x, int32_t memspace);
 /* ImplicitSchurComplement: Init + RightMultiplyAndAccumulate

@@ -71,3 +71,38 @@ def test_stable_schur_ordering_matches_oracle(oracle):
         o1, k1 = cx.stable_schur_ordering(C, P, cam, pt)
         o2, k2 = oracle.stable_schur_ordering(C, P, cam, pt)
         assert k1 == k2 and np.array_equal(o1, o2)
+
+
+@pytest.mark.parametrize("clustering", ["CANONICAL_VIEWS", "SINGLE_LINKAGE"])
+@pytest.mark.parametrize("pre", ["CLUSTER_JACOBI", "CLUSTER_TRIDIAGONAL"])
+@pytest.mark.parametrize("C,P,O,seed", [(6, 40, 130, 1), (16, 700, 2800, 2), (49, 7776, 31843, 49), (100, 3000, 14000, 3),
+                                        (400, 9000, 40000, 4)])
+def test_visibility_clusters_host_matches_oracle(oracle, C, P, O, seed, pre, clustering):
+    """The library's host-side visibility clustering (flat arrays, cached quality differences, per-point cluster
+    counting) against the oracle's restatement with ordered sets and maps: integers, compared exactly.  No device."""
+    prob = cx.bal.make_bal_like(C, P, O, seed)
+    bs, _ = cx.bal.build_structure(prob)
+    m, k, cp = cx.binding.visibility_clusters_host(bs, P, getattr(cx, pre), getattr(cx, clustering))
+    mr, kr, cpr, _ = oracle.visibility_structure(bs, P, getattr(oracle, pre), getattr(oracle, clustering))
+    assert k == kr
+    assert np.array_equal(m, mr)
+    assert np.array_equal(cp, cpr)
+
+
+def test_visibility_clusters_host_larger_problem_and_layout_check():
+    """2 000 cameras: the clustering alone (no oracle at this size, it is quadratic in the clusters): every camera
+    gets a cluster, clusters are numbered by first appearance, the forest has at most K - 1 edges of degree <= 2;
+    structures outside the static layout are refused."""
+    prob = cx.bal.make_bal_like(2000, 60000, 300000, 11)
+    bs, _ = cx.bal.build_structure(prob)
+    m, k, cp = cx.binding.visibility_clusters_host(bs, prob.num_points, cx.CLUSTER_TRIDIAGONAL, cx.CANONICAL_VIEWS)
+    assert m.min() == 0 and m.max() == k - 1
+    first = {}
+    for c, cl in enumerate(m.tolist()):
+        first.setdefault(cl, c)
+    assert [first[i] for i in range(k)] == sorted(first.values())
+    off = cp[cp[:, 0] != cp[:, 1]]
+    assert len(off) <= k - 1 and np.bincount(off.ravel(), minlength=k).max() <= 2
+    bs6, values, b, D, nelim, raw = lls_problem(6)
+    with pytest.raises(cx.CxError):
+        cx.binding.visibility_clusters_host(bs6, nelim, cx.CLUSTER_JACOBI)
