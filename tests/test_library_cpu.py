@@ -106,3 +106,29 @@ def test_visibility_clusters_host_larger_problem_and_layout_check():
     bs6, values, b, D, nelim, raw = lls_problem(6)
     with pytest.raises(cx.CxError):
         cx.binding.visibility_clusters_host(bs6, nelim, cx.CLUSTER_JACOBI)
+
+
+@pytest.mark.parametrize("seed", range(40))
+def test_visibility_clusters_host_fuzz(oracle, seed):
+    """Random small structures -- few cameras, repeated visibility patterns, cameras nobody sees, so exact ties between
+    candidate views and equal forest weights are common: the library's clustering and the oracle's must still agree
+    entry for entry (both break ties by ascending id)."""
+    rng = np.random.default_rng(1000 + seed)
+    C = int(rng.integers(2, 14))
+    P = int(rng.integers(5, 60))
+    patterns = [sorted(rng.choice(C, size=int(rng.integers(1, min(C, 5) + 1)), replace=False).tolist())
+                for _ in range(int(rng.integers(1, 6)))]
+    lists = [patterns[int(rng.integers(0, len(patterns)))] for _ in range(P)]
+    cam, pt = [], []
+    for j, cams in enumerate(lists):
+        cam.extend(cams)
+        pt.extend([j] * len(cams))
+    cam, pt = np.array(cam, dtype=np.int32), np.array(pt, dtype=np.int32)
+    O = cam.size
+    prob = cx.bal.BalProblem(C, P, cam, pt, np.zeros((O, 2)), np.zeros((C, 9)), np.zeros((P, 3)))
+    bs, _ = cx.bal.build_structure(prob)
+    for pre in ("CLUSTER_JACOBI", "CLUSTER_TRIDIAGONAL"):
+        for clustering in ("CANONICAL_VIEWS", "SINGLE_LINKAGE"):
+            m, k, cp = cx.binding.visibility_clusters_host(bs, P, getattr(cx, pre), getattr(cx, clustering))
+            mr, kr, cpr, _ = oracle.visibility_structure(bs, P, getattr(oracle, pre), getattr(oracle, clustering))
+            assert k == kr and np.array_equal(m, mr) and np.array_equal(cp, cpr), (seed, pre, clustering)
