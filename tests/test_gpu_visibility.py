@@ -283,3 +283,42 @@ def test_edge_structures(ctx, oracle, case, pre, clustering):
     assert relerr(x, xr) < 1e-8
     S.close()
     A.close()
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_random_structures(ctx, oracle, seed):
+    """Randomly drawn visibility structures (as test_gpu_parity.test_random_structures_all_solvers: 1..C observations per
+    point, cameras nobody sees, single-camera problems) through both CLUSTER_* types and both clusterings: the
+    structure exactly, the solve to convergence (|dx| / n < 1e-9, same termination as the oracle)."""
+    rng = np.random.default_rng(1000 + seed)
+    C = int(rng.integers(1, 40))
+    P = int(rng.integers(1, 80))
+    lists = []
+    for j in range(P):
+        k = int(rng.integers(1, min(C, 9) + 1))
+        if rng.random() < 0.1:
+            k = C
+        lists.append(sorted(rng.choice(C, size=k, replace=False).tolist()))
+    prob = _custom_problem(C, lists)
+    bs, _ = cx.bal.build_structure(prob)
+    O = prob.num_observations
+    vals = cx.bal.random_jacobian_values(O, seed + 1)
+    b = rng.standard_normal(2 * O)
+    D = rng.uniform(0.3, 2.0, bs.num_cols)
+    A = cx.Matrix(ctx, bs, P)
+    A.set_values(vals)
+    for pre in PRE:
+        for clustering in CLUSTERING:
+            got = cx.binding.visibility_structure(A, getattr(cx, pre), getattr(cx, clustering))
+            ref = oracle.visibility_structure(bs, P, getattr(oracle, pre), getattr(oracle, clustering))
+            assert got[1] == ref[1] and all(np.array_equal(a, r) for a, r in zip((got[0], got[2], got[3]), (ref[0], ref[2], ref[3])))
+            S = cx.Solver(ctx, type=cx.ITERATIVE_SCHUR, preconditioner_type=getattr(cx, pre), num_eliminate_blocks=P,
+                          visibility_clustering_type=getattr(cx, clustering), max_num_iterations=4 * bs.num_cols + 50)
+            x, s = S.solve(A, b, D, r_tolerance=1e-13, q_tolerance=0.0)
+            oo = oracle.make_options(type=oracle.ITERATIVE_SCHUR, preconditioner_type=getattr(oracle, pre), num_eliminate_blocks=P,
+                                     visibility_clustering_type=getattr(oracle, clustering), max_num_iterations=4 * bs.num_cols + 50)
+            xr, sr = oracle.solve(bs, vals, b, D, oo, r_tolerance=1e-13, q_tolerance=0.0)
+            assert s.termination_type == sr.termination_type == cx.SUCCESS, (pre, clustering, s.message, sr.message)
+            assert np.linalg.norm(x - xr) / x.size < 1e-9, (pre, clustering, C, P, O)
+            S.close()
+    A.close()
