@@ -12,7 +12,7 @@ constexpr int NB = 32;  // panel width: the wave-level diagonal factorisation ke
 
 typedef double double4_t __attribute__((ext_vector_type(4)));
 
-constexpr int kPotrfLds = NB * NB + NB;  // LDS doubles potrf_inverse_block needs: a copy of U and 1 / diag(U)
+constexpr int kPotrfLds = NB * NB + NB + 2 * 16 * 16;  // LDS doubles of potrf_inverse_block: U, 1 / diag(U), V11 | V22
 
 // v at lane `l` (compile-time constant), as a wave-uniform value: two v_readlane_b32
 __device__ __forceinline__ double readlane_f64(double v, int l) {
@@ -27,11 +27,13 @@ __device__ __forceinline__ double readlane_f64(double v, int l) {
 // in NB registers; right-looking, fully unrolled, pivot row broadcast by v_readlane (no LDS round trip
 // or barrier in the 32-step chain).  The inverse is then formed column by column from an LDS copy of U
 // (broadcast reads), lds: kPotrfLds doubles.
-// Measured, MI355X: 14.4 us per call warm (tools/potrf_bench.hip; 20 k of its 31 k cycles in the 496 broadcast + fp64
+// Measured, MI355X: 13.2 us per call warm (tools/potrf_bench.hip; 20 k of its 31 k cycles in the 496 broadcast + fp64
 // FMA pairs of the factorisation -- an fp64 FMA costs a lone wavefront 8 cycles --, 6 k in its 64 narrow stores,
-// 5 k in the inverse), ~22 us cold inside a step kernel.  A/B: the same routine blocked by 16 (two 16-column
-// factorisations and inverses on the vector ALU, the four 16x16x16 products of U12, the Schur update and V12 on
-// v_mfma_f64_16x16x4_f64, a third of the instructions) ran 9.3 us warm but LOST in place on the same box:
+// 5 k in the blocked inverse below; 14.4 us with the unblocked inverse: one column per lane, 496 FMAs), ~18 us cold
+// inside a step kernel (23 us before).  In place the blocked inverse is worth 4 %: Dubrovnik-356 Cholesky 3.32 ->
+// 3.17 ms, tile-sparse Final 130.5 -> 125.2 ms (same box).  A/B: blocking the FACTORISATION by 16 as well (two 16-column
+// factorisations, U12 and the Schur update of the second block on v_mfma_f64_16x16x4_f64, a third of the
+// instructions) ran 9.3 us warm but LOST in place on the same box:
 // Dubrovnik-356 reduced solve 4.18 -> 4.29 ms, tile-sparse Final 175 -> 186 ms; it is not kept.  Broadcasting the pivot
 // row through LDS (one ds_read per row instead of two v_readlane) was slower both ways: 20.1 us warm, Dubrovnik-356
 // 3.29 -> 3.82 ms.
@@ -80,18 +82,45 @@ __device__ __forceinline__ void potrf_inverse_block(const double* __restrict__ W
     if (lane < NB) lds[r * NB + lane] = (lane >= r) ? T[r] : 0.0;  // U(r, lane)
   }
   // (single wavefront: its LDS writes are ordered before its LDS reads, no barrier needed)
-  // V = U^-1, column `lane`: U V = I by back substitution
-  double V[NB];
+  // V = U^-1 by blocks of 16: U = [U11 U12; 0 U22]  =>  V = [V11  -V11 U12 V22; 0  V22].
+  //  * V11 and V22 side by side: lanes 0-15 own the columns of V11, lanes 16-31 those of V22 (16 registers each),
+  //    right-looking back substitution: 240 fp64 FMAs of this one wavefront instead of the 496 of the unblocked
+  //    inverse (an fp64 FMA costs a lone wavefront 8 cycles);
+  //  * the off-diagonal block as two 16x16x16 products on the matrix cores (8 v_mfma_f64_16x16x4_f64); the result
+  //    registers of T = U12 V22 are already the B operands of V11 T.
+  const int half = (lane >> 4) & 1, lc = lane & 15, o = 16 * half;  // lanes 32-63 mirror 0-31 and store nothing
+  double V[16];
 #pragma unroll
-  for (int r = NB - 1; r >= 0; --r) {
-    double sum = (r == lane) ? 1.0 : 0.0;
+  for (int r = 0; r < 16; ++r) V[r] = (r == lc) ? 1.0 : 0.0;
 #pragma unroll
-    for (int k = r + 1; k < NB; ++k) sum -= lds[r * NB + k] * V[k];
-    V[r] = (lane >= r) ? sum * lds[NB * NB + r] : 0.0;
+  for (int r = 15; r >= 0; --r) {
+    V[r] = (lc >= r) ? V[r] * lds[NB * NB + o + r] : 0.0;
+#pragma unroll
+    for (int q = 0; q < r; ++q) V[q] -= lds[(o + q) * NB + o + r] * V[r];
   }
+  double* __restrict__ Vs = lds + NB * NB + NB;  // V11 | V22, 16 x 16 row-major each
   if (lane < NB) {
 #pragma unroll
-    for (int r = 0; r < NB; ++r) uinv[r * NB + lane] = V[r];
+    for (int r = 0; r < 16; ++r) {
+      Vs[half * 256 + r * 16 + lc] = V[r];
+      uinv[(o + r) * NB + o + lc] = V[r];
+    }
+  }
+  if (lane < 16) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) uinv[(16 + r) * NB + lane] = 0.0;
+  }
+  {
+    const int li = lane & 15, lk = lane >> 4;
+    double4_t Tm = double4_t{0.0, 0.0, 0.0, 0.0}, X = double4_t{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int s4 = 0; s4 < 4; ++s4)  // T = U12 V22: A(i, k) = U(i, 16 + k), B(k, j) = V22(k, j)
+      Tm = __builtin_amdgcn_mfma_f64_16x16x4f64(lds[li * NB + 16 + 4 * s4 + lk], Vs[256 + (4 * s4 + lk) * 16 + li], Tm, 0, 0, 0);
+#pragma unroll
+    for (int s4 = 0; s4 < 4; ++s4)  // X = V11 T: register s4 of T holds T(4 s4 + lk, li), the B operand of step s4
+      X = __builtin_amdgcn_mfma_f64_16x16x4f64(Vs[li * 16 + 4 * s4 + lk], Tm[s4], X, 0, 0, 0);
+#pragma unroll
+    for (int g = 0; g < 4; ++g) uinv[(lk + 4 * g) * NB + 16 + li] = -X[g];
   }
 }
 
