@@ -78,10 +78,16 @@ __device__ __forceinline__ void potrf_inverse_block(const double* __restrict__ W
   if (!ok && lane == 0) *not_pd = 1;
 #pragma unroll
   for (int r = 0; r < NB; ++r) {
-    if (r < kb && lane < kb && lane >= r) Fblk[size_t(r) * ldf + lane] = T[r];
     if (lane < NB) lds[r * NB + lane] = (lane >= r) ? T[r] : 0.0;  // U(r, lane)
   }
   // (single wavefront: its LDS writes are ordered before its LDS reads, no barrier needed)
+  // U into the factor from the LDS copy, two rows per store instruction (all 64 lanes) instead of one
+#pragma unroll
+  for (int it = 0; it < NB / 2; ++it) {
+    const int r = 2 * it + (lane >> 5), c = lane & 31;
+    const double v = lds[r * NB + c];
+    if (r < kb && c < kb && c >= r) Fblk[size_t(r) * ldf + c] = v;
+  }
   // V = U^-1 by blocks of 16: U = [U11 U12; 0 U22]  =>  V = [V11  -V11 U12 V22; 0  V22].
   //  * V11 and V22 side by side: lanes 0-15 own the columns of V11, lanes 16-31 those of V22 (16 registers each),
   //    right-looking back substitution: 240 fp64 FMAs of this one wavefront instead of the 496 of the unblocked
@@ -101,14 +107,7 @@ __device__ __forceinline__ void potrf_inverse_block(const double* __restrict__ W
   double* __restrict__ Vs = lds + NB * NB + NB;  // V11 | V22, 16 x 16 row-major each
   if (lane < NB) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      Vs[half * 256 + r * 16 + lc] = V[r];
-      uinv[(o + r) * NB + o + lc] = V[r];
-    }
-  }
-  if (lane < 16) {
-#pragma unroll
-    for (int r = 0; r < 16; ++r) uinv[(16 + r) * NB + lane] = 0.0;
+    for (int r = 0; r < 16; ++r) Vs[half * 256 + r * 16 + lc] = V[r];
   }
   {
     const int li = lane & 15, lk = lane >> 4;
@@ -119,8 +118,15 @@ __device__ __forceinline__ void potrf_inverse_block(const double* __restrict__ W
 #pragma unroll
     for (int s4 = 0; s4 < 4; ++s4)  // X = V11 T: register s4 of T holds T(4 s4 + lk, li), the B operand of step s4
       X = __builtin_amdgcn_mfma_f64_16x16x4f64(Vs[li * 16 + 4 * s4 + lk], Tm[s4], X, 0, 0, 0);
+    // the whole inverse, 4 rows x 16 columns per store instruction: [V11 | -X] over [0 | V22]
 #pragma unroll
-    for (int g = 0; g < 4; ++g) uinv[(lk + 4 * g) * NB + 16 + li] = -X[g];
+    for (int g = 0; g < 4; ++g) {
+      const int r = lk + 4 * g;
+      uinv[r * NB + li] = Vs[r * 16 + li];
+      uinv[r * NB + 16 + li] = -X[g];
+      uinv[(16 + r) * NB + li] = 0.0;
+      uinv[(16 + r) * NB + 16 + li] = Vs[256 + r * 16 + li];
+    }
   }
 }
 
