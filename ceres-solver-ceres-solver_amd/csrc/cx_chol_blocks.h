@@ -27,7 +27,9 @@ __device__ __forceinline__ double readlane_f64(double v, int l) {
 // in NB registers; right-looking, fully unrolled, pivot row broadcast by v_readlane (no LDS round trip
 // or barrier in the 32-step chain).  The inverse is then formed column by column from an LDS copy of U
 // (broadcast reads), lds: kPotrfLds doubles.
-// Measured, MI355X: 13.2 us per call warm (tools/potrf_bench.hip; 20 k of its 31 k cycles in the 496 broadcast + fp64
+// Measured, MI355X: 8.9 us per call warm with the updates pinned (see the inner loop; 13.2 us before, when the
+// optimiser had turned the loop into a left-looking factorisation with 700 SGPR spills -- Dubrovnik-356 Cholesky 3.15 ->
+// 2.97 ms, tile-sparse Final 125.1 -> 120.6 ms on the same box).  Of the 13.2 us (tools/potrf_bench.hip): 20 k of its 31 k cycles in the 496 broadcast + fp64
 // FMA pairs of the factorisation -- an fp64 FMA costs a lone wavefront 8 cycles --, 6 k in its 64 narrow stores,
 // 5 k in the blocked inverse below; 14.4 us with the unblocked inverse: one column per lane, 496 FMAs), ~18 us cold
 // inside a step kernel (23 us before).  In place the blocked inverse is worth 4 %: Dubrovnik-356 Cholesky 3.32 ->
@@ -64,14 +66,17 @@ __device__ __forceinline__ void potrf_inverse_block(const double* __restrict__ W
     double rs = __builtin_amdgcn_rsq(d);
     rs = rs * (1.5 - 0.5 * d * rs * rs);
     rs = rs * (1.5 - 0.5 * d * rs * rs);
-    const double sq = d * rs;
-    T[j] = (lane == j) ? sq : T[j] * rs;
+    T[j] *= rs;  // the whole row; on the diagonal lane this is d * rs = sqrt(d) (no select: 32 lane masks kept in
+                 // SGPRs next to the step's broadcasts made the compiler spill ~22 SGPRs per step)
     if (lane == 0) lds[NB * NB + j] = rs;  // 1 / U(j, j) for the inverse below
     const double uj = T[j];
 #pragma unroll
     for (int i = j + 1; i < NB; ++i) {
       // entries below the diagonal (lane < i) are updated too; they are never read
       T[i] -= readlane_f64(T[j], i) * uj;
+      // pin the update here: left alone the optimiser sinks all updates of row i down to step i (a left-looking
+      // factorisation), which keeps every broadcast U(j, i) alive until then -- 700 SGPR spills to VGPR lanes
+      asm volatile("" : "+v"(T[i]));
     }
     __builtin_amdgcn_sched_barrier(0);  // keep the broadcasts of step j + 1 out of step j (SGPR pressure)
   }
