@@ -70,13 +70,22 @@ __device__ __forceinline__ void potrf_inverse_block(const double* __restrict__ W
                  // SGPRs next to the step's broadcasts made the compiler spill ~22 SGPRs per step)
     if (lane == 0) lds[NB * NB + j] = rs;  // 1 / U(j, j) for the inverse below
     const double uj = T[j];
+    // entries below the diagonal (lane < i) are updated too; they are never read.  Four rows at a time: four
+    // broadcasts into distinct SGPR pairs, then four FMAs (back to back on one SGPR pair every FMA waits two
+    // cycles for its v_readlane), then the four results are pinned -- an empty asm on the updated registers: left
+    // alone the optimiser sinks all updates of row i down to step i (a left-looking factorisation), which keeps every
+    // broadcast U(j, i) alive until then: 700 SGPR spills to VGPR lanes
 #pragma unroll
-    for (int i = j + 1; i < NB; ++i) {
-      // entries below the diagonal (lane < i) are updated too; they are never read
-      T[i] -= readlane_f64(T[j], i) * uj;
-      // pin the update here: left alone the optimiser sinks all updates of row i down to step i (a left-looking
-      // factorisation), which keeps every broadcast U(j, i) alive until then -- 700 SGPR spills to VGPR lanes
-      asm volatile("" : "+v"(T[i]));
+    for (int i = j + 1; i < NB; i += 4) {
+      double bc[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) bc[q] = (i + q < NB) ? readlane_f64(T[j], (i + q < NB) ? i + q : NB - 1) : 0.0;
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        if (i + q < NB) T[i + q] -= bc[q] * uj;
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        if (i + q < NB) asm volatile("" : "+v"(T[i + q]));
     }
     __builtin_amdgcn_sched_barrier(0);  // keep the broadcasts of step j + 1 out of step j (SGPR pressure)
   }
