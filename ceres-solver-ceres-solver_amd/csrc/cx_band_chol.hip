@@ -441,7 +441,10 @@ int cxv_factor(cx_matrix* A, cx_vis_plan* plan, const double* D, bool halve_offd
 
 int cxv_solve(cx_matrix* A, cx_vis_plan* plan, const double* r, double* z) {
   const bool force_global = std::getenv("CX_BAND_SOLVE_GLOBAL") != nullptr;  // A/B switch, read per call so tests can flip it
-  static const int threads = std::getenv("CX_BAND_SOLVE_THREADS") ? std::atoi(std::getenv("CX_BAND_SOLVE_THREADS")) : 512;
+  // 512 threads per path pay off on long paths (instruction issue of the one workgroup); the short walks of
+  // CLUSTER_JACOBI (a few blocks per cluster) are quicker with 256 (72 vs 78 us on the Final shape)
+  static const int forced = std::getenv("CX_BAND_SOLVE_THREADS") ? std::atoi(std::getenv("CX_BAND_SOLVE_THREADS")) : 0;
+  const int threads = forced ? forced : (plan->step_paths.size() > 32 ? 512 : 256);
   if (plan->ld + 64 <= kWin && !force_global) {
 #define CX_LAUNCH_BAND_SOLVE(NT)                                                                                                   \
   hipLaunchKernelGGL(k_band_solve_lds<NT>, dim3(unsigned(plan->num_paths)), dim3(NT), 0, A->ctx->stream, (const double*)plan->d_F.p, \
