@@ -63,9 +63,13 @@ __device__ __forceinline__ void potrf_inverse_block(const double* __restrict__ W
     ok = ok && (d > 0.0);
     // 1 / sqrt(d) from the hardware estimate and two Newton steps (a correctly rounded sqrt and a
     // division cost ~45 instructions of this single wavefront's 32-step serial chain)
+    // 1 / sqrt(d): hardware estimate and ONE Halley step (cubic) instead of two Newton steps (quadratic each):
+    // half the dependent fp64 operations of the 32-step chain
     double rs = __builtin_amdgcn_rsq(d);
-    rs = rs * (1.5 - 0.5 * d * rs * rs);
-    rs = rs * (1.5 - 0.5 * d * rs * rs);
+    {
+      const double e = fma(-d * rs, rs, 1.0);            // 1 - d rs^2
+      rs = fma(rs * e, fma(0.375, e, 0.5), rs);          // rs (1 + e / 2 + 3 e^2 / 8)
+    }
     T[j] *= rs;  // the whole row; on the diagonal lane this is d * rs = sqrt(d) (no select: 32 lane masks kept in
                  // SGPRs next to the step's broadcasts made the compiler spill ~22 SGPRs per step)
     if (lane == 0) lds[NB * NB + j] = rs;  // 1 / U(j, j) for the inverse below
