@@ -141,7 +141,6 @@ struct cx_matrix {
   DevBuf<double> d_partials;             // camera-major partial sums [S][81]
   DevBuf<double> d_partials9;            // [S][9] (fused set-up)
   DevBuf<double> d_elim_blk, d_elim_ete, d_elim_diag, d_elim_rows;  // explicit-S scratch (cx_schur.hip)
-  DevBuf<int> d_elim_flag;
   // explicit S without atomics (cx_schur.hip): the non-zero cells of the upper block triangle of S in
   // the order SparseSchurComplementSolver::InitStorage lists them (every (c,c), then co-visible c1 < c2,
   // lexicographic -- schur_complement_solver.cc:224-290) and per cell the co-observing row pairs in chunk order

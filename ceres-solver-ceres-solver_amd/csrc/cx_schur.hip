@@ -1194,8 +1194,9 @@ int cxs_assemble_pair_items(cx_matrix* A, const double* D, const int32_t* item_i
   hipStream_t st = A->ctx->stream;
   CX_TRY(A->d_elim_ete.alloc(size_t(std::max<int64_t>(9 * int64_t(A->P), 1))));
   CX_TRY(A->d_elim_diag.alloc(size_t(std::max<int64_t>(81 * int64_t(A->C), 1))));
-  CX_TRY(A->d_elim_flag.alloc(1));
-  CX_TRY(cxs_compute_ete_inverse(A, D, nullptr, A->d_elim_ete.p, nullptr, false, A->d_elim_flag.p));
+  // the cofactor inverse reports nothing, exactly as InvertPSDMatrix<3> (invert_psd_matrix.h:60-63): a singular
+  // E'E + D^2 shows as Inf/NaN in S and ends the solve in the Cholesky factorisation, as in the reference
+  CX_TRY(cxs_compute_ete_inverse(A, D, nullptr, A->d_elim_ete.p, nullptr, false, nullptr));
   const size_t rows18 = size_t(std::max<int64_t>(18 * A->O, 1));
   CX_TRY(A->d_elim_bg0.alloc(rows18));
   CX_TRY(A->d_elim_bg1.alloc(rows18));
@@ -1244,8 +1245,7 @@ int cxs_eliminate_dense(cx_matrix* A, const double* b, const double* D, bool add
     // scatter path: fp64 atomics into a block-major copy of S
     CX_TRY(A->d_elim_ete.alloc(size_t(std::max<int64_t>(9 * int64_t(A->P), 1))));
     CX_TRY(A->d_elim_diag.alloc(size_t(std::max<int64_t>(81 * int64_t(C), 1))));
-    CX_TRY(A->d_elim_flag.alloc(1));
-    CX_TRY(cxs_compute_ete_inverse(A, D, nullptr, A->d_elim_ete.p, nullptr, false, A->d_elim_flag.p));
+    CX_TRY(cxs_compute_ete_inverse(A, D, nullptr, A->d_elim_ete.p, nullptr, false, nullptr));
     CX_TRY(A->d_elim_blk.alloc(size_t(std::max<int64_t>(int64_t(C) * C * 81, 1))));
     CX_HIP(hipMemsetAsync(A->d_elim_blk.p, 0, size_t(C) * C * 81 * sizeof(double), st));
     if (A->num_tiles > 0) {

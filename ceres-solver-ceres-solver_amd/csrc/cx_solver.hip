@@ -120,11 +120,12 @@ __global__ __launch_bounds__(256) void k_dot2_final(const double* __restrict__ p
 // right-hand side, converged at the start, or a preconditioner that could not be formed); a raised flag is
 // published as "iteration 1" so that the host's pipeline reads it where it expects the first outcome.
 __global__ void k_cg_prologue(CgState* __restrict__ st, CgState* __restrict__ ring, int ring_slots,
-                              const int* __restrict__ preconditioner_failed) {
+                              const int* __restrict__ preconditioner_failed,
+                              const int* __restrict__ preconditioner_failed2) {
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
   const double norm_rhs = sqrt(st->s0);
   st->norm_r = norm_rhs;
-  if (preconditioner_failed && *preconditioner_failed) {
+  if ((preconditioner_failed && *preconditioner_failed) || (preconditioner_failed2 && *preconditioner_failed2)) {
     st->flag = CG_FAIL_PRECONDITIONER;
   } else if (norm_rhs == 0.0) {
     st->flag = CG_ZERO_RHS;
@@ -153,10 +154,14 @@ __device__ __forceinline__ void dot2_finish(double a0, double a1, const DotTail&
   if (threadIdx.x == 0) {
     __hip_atomic_store(&t.partial[blockIdx.x], s[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __hip_atomic_store(&t.partial[kRedBlocks + blockIdx.x], s[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    // The two stores above are agent-scope atomics (performed at the device's coherence point), so it is
-    // enough to wait for them to complete before taking the ticket: a workgroup-scope release does that
-    // (s_waitcnt) without the L2 write-back / invalidate an agent-scope fence adds (~10 us per kernel here).
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    // The two stores above are agent-scope atomics (write-through, performed at the device's coherence
+    // point), so they only have to be COMPLETE before the ticket is taken: partials and ticket are different
+    // addresses and may sit in different L2 channels, so program order alone does not order them.  gfx9
+    // counts stores on vmcnt; an explicit wait does it (a workgroup-scope fence emits no s_waitcnt vmcnt
+    // outside tgsplit mode -- checked in the ISA) without the L2 write-back / invalidate an agent-scope
+    // release fence adds (~10 us per kernel here).  The reader side is ordered by data dependence: the last
+    // workgroup issues its agent-scope loads only after its own ticket atomic has returned.
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     const unsigned ticket = __hip_atomic_fetch_add(t.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     is_last = (ticket == gridDim.x - 1) ? 1 : 0;
   }
@@ -388,6 +393,7 @@ struct CgDriver {
   // set by solvers whose set-up raises a device flag when the preconditioner cannot be formed: the prologue then
   // ends the run before the first iteration (no host check, no synchronisation, in between)
   const int* preconditioner_failed = nullptr;
+  const int* preconditioner_failed2 = nullptr;  // a second, independently raised flag (factorisation of a visibility preconditioner)
 
   // vectors replicated on every rank (or a single rank): dot products need no exchange
   bool fused() const { return !(ctx->nranks > 1 && shared0 < n); }
@@ -544,16 +550,19 @@ struct CgDriver {
       init->seq = -1;
       CX_HIP(hipMemcpyAsync(ds, init, sizeof(CgState), hipMemcpyHostToDevice, st));
       CX_TRY(dot2(rhs, rhs, nullptr, nullptr, FIN_STORE, 0, ds));
-      hipLaunchKernelGGL(k_cg_prologue, dim3(1), dim3(1), 0, st, ds, S->ring_d, kRingSlots, preconditioner_failed);
+      hipLaunchKernelGGL(k_cg_prologue, dim3(1), dim3(1), 0, st, ds, S->ring_d, kRingSlots, preconditioner_failed,
+                         preconditioner_failed2);
       CX_HIP(hipMemcpyAsync(r, rhs, n * sizeof(double), hipMemcpyDeviceToDevice, st));
     } else {
       CX_HIP(hipMemcpyAsync(ds, &h, sizeof(h), hipMemcpyHostToDevice, st));
       CX_TRY(dot2(rhs, rhs, nullptr, nullptr, FIN_STORE, 0, ds));
-      int precond_flag = 0;
+      int precond_flag = 0, precond_flag2 = 0;
       if (preconditioner_failed)
         CX_HIP(hipMemcpyAsync(&precond_flag, preconditioner_failed, sizeof(int), hipMemcpyDeviceToHost, st));
+      if (preconditioner_failed2)
+        CX_HIP(hipMemcpyAsync(&precond_flag2, preconditioner_failed2, sizeof(int), hipMemcpyDeviceToHost, st));
       CX_TRY(read_state(&h));  // this path waits for the device anyway
-      if (precond_flag) {
+      if (precond_flag || precond_flag2) {
         summary->termination_type = CX_FAILURE;
         std::snprintf(summary->message, sizeof(summary->message), "Preconditioner update failed.");
         return CX_OK;
@@ -959,8 +968,13 @@ int SolveIterativeSchur239(cx_solver* S, cx_matrix* A, const double* b, const do
   CX_TRY(S->v_rows.alloc(size_t(A->num_rows)));
   CX_TRY(S->v_rhs.alloc(nf));
   CX_TRY(S->v_x.alloc(nf));
-  CX_TRY(S->flag.alloc(1));
-  CX_HIP(hipMemsetAsync(S->flag.p, 0, sizeof(int), st));
+  // flag[0]: set-up (a point's E'E + D^2 or a camera block that cannot be inverted); flag[1]: the factorisation of a
+  // visibility based preconditioner.  Kept apart so that the CLUSTER_TRIDIAGONAL retry below, which the reference
+  // takes only when Factorize() of the preconditioner itself fails (visibility_based_preconditioner.cc:331-360),
+  // neither reacts to nor erases a set-up failure.
+  CX_TRY(S->flag.alloc(2));
+  CX_HIP(hipMemsetAsync(S->flag.p, 0, 2 * sizeof(int), st));
+  int* const vis_flag = S->flag.p + 1;
   CX_TRY(sw.start());
   // ImplicitSchurComplement::Init + UpdateRhs (implicit_schur_complement.cc:49-97, 251-276) fused into
   // one pass over E and one over F (cxs_implicit_init)
@@ -996,16 +1010,16 @@ int SolveIterativeSchur239(cx_solver* S, cx_matrix* A, const double* b, const do
   if (want_blocks) CX_TRY(cxs_block9_add_diag_invert(ctx, S->cam_blocks.p, D ? D + ne : nullptr, A->C, S->flag.p));
   if (visibility) {
     // VisibilityBasedPreconditioner::UpdateImpl (visibility_based_preconditioner.cc:321-364)
-    CX_TRY(cxv_factor(A, vis_plan, D, false, S->flag.p));
+    CX_TRY(cxv_factor(A, vis_plan, D, false, vis_flag));
     if (o.preconditioner_type == CX_CLUSTER_TRIDIAGONAL) {
       // "If it works, great, otherwise we scale all the cells in the preconditioner corresponding to the edges
       // in the degree-2 forest and that guarantees positive definiteness" (:331-360) -- the one host check
-      bool failed = false;
-      cx_summary unused{};
-      CX_TRY(CheckFlag(S, "", &unused, &failed));
+      int failed = 0;
+      CX_HIP(hipMemcpyAsync(&failed, vis_flag, sizeof(int), hipMemcpyDeviceToHost, st));
+      CX_HIP(hipStreamSynchronize(st));
       if (failed) {
-        CX_HIP(hipMemsetAsync(S->flag.p, 0, sizeof(int), st));
-        CX_TRY(cxv_factor(A, vis_plan, D, true, S->flag.p));
+        CX_HIP(hipMemsetAsync(vis_flag, 0, sizeof(int), st));
+        CX_TRY(cxv_factor(A, vis_plan, D, true, vis_flag));
       }
     }
   }
@@ -1040,6 +1054,7 @@ int SolveIterativeSchur239(cx_solver* S, cx_matrix* A, const double* b, const do
                             : static_cast<LinOp&>(bd);
   CgDriver cg{S, ctx, st, nf, nf};
   cg.preconditioner_failed = S->flag.p;
+  cg.preconditioner_failed2 = vis_flag;
   CX_TRY(S->state.alloc(1));
   // use_mixed_precision_solves: S x inside CG streams fp32 copies of the cells (fp64 accumulation, fp64
   // vectors); set-up, right-hand side and back substitution stay on the fp64 values.  Not in the reference
@@ -1223,7 +1238,10 @@ int SolveSparseSchur239(cx_solver* S, cx_matrix* A, const double* b, const doubl
   CX_TRY(cxsp_factor_and_solve(A, D ? D + ne : nullptr, S->v_rhs.p, z, S->flag.p));
   bool failed = false;
   CX_TRY(CheckFlag(S, "Sparse Cholesky factorization failed: the reduced camera matrix is not positive definite.", summary, &failed));
-  if (failed) summary->num_iterations = 1;
+  if (failed) {
+    summary->num_iterations = 1;
+    CX_HIP(hipMemsetAsync(z, 0, size_t(nf) * sizeof(double), st));  // not the NaNs of the failed factorisation
+  }
   CX_TRY(sw.stop(&S->timing.reduced_solve_ms));
   CX_TRY(sw.start());
   if (summary->termination_type == CX_SUCCESS) CX_TRY(cxs_chunk_pass(A, 2, A->d_elim_ete.p, z, b, x));
@@ -1281,7 +1299,10 @@ int SolveDenseSchur239(cx_solver* S, cx_matrix* A, const double* b, const double
     summary->num_iterations = 1;
     bool failed = false;
     CX_TRY(CheckFlag(S, "Dense Cholesky factorization failed: the reduced camera matrix is not positive definite.", summary, &failed));
-    if (failed) summary->num_iterations = 1;
+    if (failed) {
+      summary->num_iterations = 1;
+      CX_HIP(hipMemsetAsync(z, 0, size_t(nf) * sizeof(double), st));  // not the NaNs of the failed factorisation
+    }
   }
   CX_TRY(sw.stop(&S->timing.reduced_solve_ms));
   CX_TRY(sw.start());
@@ -1411,6 +1432,9 @@ int cx_solver_solve(cx_solver* S, cx_matrix* A, const double* b, const cx_per_so
   CX_TRY(hD.in(ps->D, size_t(A->num_cols), ps->memspace));
   CX_TRY(hx.inout(x, size_t(A->num_cols), ps->memspace, false));
   CX_HIP(hipEventRecord(ctx->ev[4], ctx->stream));
+  // "std::fill(x, x + A->num_cols(), 0.0)" (schur_complement_solver.cc:137): whatever a failed solve leaves
+  // unwritten is zero, in the caller's host buffer as well (the staging copy is not initialised otherwise)
+  CX_HIP(hipMemsetAsync(hx.dptr, 0, size_t(A->num_cols) * sizeof(double), ctx->stream));
   int rc;
   if (A->is239) {
     switch (o.type) {

@@ -624,10 +624,15 @@ def test_sparse_schur_tile_cholesky(ctx, oracle, C, P, O, seed):
     A.set_values(vals_bad)
     os.environ["CX_SPARSE_CHOLESKY"] = "1"
     try:
-        _, sbad = Ss.solve(A, b, Dneg)
+        xbad, sbad = Ss.solve(A, b, Dneg)
     finally:
         del os.environ["CX_SPARSE_CHOLESKY"]
     assert sbad.termination_type == cx.FAILURE
+    # host buffers of a failed solve come back as the zeros the reference writes first
+    # (schur_complement_solver.cc:137), not as the staging copy's garbage or the factorisation's NaNs
+    assert not xbad.any()
+    xbad_d, sbad_d = Sd.solve(A, b, Dneg)
+    assert sbad_d.termination_type == cx.FAILURE and not xbad_d.any()
     Sd.close()
     Ss.close()
     A.close()
@@ -763,6 +768,7 @@ def test_preconditioner_failure_is_reported(ctx, oracle, explicit):
     x, s = S.solve(A, b, D, q_tolerance=0.1)
     assert s.termination_type == cx.FAILURE and s.num_iterations == 0
     assert "Preconditioner update failed" in s.message.decode()
+    assert not x.any()   # zeroed at the start of the solve, nothing else was written
     # the same solver object recovers on a healthy system
     prob2, bs2, order2, vals2, b2, D2 = make(C, P, O, 5, "random")
     A.set_values(vals2)

@@ -149,6 +149,31 @@ def test_tridiagonal_retry_with_halved_off_diagonal_cells(ctx, oracle):
     A.close()
 
 
+def test_setup_failure_survives_the_tridiagonal_retry(ctx):
+    """The retry is the reference's answer to a failed Factorize() of the preconditioner only
+    (visibility_based_preconditioner.cc:331-360).  A point block E'E + D_e^2 that cannot be inverted is a different
+    failure with its own device flag: the retry must neither react to it nor erase it, and the solve must end with
+    "Preconditioner update failed." instead of running CG on a broken (E'E)^-1."""
+    prob, bs, vals, b, D, P = crafted_indefinite_tridiagonal(0)
+    O = vals.size // 24
+    vals, D = vals.copy(), D.copy()
+    row_pt = bs.cells["block_id"][0::2]
+    p_bad = P - 1                                   # a private point of camera 2: one row
+    for r in np.nonzero(row_pt == p_bad)[0]:
+        vals[6 * r: 6 * r + 6] = 0.0                # E = 0 ...
+    D[3 * p_bad: 3 * p_bad + 3] = 0.0               # ... and D_e = 0: E'E + D_e^2 = 0
+    A = cx.Matrix(ctx, bs, P)
+    A.set_values(vals)
+    S = cx.Solver(ctx, type=cx.ITERATIVE_SCHUR, preconditioner_type=cx.CLUSTER_TRIDIAGONAL, num_eliminate_blocks=P,
+                  visibility_clustering_type=cx.SINGLE_LINKAGE, max_num_iterations=100)
+    x, s = S.solve(A, b, D, r_tolerance=-1.0, q_tolerance=0.01)
+    assert s.termination_type == cx.FAILURE and s.num_iterations == 0, s.message
+    assert "Preconditioner update failed" in s.message.decode()
+    assert not x.any()                              # x comes back zeroed, not uninitialised staging memory
+    S.close()
+    A.close()
+
+
 def test_one_cluster_is_the_exact_inverse(ctx, oracle):
     """All cameras see all points: one cluster, the preconditioner is S, CG converges at once."""
     C, P = 5, 60
