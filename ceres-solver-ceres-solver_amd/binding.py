@@ -38,7 +38,7 @@ EXPORTED_SYMBOLS = [
     "cx_implicit_schur_multiply", "cx_dense_cholesky_solve", "cx_evaluator_create_bal", "cx_evaluator_destroy",
     "cx_evaluator_jacobian", "cx_evaluator_row_of_observation", "cx_evaluator_evaluate", "cx_evaluator_set_loss", "cx_minimizer_default_options", "cx_minimize", "cx_schur_sparse_structure", "cx_visibility_structure", "cx_visibility_clusters_host",
     "cx_evaluator_set_camera_model", "cx_evaluator_num_parameters", "cx_evaluator_num_effective_parameters", "cx_evaluator_plus",
-    "cx_evaluator_last_kernel_ms", "cx_detect_structure", "cx_partition_points", "cx_stable_schur_ordering",
+    "cx_evaluator_last_kernel_ms", "cx_evaluator_device_residuals", "cx_detect_structure", "cx_partition_points", "cx_stable_schur_ordering",
 ]
 
 
@@ -72,7 +72,7 @@ class cx_per_solve_options(ctypes.Structure):
         ("r_tolerance", ctypes.c_double),
         ("q_tolerance", ctypes.c_double),
         ("memspace", ctypes.c_int32),
-        ("reserved", ctypes.c_int32),
+        ("b_on_device", ctypes.c_int32),
     ]
 
 
@@ -159,6 +159,7 @@ def load_library():
     lib.cx_matrix_device_values.restype = ctypes.c_void_p
     lib.cx_matrix_last_kernel_ms.restype = ctypes.c_double
     lib.cx_evaluator_last_kernel_ms.restype = ctypes.c_double
+    lib.cx_evaluator_device_residuals.restype = ctypes.c_void_p
     lib.cx_evaluator_num_parameters.restype = ctypes.c_int64
     lib.cx_evaluator_num_effective_parameters.restype = ctypes.c_int64
     lib.cx_evaluator_jacobian.restype = ctypes.c_void_p
@@ -166,7 +167,8 @@ def load_library():
     for name in ("cx_matrix_destroy", "cx_solver_destroy", "cx_evaluator_destroy", "cx_context_destroy",
                  "cx_matrix_num_rows", "cx_matrix_num_cols", "cx_matrix_num_nonzeros", "cx_matrix_is_static_239",
                  "cx_matrix_device_values", "cx_matrix_last_kernel_ms", "cx_evaluator_jacobian",
-                 "cx_evaluator_last_kernel_ms", "cx_context_stream", "cx_context_rank", "cx_context_num_ranks"):
+                 "cx_evaluator_last_kernel_ms", "cx_evaluator_device_residuals", "cx_context_stream", "cx_context_rank",
+                 "cx_context_num_ranks"):
         getattr(lib, name).argtypes = [ctypes.c_void_p]
     _lib = lib
     return lib

@@ -506,17 +506,20 @@ int cx_evaluator_evaluate(cx_evaluator* e, const double* state, double* cost, do
   hipStream_t st = ctx->stream;
   CX_HIP(hipSetDevice(ctx->device));
   const int64_t ncols = A->num_cols, nrows = A->num_rows;
-  HostOrDevice hs(ctx), hr(ctx), hg(ctx);
+  HostOrDevice hs(ctx), hg(ctx);
   const int64_t nstate = 3 * int64_t(e->P) + (e->camera_model == CX_CAMERA_ANGLE_AXIS ? 9 : 10) * int64_t(e->C);
   CX_TRY(hs.in(state, size_t(nstate), memspace));
-  CX_TRY(hr.inout(residuals, size_t(nrows), memspace, false));
   CX_TRY(hg.inout(gradient, size_t(ncols), memspace, false));
   const bool with_j = evaluate_jacobian != 0 || gradient != nullptr;
-  double* res_dev = hr.dptr;
-  if (gradient && !res_dev) {
+  // Residuals asked for in host memory are produced in the evaluator's own device buffer and copied out, so that
+  // they also stay available in HBM (cx_evaluator_device_residuals) for the linear solve that follows.
+  const bool res_to_host = residuals != nullptr && memspace == CX_HOST;
+  double* res_dev = (memspace == CX_DEVICE) ? residuals : nullptr;
+  if (res_to_host || (gradient && !res_dev)) {
     CX_TRY(e->d_res.alloc(size_t(nrows)));
     res_dev = e->d_res.p;
   }
+  if (residuals != nullptr) e->res_valid = res_to_host;
   const int grid = int((e->O + kBlock - 1) / kBlock);
   double* E = A->d_values.p;
   double* F = A->d_values.p + 6 * e->O;
@@ -550,11 +553,13 @@ int cx_evaluator_evaluate(cx_evaluator* e, const double* state, double* cost, do
   }
   CX_HIP(hipEventSynchronize(ctx->ev[7]));
   CX_HIP(hipEventElapsedTime(&e->last_ms, ctx->ev[6], ctx->ev[7]));
-  CX_TRY(hr.out());
+  if (res_to_host) CX_HIP(hipMemcpyAsync(residuals, res_dev, size_t(nrows) * sizeof(double), hipMemcpyDeviceToHost, st));
   CX_TRY(hg.out());
   CX_HIP(hipStreamSynchronize(st));
   return CX_OK;
 }
+
+const double* cx_evaluator_device_residuals(const cx_evaluator* e) { return (e && e->res_valid) ? e->d_res.p : nullptr; }
 
 int cx_evaluator_set_camera_model(cx_evaluator* e, int32_t camera_model) {
   CX_CHECK_ARG(e != nullptr && (camera_model == CX_CAMERA_ANGLE_AXIS || camera_model == CX_CAMERA_QUATERNION_MANIFOLD));

@@ -219,6 +219,7 @@ struct cx_evaluator {
   std::vector<int64_t> row_of_obs;   // input observation -> row block
   DevBuf<double> d_obs;              // [2O] in row order
   DevBuf<double> d_partial, d_state, d_res;
+  bool res_valid = false;            // d_res holds the residuals last handed out in host memory
   float last_ms = 0.f;
   int32_t loss_type = CX_LOSS_NONE;
   double loss_a = 0.0, loss_b = 0.0;

@@ -1428,7 +1428,7 @@ int cx_solver_solve(cx_solver* S, cx_matrix* A, const double* b, const cx_per_so
   S->ktimer.reset();
   ctx->allreduce_host_ms = 0.0;
   HostOrDevice hb(ctx), hD(ctx), hx(ctx);
-  CX_TRY(hb.in(b, size_t(A->num_rows), ps->memspace));
+  CX_TRY(hb.in(b, size_t(A->num_rows), ps->b_on_device ? CX_DEVICE : ps->memspace));
   CX_TRY(hD.in(ps->D, size_t(A->num_cols), ps->memspace));
   CX_TRY(hx.inout(x, size_t(A->num_cols), ps->memspace, false));
   CX_HIP(hipEventRecord(ctx->ev[4], ctx->stream));

@@ -1,30 +1,43 @@
-// CxLinearSolver: the adapter that puts libcxschur behind Ceres' LinearSolver interface.
+// CxLinearSolver: the adapter that puts libcxschur behind Ceres' LinearSolver interface (linear_solver.h:148-354).
 //
-// It derives from TypedLinearSolver<BlockSparseMatrix> exactly like
-// SchurComplementSolver / IterativeSchurComplementSolver / CgnrSolver do
-// (schur_complement_solver.h:107-140, iterative_schur_complement_solver.h:72-98,
-// cgnr_solver.h:52-80), caches the device structure on the first Solve as they cache
-// theirs (schur_complement_solver.cc:109-135) and returns the reference's Summary.
-// Inside a Ceres checkout replace "ceres_mirror.h" by the real headers.
+// It overrides LinearSolver::Solve(LinearOperator*, ...) itself instead of deriving from
+// TypedLinearSolver<BlockSparseMatrix> (linear_solver.h:363-390) because it accepts two kinds of Jacobian:
+//   * CxDeviceJacobian (from CxBalEvaluator::CreateJacobian): values already in HBM, nothing is uploaded;
+//   * BlockSparseMatrix (from the reference's ProgramEvaluator): values() uploaded verbatim every Solve, as
+//     SchurComplementSolver / IterativeSchurComplementSolver / CgnrSolver would read them
+//     (schur_complement_solver.h:107-140, iterative_schur_complement_solver.h:72-98, cgnr_solver.h:52-80).
+// Like those it caches its per-structure state on the first Solve (schur_complement_solver.cc:109-135; "a single
+// instance ... solves multiple systems with the same sparsity structure", linear_solver.h:137-142), times
+// "LinearSolver::Solve" into an ExecutionSummary exactly as TypedLinearSolver does (:366-380), and never throws:
+// every failure comes back as a Summary (FATAL_ERROR for device / library errors, which makes TrustRegionMinimizer
+// stop, trust_region_minimizer.cc:404-411).
+// Inside a Ceres checkout compile with -DCX_USE_CERES_HEADERS; nothing else changes.
 #ifndef CX_LINEAR_SOLVER_H_
 #define CX_LINEAR_SOLVER_H_
 
 #include <cstring>
 #include <map>
-#include <stdexcept>
 #include <string>
 #include <vector>
 
 #include "../../include/cxschur.h"
-#include "ceres_mirror.h"
+#include "cx_device_jacobian.h"
+#ifdef CX_USE_CERES_HEADERS
+#include "ceres/block_sparse_matrix.h"
+#include "ceres/execution_summary.h"
+#include "ceres/linear_solver.h"
+#endif
 
 namespace ceres::internal {
 
 // One process-wide device context, the analogue of ContextImpl::InitCuda (context_impl.cc:125-203).
+// nullptr (and cx_last_error()) when there is no usable gfx950 device; the adapters turn that into FATAL_ERROR.
 inline cx_context* CxSharedContext(int device = 0) {
   static cx_context* ctx = nullptr;
-  if (ctx == nullptr && cx_context_create(device, &ctx) != CX_OK) {
-    throw std::runtime_error(std::string("cxschur: ") + cx_last_error());
+  static bool tried = false;
+  if (!tried) {
+    tried = true;
+    if (cx_context_create(device, &ctx) != CX_OK) ctx = nullptr;
   }
   return ctx;
 }
@@ -56,96 +69,148 @@ struct CxFlatStructure {
   }
 };
 
-class CxLinearSolver final : public BlockSparseMatrixSolver {
+class CxLinearSolver final : public LinearSolver {
  public:
   explicit CxLinearSolver(LinearSolver::Options options) : options_(std::move(options)) {}
   ~CxLinearSolver() override {
     if (solver_) cx_solver_destroy(solver_);
-    if (matrix_) cx_matrix_destroy(matrix_);
+    if (owned_matrix_) cx_matrix_destroy(owned_matrix_);
   }
-  // execution_summary.h:45-83 -> Solver::Summary::linear_solver_time_in_seconds (solver.cc:636-643)
-  std::map<std::string, double> Statistics() const override { return {{"LinearSolver::Solve", total_seconds_}}; }
-  const cx_solve_timing& last_timing() const { return timing_; }
+  CxLinearSolver(const CxLinearSolver&) = delete;
+  void operator=(const CxLinearSolver&) = delete;
 
- private:
-  LinearSolver::Summary SolveImpl(BlockSparseMatrix* A, const double* b,
-                                  const LinearSolver::PerSolveOptions& per_solve_options, double* x) final {
+  // True for the option sets this library implements; the factory patch asks before constructing.
+  static bool Supports(const LinearSolver::Options& options) {
+    switch (options.type) {
+      case DENSE_SCHUR: case SPARSE_SCHUR: case ITERATIVE_SCHUR: case CGNR: break;
+      default: return false;
+    }
+    if (options.preconditioner_type == SUBSET) return false;
+    if (options.dynamic_sparsity) return false;
+    return true;
+  }
+
+  // When the right-hand side handed to Solve is the very host array the CxBalEvaluator behind the Jacobian last
+  // wrote its residuals to -- which is what LevenbergMarquardtStrategy::ComputeStep passes
+  // (levenberg_marquardt_strategy.cc:113, trust_region_minimizer.cc:404-408) -- use the copy the evaluator kept in
+  // HBM instead of uploading 2 * num_residual_blocks doubles again.  Off by default: LinearSolver::Solve promises
+  // nothing about who owns b, so the caller has to vouch that it does not modify the residual array between
+  // Evaluate and Solve (TrustRegionMinimizer does not).
+  void set_alias_evaluator_residuals(bool on) { alias_evaluator_residuals_ = on; }
+
+  LinearSolver::Summary Solve(LinearOperator* A, const double* b, const LinearSolver::PerSolveOptions& per_solve_options,
+                              double* x) final {
+    ScopedExecutionTimer total_time("LinearSolver::Solve", &execution_summary_);
     LinearSolver::Summary summary;
+    if (A == nullptr || b == nullptr || x == nullptr) return Fatal(&summary, "null argument");  // CHECKs in the reference (:369-371)
+    if (per_solve_options.preconditioner != nullptr)
+      return Fatal(&summary, "a user-supplied preconditioner operator cannot be applied on the device");
     cx_context* ctx = CxSharedContext();
+    if (ctx == nullptr) return Fatal(&summary);
     const int num_eliminate_blocks =
         (options_.type == CGNR || options_.elimination_groups.empty()) ? 0 : options_.elimination_groups[0];
-    if (matrix_ == nullptr) {  // structure is fixed for the life of the solver (linear_solver.h:137-142)
-      CxFlatStructure flat(*A->block_structure());
-      if (cx_matrix_create(ctx, &flat.view, num_eliminate_blocks, &matrix_) != CX_OK) return Fatal(&summary);
+
+    cx_matrix* matrix = nullptr;
+    const double* device_b = nullptr;
+    if (auto* device_jacobian = dynamic_cast<CxDeviceJacobian*>(A)) {
+      matrix = device_jacobian->device_matrix();  // values are in HBM already
+      if (alias_evaluator_residuals_ && device_jacobian->handle()->last_residuals_host == b)
+        device_b = cx_evaluator_device_residuals(device_jacobian->handle()->evaluator);
+    } else if (auto* host_jacobian = dynamic_cast<BlockSparseMatrix*>(A)) {
+      if (owned_matrix_ == nullptr) {  // structure is fixed for the life of the solver (linear_solver.h:137-142)
+        CxFlatStructure flat(*host_jacobian->block_structure());
+        if (cx_matrix_create(ctx, &flat.view, num_eliminate_blocks, &owned_matrix_) != CX_OK) return Fatal(&summary);
+      }
+      // values change every LM iteration: upload them verbatim (same cell layout)
+      if (cx_matrix_set_values(owned_matrix_, host_jacobian->values(), CX_HOST) != CX_OK) return Fatal(&summary);
+      matrix = owned_matrix_;
+    } else {
+      return Fatal(&summary, "the Jacobian is neither a BlockSparseMatrix nor a CxDeviceJacobian");
+    }
+
+    if (solver_ == nullptr) {
       cx_solver_options o;
-      cx_solver_default_options(&o);
-      switch (options_.type) {
-        case DENSE_SCHUR: o.type = CX_DENSE_SCHUR; break;
-        case SPARSE_SCHUR: o.type = CX_SPARSE_SCHUR; break;
-        case ITERATIVE_SCHUR: o.type = CX_ITERATIVE_SCHUR; break;
-        case CGNR: o.type = CX_CGNR; break;
-        default:
-          summary.termination_type = LinearSolverTerminationType::FATAL_ERROR;
-          summary.message = "cxschur implements DENSE_SCHUR, SPARSE_SCHUR, ITERATIVE_SCHUR and CGNR only.";
-          return summary;
-      }
-      switch (options_.preconditioner_type) {
-        case IDENTITY: o.preconditioner_type = CX_IDENTITY; break;
-        case JACOBI: o.preconditioner_type = CX_JACOBI; break;
-        case SCHUR_JACOBI: o.preconditioner_type = CX_SCHUR_JACOBI; break;
-        case SCHUR_POWER_SERIES_EXPANSION: o.preconditioner_type = CX_SCHUR_POWER_SERIES_EXPANSION; break;
-        case CLUSTER_JACOBI: o.preconditioner_type = CX_CLUSTER_JACOBI; break;
-        case CLUSTER_TRIDIAGONAL: o.preconditioner_type = CX_CLUSTER_TRIDIAGONAL; break;
-        default:
-          summary.termination_type = LinearSolverTerminationType::FATAL_ERROR;
-          summary.message = "Preconditioner not available in cxschur.";
-          return summary;
-      }
-      o.min_num_iterations = options_.min_num_iterations;
-      o.max_num_iterations = options_.max_num_iterations;
-      o.residual_reset_period = options_.residual_reset_period;
-      o.num_eliminate_blocks = num_eliminate_blocks;
-      o.use_mixed_precision_solves = options_.use_mixed_precision_solves;
-      o.max_num_refinement_iterations = options_.max_num_refinement_iterations;
-      o.max_num_spse_iterations = options_.max_num_spse_iterations;
-      o.use_spse_initialization = options_.use_spse_initialization;
-      o.spse_tolerance = options_.spse_tolerance;
-      o.use_explicit_schur_complement = options_.use_explicit_schur_complement;
-      o.visibility_clustering_type = options_.visibility_clustering_type == SINGLE_LINKAGE ? CX_SINGLE_LINKAGE : CX_CANONICAL_VIEWS;
+      if (!TranslateOptions(num_eliminate_blocks, &o, &summary)) return summary;
       if (cx_solver_create(ctx, &o, &solver_) != CX_OK) return Fatal(&summary);
     }
-    // Values change every LM iteration: upload them verbatim (same cell layout).
-    if (cx_matrix_set_values(matrix_, A->values(), CX_HOST) != CX_OK) return Fatal(&summary);
     cx_per_solve_options ps{};
     ps.D = per_solve_options.D;
     ps.r_tolerance = per_solve_options.r_tolerance;
     ps.q_tolerance = per_solve_options.q_tolerance;
     ps.memspace = CX_HOST;
+    ps.b_on_device = device_b != nullptr ? 1 : 0;
     cx_summary s;
-    if (cx_solver_solve(solver_, matrix_, b, &ps, x, &s) != CX_OK) return Fatal(&summary);
+    if (cx_solver_solve(solver_, matrix, device_b != nullptr ? device_b : b, &ps, x, &s) != CX_OK) return Fatal(&summary);
     summary.residual_norm = s.residual_norm;
     summary.num_iterations = s.num_iterations;
     summary.termination_type = static_cast<LinearSolverTerminationType>(s.termination_type);
     summary.message = s.message;
     cx_solver_last_timing(solver_, &timing_);
-    total_seconds_ += timing_.total_ms * 1e-3;
+    aliased_last_b_ = device_b != nullptr;
     return summary;
+  }
+
+  // execution_summary.h:45-83 -> Solver::Summary::linear_solver_time_in_seconds (solver.cc:636-643)
+  std::map<std::string, CallStatistics> Statistics() const final { return execution_summary_.statistics(); }
+
+  const cx_solve_timing& last_timing() const { return timing_; }  // device-side phase times of the last Solve
+  bool last_solve_aliased_residuals() const { return aliased_last_b_; }
+
+ private:
+  bool TranslateOptions(int num_eliminate_blocks, cx_solver_options* o, LinearSolver::Summary* summary) const {
+    cx_solver_default_options(o);
+    switch (options_.type) {
+      case DENSE_SCHUR: o->type = CX_DENSE_SCHUR; break;
+      case SPARSE_SCHUR: o->type = CX_SPARSE_SCHUR; break;
+      case ITERATIVE_SCHUR: o->type = CX_ITERATIVE_SCHUR; break;
+      case CGNR: o->type = CX_CGNR; break;
+      default:
+        Fatal(summary, "cxschur implements DENSE_SCHUR, SPARSE_SCHUR, ITERATIVE_SCHUR and CGNR only.");
+        return false;
+    }
+    switch (options_.preconditioner_type) {
+      case IDENTITY: o->preconditioner_type = CX_IDENTITY; break;
+      case JACOBI: o->preconditioner_type = CX_JACOBI; break;
+      case SCHUR_JACOBI: o->preconditioner_type = CX_SCHUR_JACOBI; break;
+      case SCHUR_POWER_SERIES_EXPANSION: o->preconditioner_type = CX_SCHUR_POWER_SERIES_EXPANSION; break;
+      case CLUSTER_JACOBI: o->preconditioner_type = CX_CLUSTER_JACOBI; break;
+      case CLUSTER_TRIDIAGONAL: o->preconditioner_type = CX_CLUSTER_TRIDIAGONAL; break;
+      default:
+        Fatal(summary, "Preconditioner not available in cxschur.");
+        return false;
+    }
+    o->min_num_iterations = options_.min_num_iterations;
+    o->max_num_iterations = options_.max_num_iterations;
+    o->residual_reset_period = options_.residual_reset_period;
+    o->num_eliminate_blocks = num_eliminate_blocks;
+    o->use_mixed_precision_solves = options_.use_mixed_precision_solves;
+    o->max_num_refinement_iterations = options_.max_num_refinement_iterations;
+    o->max_num_spse_iterations = options_.max_num_spse_iterations;
+    o->use_spse_initialization = options_.use_spse_initialization;
+    o->spse_tolerance = options_.spse_tolerance;
+    o->use_explicit_schur_complement = options_.use_explicit_schur_complement;
+    o->visibility_clustering_type = options_.visibility_clustering_type == SINGLE_LINKAGE ? CX_SINGLE_LINKAGE : CX_CANONICAL_VIEWS;
+    // ordering_type (linear_solver.h:157): the tile-sparse Cholesky chooses its own fill-reducing ordering and the
+    // eliminator keeps the natural camera order; dense / sparse library types do not apply.
+    return true;
   }
 
   // HIP / RCCL errors map to FATAL_ERROR, which makes TrustRegionMinimizer abort the solve
   // (trust_region_minimizer.cc:404-411)
-  static LinearSolver::Summary Fatal(LinearSolver::Summary* s) {
+  static LinearSolver::Summary Fatal(LinearSolver::Summary* s, const char* what = nullptr) {
     s->termination_type = LinearSolverTerminationType::FATAL_ERROR;
     s->num_iterations = 0;
-    s->message = std::string("cxschur: ") + cx_last_error();
+    s->message = std::string("cxschur: ") + (what != nullptr ? what : cx_last_error());
     return *s;
   }
 
   LinearSolver::Options options_;
-  cx_matrix* matrix_ = nullptr;
+  cx_matrix* owned_matrix_ = nullptr;  // only for host BlockSparseMatrix Jacobians
   cx_solver* solver_ = nullptr;
   cx_solve_timing timing_{};
-  double total_seconds_ = 0.0;
+  bool alias_evaluator_residuals_ = false;
+  bool aliased_last_b_ = false;
+  ExecutionSummary execution_summary_;
 };
 
 }  // namespace ceres::internal

@@ -1,20 +1,140 @@
-// Exercises CxLinearSolver the way the reference's own callers and tests do:
-//   * the LM strategy call sequence   levenberg_marquardt_strategy.cc:97-133
-//     (InvalidateArray, Solve(J, residuals, {D, q_tol = eta, r_tol = -1}), IsArrayValid, negate)
-//   * schur_complement_solver_test.cc / iterative_schur_complement_solver_test.cc:
-//     every solver type against the normal equations, |dx| / n < 1e-10
-// on a synthetic bundle-adjustment Jacobian in the spirit of
-// CreateFakeBundleAdjustmentJacobian (fake_bundle_adjustment_jacobian.cc:44-97).
+// Exercises the drop-in adapters the way the reference's own callers and tests do.
+//
+//  0. A signature table: every virtual the adapters override, every Options field they read and every enumerator
+//     they switch on is pinned by static_assert to the type / value the reference declares (file:line beside each
+//     line), so the adapters cannot drift away from the interface they claim to implement.
+//  1. CxLinearSolver on a host BlockSparseMatrix: every solver type against the normal equations
+//     (schur_complement_solver_test.cc:186-227 / iterative_schur_complement_solver_test.cc: |dx| / n < 1e-10) and the
+//     LM call sequence (levenberg_marquardt_strategy.cc:97-133: InvalidateArray, Solve(J, residuals, {D, q_tol = eta,
+//     r_tol = -1}), IsArrayValid, negate), on a Jacobian in the spirit of CreateFakeBundleAdjustmentJacobian
+//     (fake_bundle_adjustment_jacobian.cc:44-97).
+//  2. Evaluator -> LM strategy -> LinearSolver through the mirrored virtuals only: a bundle-adjustment Program goes
+//     through CxBalEvaluator::TryCreate (the factory hook), the Jacobian is the CxDeviceJacobian it creates, and a
+//     trust-region loop written against Evaluator / SparseMatrix / LinearSolver (the calls of
+//     trust_region_minimizer.cc:246-313, 381-463 and levenberg_marquardt_strategy.cc:69-156) minimises it with J never
+//     leaving the device.  Checked against (a) the same loop run on a host BlockSparseMatrix that holds a copy of
+//     every Jacobian (host products, values uploaded per solve) and (b) cx_minimize, the device-resident minimizer.
 // Needs a gfx950 device.  Exit code 0 = all checks passed.
+#include <algorithm>
 #include <cstdio>
 #include <cstdlib>
+#include <numeric>
 #include <random>
+#include <type_traits>
 
+#include "cx_bal_evaluator.h"
 #include "cx_linear_solver.h"
 
 using namespace ceres;
 using namespace ceres::internal;
 
+// ------------------------------------------------------------------------------------------------ 0. signatures
+namespace signature_table {
+template <typename T, typename U> constexpr bool same = std::is_same<T, U>::value;
+using StatsMap = std::map<std::string, CallStatistics>;
+
+// linear_solver.h:338-341  virtual Summary Solve(LinearOperator* A, const double* b, const PerSolveOptions&, double* x) = 0;
+static_assert(same<decltype(&LinearSolver::Solve),
+                   LinearSolver::Summary (LinearSolver::*)(LinearOperator*, const double*, const LinearSolver::PerSolveOptions&, double*)>);
+// linear_solver.h:348-350  virtual std::map<std::string, CallStatistics> Statistics() const
+static_assert(same<decltype(&LinearSolver::Statistics), StatsMap (LinearSolver::*)() const>);
+// execution_summary.h:45-49
+static_assert(same<decltype(CallStatistics::time), absl::Duration> && same<decltype(CallStatistics::calls), int>);
+// CxLinearSolver overrides exactly those two
+static_assert(std::is_base_of<LinearSolver, CxLinearSolver>::value && !std::is_abstract<CxLinearSolver>::value);
+static_assert(same<decltype(&CxLinearSolver::Solve),
+                   LinearSolver::Summary (CxLinearSolver::*)(LinearOperator*, const double*, const LinearSolver::PerSolveOptions&, double*)>);
+static_assert(same<decltype(&CxLinearSolver::Statistics), StatsMap (CxLinearSolver::*)() const>);
+// linear_solver.h:57-74: numeric order the C ABI's cx_termination repeats
+static_assert(int(LinearSolverTerminationType::SUCCESS) == CX_SUCCESS && int(LinearSolverTerminationType::NO_CONVERGENCE) == CX_NO_CONVERGENCE &&
+              int(LinearSolverTerminationType::FAILURE) == CX_FAILURE && int(LinearSolverTerminationType::FATAL_ERROR) == CX_FATAL_ERROR);
+// linear_solver.h:150-230: the Options fields the adapter and the factory patch of INTEGRATION.md read
+using O = LinearSolver::Options;
+static_assert(same<decltype(O::type), LinearSolverType> && same<decltype(O::preconditioner_type), PreconditionerType> &&
+              same<decltype(O::visibility_clustering_type), VisibilityClusteringType> &&
+              same<decltype(O::dense_linear_algebra_library_type), DenseLinearAlgebraLibraryType> &&
+              same<decltype(O::sparse_linear_algebra_library_type), SparseLinearAlgebraLibraryType> &&
+              same<decltype(O::ordering_type), OrderingType> && same<decltype(O::dynamic_sparsity), bool> &&
+              same<decltype(O::use_explicit_schur_complement), bool> && same<decltype(O::min_num_iterations), int> &&
+              same<decltype(O::max_num_iterations), int> && same<decltype(O::max_num_spse_iterations), int> &&
+              same<decltype(O::use_spse_initialization), bool> && same<decltype(O::spse_tolerance), double> &&
+              same<decltype(O::num_threads), int> && same<decltype(O::elimination_groups), std::vector<int>> &&
+              same<decltype(O::residual_reset_period), int> && same<decltype(O::row_block_size), int> &&
+              same<decltype(O::e_block_size), int> && same<decltype(O::f_block_size), int> &&
+              same<decltype(O::use_mixed_precision_solves), bool> && same<decltype(O::max_num_refinement_iterations), int> &&
+              same<decltype(O::subset_preconditioner_start_row_block), int> && same<decltype(O::context), ContextImpl*>);
+// linear_solver.h:232-318, :320-326
+static_assert(same<decltype(LinearSolver::PerSolveOptions::D), double*> &&
+              same<decltype(LinearSolver::PerSolveOptions::preconditioner), LinearOperator*> &&
+              same<decltype(LinearSolver::PerSolveOptions::r_tolerance), double> &&
+              same<decltype(LinearSolver::PerSolveOptions::q_tolerance), double>);
+static_assert(same<decltype(LinearSolver::Summary::residual_norm), double> && same<decltype(LinearSolver::Summary::num_iterations), int> &&
+              same<decltype(LinearSolver::Summary::termination_type), LinearSolverTerminationType> &&
+              same<decltype(LinearSolver::Summary::message), std::string>);
+// include/ceres/types.h:57-141: enumerator values the adapter switches on
+static_assert(DENSE_SCHUR == 3 && SPARSE_SCHUR == 4 && ITERATIVE_SCHUR == 5 && CGNR == 6);
+static_assert(IDENTITY == 0 && JACOBI == 1 && SCHUR_JACOBI == 2 && SCHUR_POWER_SERIES_EXPANSION == 3 && CLUSTER_JACOBI == 4 &&
+              CLUSTER_TRIDIAGONAL == 5 && SUBSET == 6);
+static_assert(CANONICAL_VIEWS == 0 && SINGLE_LINKAGE == 1);
+
+// evaluator.h:95  virtual std::unique_ptr<SparseMatrix> CreateJacobian() const = 0;
+static_assert(same<decltype(&Evaluator::CreateJacobian), std::unique_ptr<SparseMatrix> (Evaluator::*)() const>);
+// evaluator.h:116-121 (the virtual; the 5-argument overload :127-134 forwards to it)
+using EvaluateVirtual = bool (Evaluator::*)(const Evaluator::EvaluateOptions&, const double*, double*, double*, double*, SparseMatrix*);
+static_assert(same<decltype(static_cast<EvaluateVirtual>(&Evaluator::Evaluate)), EvaluateVirtual>);
+// evaluator.h:146-148, :151, :155, :158, :164-166
+static_assert(same<decltype(&Evaluator::Plus), bool (Evaluator::*)(const double*, const double*, double*) const>);
+static_assert(same<decltype(&Evaluator::NumParameters), int (Evaluator::*)() const> &&
+              same<decltype(&Evaluator::NumEffectiveParameters), int (Evaluator::*)() const> &&
+              same<decltype(&Evaluator::NumResiduals), int (Evaluator::*)() const>);
+static_assert(same<decltype(&Evaluator::Statistics), StatsMap (Evaluator::*)() const>);
+// evaluator.h:64-73, :99-112
+static_assert(same<decltype(Evaluator::Options::num_threads), int> && same<decltype(Evaluator::Options::num_eliminate_blocks), int> &&
+              same<decltype(Evaluator::Options::linear_solver_type), LinearSolverType> &&
+              same<decltype(Evaluator::Options::sparse_linear_algebra_library_type), SparseLinearAlgebraLibraryType> &&
+              same<decltype(Evaluator::Options::dynamic_sparsity), bool> && same<decltype(Evaluator::Options::context), ContextImpl*> &&
+              same<decltype(Evaluator::Options::evaluation_callback), EvaluationCallback*>);
+static_assert(same<decltype(Evaluator::EvaluateOptions::apply_loss_function), bool> &&
+              same<decltype(Evaluator::EvaluateOptions::new_evaluation_point), bool>);
+static_assert(std::is_base_of<Evaluator, CxBalEvaluator>::value && !std::is_abstract<CxBalEvaluator>::value);
+
+// sparse_matrix.h:66-113 / linear_operator.h:46-86: what CxDeviceJacobian overrides
+using RightLeft = void (SparseMatrix::*)(const double*, double*) const;
+static_assert(same<decltype(static_cast<RightLeft>(&SparseMatrix::RightMultiplyAndAccumulate)), RightLeft>);   // :72-73
+static_assert(same<decltype(static_cast<RightLeft>(&SparseMatrix::LeftMultiplyAndAccumulate)), RightLeft>);    // :76
+using Norm1 = void (SparseMatrix::*)(double*) const;
+using Norm3 = void (SparseMatrix::*)(double*, ContextImpl*, int) const;
+static_assert(same<decltype(static_cast<Norm1>(&SparseMatrix::SquaredColumnNorm)), Norm1> &&                    // :79
+              same<decltype(static_cast<Norm3>(&SparseMatrix::SquaredColumnNorm)), Norm3>);                     // :80-82
+using Scale1 = void (SparseMatrix::*)(const double*);
+using Scale3 = void (SparseMatrix::*)(const double*, ContextImpl*, int);
+static_assert(same<decltype(static_cast<Scale1>(&SparseMatrix::ScaleColumns)), Scale1> &&                       // :84
+              same<decltype(static_cast<Scale3>(&SparseMatrix::ScaleColumns)), Scale3>);                        // :85-87
+static_assert(same<decltype(&SparseMatrix::ToDenseMatrix), void (SparseMatrix::*)(Matrix*) const> &&            // :98
+              same<decltype(&SparseMatrix::ToTextFile), void (SparseMatrix::*)(FILE*) const> &&                 // :101
+              same<decltype(&SparseMatrix::mutable_values), double* (SparseMatrix::*)()> &&                     // :107
+              same<decltype(&SparseMatrix::values), const double* (SparseMatrix::*)() const> &&                 // :108
+              same<decltype(&SparseMatrix::num_nonzeros), int (SparseMatrix::*)() const>);                      // :112
+static_assert(same<decltype(&LinearOperator::num_rows), int (LinearOperator::*)() const> &&                     // linear_operator.h:85-86
+              same<decltype(&LinearOperator::num_cols), int (LinearOperator::*)() const>);
+static_assert(std::is_base_of<SparseMatrix, CxDeviceJacobian>::value && !std::is_abstract<CxDeviceJacobian>::value);
+static_assert(std::is_final<BlockSparseMatrix>::value);  // block_sparse_matrix.h:60 -- why CxDeviceJacobian is a sibling
+// block_structure.h:54-75: Block / Cell are laid out like the C ABI's cx_block / cx_cell
+static_assert(sizeof(Block) == sizeof(cx_block) && sizeof(Cell) == sizeof(cx_cell));
+}  // namespace signature_table
+
+static int failures = 0;
+#define EXPECT(cond, ...)                                   \
+  do {                                                      \
+    if (!(cond)) {                                          \
+      ++failures;                                           \
+      std::printf("FAIL %s:%d  %s  ", __FILE__, __LINE__, #cond); \
+      std::printf(__VA_ARGS__);                             \
+      std::printf("\n");                                    \
+    }                                                       \
+  } while (0)
+
+// ------------------------------------------------------------------------------------------------ 1. host Jacobian
 static std::unique_ptr<BlockSparseMatrix> FakeBundleAdjustmentJacobian(int num_cameras, int num_points, double visibility,
                                                                        std::mt19937& prng) {
   auto* bs = new CompressedRowBlockStructure;
@@ -45,40 +165,28 @@ static std::unique_ptr<BlockSparseMatrix> FakeBundleAdjustmentJacobian(int num_c
   return A;
 }
 
-// y = (J'J + D'D) x - J'b computed with plain host loops (independent of the library)
-static double NormalEquationResidual(const BlockSparseMatrix& A, const double* b, const double* D, const double* x) {
-  const auto* bs = A.block_structure();
-  std::vector<double> Jx(A.num_rows(), 0.0), g(A.num_cols(), 0.0);
-  for (auto& row : bs->rows)
-    for (auto& cell : row.cells) {
-      const Block& col = bs->cols[cell.block_id];
-      for (int i = 0; i < row.block.size; ++i)
-        for (int j = 0; j < col.size; ++j) Jx[row.block.position + i] += A.values()[cell.position + i * col.size + j] * x[col.position + j];
-    }
-  for (int i = 0; i < A.num_rows(); ++i) Jx[i] -= b[i];
-  for (auto& row : bs->rows)
-    for (auto& cell : row.cells) {
-      const Block& col = bs->cols[cell.block_id];
-      for (int i = 0; i < row.block.size; ++i)
-        for (int j = 0; j < col.size; ++j) g[col.position + j] += A.values()[cell.position + i * col.size + j] * Jx[row.block.position + i];
-    }
+// |(J'J + D'D) x - J'b| with the SparseMatrix virtuals of the host container (independent of the library)
+static double NormalEquationResidual(const SparseMatrix& A, const double* b, const double* D, const double* x) {
+  std::vector<double> Jx(size_t(A.num_rows()), 0.0), g(size_t(A.num_cols()), 0.0);
+  A.RightMultiplyAndAccumulate(x, Jx.data());
+  for (int i = 0; i < A.num_rows(); ++i) Jx[size_t(i)] -= b[i];
+  A.LeftMultiplyAndAccumulate(Jx.data(), g.data());
   double n2 = 0.0;
-  for (int j = 0; j < A.num_cols(); ++j) { const double v = g[j] + D[j] * D[j] * x[j]; n2 += v * v; }
+  for (int j = 0; j < A.num_cols(); ++j) { const double v = g[size_t(j)] + D[j] * D[j] * x[j]; n2 += v * v; }
   return std::sqrt(n2);
 }
 
-int main() {
+static void TestSolversOnHostJacobian() {
   std::mt19937 prng(5489u);
   const int kCameras = 12, kPoints = 300;
   auto A = FakeBundleAdjustmentJacobian(kCameras, kPoints, 0.4, prng);
   std::normal_distribution<double> normal(0.0, 1.0);
-  std::vector<double> b(A->num_rows()), D(A->num_cols());
+  std::vector<double> b(static_cast<size_t>(A->num_rows())), D(static_cast<size_t>(A->num_cols()));
   for (auto& v : b) v = normal(prng);
   for (auto& v : D) v = 0.5 + std::abs(normal(prng));
-  std::printf("J: %d x %d, %lld non-zeros\n", A->num_rows(), A->num_cols(), (long long)A->num_nonzeros());
-  int failures = 0;
+  std::printf("J: %d x %d, %d non-zeros\n", A->num_rows(), A->num_cols(), A->num_nonzeros());
   std::vector<double> reference;
-  const std::vector<double> zero(A->num_cols(), 0.0);
+  const std::vector<double> zero(size_t(A->num_cols()), 0.0);
   const double norm_rhs = NormalEquationResidual(*A, b.data(), D.data(), zero.data());  // |J'b|
   struct Case { LinearSolverType type; PreconditionerType pre; const char* name; };
   const Case cases[] = {{DENSE_SCHUR, IDENTITY, "DENSE_SCHUR"}, {SPARSE_SCHUR, IDENTITY, "SPARSE_SCHUR"},
@@ -91,28 +199,31 @@ int main() {
     options.elimination_groups = {kPoints, kCameras};
     options.min_num_iterations = 0;
     options.max_num_iterations = A->num_cols();
-    CxLinearSolver solver(options);
+    EXPECT(CxLinearSolver::Supports(options), "%s", c.name);
+    std::unique_ptr<LinearSolver> solver = std::make_unique<CxLinearSolver>(options);  // used through the base class only
     LinearSolver::PerSolveOptions ps;
     ps.D = D.data();
     ps.r_tolerance = 1e-13;   // run to convergence, as the reference's solver tests do
     ps.q_tolerance = 0.0;
-    std::vector<double> x(A->num_cols());
+    std::vector<double> x(static_cast<size_t>(A->num_cols()));
     InvalidateArray(A->num_cols(), x.data());
-    LinearSolver::Summary s = solver.Solve(A.get(), b.data(), ps, x.data());
+    LinearSolver::Summary s = solver->Solve(A.get(), b.data(), ps, x.data());
     const bool valid = IsArrayValid(A->num_cols(), x.data());
     const double res = NormalEquationResidual(*A, b.data(), D.data(), x.data());
     double diff = 0.0;
     if (reference.empty()) reference = x;
     for (size_t i = 0; i < x.size(); ++i) diff += (x[i] - reference[i]) * (x[i] - reference[i]);
-    diff = std::sqrt(diff) / x.size();
+    diff = std::sqrt(diff) / double(x.size());
     const bool ok = s.termination_type == LinearSolverTerminationType::SUCCESS && valid && res < 1e-9 * norm_rhs && diff < 1e-10;
     std::printf("%-30s %s  iterations %3d  |normal eq residual| %.2e  |x - x_dense_schur|/n %.2e  (%s)\n", c.name,
                 ok ? "ok  " : "FAIL", s.num_iterations, res, diff, s.message.c_str());
-    if (!ok) ++failures;
-    if (solver.Statistics().count("LinearSolver::Solve") != 1) ++failures;
+    EXPECT(ok, "%s", c.name);
+    // TypedLinearSolver's bookkeeping (linear_solver.h:366-380): one timed call
+    const auto stats = solver->Statistics();
+    EXPECT(stats.count("LinearSolver::Solve") == 1 && stats.at("LinearSolver::Solve").calls == 1 &&
+               absl::ToDoubleSeconds(stats.at("LinearSolver::Solve").time) > 0.0, "%s statistics", c.name);
   }
-  // the LM call: truncated solve with q_tolerance = eta, step = -x
-  {
+  {  // the LM call: truncated solve with q_tolerance = eta, step = -x
     LinearSolver::Options options;
     options.type = ITERATIVE_SCHUR;
     options.preconditioner_type = JACOBI;
@@ -124,14 +235,435 @@ int main() {
     ps.D = D.data();
     ps.q_tolerance = 0.1;
     ps.r_tolerance = -1.0;
-    std::vector<double> step(A->num_cols());
+    std::vector<double> step(static_cast<size_t>(A->num_cols()));
     InvalidateArray(A->num_cols(), step.data());
     LinearSolver::Summary s = solver.Solve(A.get(), b.data(), ps, step.data());
     const bool ok = s.termination_type == LinearSolverTerminationType::SUCCESS && IsArrayValid(A->num_cols(), step.data());
-    for (auto& v : step) v = -v;
     std::printf("LM-style truncated solve        %s  iterations %3d  (%s)\n", ok ? "ok  " : "FAIL", s.num_iterations, s.message.c_str());
-    if (!ok) ++failures;
+    EXPECT(ok, "LM-style solve");
   }
+  {  // no exception, no abort on misuse: failures come back as FATAL_ERROR summaries (linear_solver.h:66-73)
+    LinearSolver::Options options;
+    options.type = DENSE_QR;
+    EXPECT(!CxLinearSolver::Supports(options), "DENSE_QR must not be claimed");
+    CxLinearSolver solver(options);
+    std::vector<double> x(static_cast<size_t>(A->num_cols()));
+    LinearSolver::PerSolveOptions ps;
+    ps.D = D.data();
+    LinearSolver::Summary s = solver.Solve(A.get(), b.data(), ps, x.data());
+    EXPECT(s.termination_type == LinearSolverTerminationType::FATAL_ERROR, "unsupported type -> FATAL_ERROR (%s)", s.message.c_str());
+    options.type = ITERATIVE_SCHUR;
+    options.elimination_groups = {kPoints, kCameras};
+    CxLinearSolver solver2(options);
+    ps.preconditioner = A.get();  // a user-supplied preconditioner operator cannot run on the device
+    s = solver2.Solve(A.get(), b.data(), ps, x.data());
+    EXPECT(s.termination_type == LinearSolverTerminationType::FATAL_ERROR, "user preconditioner -> FATAL_ERROR");
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ 2. the program
+// Owns a synthetic bundle-adjustment problem modelled with the (mirrored) modelling-layer classes, in the state
+// Solver::Solve leaves it in for a Schur-type solver: parameter blocks = points then cameras
+// (ApplyOrdering, reorder_program.cc:216-254), residual blocks ordered by LexicographicallyOrderResidualBlocks.
+struct BalProgram {
+  using Snavely = AutoDiffCostFunction<examples::SnavelyReprojectionError, 2, 9, 3>;
+  int C = 0, P = 0;
+  std::vector<double> user_state;  // [cameras (9 each) | points (3 each)] like BALProblem (bal_problem.cc:93-108)
+  std::vector<std::unique_ptr<ParameterBlock>> parameter_blocks;
+  std::vector<std::unique_ptr<CostFunction>> cost_functions;
+  std::vector<std::unique_ptr<ResidualBlock>> residual_blocks;
+  std::vector<int32_t> camera_index, point_index;  // input order
+  std::vector<double> observations;
+  Program program;
+
+  // SnavelyReprojectionError::operator() on doubles (snavely_reprojection_error.h:60-93, rotation.h:792-857)
+  static void Project(const double* cam, const double* pt, double* xy) {
+    const double theta = std::sqrt(cam[0] * cam[0] + cam[1] * cam[1] + cam[2] * cam[2]);
+    double p[3];
+    if (theta > 0.0) {
+      const double ct = std::cos(theta), st = std::sin(theta), ti = 1.0 / theta;
+      const double w[3] = {cam[0] * ti, cam[1] * ti, cam[2] * ti};
+      const double wx[3] = {w[1] * pt[2] - w[2] * pt[1], w[2] * pt[0] - w[0] * pt[2], w[0] * pt[1] - w[1] * pt[0]};
+      const double tmp = (w[0] * pt[0] + w[1] * pt[1] + w[2] * pt[2]) * (1.0 - ct);
+      for (int i = 0; i < 3; ++i) p[i] = pt[i] * ct + wx[i] * st + w[i] * tmp;
+    } else {
+      p[0] = pt[0] + cam[1] * pt[2] - cam[2] * pt[1];
+      p[1] = pt[1] + cam[2] * pt[0] - cam[0] * pt[2];
+      p[2] = pt[2] + cam[0] * pt[1] - cam[1] * pt[0];
+    }
+    p[0] += cam[3]; p[1] += cam[4]; p[2] += cam[5];
+    const double xp = -p[0] / p[2], yp = -p[1] / p[2];
+    const double r2 = xp * xp + yp * yp;
+    const double distortion = 1.0 + r2 * (cam[7] + cam[8] * r2);
+    xy[0] = cam[6] * distortion * xp;
+    xy[1] = cam[6] * distortion * yp;
+  }
+
+  BalProgram(int num_cameras, int num_points, double visibility, unsigned seed, const LossFunction* loss = nullptr) : C(num_cameras), P(num_points) {
+    std::mt19937 prng(seed);
+    std::normal_distribution<double> normal(0.0, 1.0);
+    std::uniform_real_distribution<double> uni(0.0, 1.0);
+    user_state.assign(size_t(9 * C + 3 * P), 0.0);
+    std::vector<double> truth(user_state.size());
+    double* cams = truth.data();
+    double* pts = truth.data() + 9 * C;
+    for (int i = 0; i < C; ++i) {  // cameras around the origin looking roughly down -z at a cloud near z = -10
+      double* c = cams + 9 * i;
+      for (int k = 0; k < 3; ++k) c[k] = 0.1 * normal(prng);
+      c[3] = 0.5 * normal(prng); c[4] = 0.5 * normal(prng); c[5] = -10.0 + 0.5 * normal(prng);
+      c[6] = 500.0 + 20.0 * normal(prng); c[7] = 1e-3 * normal(prng); c[8] = 1e-5 * normal(prng);
+    }
+    for (int j = 0; j < P; ++j) for (int k = 0; k < 3; ++k) pts[3 * j + k] = 2.0 * normal(prng);
+    for (int j = 0; j < P; ++j) {
+      int seen = 0;
+      for (int i = 0; i < C; ++i) {
+        if (uni(prng) < visibility || (seen < 2 && i >= C - 2 + seen)) {
+          double xy[2];
+          Project(cams + 9 * i, pts + 3 * j, xy);
+          camera_index.push_back(i);
+          point_index.push_back(j);
+          observations.push_back(xy[0] + 0.5 * normal(prng));
+          observations.push_back(xy[1] + 0.5 * normal(prng));
+          ++seen;
+        }
+      }
+    }
+    // shuffle the observations so that the input order is not already the Schur order
+    std::vector<int> perm(camera_index.size());
+    std::iota(perm.begin(), perm.end(), 0);
+    std::shuffle(perm.begin(), perm.end(), prng);
+    {
+      std::vector<int32_t> ci(perm.size()), pi(perm.size());
+      std::vector<double> ob(2 * perm.size());
+      for (size_t k = 0; k < perm.size(); ++k) {
+        ci[k] = camera_index[size_t(perm[k])]; pi[k] = point_index[size_t(perm[k])];
+        ob[2 * k] = observations[size_t(2 * perm[k])]; ob[2 * k + 1] = observations[size_t(2 * perm[k] + 1)];
+      }
+      camera_index.swap(ci); point_index.swap(pi); observations.swap(ob);
+    }
+    // the start point: the truth, perturbed (BALProblem::Perturb, bal_problem.cc:294-333)
+    for (size_t k = 0; k < truth.size(); ++k) user_state[k] = truth[k];
+    for (int i = 0; i < C; ++i) { for (int k = 0; k < 3; ++k) user_state[size_t(9 * i + k)] += 0.01 * normal(prng); for (int k = 3; k < 6; ++k) user_state[size_t(9 * i + k)] += 0.05 * normal(prng); }
+    for (int j = 0; j < 3 * P; ++j) user_state[size_t(9 * C + j)] += 0.05 * normal(prng);
+
+    // Problem -> Program: parameter blocks in the order ApplyOrdering gives for ordering {points: 0, cameras: 1}
+    for (int j = 0; j < P; ++j) parameter_blocks.emplace_back(new ParameterBlock(&user_state[size_t(9 * C + 3 * j)], 3, j));
+    for (int i = 0; i < C; ++i) parameter_blocks.emplace_back(new ParameterBlock(&user_state[size_t(9 * i)], 9, P + i));
+    for (auto& pb : parameter_blocks) program.mutable_parameter_blocks()->push_back(pb.get());
+    program.SetParameterOffsetsAndIndex();
+    // residual blocks in input order, then LexicographicallyOrderResidualBlocks (reorder_program.cc:256-338)
+    const size_t O = camera_index.size();
+    std::vector<ResidualBlock*> input(O);
+    for (size_t k = 0; k < O; ++k) {
+      cost_functions.emplace_back(new Snavely(new examples::SnavelyReprojectionError(observations[2 * k], observations[2 * k + 1])));
+      std::vector<ParameterBlock*> blocks = {parameter_blocks[size_t(P + camera_index[k])].get(), parameter_blocks[size_t(point_index[k])].get()};
+      residual_blocks.emplace_back(new ResidualBlock(cost_functions.back().get(), loss, blocks, int(k)));
+      input[k] = residual_blocks.back().get();
+    }
+    std::vector<int> offsets(size_t(P) + 1, 0);
+    for (size_t k = 0; k < O; ++k) offsets[size_t(point_index[k])]++;
+    std::partial_sum(offsets.begin(), offsets.end(), offsets.begin());
+    std::vector<ResidualBlock*> reordered(O, nullptr);
+    for (size_t k = 0; k < O; ++k) reordered[size_t(--offsets[size_t(point_index[k])])] = input[k];
+    *program.mutable_residual_blocks() = reordered;
+  }
+
+  // Program::ParameterBlocksToStateVector (program.cc:186-193)
+  std::vector<double> StateVector() const {
+    std::vector<double> state(static_cast<size_t>(program.NumParameters()));
+    for (const ParameterBlock* pb : program.parameter_blocks())
+      std::copy(pb->user_state(), pb->user_state() + pb->Size(), state.begin() + pb->state_offset());
+    return state;
+  }
+};
+
+// The trust-region loop of the reference reduced to the calls that cross the boundary: everything it does with the
+// evaluator, the Jacobian and the linear solver goes through the abstract interfaces.
+struct LmTrace {
+  std::vector<double> costs;        // cost after every successful step (cost[0] = initial)
+  std::vector<int> linear_iterations;
+  std::vector<double> final_state;
+  int num_successful = 0, num_unsuccessful = 0;
+  bool ok = true;
+};
+
+static LmTrace RunTrustRegionLoop(Evaluator* evaluator, SparseMatrix* jacobian, LinearSolver* linear_solver, std::vector<double> x,
+                                  int max_iterations, double eta) {
+  LmTrace trace;
+  const int num_parameters = evaluator->NumParameters(), num_effective = evaluator->NumEffectiveParameters();
+  const int num_residuals = evaluator->NumResiduals();
+  std::vector<double> residuals(static_cast<size_t>(num_residuals)), gradient(static_cast<size_t>(num_effective)), scaling(static_cast<size_t>(num_effective)),
+      diagonal(static_cast<size_t>(num_effective)), lm_diagonal(static_cast<size_t>(num_effective)), step(static_cast<size_t>(num_effective)), delta(static_cast<size_t>(num_effective)),
+      model_residuals(static_cast<size_t>(num_residuals)), candidate(static_cast<size_t>(num_parameters));
+  double cost = 0.0;
+  double radius = 1e4, decrease_factor = 2.0;  // Solver::Options defaults (solver.h:270-290)
+  const double max_radius = 1e16, min_relative_decrease = 1e-3, min_diagonal = 1e-6, max_diagonal = 1e32;
+  bool reuse_diagonal = false;
+  // TrustRegionMinimizer::EvaluateGradientAndJacobian (trust_region_minimizer.cc:246-313)
+  auto evaluate_gradient_and_jacobian = [&](bool first) {
+    Evaluator::EvaluateOptions evaluate_options;
+    evaluate_options.new_evaluation_point = true;
+    if (!evaluator->Evaluate(evaluate_options, x.data(), &cost, residuals.data(), gradient.data(), jacobian)) return false;
+    if (first) {
+      jacobian->SquaredColumnNorm(scaling.data());
+      for (auto& s : scaling) s = 1.0 / (1.0 + std::sqrt(s));
+    }
+    jacobian->ScaleColumns(scaling.data(), nullptr, 1);
+    return true;
+  };
+  if (!evaluate_gradient_and_jacobian(true)) { trace.ok = false; return trace; }
+  trace.costs.push_back(cost);
+  for (int iteration = 1; iteration <= max_iterations; ++iteration) {
+    // LevenbergMarquardtStrategy::ComputeStep (levenberg_marquardt_strategy.cc:69-156)
+    if (!reuse_diagonal) {
+      jacobian->SquaredColumnNorm(diagonal.data(), nullptr, 1);
+      for (auto& d : diagonal) d = std::min(std::max(d, min_diagonal), max_diagonal);
+    }
+    for (int i = 0; i < num_effective; ++i) lm_diagonal[size_t(i)] = std::sqrt(diagonal[size_t(i)] / radius);
+    LinearSolver::PerSolveOptions solve_options;
+    solve_options.D = lm_diagonal.data();
+    solve_options.q_tolerance = eta;
+    solve_options.r_tolerance = -1.0;
+    InvalidateArray(num_effective, step.data());
+    LinearSolver::Summary summary = linear_solver->Solve(jacobian, residuals.data(), solve_options, step.data());
+    if (summary.termination_type == LinearSolverTerminationType::FATAL_ERROR) { trace.ok = false; std::printf("  %s\n", summary.message.c_str()); return trace; }
+    bool step_is_valid = false;
+    if (summary.termination_type != LinearSolverTerminationType::FAILURE && IsArrayValid(num_effective, step.data())) {
+      for (auto& v : step) v = -v;
+      reuse_diagonal = true;
+      trace.linear_iterations.push_back(summary.num_iterations);
+      // TrustRegionMinimizer::ComputeTrustRegionStep (trust_region_minimizer.cc:381-463)
+      std::fill(model_residuals.begin(), model_residuals.end(), 0.0);
+      jacobian->RightMultiplyAndAccumulate(step.data(), model_residuals.data(), nullptr, 1);
+      double model_cost_change = 0.0;
+      for (int i = 0; i < num_residuals; ++i) model_cost_change -= model_residuals[size_t(i)] * (residuals[size_t(i)] + model_residuals[size_t(i)] / 2.0);
+      step_is_valid = model_cost_change > 0.0;
+      if (step_is_valid) {
+        for (int i = 0; i < num_effective; ++i) delta[size_t(i)] = step[size_t(i)] * scaling[size_t(i)];
+        // ComputeCandidatePointAndEvaluateCost (:720-748): cost only
+        double candidate_cost = 0.0;
+        if (!evaluator->Plus(x.data(), delta.data(), candidate.data()) ||
+            !evaluator->Evaluate(candidate.data(), &candidate_cost, nullptr, nullptr, nullptr)) { trace.ok = false; return trace; }
+        const double relative_decrease = (cost - candidate_cost) / model_cost_change;  // TrustRegionStepEvaluator, monotonic
+        if (relative_decrease > min_relative_decrease) {
+          // HandleSuccessfulStep (:790-812) + LevenbergMarquardtStrategy::StepAccepted (:158-166)
+          x = candidate;
+          radius = std::min(max_radius, radius / std::max(1.0 / 3.0, 1.0 - std::pow(2.0 * relative_decrease - 1.0, 3)));
+          decrease_factor = 2.0;
+          reuse_diagonal = false;
+          ++trace.num_successful;
+          if (!evaluate_gradient_and_jacobian(false)) { trace.ok = false; return trace; }
+          trace.costs.push_back(cost);
+          continue;
+        }
+      }
+    }
+    // HandleUnsuccessfulStep / StepRejected (:168-173)
+    radius /= decrease_factor;
+    decrease_factor *= 2.0;
+    reuse_diagonal = true;
+    ++trace.num_unsuccessful;
+    (void)step_is_valid;
+  }
+  trace.final_state = x;
+  return trace;
+}
+
+// A reference-style host evaluator for the comparison run: Evaluate() forwards to the device evaluator (the Jacobian
+// arithmetic under test elsewhere) but hands J out as a host BlockSparseMatrix -- the path a Ceres build without
+// CxBalEvaluator takes: host container, host products, values uploaded by CxLinearSolver on every Solve.
+class HostJacobianEvaluator final : public Evaluator {
+ public:
+  explicit HostJacobianEvaluator(Evaluator* device_evaluator) : device_(device_evaluator), device_jacobian_(device_evaluator->CreateJacobian()) {}
+  std::unique_ptr<SparseMatrix> CreateJacobian() const final {
+    const auto* dj = static_cast<const CxDeviceJacobian*>(device_jacobian_.get());
+    return std::make_unique<BlockSparseMatrix>(new CompressedRowBlockStructure(*dj->block_structure()));
+  }
+  bool Evaluate(const EvaluateOptions& o, const double* state, double* cost, double* residuals, double* gradient, SparseMatrix* jacobian) final {
+    if (!device_->Evaluate(o, state, cost, residuals, gradient, jacobian ? device_jacobian_.get() : nullptr)) return false;
+    if (jacobian) std::copy(device_jacobian_->values(), device_jacobian_->values() + jacobian->num_nonzeros(), jacobian->mutable_values());
+    return true;
+  }
+  bool Plus(const double* state, const double* delta, double* out) const final { return device_->Plus(state, delta, out); }
+  int NumParameters() const final { return device_->NumParameters(); }
+  int NumEffectiveParameters() const final { return device_->NumEffectiveParameters(); }
+  int NumResiduals() const final { return device_->NumResiduals(); }
+ private:
+  Evaluator* device_;
+  std::unique_ptr<SparseMatrix> device_jacobian_;
+};
+
+class SoftLOneStandIn final : public LossFunction {
+ public:
+  void Evaluate(double s, double rho[3]) const final { rho[0] = s; rho[1] = 1.0; rho[2] = 0.0; }
+};
+
+static void TestEvaluatorToSolverThroughTheInterfaces() {
+  const int kCameras = 24, kPoints = 1500, kIterations = 6;
+  const double kEta = 1e-2;
+  BalProgram bal(kCameras, kPoints, 0.35, 11u);
+  Evaluator::Options evaluator_options;
+  evaluator_options.linear_solver_type = ITERATIVE_SCHUR;
+  evaluator_options.num_eliminate_blocks = kPoints;
+  std::string why;
+  std::unique_ptr<Evaluator> evaluator = CxBalEvaluator::TryCreate(evaluator_options, &bal.program, &why);
+  EXPECT(evaluator != nullptr, "TryCreate declined: %s", why.c_str());
+  if (!evaluator) return;
+  EXPECT(evaluator->NumParameters() == 3 * kPoints + 9 * kCameras && evaluator->NumEffectiveParameters() == evaluator->NumParameters() &&
+             evaluator->NumResiduals() == 2 * bal.program.NumResidualBlocks(), "sizes");
+  std::printf("BA program: %d cameras, %d points, %d residual blocks\n", kCameras, kPoints, bal.program.NumResidualBlocks());
+
+  // the hook declines what the device does not implement, with a reason, and the factory falls through
+  {
+    Evaluator::Options o = evaluator_options;
+    o.linear_solver_type = CGNR;
+    EXPECT(CxBalEvaluator::TryCreate(o, &bal.program, &why) == nullptr && !why.empty(), "CGNR program must be declined");
+    o = evaluator_options;
+    o.num_eliminate_blocks = kPoints - 1;
+    EXPECT(CxBalEvaluator::TryCreate(o, &bal.program, &why) == nullptr, "wrong elimination group must be declined (%s)", why.c_str());
+    SoftLOneStandIn loss;
+    BalProgram robust(4, 40, 0.6, 3u, &loss);
+    o = evaluator_options;
+    o.num_eliminate_blocks = 40;
+    EXPECT(CxBalEvaluator::TryCreate(o, &robust.program, &why) == nullptr && why == "loss function present", "loss: %s", why.c_str());
+  }
+
+  // residual r of the program's block k must be the reprojection error of ITS observation: checks the row order
+  std::unique_ptr<SparseMatrix> jacobian = evaluator->CreateJacobian();
+  auto* device_jacobian = dynamic_cast<CxDeviceJacobian*>(jacobian.get());
+  EXPECT(device_jacobian != nullptr, "CreateJacobian must return the device-resident matrix");
+  const std::vector<double> x0 = bal.StateVector();
+  {
+    std::vector<double> residuals(static_cast<size_t>(evaluator->NumResiduals()));
+    double cost = 0.0;
+    EXPECT(evaluator->Evaluate(x0.data(), &cost, residuals.data(), nullptr, nullptr), "residual-only evaluation");
+    double worst = 0.0, half_sum = 0.0;
+    const auto& blocks = bal.program.residual_blocks();
+    for (size_t k = 0; k < blocks.size(); ++k) {
+      const auto* cost_function = static_cast<const BalProgram::Snavely*>(blocks[k]->cost_function());
+      const double* cam = x0.data() + blocks[k]->parameter_blocks()[0]->state_offset();
+      const double* pt = x0.data() + blocks[k]->parameter_blocks()[1]->state_offset();
+      double xy[2];
+      BalProgram::Project(cam, pt, xy);
+      const double r0 = xy[0] - cost_function->functor().observed_x, r1 = xy[1] - cost_function->functor().observed_y;
+      worst = std::max(worst, std::max(std::abs(r0 - residuals[2 * k]), std::abs(r1 - residuals[2 * k + 1])));
+      half_sum += 0.5 * (r0 * r0 + r1 * r1);
+    }
+    EXPECT(worst < 1e-9, "residuals are in program order: max |difference| %.3e", worst);
+    EXPECT(std::abs(cost - half_sum) < 1e-10 * half_sum, "cost %.12e vs %.12e", cost, half_sum);
+  }
+
+  LinearSolver::Options solver_options;
+  solver_options.type = ITERATIVE_SCHUR;
+  solver_options.preconditioner_type = JACOBI;
+  solver_options.elimination_groups = {kPoints, kCameras};
+  solver_options.min_num_iterations = 0;
+  solver_options.max_num_iterations = 500;
+
+  // (i) device-resident: evaluator -> strategy -> solver, J never crosses PCIe
+  CxLinearSolver device_solver(solver_options);
+  LmTrace device_trace = RunTrustRegionLoop(evaluator.get(), jacobian.get(), &device_solver, x0, kIterations, kEta);
+  EXPECT(device_trace.ok && device_trace.num_successful >= 3, "device-resident loop: %d successful steps", device_trace.num_successful);
+  EXPECT(device_jacobian->num_downloads() == 0 && device_jacobian->num_uploads() == 0,
+         "J must stay in HBM: %d downloads, %d uploads", device_jacobian->num_downloads(), device_jacobian->num_uploads());
+  const auto evaluator_stats = evaluator->Statistics();
+  EXPECT(evaluator_stats.count("Evaluator::Total") == 1 && evaluator_stats.count("Evaluator::Jacobian") == 1 &&
+             evaluator_stats.count("Evaluator::Residual") == 1, "Evaluator::Statistics keys (program_evaluator.h:143-147)");
+  EXPECT(device_solver.Statistics().at("LinearSolver::Solve").calls == device_trace.num_successful + device_trace.num_unsuccessful,
+         "LinearSolver::Solve call count");
+
+  // (ii) the same loop with the residual vector aliased to the evaluator's device copy: identical arithmetic
+  {
+    std::unique_ptr<Evaluator> evaluator2 = CxBalEvaluator::TryCreate(evaluator_options, &bal.program, &why);
+    std::unique_ptr<SparseMatrix> jacobian2 = evaluator2->CreateJacobian();
+    CxLinearSolver aliasing_solver(solver_options);
+    aliasing_solver.set_alias_evaluator_residuals(true);
+    LmTrace t = RunTrustRegionLoop(evaluator2.get(), jacobian2.get(), &aliasing_solver, x0, kIterations, kEta);
+    EXPECT(t.ok && aliasing_solver.last_solve_aliased_residuals(), "residual aliasing was not taken");
+    EXPECT(t.costs == device_trace.costs && t.linear_iterations == device_trace.linear_iterations, "aliased residuals change nothing");
+  }
+
+  // (iii) the reference-style path: host BlockSparseMatrix, host products, values uploaded on every Solve
+  HostJacobianEvaluator host_evaluator(evaluator.get());
+  std::unique_ptr<SparseMatrix> host_jacobian = host_evaluator.CreateJacobian();
+  CxLinearSolver host_solver(solver_options);
+  LmTrace host_trace = RunTrustRegionLoop(&host_evaluator, host_jacobian.get(), &host_solver, x0, kIterations, kEta);
+  EXPECT(host_trace.ok && host_trace.costs.size() == device_trace.costs.size() && host_trace.linear_iterations == device_trace.linear_iterations,
+         "host-Jacobian loop takes the same steps (%zu vs %zu successful)", host_trace.costs.size(), device_trace.costs.size());
+  for (size_t k = 0; k < std::min(host_trace.costs.size(), device_trace.costs.size()); ++k)
+    EXPECT(std::abs(host_trace.costs[k] - device_trace.costs[k]) <= 1e-9 * device_trace.costs[k], "cost %zu: %.12e vs %.12e", k,
+           host_trace.costs[k], device_trace.costs[k]);
+
+  // (iv) cx_minimize, the device-resident minimizer of the C ABI, on the same problem in INPUT observation order
+  {
+    cx_context* ctx = CxSharedContext();
+    cx_evaluator* e = nullptr;
+    cx_solver* s = nullptr;
+    EXPECT(cx_evaluator_create_bal(ctx, kCameras, kPoints, int64_t(bal.camera_index.size()), bal.camera_index.data(), bal.point_index.data(),
+                                   bal.observations.data(), &e) == CX_OK, "%s", cx_last_error());
+    cx_solver_options so;
+    cx_solver_default_options(&so);
+    so.type = CX_ITERATIVE_SCHUR;
+    so.preconditioner_type = CX_JACOBI;
+    so.num_eliminate_blocks = kPoints;
+    EXPECT(cx_solver_create(ctx, &so, &s) == CX_OK, "%s", cx_last_error());
+    cx_minimizer_options mo;
+    cx_minimizer_default_options(&mo);
+    mo.max_num_iterations = kIterations;
+    mo.eta = kEta;
+    mo.function_tolerance = 0.0;
+    mo.gradient_tolerance = 0.0;
+    mo.parameter_tolerance = 0.0;
+    std::vector<double> state = x0;
+    cx_minimizer_summary ms;
+    std::vector<cx_iteration_summary> its(static_cast<size_t>(kIterations + 2));
+    EXPECT(cx_minimize(e, s, &mo, state.data(), CX_HOST, &ms, its.data(), int32_t(its.size())) == CX_OK, "%s", cx_last_error());
+    std::vector<double> costs;
+    for (int k = 0; k < ms.num_iterations && k < int(its.size()); ++k)
+      if (k == 0 || its[size_t(k)].step_is_successful) costs.push_back(its[size_t(k)].cost);
+    EXPECT(costs.size() == device_trace.costs.size(), "cx_minimize: %zu accepted costs vs %zu", costs.size(), device_trace.costs.size());
+    for (size_t k = 0; k < std::min(costs.size(), device_trace.costs.size()); ++k)
+      EXPECT(std::abs(costs[k] - device_trace.costs[k]) <= 1e-7 * device_trace.costs[k], "cx_minimize cost %zu: %.12e vs %.12e", k, costs[k],
+             device_trace.costs[k]);
+    cx_solver_destroy(s);
+    cx_evaluator_destroy(e);
+  }
+  std::printf("LM through Evaluator/LinearSolver: cost %.6e -> %.6e in %d successful + %d unsuccessful steps, CG iterations",
+              device_trace.costs.front(), device_trace.costs.back(), device_trace.num_successful, device_trace.num_unsuccessful);
+  for (int n : device_trace.linear_iterations) std::printf(" %d", n);
+  std::printf("\n");
+
+  // host access on demand: values() materialises a copy, mutable_values() is written back before the next product
+  {
+    std::vector<double> ones(size_t(jacobian->num_cols()), 1.0), y0(size_t(jacobian->num_rows()), 0.0), y1 = y0;
+    jacobian->RightMultiplyAndAccumulate(ones.data(), y0.data());
+    double* v = jacobian->mutable_values();
+    EXPECT(device_jacobian->num_downloads() == 1, "values are downloaded on first request only");
+    for (int i = 0; i < jacobian->num_nonzeros(); ++i) v[i] *= 2.0;
+    jacobian->RightMultiplyAndAccumulate(ones.data(), y1.data());
+    EXPECT(device_jacobian->num_uploads() == 1, "modified host values are written back once");
+    double worst = 0.0, scale = 0.0;
+    for (size_t i = 0; i < y0.size(); ++i) { worst = std::max(worst, std::abs(y1[i] - 2.0 * y0[i])); scale = std::max(scale, std::abs(y0[i])); }
+    EXPECT(worst <= 1e-12 * scale, "product after mutable_values(): %.3e", worst);
+    Matrix dense;
+    jacobian->ToDenseMatrix(&dense);
+    EXPECT(dense.rows() == jacobian->num_rows() && dense.cols() == jacobian->num_cols(), "ToDenseMatrix shape");
+    std::vector<double> yd(size_t(jacobian->num_rows()), 0.0);
+    for (int r = 0; r < jacobian->num_rows(); ++r) for (int c = 0; c < jacobian->num_cols(); ++c) yd[size_t(r)] += dense(r, c);
+    worst = 0.0;
+    for (size_t i = 0; i < yd.size(); ++i) worst = std::max(worst, std::abs(yd[i] - y1[i]));
+    EXPECT(worst <= 1e-11 * 2.0 * scale, "ToDenseMatrix row sums: %.3e", worst);
+  }
+  // the Jacobian may outlive the evaluator (shared ownership of the device objects)
+  evaluator.reset();
+  std::vector<double> norms(static_cast<size_t>(jacobian->num_cols()));
+  jacobian->SquaredColumnNorm(norms.data());
+  EXPECT(IsArrayValid(jacobian->num_cols(), norms.data()), "Jacobian usable after the evaluator is gone");
+}
+
+int main() {
+  TestSolversOnHostJacobian();
+  TestEvaluatorToSolverThroughTheInterfaces();
   std::printf("%s\n", failures ? "FAILED" : "ALL OK");
   return failures ? 1 : 0;
 }

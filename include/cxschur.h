@@ -139,7 +139,8 @@ typedef struct {
   double r_tolerance;    /* default -1 */
   double q_tolerance;    /* default 0  */
   int32_t memspace;      /* cx_memspace of b, D and x */
-  int32_t reserved;
+  int32_t b_on_device;   /* non-zero: b is a device pointer whatever memspace says (the residuals an evaluator
+                          * left in HBM, cx_evaluator_device_residuals) */
 } cx_per_solve_options;
 
 /* LinearSolver::Summary (linear_solver.h:320-326) */
@@ -359,6 +360,11 @@ int64_t cx_evaluator_num_effective_parameters(const cx_evaluator* e);  /* Evalua
 /* Evaluator::Plus (evaluator.h:152-158): x_plus_delta = x [+] delta; x, x_plus_delta ambient, delta tangent */
 int cx_evaluator_plus(cx_evaluator* e, const double* x, const double* delta, double* x_plus_delta, int32_t memspace);
 double cx_evaluator_last_kernel_ms(const cx_evaluator* e);
+/* Device copy of the residuals the last cx_evaluator_evaluate wrote to HOST memory (NULL when it wrote none, or
+ * wrote them to a caller's device buffer): the same vector can go into cx_solver_solve as b with
+ * cx_per_solve_options.b_on_device = 1, without a second trip across PCIe.  Valid until the next evaluate that
+ * produces residuals. */
+const double* cx_evaluator_device_residuals(const cx_evaluator* e);
 
 /* -------------------------------------------------------------- minimizer */
 
