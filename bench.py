@@ -78,9 +78,25 @@ def lm_prepare_device(cx, ctx, prob):
     scale = 1.0 / (1.0 + np.sqrt(colnorm()))
     dscale = ctx.to_device(scale)
     A.scale_columns(dscale)
+    # What an LM iteration spends on producing the values the solve reads: the evaluation and the column scaling,
+    # repeated on the same state (same J every time).  Both kernels also keep the camera-major copy of the F cells
+    # current, which in round 1 was a separate pass (k_permute_ft) charged to the solve.
+    ev.set_emit_camera_major(False)      # ScaleColumns follows every evaluation here, as in TrustRegionMinimizer
+    eval_t, scale_t = [], []
+    for _ in range(3):
+        ev.evaluate(state, residuals=res, gradient=None, want_jacobian=True)
+        eval_t.append(ev.last_kernel_ms)
+        ctx.synchronize()
+        t0 = time.perf_counter()
+        A.scale_columns(dscale)
+        ctx.synchronize()
+        scale_t.append((time.perf_counter() - t0) * 1e3)
+    update = {"jacobian_eval_ms": float(np.median(eval_t)), "scale_columns_ms": float(np.median(scale_t)),
+              "camera_major_copy": "separate k_permute_ft pass inside the solve (CX_NO_FT_EMIT)" if os.environ.get("CX_NO_FT_EMIT")
+              else "written by k_scale_239 / k_bal_evaluate"}
     diag = np.clip(colnorm(), MIN_LM_DIAGONAL, MAX_LM_DIAGONAL)
     D = ctx.to_device(np.sqrt(diag / INITIAL_RADIUS))
-    return ev, A, res, D, cost, eval_ms
+    return ev, A, res, D, cost, eval_ms, update
 
 
 def cpu_baseline(cx, prob, solver_kw, threads, fraction):
@@ -190,7 +206,7 @@ def main():
         prob = full
     t_gen = time.time() - t_gen
 
-    ev, A, b, D, cost, eval_ms = lm_prepare_device(cx, ctx, prob)
+    ev, A, b, D, cost, eval_ms, values_update = lm_prepare_device(cx, ctx, prob)
     stype = {"iterative_schur": cx.ITERATIVE_SCHUR, "dense_schur": cx.DENSE_SCHUR, "sparse_schur": cx.SPARSE_SCHUR,
              "cgnr": cx.CGNR}[args.solver]
     ptype = {"jacobi": cx.JACOBI, "schur_jacobi": cx.SCHUR_JACOBI, "identity": cx.IDENTITY, "cluster_jacobi": cx.CLUSTER_JACOBI,
@@ -208,10 +224,14 @@ def main():
     t0 = time.perf_counter()
     kstats = {}
     phases = {}
+    separate_permute = bool(os.environ.get("CX_NO_FT_EMIT"))
     for _ in range(args.steps):
-        # every LM iteration hands the solver a freshly evaluated J: the camera-major copy of
-        # the F cells has to be rebuilt inside the solve, so invalidate it here
-        A.values_changed()
+        # Every LM iteration hands the solver freshly evaluated and scaled values.  The kernels that produce them
+        # (k_bal_evaluate, k_scale_239) now write the camera-major copy of the F cells as well, so the solve finds
+        # it current -- exactly the state lm_prepare_device leaves.  With CX_NO_FT_EMIT=1 (round-1 behaviour, kept
+        # for A/B runs) that copy is rebuilt by a separate pass inside every solve, so it is invalidated here.
+        if separate_permute:
+            A.values_changed()
         _, summ = S.solve(A, b, D, r_tolerance=-1.0, q_tolerance=ETA, x=x)
         for k in S.kernel_stats():
             e = kstats.setdefault(k["name"], [0.0, 0, 0])
@@ -313,6 +333,7 @@ def main():
             "at_bundle_adjuster_eta": tight,
             "explicit_s": explicit_info,
             "jacobian_eval_ms": eval_ms,
+            "values_update_per_lm_iteration": values_update,
             "spmv": spmv,
             "kernels": {k: {"avg_ms": v[0] / max(1, v[1]), "launches_per_solve": v[2] / max(1, args.steps)} for k, v in kstats.items()},
             "roofline": roof,

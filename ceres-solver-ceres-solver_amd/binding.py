@@ -38,7 +38,7 @@ EXPORTED_SYMBOLS = [
     "cx_implicit_schur_multiply", "cx_dense_cholesky_solve", "cx_evaluator_create_bal", "cx_evaluator_destroy",
     "cx_evaluator_jacobian", "cx_evaluator_row_of_observation", "cx_evaluator_evaluate", "cx_evaluator_set_loss", "cx_minimizer_default_options", "cx_minimize", "cx_schur_sparse_structure", "cx_visibility_structure", "cx_visibility_clusters_host",
     "cx_evaluator_set_camera_model", "cx_evaluator_num_parameters", "cx_evaluator_num_effective_parameters", "cx_evaluator_plus",
-    "cx_evaluator_last_kernel_ms", "cx_evaluator_device_residuals", "cx_detect_structure", "cx_partition_points", "cx_stable_schur_ordering",
+    "cx_evaluator_last_kernel_ms", "cx_evaluator_device_residuals", "cx_evaluator_set_emit_camera_major", "cx_detect_structure", "cx_partition_points", "cx_stable_schur_ordering",
 ]
 
 
@@ -525,6 +525,10 @@ class Evaluator:
         return out
 
     last_kernel_ms = property(lambda s: s.lib.cx_evaluator_last_kernel_ms(s._h))
+
+    def set_emit_camera_major(self, on):
+        """Whether Jacobian evaluations also write the camera-major copy of F (off when ScaleColumns always follows)."""
+        _check(self.lib.cx_evaluator_set_emit_camera_major(self._h, int(bool(on))))
 
     def set_camera_model(self, model):
         """CAMERA_ANGLE_AXIS (9 parameters) or CAMERA_QUATERNION_MANIFOLD (10 parameters, 9 tangent)."""

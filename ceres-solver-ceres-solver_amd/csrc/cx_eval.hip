@@ -311,7 +311,8 @@ __global__ __launch_bounds__(kBlock) void k_bal_evaluate(const double* __restric
                                                          const int32_t* __restrict__ row_cam, int64_t O,
                                                          int64_t cam_off, double* __restrict__ residuals,
                                                          double* __restrict__ E, double* __restrict__ F,
-                                                         double* __restrict__ cost_partial, LossParams loss) {
+                                                         double* __restrict__ cost_partial, LossParams loss,
+                                                         double* __restrict__ Ft, const int32_t* __restrict__ cam_pos) {
   __shared__ double lds[kBlock * 18];
   __shared__ double red[4];
   const int64_t r0i = int64_t(blockIdx.x) * kBlock;
@@ -363,7 +364,8 @@ __global__ __launch_bounds__(kBlock) void k_bal_evaluate(const double* __restric
     if (residuals) reinterpret_cast<double2*>(residuals)[r] = make_double2(res0, res1);
   }
   if (WITH_J) {
-    unstage_cells<18>(F + 18 * r0i, nvalid, lds, jc);
+    // F cells: row-major run and (Ft != nullptr) the camera-major copy in the same pass, see unstage_f_cells_two
+    unstage_f_cells_two(F + 18 * r0i, Ft, cam_pos + r0i, nvalid, lds, jc);
     unstage_cells<6>(E + 6 * r0i, nvalid, lds, jp);
   }
   if (cost_partial) {
@@ -524,11 +526,20 @@ int cx_evaluator_evaluate(cx_evaluator* e, const double* state, double* cost, do
   double* E = A->d_values.p;
   double* F = A->d_values.p + 6 * e->O;
   const LossParams loss{e->loss_type, e->loss_a, e->loss_b};
+  // the camera-major copy of F is written by the same kernel unless the caller said that a ScaleColumns follows
+  // (which rewrites it anyway) -- cx_evaluator_set_emit_camera_major
+  static const bool emit_allowed = std::getenv("CX_NO_FT_EMIT") == nullptr;  // A/B switch
+  double* ft_out = nullptr;
+  if (with_j && e->emit_ft && emit_allowed) {
+    CX_TRY(A->d_Ft.alloc(size_t(A->O) * 18));
+    ft_out = A->d_Ft.p;
+  }
   CX_HIP(hipEventRecord(ctx->ev[6], st));
 #define CX_LAUNCH_EVAL(WJ, MODEL)                                                                                      \
   hipLaunchKernelGGL((k_bal_evaluate<WJ, MODEL>), dim3(grid), dim3(kBlock), 0, st, (const double*)hs.dptr,              \
                      (const double*)e->d_obs.p, (const int32_t*)A->d_row_pt.p, (const int32_t*)A->d_row_cam.p, e->O,    \
-                     3 * int64_t(e->P), res_dev, E, F, cost ? e->d_partial.p : nullptr, loss)
+                     3 * int64_t(e->P), res_dev, E, F, cost ? e->d_partial.p : nullptr, loss, ft_out,                  \
+                     (const int32_t*)A->d_cam_pos.p)
   if (e->camera_model == CX_CAMERA_ANGLE_AXIS) {
     if (with_j) CX_LAUNCH_EVAL(true, CX_CAMERA_ANGLE_AXIS);
     else CX_LAUNCH_EVAL(false, CX_CAMERA_ANGLE_AXIS);
@@ -540,7 +551,7 @@ int cx_evaluator_evaluate(cx_evaluator* e, const double* state, double* cost, do
   if (cost) hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(256), 0, st, (const double*)e->d_partial.p, int64_t(grid), e->d_partial.p + grid);
   CX_HIP(hipGetLastError());
   CX_HIP(hipEventRecord(ctx->ev[7], st));
-  if (with_j) { A->ft_valid = false; A->f32_valid = false; }
+  if (with_j) { A->ft_valid = ft_out != nullptr; A->f32_valid = false; }
   if (gradient) {
     // g = J' r (program_evaluator.h:242-258)
     CX_HIP(hipMemsetAsync(hg.dptr, 0, size_t(ncols) * sizeof(double), st));
@@ -560,6 +571,12 @@ int cx_evaluator_evaluate(cx_evaluator* e, const double* state, double* cost, do
 }
 
 const double* cx_evaluator_device_residuals(const cx_evaluator* e) { return (e && e->res_valid) ? e->d_res.p : nullptr; }
+
+int cx_evaluator_set_emit_camera_major(cx_evaluator* e, int32_t on) {
+  CX_CHECK_ARG(e != nullptr);
+  e->emit_ft = on != 0;
+  return CX_OK;
+}
 
 int cx_evaluator_set_camera_model(cx_evaluator* e, int32_t camera_model) {
   CX_CHECK_ARG(e != nullptr && (camera_model == CX_CAMERA_ANGLE_AXIS || camera_model == CX_CAMERA_QUATERNION_MANIFOLD));

@@ -130,6 +130,7 @@ struct cx_matrix {
   int32_t num_tiles = 0;
   bool has_big_tiles = false;            // some chunk is longer than kTileRows
   DevBuf<int32_t> d_cam_rows;            // [O] rows in camera-major order
+  DevBuf<int32_t> d_cam_pos;             // [O] inverse: position of row r in camera-major order (d_cam_rows[d_cam_pos[r]] == r)
   DevBuf<int32_t> d_seg_begin, d_seg_cam;  // [S+1], [S] camera-major segments (positions in d_cam_rows)
   DevBuf<int32_t> d_cam_seg_start;       // [C+1] segments of each camera
   int32_t num_segs = 0;
@@ -219,6 +220,7 @@ struct cx_evaluator {
   std::vector<int64_t> row_of_obs;   // input observation -> row block
   DevBuf<double> d_obs;              // [2O] in row order
   DevBuf<double> d_partial, d_state, d_res;
+  bool emit_ft = true;               // Jacobian evaluations also write the camera-major copy of F (cx_matrix::d_Ft)
   bool res_valid = false;            // d_res holds the residuals last handed out in host memory
   float last_ms = 0.f;
   int32_t loss_type = CX_LOSS_NONE;

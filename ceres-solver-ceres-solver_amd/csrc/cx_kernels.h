@@ -200,6 +200,42 @@ __device__ __forceinline__ void unstage_cells(double* __restrict__ base, int nva
   __syncthreads();
 }
 
+// unstage_cells for the F cells with a second destination: the camera-major copy Ft (cx_matrix.hip).  The
+// row-major run leaves as one contiguous stream; the same 16-byte pieces then go to cell cam_pos[row] of Ft,
+// nine consecutive lanes writing the 144 contiguous bytes of one cell.  This is what lets the kernels that
+// produce F values (evaluation, column scaling) keep Ft current, so that no separate permutation pass over
+// F is needed afterwards.  ft == nullptr: plain unstage_cells.
+__device__ __forceinline__ void unstage_f_cells_two(double* __restrict__ base, double* __restrict__ ft,
+                                                    const int32_t* __restrict__ cam_pos_of_row, int nvalid,
+                                                    double* __restrict__ lds, const double (&in)[18]) {
+  constexpr int kPieces = 9;
+  const int tid = threadIdx.x;
+  double2* l2 = reinterpret_cast<double2*>(lds);
+#pragma unroll
+  for (int i = 0; i < kPieces; ++i) l2[tid * kPieces + i] = make_double2(in[2 * i], in[2 * i + 1]);
+  __syncthreads();
+  double2* dst = reinterpret_cast<double2*>(base);
+  const int total = nvalid * kPieces;
+#pragma unroll
+  for (int i = 0; i < kPieces; ++i) {
+    const int idx = i * kBlock + tid;
+    if (idx < total) dst[idx] = l2[idx];
+  }
+  if (ft != nullptr) {
+    double2* dft = reinterpret_cast<double2*>(ft);
+#pragma unroll
+    for (int i = 0; i < kPieces; ++i) {
+      const int idx = i * kBlock + tid;
+      if (idx < total) {
+        const int cell = idx / kPieces;
+        const int part = idx - cell * kPieces;
+        dft[int64_t(cam_pos_of_row[cell]) * kPieces + part] = l2[idx];
+      }
+    }
+  }
+  __syncthreads();
+}
+
 // XCD-aware block -> work item map for camera-major kernels.  Workgroups are dealt round-robin
 // over the 8 XCDs (blockIdx % 8 picks the XCD), so giving XCD x the contiguous range
 // [x*per, (x+1)*per) of segments makes workgroups that run at the same time on one XCD work on

@@ -243,12 +243,15 @@ __global__ __launch_bounds__(kBlock) void k_cam_sqnorm(const double* __restrict_
 }
 
 // J <- J diag(scale)   (block_sparse_matrix.cc:403-450): cells in through LDS, scaled in
-// registers, out through LDS -- coalesced both ways (416 B per residual block incl. ids)
+// registers, out through LDS -- coalesced both ways (416 B per residual block incl. ids).  The scaled F cells
+// also go to their places in the camera-major copy Ft (+148 B per residual block), which is therefore current
+// when the kernel ends: the LM iteration needs no k_permute_ft pass (292 B per residual block) afterwards.
 __global__ __launch_bounds__(kBlock) void k_scale_239(double* __restrict__ E, double* __restrict__ F,
                                                       const int32_t* __restrict__ row_pt,
                                                       const int32_t* __restrict__ row_cam,
                                                       const double* __restrict__ scale, int64_t O,
-                                                      int64_t xf_off) {
+                                                      int64_t xf_off, double* __restrict__ Ft,
+                                                      const int32_t* __restrict__ cam_pos) {
   __shared__ double lds[kBlock * 18];
   const int64_t r0 = int64_t(blockIdx.x) * kBlock;
   const int nvalid = int(min(int64_t(kBlock), O - r0));
@@ -262,7 +265,7 @@ __global__ __launch_bounds__(kBlock) void k_scale_239(double* __restrict__ E, do
 #pragma unroll
       for (int k = 0; k < 9; ++k) { const double sv = sc[k]; f[k] *= sv; f[9 + k] *= sv; }
     }
-    unstage_cells<18>(F + 18 * r0, nvalid, lds, f);
+    unstage_f_cells_two(F + 18 * r0, Ft, cam_pos + r0, nvalid, lds, f);
   }
   {
     double e[6];
@@ -491,6 +494,11 @@ static int Build239(cx_matrix* A) {
   CX_TRY(A->d_tile_row.upload(tile_row, st));
   CX_TRY(A->d_tile_pt.upload(tile_pt, st));
   CX_TRY(A->d_cam_rows.upload(cam_rows, st));
+  {
+    std::vector<int32_t> cam_pos(static_cast<size_t>(O));
+    for (int64_t k = 0; k < O; ++k) cam_pos[size_t(cam_rows[size_t(k)])] = int32_t(k);
+    CX_TRY(A->d_cam_pos.upload(cam_pos, st));
+  }
   CX_TRY(A->d_seg_begin.upload(seg_begin, st));
   CX_TRY(A->d_seg_cam.upload(seg_cam, st));
   CX_TRY(A->d_cam_seg_start.upload(cam_seg_start, st));
@@ -613,14 +621,17 @@ int cxk_squared_column_norm(cx_matrix* A, double* x) {
 int cxk_scale_columns(cx_matrix* A, const double* scale) {
   hipStream_t st = A->ctx->stream;
   if (A->is239) {
+    static const bool emit_ft = std::getenv("CX_NO_FT_EMIT") == nullptr;  // A/B switch: separate k_permute_ft pass
+    if (emit_ft) CX_TRY(A->d_Ft.alloc(size_t(A->O) * 18));
     hipLaunchKernelGGL(k_scale_239, dim3(grid_for(A->O, kBlock)), dim3(kBlock), 0, st, A->d_values.p,
                        A->d_values.p + 6 * A->O, A->d_row_pt.p, A->d_row_cam.p, scale, A->O,
-                       3 * int64_t(A->P));
+                       3 * int64_t(A->P), emit_ft ? A->d_Ft.p : (double*)nullptr, (const int32_t*)A->d_cam_pos.p);
+    A->ft_valid = emit_ft;
   } else if (A->R > 0) {
     hipLaunchKernelGGL(kg_scale, dim3(grid_for(A->R, 128)), dim3(128), 0, st, A->d_rows.p, A->d_cols.p,
                        A->d_rcb.p, A->d_cells.p, A->d_values.p, scale, A->R);
+    A->ft_valid = false;
   }
-  A->ft_valid = false;
   A->f32_valid = false;
   CX_HIP(hipGetLastError());
   return CX_OK;

@@ -271,7 +271,13 @@ struct Minimizer {
   int EvaluateGradientAndJacobian(bool* ok) {
     hipStream_t st = ctx->stream;
     *ok = false;
-    CX_TRY(cx_evaluator_evaluate(e, x.p, &x_cost, residuals.p, gradient.p, 1, CX_DEVICE));
+    // with Jacobi scaling the ScaleColumns below rewrites F and its camera-major copy: no point in the
+    // evaluation kernel writing that copy as well
+    const bool emit_saved = e->emit_ft;
+    if (o.jacobi_scaling) e->emit_ft = false;
+    const int eval_rc = cx_evaluator_evaluate(e, x.p, &x_cost, residuals.p, gradient.p, 1, CX_DEVICE);
+    e->emit_ft = emit_saved;
+    CX_TRY(eval_rc);
     it.jacobian_ms = cx_evaluator_last_kernel_ms(e);
     if (!std::isfinite(x_cost)) {
       std::snprintf(out->message, sizeof(out->message), "Residual and Jacobian evaluation failed.");

@@ -360,6 +360,12 @@ int64_t cx_evaluator_num_effective_parameters(const cx_evaluator* e);  /* Evalua
 /* Evaluator::Plus (evaluator.h:152-158): x_plus_delta = x [+] delta; x, x_plus_delta ambient, delta tangent */
 int cx_evaluator_plus(cx_evaluator* e, const double* x, const double* delta, double* x_plus_delta, int32_t memspace);
 double cx_evaluator_last_kernel_ms(const cx_evaluator* e);
+/* The library keeps a second, camera-major copy of the F cells (what the reference's transpose block structure
+ * is for, block_sparse_matrix.cc:784-808).  By default a Jacobian evaluation writes it in the same kernel
+ * (+148 B per residual block); a caller that always follows Evaluate with ScaleColumns -- TrustRegionMinimizer
+ * with jacobi_scaling, trust_region_minimizer.cc:263-279 -- turns that off (on = 0) because cx_matrix_scale_columns
+ * rewrites the copy anyway.  Either way the copy is rebuilt lazily if it is ever found stale. */
+int cx_evaluator_set_emit_camera_major(cx_evaluator* e, int32_t on);
 /* Device copy of the residuals the last cx_evaluator_evaluate wrote to HOST memory (NULL when it wrote none, or
  * wrote them to a caller's device buffer): the same vector can go into cx_solver_solve as b with
  * cx_per_solve_options.b_on_device = 1, without a second trip across PCIe.  Valid until the next evaluate that
