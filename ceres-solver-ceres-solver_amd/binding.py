@@ -186,7 +186,7 @@ def _ptr(a):
     if isinstance(a, DeviceArray):
         return ctypes.c_void_p(a.ptr)
     assert isinstance(a, np.ndarray) and a.flags["C_CONTIGUOUS"]
-    return ctypes.c_void_p(a.ctypes.data)
+    return a.ctypes.data_as(ctypes.c_void_p)   # holds a reference: a temporary stays alive for the call
 
 
 def _space(*arrays):

@@ -10,6 +10,7 @@
 // writes into the reference cell layout.  Algorithmic traffic: 208 B written and
 // 24 B read per residual block plus the parameter gathers (L2 resident).
 #include <algorithm>
+#include <cstdlib>
 #include <numeric>
 
 #include "cx_internal.h"
@@ -312,10 +313,14 @@ __global__ __launch_bounds__(kBlock) void k_bal_evaluate(const double* __restric
                                                          int64_t cam_off, double* __restrict__ residuals,
                                                          double* __restrict__ E, double* __restrict__ F,
                                                          double* __restrict__ cost_partial, LossParams loss,
-                                                         double* __restrict__ Ft, const int32_t* __restrict__ cam_pos) {
+                                                         double* __restrict__ Ft, const int32_t* __restrict__ cam_pos,
+                                                         int num_tiles) {
   __shared__ double lds[kBlock * 18];
   __shared__ double red[4];
-  const int64_t r0i = int64_t(blockIdx.x) * kBlock;
+  // num_tiles > 0: XCD-aware tile map, see k_scale_239 (cx_matrix.hip)
+  const int tile = num_tiles > 0 ? xcd_segment(num_tiles) : int(blockIdx.x);
+  if (tile < 0) return;
+  const int64_t r0i = int64_t(tile) * kBlock;
   const int nvalid = int(min(int64_t(kBlock), O - r0i));
   const int tid = threadIdx.x;
   const int64_t r = r0i + tid;
@@ -371,7 +376,7 @@ __global__ __launch_bounds__(kBlock) void k_bal_evaluate(const double* __restric
   if (cost_partial) {
     double c[1] = {cost_term};
     block_sum<1>(c, red);
-    if (tid == 0) cost_partial[blockIdx.x] = c[0];
+    if (tid == 0) cost_partial[tile] = c[0];
   }
 }
 
@@ -534,12 +539,15 @@ int cx_evaluator_evaluate(cx_evaluator* e, const double* state, double* cost, do
     CX_TRY(A->d_Ft.alloc(size_t(A->O) * 18));
     ft_out = A->d_Ft.p;
   }
+  static const bool xcd_env = std::getenv("CX_NO_XCD_TILES") == nullptr;
+  const bool xcd_tiles = xcd_env && ft_out != nullptr;
+  const int launch_grid = xcd_tiles ? xcd_grid(grid) : grid;
   CX_HIP(hipEventRecord(ctx->ev[6], st));
 #define CX_LAUNCH_EVAL(WJ, MODEL)                                                                                      \
-  hipLaunchKernelGGL((k_bal_evaluate<WJ, MODEL>), dim3(grid), dim3(kBlock), 0, st, (const double*)hs.dptr,              \
+  hipLaunchKernelGGL((k_bal_evaluate<WJ, MODEL>), dim3(launch_grid), dim3(kBlock), 0, st, (const double*)hs.dptr,       \
                      (const double*)e->d_obs.p, (const int32_t*)A->d_row_pt.p, (const int32_t*)A->d_row_cam.p, e->O,    \
                      3 * int64_t(e->P), res_dev, E, F, cost ? e->d_partial.p : nullptr, loss, ft_out,                  \
-                     (const int32_t*)A->d_cam_pos.p)
+                     (const int32_t*)A->d_cam_pos.p, xcd_tiles ? grid : 0)
   if (e->camera_model == CX_CAMERA_ANGLE_AXIS) {
     if (with_j) CX_LAUNCH_EVAL(true, CX_CAMERA_ANGLE_AXIS);
     else CX_LAUNCH_EVAL(false, CX_CAMERA_ANGLE_AXIS);

@@ -251,9 +251,13 @@ __global__ __launch_bounds__(kBlock) void k_scale_239(double* __restrict__ E, do
                                                       const int32_t* __restrict__ row_cam,
                                                       const double* __restrict__ scale, int64_t O,
                                                       int64_t xf_off, double* __restrict__ Ft,
-                                                      const int32_t* __restrict__ cam_pos) {
+                                                      const int32_t* __restrict__ cam_pos, int num_tiles) {
   __shared__ double lds[kBlock * 18];
-  const int64_t r0 = int64_t(blockIdx.x) * kBlock;
+  // num_tiles > 0: XCD-aware tile map (xcd_segment) -- consecutive tiles run on ONE XCD, so the partially written
+  // cache lines of Ft (a 144-byte cell straddles two) are completed in that XCD's L2 by the neighbouring tiles
+  const int tile = num_tiles > 0 ? xcd_segment(num_tiles) : int(blockIdx.x);
+  if (tile < 0) return;
+  const int64_t r0 = int64_t(tile) * kBlock;
   const int nvalid = int(min(int64_t(kBlock), O - r0));
   const int tid = threadIdx.x;
   const bool live = tid < nvalid;
@@ -623,9 +627,12 @@ int cxk_scale_columns(cx_matrix* A, const double* scale) {
   if (A->is239) {
     static const bool emit_ft = std::getenv("CX_NO_FT_EMIT") == nullptr;  // A/B switch: separate k_permute_ft pass
     if (emit_ft) CX_TRY(A->d_Ft.alloc(size_t(A->O) * 18));
-    hipLaunchKernelGGL(k_scale_239, dim3(grid_for(A->O, kBlock)), dim3(kBlock), 0, st, A->d_values.p,
+    static const bool xcd_tiles = std::getenv("CX_NO_XCD_TILES") == nullptr;
+    const int ntiles = grid_for(A->O, kBlock);
+    hipLaunchKernelGGL(k_scale_239, dim3(xcd_tiles ? xcd_grid(ntiles) : ntiles), dim3(kBlock), 0, st, A->d_values.p,
                        A->d_values.p + 6 * A->O, A->d_row_pt.p, A->d_row_cam.p, scale, A->O,
-                       3 * int64_t(A->P), emit_ft ? A->d_Ft.p : (double*)nullptr, (const int32_t*)A->d_cam_pos.p);
+                       3 * int64_t(A->P), emit_ft ? A->d_Ft.p : (double*)nullptr, (const int32_t*)A->d_cam_pos.p,
+                       xcd_tiles ? ntiles : 0);
     A->ft_valid = emit_ft;
   } else if (A->R > 0) {
     hipLaunchKernelGGL(kg_scale, dim3(grid_for(A->R, 128)), dim3(128), 0, st, A->d_rows.p, A->d_cols.p,

@@ -122,7 +122,8 @@ typedef struct {
   int32_t max_num_iterations;         /* default 500 (solver.h max_linear_solver_iterations) */
   int32_t residual_reset_period;      /* default 10  */
   int32_t num_eliminate_blocks;       /* == elimination_groups[0]; 0 for CGNR */
-  int32_t use_mixed_precision_solves; /* dense Cholesky: fp32 factor + fp64 refinement */
+  int32_t use_mixed_precision_solves; /* CGNR / ITERATIVE_SCHUR: CG operator streams fp32 copies of the J values (fp64
+                                       * accumulation and vectors); DENSE_SCHUR / SPARSE_SCHUR: see DESIGN.md */
   int32_t max_num_refinement_iterations;
   int32_t max_num_spse_iterations;    /* default 5 */
   int32_t use_spse_initialization;    /* default 0 */

@@ -135,7 +135,7 @@ def _p(a):
     if a is None:
         return None
     assert a.flags["C_CONTIGUOUS"]
-    return ctypes.c_void_p(a.ctypes.data)
+    return a.ctypes.data_as(ctypes.c_void_p)   # keeps the (possibly temporary) array alive for the call
 
 
 def _f64(a):
@@ -503,6 +503,13 @@ def minimize_dense(fun, x0, options=None):
 
 
 ANGLE_AXIS, QUATERNION_MANIFOLD = 0, 1
+
+
+def angle_axis_to_rotation_matrix(aa):
+    """rotation.h:452-494; returns the 9 entries COLUMN-major, as the reference's tests read them."""
+    R = np.zeros(9)
+    lib().orc_angle_axis_to_rotation_matrix(_p(_f64(aa)), _p(R))
+    return R
 
 
 def angle_axis_to_quaternion(aa):

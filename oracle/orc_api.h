@@ -105,6 +105,7 @@ int orc_cg_dense(int n, const double* A, const double* b, double* x, int min_num
 void orc_snavely(const double* camera9, const double* point3, const double* obs2,
                  double* residual, double* jac_cam, double* jac_pt);
 void orc_angle_axis_rotate_point(const double* aa, const double* pt, double* out);
+void orc_angle_axis_to_rotation_matrix(const double* angle_axis, double* R_column_major);
 
 /* LexicographicallyOrderResidualBlocks (reorder_program.cc:256-338) for BAL:
  * order[k] = input observation index placed at row block k. */

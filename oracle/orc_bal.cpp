@@ -255,6 +255,31 @@ void orc_angle_axis_rotate_point(const double* aa, const double* pt, double* out
   AngleAxisRotatePoint<double>(aa, pt, out);
 }
 
+// AngleAxisToRotationMatrix (rotation.h:452-494), COLUMN-major R like the reference's default
+// (ColumnMajorAdapter3x3, rotation.h:441-444).  Not on the solve path: it is the independent formula
+// rotation_test.cc:1707-1800 checks AngleAxisRotatePoint against, restated for the same purpose.
+void orc_angle_axis_to_rotation_matrix(const double* aa, double* R) {
+  const double theta = std::hypot(aa[0], aa[1], aa[2]);
+  auto at = [&](int r, int c) -> double& { return R[c * 3 + r]; };
+  if (std::fpclassify(theta) != FP_ZERO) {
+    const double wx = aa[0] / theta, wy = aa[1] / theta, wz = aa[2] / theta;
+    const double costheta = std::cos(theta), sintheta = std::sin(theta);
+    at(0, 0) = costheta + wx * wx * (1.0 - costheta);
+    at(1, 0) = wz * sintheta + wx * wy * (1.0 - costheta);
+    at(2, 0) = -wy * sintheta + wx * wz * (1.0 - costheta);
+    at(0, 1) = wx * wy * (1.0 - costheta) - wz * sintheta;
+    at(1, 1) = costheta + wy * wy * (1.0 - costheta);
+    at(2, 1) = wx * sintheta + wy * wz * (1.0 - costheta);
+    at(0, 2) = wy * sintheta + wx * wz * (1.0 - costheta);
+    at(1, 2) = -wx * sintheta + wy * wz * (1.0 - costheta);
+    at(2, 2) = costheta + wz * wz * (1.0 - costheta);
+  } else {  // first order Taylor expansion at zero
+    at(0, 0) = 1.0; at(1, 0) = aa[2]; at(2, 0) = -aa[1];
+    at(0, 1) = -aa[2]; at(1, 1) = 1.0; at(2, 1) = aa[0];
+    at(0, 2) = aa[1]; at(1, 2) = -aa[0]; at(2, 2) = 1.0;
+  }
+}
+
 // reorder_program.cc:256-338 with MinParameterBlock == point index (the only
 // parameter block of a BAL residual that lies in the first elimination group)
 void orc_bal_residual_order(int num_points, int64_t num_obs, const int32_t* point_index, int64_t* order) {
