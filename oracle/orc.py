@@ -116,10 +116,30 @@ def build():
     subprocess.check_call(["make", "-s", "-C", _HERE, "liborc.so"])
 
 
+def use_native_build():
+    """Build liborc_native.so (-O3 -march=native) on THIS machine and use it from now on: for the CPU baseline,
+    which is timed on the host it runs on.  Falls back to the portable liborc.so when the build fails.
+    Returns the compiler flags in use."""
+    global _LIB
+    try:
+        subprocess.check_call(["make", "-s", "-C", _HERE, "-B", "liborc_native.so"])
+        _LIB = None
+        _LIB_PATH[0] = os.path.join(_HERE, "liborc_native.so")
+        lib()
+        return "-O3 -march=native -fopenmp (built on this host)"
+    except Exception:
+        _LIB = None
+        _LIB_PATH[0] = os.path.join(_HERE, "liborc.so")
+        return "-O3 -march=x86-64-v3 -fopenmp"
+
+
+_LIB_PATH = [os.path.join(_HERE, "liborc.so")]
+
+
 def lib():
     global _LIB
     if _LIB is None:
-        path = os.path.join(_HERE, "liborc.so")
+        path = _LIB_PATH[0]
         if not os.path.exists(path):
             build()
         _LIB = ctypes.CDLL(path)
@@ -346,6 +366,15 @@ def solve(bs, values, b, D, options, r_tolerance=-1.0, q_tolerance=0.0, allreduc
         rc = lib().orc_solve_sharded(*args, cb, None)
     assert rc == 0
     return x, s
+
+
+def sparse_schur_stats():
+    """Of the last SPARSE_SCHUR solve: seconds of analysis / eliminate / factor / triangular solves, blocks of L,
+    factor flops, elimination-tree heights, cells of S."""
+    out = np.zeros(8)
+    lib().orc_sparse_schur_stats(_p(out))
+    return dict(zip(["analyze_s", "eliminate_s", "factor_s", "solve_s", "factor_blocks", "factor_flops", "etree_heights",
+                     "s_cells"], out.tolist()))
 
 
 def last_solve_seconds():

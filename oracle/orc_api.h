@@ -84,6 +84,7 @@ int64_t orc_schur_sparse_structure(const cx_block_structure* bs, int num_elimina
 
 /* wall seconds of the numeric part of the last orc_solve (structure set-up excluded) */
 double orc_last_solve_seconds(void);
+void orc_sparse_schur_stats(double* out8);
 
 /* The same solve on one shard of a point-partitioned J; camera-space sums go
  * through the callback (sum-all-reduce in place).  Used by the gloo tests. */

@@ -10,12 +10,14 @@
 // can check sharded == unsharded.
 #include <omp.h>
 
+#include <numeric>
 #include <set>
 
 #include <cstdio>
 #include <functional>
 
 #include "orc_schur.h"
+#include "orc_sparse_chol.h"
 #include "orc_visibility.h"
 
 namespace orc {
@@ -692,9 +694,15 @@ static cx_summary SolveDenseSchur(const cx_block_structure* s, const double* val
 // f x f cells of rows without an e-block; std::set order = lexicographic.
 static std::vector<std::pair<int, int>> SparseSchurCells(const cx_block_structure* s, int num_eliminate_blocks) {
   BS bs(s);
-  std::set<std::pair<int, int>> block_pairs;
   const int num_f = bs.C - num_eliminate_blocks;
-  for (int i = 0; i < num_f; ++i) block_pairs.emplace(i, i);
+  // The reference inserts into a std::set<pair<int,int>>; the set's iteration order is lexicographic, which is
+  // what sorting and de-duplicating every block row's list gives as well (and scales to 10^8 insertions).
+  std::vector<std::vector<int>> row_cols(static_cast<size_t>(num_f));
+  for (int i = 0; i < num_f; ++i) row_cols[size_t(i)].push_back(i);
+  auto compact = [](std::vector<int>& v) {
+    std::sort(v.begin(), v.end());
+    v.erase(std::unique(v.begin(), v.end()), v.end());
+  };
   int r = 0;
   while (r < bs.R) {
     const int e_block_id = bs.cells[bs.rcb[r]].block_id;
@@ -704,21 +712,139 @@ static std::vector<std::pair<int, int>> SparseSchurCells(const cx_block_structur
       if (bs.cells[bs.rcb[r]].block_id != e_block_id) break;
       for (int c = bs.rcb[r] + 1; c < bs.rcb[r + 1]; ++c) f_blocks.push_back(bs.cells[c].block_id - num_eliminate_blocks);
     }
-    std::sort(f_blocks.begin(), f_blocks.end());
-    f_blocks.erase(std::unique(f_blocks.begin(), f_blocks.end()), f_blocks.end());
-    for (size_t i = 0; i < f_blocks.size(); ++i)
-      for (size_t j = i + 1; j < f_blocks.size(); ++j) block_pairs.emplace(f_blocks[i], f_blocks[j]);
+    compact(f_blocks);
+    for (size_t i = 0; i < f_blocks.size(); ++i) {
+      std::vector<int>& row = row_cols[size_t(f_blocks[i])];
+      for (size_t j = i + 1; j < f_blocks.size(); ++j) row.push_back(f_blocks[j]);
+      if (row.size() > 4096 && row.size() > 4 * size_t(num_f)) compact(row);
+    }
   }
   for (; r < bs.R; ++r) {
     for (int i = bs.rcb[r]; i < bs.rcb[r + 1]; ++i) {
       const int b1 = bs.cells[i].block_id - num_eliminate_blocks;
       for (int j = bs.rcb[r]; j < bs.rcb[r + 1]; ++j) {
         const int b2 = bs.cells[j].block_id - num_eliminate_blocks;
-        if (b1 <= b2) block_pairs.emplace(b1, b2);
+        if (b1 <= b2) row_cols[size_t(b1)].push_back(b2);
       }
     }
   }
-  return std::vector<std::pair<int, int>>(block_pairs.begin(), block_pairs.end());
+  std::vector<std::pair<int, int>> cells;
+  for (int i = 0; i < num_f; ++i) {
+    compact(row_cols[size_t(i)]);
+    for (int j : row_cols[size_t(i)]) cells.emplace_back(i, j);
+  }
+  return cells;
+}
+
+// BlockRandomAccessSparseMatrix (block_random_access_sparse_matrix.cc:48-122): the cells of a block-pair set, each
+// a contiguous row-major array of its own (row_stride = col_stride = column block size), looked up by block pair
+// (a hash map in the reference; a binary search in the sorted row here).
+struct SparseBRAM : BRAM {
+  std::vector<int> sizes, pos;
+  std::vector<int64_t> row_begin;   // cells of block row i: [row_begin[i], row_begin[i+1])
+  std::vector<int> cell_col;
+  std::vector<int64_t> cell_off;
+  std::vector<double> values;
+  int n = 0;
+  SparseBRAM(const std::vector<int>& block_sizes, const std::vector<std::pair<int, int>>& cells) : sizes(block_sizes) {
+    for (int f : sizes) { pos.push_back(n); n += f; }
+    row_begin.assign(sizes.size() + 1, 0);
+    for (const auto& c : cells) row_begin[size_t(c.first) + 1]++;
+    std::partial_sum(row_begin.begin(), row_begin.end(), row_begin.begin());
+    int64_t off = 0;
+    for (const auto& c : cells) {  // lexicographic: already grouped by row, ascending column
+      cell_col.push_back(c.second);
+      cell_off.push_back(off);
+      off += int64_t(sizes[size_t(c.first)]) * sizes[size_t(c.second)];
+    }
+    values.assign(size_t(off), 0.0);
+  }
+  double* Find(int i, int j) {
+    const auto first = cell_col.begin() + row_begin[size_t(i)], last = cell_col.begin() + row_begin[size_t(i) + 1];
+    const auto it = std::lower_bound(first, last, j);
+    if (it == last || *it != j) return nullptr;
+    return values.data() + cell_off[size_t(it - cell_col.begin())];
+  }
+  double* GetCell(int i, int j, int* r, int* c, int* rs, int* cs) override {
+    double* v = Find(i, j);
+    if (!v) return nullptr;
+    *r = 0; *c = 0; *rs = sizes[size_t(i)]; *cs = sizes[size_t(j)];
+    return v;
+  }
+  void SetZero() override { std::fill(values.begin(), values.end(), 0.0); }
+  int num_rows() const override { return n; }
+};
+
+static double g_sparse_chol_stats[8] = {0};
+
+// SparseSchurComplementSolver with a sparse direct reduced solve (schur_complement_solver.cc:101-159, 224-335): the
+// eliminator writes into the block-sparse storage of InitStorage, the reduced system is factored by the block-sparse
+// Cholesky of orc_sparse_chol.h (the stand-in for SuiteSparse, third party).
+static cx_summary SolveSparseSchur(const cx_block_structure* s, const double* values, const double* b,
+                                   const double* D, const cx_solver_options& o, double* x,
+                                   const Comm& comm, int threads) {
+  const int nelim = o.num_eliminate_blocks;
+  Eliminator el(s, values, nelim);
+  auto sizes = el.FBlockSizes();
+  const int num_cols = el.bs.num_cols();
+  const auto cells = SparseSchurCells(s, nelim);
+  SparseBRAM m(sizes, cells);
+  const int n = m.n;
+  Vec rhs(static_cast<size_t>(n));
+  BlockSparseCholesky chol;
+  double t0 = omp_get_wtime();
+  if (n > 0) chol.Analyze(sizes, cells);
+  g_sparse_chol_stats[0] = omp_get_wtime() - t0;
+  MarkSolveStart();
+  std::fill(x, x + num_cols, 0.0);
+  t0 = omp_get_wtime();
+  if (!comm.active()) {
+    el.Eliminate(b, D, &m, rhs.data(), threads);
+  } else {
+    Vec Dmod;
+    const double* Duse = nullptr;
+    if (D) {
+      Dmod.assign(D, D + num_cols);
+      std::fill(Dmod.begin() + (num_cols - n), Dmod.end(), 0.0);
+      Duse = Dmod.data();
+    }
+    el.Eliminate(b, Duse, &m, rhs.data(), threads);
+    comm.Sum(m.values.data(), int64_t(m.values.size()));
+    comm.Sum(rhs.data(), n);
+    if (D)
+      for (size_t i = 0; i < sizes.size(); ++i) {
+        double* v = m.Find(int(i), int(i));
+        for (int k = 0; k < sizes[i]; ++k) v[k * sizes[i] + k] += D[num_cols - n + m.pos[i] + k] * D[num_cols - n + m.pos[i] + k];
+      }
+  }
+  g_sparse_chol_stats[1] = omp_get_wtime() - t0;
+  cx_summary summary;
+  std::memset(&summary, 0, sizeof(summary));
+  double* reduced = x + num_cols - n;
+  if (n == 0) {
+    summary.termination_type = CX_SUCCESS;
+  } else {
+    t0 = omp_get_wtime();
+    const bool ok = chol.Factor([&](int i, int j) { return static_cast<const double*>(m.Find(i, j)); }, threads);
+    g_sparse_chol_stats[2] = omp_get_wtime() - t0;
+    summary.num_iterations = 1;
+    if (!ok) {
+      summary.termination_type = CX_FAILURE;
+      SetMessage(&summary, "Sparse Cholesky factorization failed: the reduced camera matrix is not positive definite.");
+    } else {
+      t0 = omp_get_wtime();
+      chol.Solve(rhs.data(), reduced, threads);
+      g_sparse_chol_stats[3] = omp_get_wtime() - t0;
+      summary.termination_type = CX_SUCCESS;
+      SetMessage(&summary, "Success.");
+    }
+    g_sparse_chol_stats[4] = double(chol.num_factor_blocks());
+    g_sparse_chol_stats[5] = chol.factor_flops();
+    g_sparse_chol_stats[6] = double(chol.num_heights());
+    g_sparse_chol_stats[7] = double(cells.size());
+  }
+  if (summary.termination_type == CX_SUCCESS) el.BackSubstitute(b, D, reduced, x, threads);
+  return summary;
 }
 
 // ITERATIVE_SCHUR with use_explicit_schur_complement: SparseSchurComplementSolver (linear_solver.cc:111-116)
@@ -831,8 +957,8 @@ static int Solve(const cx_block_structure* bs, const double* values, const doubl
       s = o->use_explicit_schur_complement ? SolveExplicitSchur(bs, values, b, D, *o, r_tol, q_tol, x, comm, threads)
                                            : SolveIterativeSchur(bs, values, b, D, *o, r_tol, q_tol, x, comm, threads);
       break;
-    case CX_DENSE_SCHUR:
-    case CX_SPARSE_SCHUR: s = SolveDenseSchur(bs, values, b, D, *o, x, comm, threads); break;
+    case CX_DENSE_SCHUR: s = SolveDenseSchur(bs, values, b, D, *o, x, comm, threads); break;
+    case CX_SPARSE_SCHUR: s = SolveSparseSchur(bs, values, b, D, *o, x, comm, threads); break;
     default: return -1;
   }
   g_last_solve_seconds = omp_get_wtime() - g_solve_t0;
@@ -847,6 +973,10 @@ using namespace orc;
 extern "C" {
 
 double orc_last_solve_seconds(void) { return g_last_solve_seconds; }
+
+// last SPARSE_SCHUR solve: seconds of {analysis, eliminate, factor, triangular solves}, then blocks of L, factor
+// flops, elimination-tree heights, cells of S
+void orc_sparse_schur_stats(double* out8) { std::copy(g_sparse_chol_stats, g_sparse_chol_stats + 8, out8); }
 
 int64_t orc_schur_sparse_structure(const cx_block_structure* bs, int num_eliminate_blocks, int32_t* cell_row,
                                    int32_t* cell_col, int64_t capacity) {
