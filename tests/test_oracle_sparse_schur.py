@@ -61,7 +61,7 @@ def test_fixture_problems(oracle, pid):
     xd, sd = oracle.solve(bs, vals, b, D, oracle.make_options(type=oracle.DENSE_SCHUR, num_eliminate_blocks=nelim))
     assert ss.termination_type == 0
     assert np.linalg.norm(xs - xd) / xs.size < 1e-10
-    J = oracle.to_dense(bs, vals)
+    J = bs.to_dense(vals)
     ref = np.linalg.lstsq(np.vstack([J, np.diag(D)]), np.concatenate([b, np.zeros(bs.num_cols)]), rcond=None)[0]
     assert np.linalg.norm(xs - ref) / xs.size < 1e-10                        # schur_complement_solver_test.cc:186-227
 
