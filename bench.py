@@ -99,11 +99,14 @@ def lm_prepare_device(cx, ctx, prob):
     return ev, A, res, D, cost, eval_ms, update
 
 
-def cpu_baseline(cx, prob, solver_kw, threads, fraction):
+def cpu_baseline(cx, prob, solver_kw, threads, fraction, solver="iterative_schur"):
     """Oracle (CPU restatement, kind 'port'), same LM preparation and solve, on the first `fraction` of the
     points (1.0 = the whole workload; smaller samples use the sharding rule of the multi-GPU path and
-    are scaled by the residual-block ratio)."""
+    are scaled by the residual-block ratio).  solver = "sparse_schur": SparseSchurComplementSolver with the oracle's
+    block-sparse Cholesky in SuiteSparse's place (oracle/orc_sparse_chol.h) -- the north star's host SPARSE_SCHUR
+    denominator; its factorisation does not scale with a point sample, so that baseline is timed on the whole workload."""
     orc = load_oracle()
+    flags = orc.use_native_build()     # -O3 -march=native, compiled on the host that is being timed
     orc.lib()
     orc.set_num_threads(threads)
     P = prob.num_points
@@ -117,6 +120,23 @@ def cpu_baseline(cx, prob, solver_kw, threads, fraction):
     diag = np.clip(orc.squared_column_norm(bs, vals), MIN_LM_DIAGONAL, MAX_LM_DIAGONAL)
     # cameras unseen by the sample keep only the clamp value; the solve stays well posed
     D = np.sqrt(diag / INITIAL_RADIUS)
+    if solver == "sparse_schur":
+        o = orc.make_options(type=orc.SPARSE_SCHUR, num_eliminate_blocks=sub.num_points)
+        t0 = time.time()
+        x, s = orc.solve(bs, vals, res, D, o)
+        wall = time.time() - t0
+        numeric_s = orc.last_solve_seconds()
+        st = orc.sparse_schur_stats()
+        return {
+            "value": numeric_s * 1e3, "unit": "ms", "cores": threads, "kind": "port", "compiler_flags": flags,
+            "phases_s": {k: st[k] for k in ("eliminate_s", "factor_s", "solve_s")}, "analysis_s": st["analyze_s"],
+            "factor_gflops": st["factor_flops"] / max(st["factor_s"], 1e-9) * 1e-9,
+            "sample": "oracle SPARSE_SCHUR (eliminator into block-sparse S of %d cells, own nested-dissection block "
+                      "Cholesky: %d blocks in L, %.3g flop, %d elimination-tree heights) on points [0,%d) of the workload "
+                      "(%d of %d residual blocks): %.0f ms numeric, %.0f ms with structure analysis" % (
+                          int(st["s_cells"]), int(st["factor_blocks"]), st["factor_flops"], int(st["etree_heights"]), hi,
+                          sub.num_observations, prob.num_observations, numeric_s * 1e3, wall * 1e3),
+        }
     o = orc.make_options(type=orc.ITERATIVE_SCHUR, preconditioner_type=orc.JACOBI,
                          num_eliminate_blocks=sub.num_points, max_num_iterations=solver_kw["max_num_iterations"])
     t0 = time.time()
@@ -129,6 +149,7 @@ def cpu_baseline(cx, prob, solver_kw, threads, fraction):
         "unit": "ms",
         "cores": threads,
         "kind": "port",
+        "compiler_flags": flags,
         "sample": "oracle ITERATIVE_SCHUR+JACOBI on points [0,%d) of the workload (%d of %d residual blocks, all "
                   "cameras): %.0f ms for %d CG iterations (%.0f ms incl. structure set-up), scaled by the residual-"
                   "block ratio %.2f" % (hi, sub.num_observations, prob.num_observations, numeric_s * 1e3,
@@ -315,9 +336,11 @@ def main():
     out = None
     if rank == 0:
         cpu = None
+        threads = args.cpu_threads or min(16, os.cpu_count() or 1)
         if world == 1 and not args.no_cpu_baseline and args.solver == "iterative_schur" and args.preconditioner == "jacobi":
-            threads = args.cpu_threads or min(16, os.cpu_count() or 1)
             cpu = cpu_baseline(cx, full, solver_kw, threads, args.cpu_sample_fraction)
+        elif world == 1 and not args.no_cpu_baseline and args.solver == "sparse_schur":
+            cpu = cpu_baseline(cx, full, solver_kw, threads, args.cpu_sample_fraction, solver="sparse_schur")
         out = {
             "metric": "linear_solve_ms_per_iter", "value": ms_per_step, "unit": "ms",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,

@@ -166,6 +166,11 @@ struct cx_matrix {
   std::vector<int32_t> h_sp_row_start, h_sp_col_start;
   DevBuf<int32_t> d_sp_cam_pos, d_sp_row_start, d_sp_row_tiles, d_sp_col_start, d_sp_col_pool, d_sp_col_row;
   DevBuf<double> d_sp_W, d_sp_F, d_sp_x;
+  // level schedule of the tile elimination tree (tile rows of one height are factored together)
+  int sp_num_levels = 0;
+  std::vector<int32_t> h_sp_level_row_begin, h_sp_level_panel_begin, h_sp_level_tgt_begin;  // [levels + 1]
+  DevBuf<int32_t> d_sp_level_rows, d_sp_panel_row, d_sp_panel_pool;
+  DevBuf<int32_t> d_sp_tgt_pool, d_sp_tgt_flags, d_sp_src_begin, d_sp_src_a, d_sp_src_b;
   int pairs_state = 0;                   // 0 not built, 1 ready, 2 too many pairs (atomic path)
   // visibility based preconditioners of this structure (cx_visibility.h), one plan per (preconditioner type,
   // clustering type), built on first use

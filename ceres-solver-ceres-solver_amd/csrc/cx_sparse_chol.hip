@@ -7,23 +7,30 @@
 // library's own and parity is stated on the solution (it must equal the dense solve), not on the ordering
 // ("parity unpinned" for CAMD / AMD).
 //
-//   ordering   reverse Cuthill-McKee on the camera graph of S, optionally followed by minimum degree on groups
-//              of 64 cameras -- whichever leaves fewer tiles after fill (host, once per structure)
+//   ordering   nested dissection of the camera graph of S (recursive bisection of a reverse Cuthill-McKee
+//              arrangement: the smaller of the two boundary sets of a cut is the separator), host, once per
+//              structure -- the role of CHOLMOD's ordering step (suitesparse.cc:218-279).  CX_SPARSE_ORDERING=rcm
+//              keeps the band ordering of round 1 (reverse Cuthill-McKee, optionally minimum degree on groups of 64)
 //   structure  S in 64x64 tiles (upper triangle), symbolic fill at tile level; every tile row ends with one
 //              extra tile that carries the right-hand side as its column 0, so the forward substitution
 //              is part of the factorisation (as in the dense solver)
 //   assembly   the gather assembly of cx_schur.hip (k_pair_items) scattered into the tile pool at the
 //              permuted positions
-//   numeric    the dense solver's step kernel with tile indirection: one launch per 32-column block step,
-//              a workgroup per pair of non-zero tiles of the step's tile row, panel solve and trailing
-//              update on fp64 MFMA, look-ahead factorisation of the next diagonal block
-//   solve      one launch per tile row (64 rows) for the backward substitution, with the kept inverses of the
-//              diagonal blocks, then the inverse permutation
-// The factorisation is bound by the ~25 us a dependent launch + diagonal block cost on this part
-// (n / 32 steps), not by flops or bytes.
+//   numeric    by LEVELS of the tile elimination tree (tile rows of equal height are independent): per level
+//              k_sp_diag (the diagonal tiles: two 32x32 factor + inverse blocks each), k_sp_panel (the rows of
+//              the factor, F(I, J) = U_II^-T W(I, J) on fp64 MFMA, in place) and k_sp_update (every tile that
+//              receives contributions from this level's rows subtracts F(I, Ja)' F(I, Jb) for its sources in
+//              ascending I: a gather, no atomics, bitwise reproducible).  The dependent chain is the tree
+//              height (about a hundred to a few hundred levels on the Final-13682 shape) instead of n / 32 = 3 848
+//              block steps.
+//   solve      backward substitution by the same levels, top down: one workgroup per tile row gathers
+//              F(I, J) x_J over its row and applies the kept inverses; then the inverse permutation
+// CX_SPARSE_CHOLESKY_STEPS=1 runs round 1's numeric phase instead (one launch per 32-column block step in
+// elimination order, look-ahead of the next diagonal block), kept for A/B runs.
 #include <algorithm>
 #include <cstdlib>
 #include <queue>
+#include <string>
 
 #include "cx_chol_blocks.h"
 #include "cx_internal.h"
@@ -220,6 +227,224 @@ __device__ __forceinline__ void sp_gemv32(const double* __restrict__ M, int ldm,
   if (part == 0) out[m] = s;
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Level-scheduled factorisation (see the file header).  Everything is in place in ONE tile pool W: after its
+// level a tile row holds rows of the factor U (diagonal tile: U_II, upper; other tiles: F(I, J); last tile: the
+// forward-substituted right-hand side in column 0).
+
+// X (see cxchol::panel_x) -> rows of a tile: X[m][c], m < kb, c < ncols
+__device__ __forceinline__ void store_rows(const double4_t (&X)[2][2], double* __restrict__ dst, int kb, int ncols) {
+  const int lane = threadIdx.x & 63, li = lane & 15, lk = lane >> 4;
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int m = 16 * mt + lk + 4 * g, c = 16 * nt + li;
+        if (m < kb && c < ncols) dst[size_t(m) * kTile + c] = X[mt][nt][g];
+      }
+}
+
+// a 32 x 32 block of a tile in the operand layout of the trailing update (register g of tile (mt, nt) of lane l is
+// element [16 mt + (l >> 4) + 4 g][16 nt + (l & 15)]); rows >= kb and columns >= ncols read as zero
+__device__ __forceinline__ void load_operand(const double* __restrict__ src, int kb, int ncols, double4_t (&X)[2][2]) {
+  const int lane = threadIdx.x & 63, li = lane & 15, lk = lane >> 4;
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int m = 16 * mt + lk + 4 * g, c = 16 * nt + li;
+        X[mt][nt][g] = (m < kb && c < ncols) ? src[size_t(m) * kTile + c] : 0.0;
+      }
+}
+
+// acc[a][b] (+)= A' B for two operands in that layout (32 rows of K): 32 x v_mfma_f64_16x16x4_f64
+__device__ __forceinline__ void mfma_atb(const double4_t (&A)[2][2], const double4_t (&B)[2][2], double4_t (&acc)[2][2]) {
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(A[mt][a][g], B[mt][b][g], acc[a][b], 0, 0, 0);
+}
+
+// dst[i][j] -= acc[i][j] for the 32 x 32 block at dst (C layout of mfma_atb), i < rows, j < cols, optionally j >= i only
+__device__ __forceinline__ void subtract_block(const double4_t (&acc)[2][2], double* __restrict__ dst, int rows, int cols, bool upper_only) {
+  const int lane = threadIdx.x & 63, li = lane & 15, lk = lane >> 4;
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int i = 16 * a + lk + 4 * g, j = 16 * b + li;
+        if (i < rows && j < cols && (!upper_only || j >= i)) dst[size_t(i) * kTile + j] -= acc[a][b][g];
+      }
+}
+
+// same-wavefront read-after-write through global memory (see k_chol_step's look-ahead): wait for the stores
+__device__ __forceinline__ void own_stores_visible() {
+  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+// Level, part 1: the diagonal tiles of the level's tile rows, one wavefront each.  U11 = chol(A11) and its inverse;
+// U12 = U11^-T A12; A22 -= U12' U12; U22 = chol(A22) and its inverse.
+__global__ __launch_bounds__(64) void k_sp_diag(double* __restrict__ W, const int32_t* __restrict__ row_start,
+                                                const int32_t* __restrict__ level_rows, int n, double* __restrict__ uinv,
+                                                int* __restrict__ not_pd) {
+  __shared__ double lds[cxchol::kPotrfLds];
+  const int I = level_rows[blockIdx.x];
+  double* D = W + size_t(row_start[I]) * kTileDoubles;
+  const int k0 = kTile * I;
+  const int kb1 = min(NB, n - k0), kb2 = max(0, min(NB, n - k0 - NB));
+  double* ui1 = uinv + size_t(2 * I) * NB * NB;
+  cxchol::potrf_inverse_block(D, kTile, D, kTile, kb1, ui1, not_pd, lds);
+  if (kb2 <= 0) return;
+  own_stores_visible();
+  double4_t X[2][2];
+  cxchol::panel_x(D + NB, kTile, ui1, kb1, kb2, X);
+  store_rows(X, D + NB, kb1, kb2);
+  double4_t acc[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b) acc[a][b] = double4_t{0.0, 0.0, 0.0, 0.0};
+  mfma_atb(X, X, acc);
+  double* D22 = D + size_t(NB) * kTile + NB;
+  subtract_block(acc, D22, kb2, kb2, true);
+  own_stores_visible();
+  cxchol::potrf_inverse_block(D22, kTile, D22, kTile, kb2, ui1 + NB * NB, not_pd, lds);
+}
+
+// Level, part 2: the other tiles of those rows become rows of the factor, F(I, J) = U_II^-T W(I, J), in place:
+// X1 = U11^-T W1; X2 = U22^-T (W2 - U12' X1).  One workgroup of two wavefronts per tile, wavefront q = columns 32 q ...
+__global__ __launch_bounds__(128) void k_sp_panel(double* __restrict__ W, const int32_t* __restrict__ row_start,
+                                                  const int32_t* __restrict__ row_tiles, const int32_t* __restrict__ panel_row,
+                                                  const int32_t* __restrict__ panel_pool, int n, int T, const double* __restrict__ uinv) {
+  const int I = panel_row[blockIdx.x], q = panel_pool[blockIdx.x];
+  const int J = row_tiles[q];
+  const int wave = threadIdx.x >> 6;
+  const int ncols = (J < T) ? max(0, min(32, n - (kTile * J + 32 * wave))) : (wave == 0 ? 1 : 0);
+  if (ncols <= 0) return;
+  double* Wt = W + size_t(q) * kTileDoubles + 32 * wave;
+  const double* D = W + size_t(row_start[I]) * kTileDoubles;
+  const int k0 = kTile * I;
+  const int kb1 = min(NB, n - k0), kb2 = max(0, min(NB, n - k0 - NB));
+  const double* ui1 = uinv + size_t(2 * I) * NB * NB;
+  double4_t X1[2][2];
+  cxchol::panel_x(Wt, kTile, ui1, kb1, ncols, X1);
+  store_rows(X1, Wt, kb1, ncols);
+  if (kb2 <= 0) return;
+  double4_t U12[2][2], acc[2][2];
+  load_operand(D + NB, kb1, kb2, U12);
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b) acc[a][b] = double4_t{0.0, 0.0, 0.0, 0.0};
+  mfma_atb(U12, X1, acc);
+  double* W2 = Wt + size_t(NB) * kTile;
+  subtract_block(acc, W2, kb2, ncols, false);
+  own_stores_visible();
+  double4_t X2[2][2];
+  cxchol::panel_x(W2, kTile, ui1 + NB * NB, kb2, ncols, X2);
+  store_rows(X2, W2, kb2, ncols);
+}
+
+// Level, part 3: every tile that receives contributions from this level's rows: W(Ja, Jb) -= sum_I F(I, Ja)' F(I, Jb)
+// over its sources I of the level, ascending I.  Workgroup = target tile, wavefront = 32 x 32 quadrant.
+// flags: 1 = diagonal target (the lower-left quadrant is not needed), 2 = right-hand-side target (one column).
+__global__ __launch_bounds__(256) void k_sp_update(double* __restrict__ W, const int32_t* __restrict__ tgt_pool,
+                                                   const int32_t* __restrict__ tgt_flags, const int32_t* __restrict__ src_begin,
+                                                   const int32_t* __restrict__ src_a, const int32_t* __restrict__ src_b) {
+  const int t = blockIdx.x;
+  const int wave = threadIdx.x >> 6;
+  const int qi = wave >> 1, qj = wave & 1;
+  const int flags = tgt_flags[t];
+  if ((flags & 1) && qi == 1 && qj == 0) return;
+  if ((flags & 2) && qj == 1) return;
+  double4_t acc[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b) acc[a][b] = double4_t{0.0, 0.0, 0.0, 0.0};
+  const int s1 = src_begin[t + 1];
+  for (int s = src_begin[t]; s < s1; ++s) {
+    const double* Fa = W + size_t(src_a[s]) * kTileDoubles + 32 * qi;
+    const double* Fb = W + size_t(src_b[s]) * kTileDoubles + 32 * qj;
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+      double4_t A[2][2], B[2][2];
+      load_operand(Fb + size_t(32 * half) * kTile, 32, 32, B);
+      if (Fa == Fb) {
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+          for (int nt = 0; nt < 2; ++nt) A[mt][nt] = B[mt][nt];
+      } else {
+        load_operand(Fa + size_t(32 * half) * kTile, 32, 32, A);
+      }
+      mfma_atb(A, B, acc);
+    }
+  }
+  double* dst = W + size_t(tgt_pool[t]) * kTileDoubles + size_t(32 * qi) * kTile + 32 * qj;
+  subtract_block(acc, dst, 32, 32, (flags & 1) && qi == qj);
+}
+
+// Backward substitution of one level (top down): workgroup = tile row I.  y_I (column 0 of the row's last tile)
+// minus sum_J F(I, J) x_J over the row's tiles right of the diagonal, then the 64 x 64 triangular solve with the
+// kept inverses (x2 = U22^-1 y2, x1 = U11^-1 (y1 - U12 x2)).
+__global__ __launch_bounds__(256) void k_sp_bwd_level(const double* __restrict__ W, const int32_t* __restrict__ row_start,
+                                                      const int32_t* __restrict__ row_tiles, const int32_t* __restrict__ level_rows,
+                                                      int n, const double* __restrict__ uinv, double* __restrict__ x) {
+  __shared__ double y1[NB], y2[NB], x1[NB], x2[NB], tmp[NB];
+  const int I = level_rows[blockIdx.x];
+  const int t = threadIdx.x, r = t >> 2, part = t & 3;
+  const int k0 = kTile * I;
+  const int kb1 = min(NB, n - k0), kb2 = max(0, min(NB, n - k0 - NB));
+  const int q0 = row_start[I], q1 = row_start[I + 1] - 1;  // [q0] diagonal tile, [q1] right-hand-side tile
+  double s = 0.0;
+  for (int q = q0 + 1; q < q1; ++q) {
+    const int J = row_tiles[q];
+    const double* __restrict__ row = W + size_t(q) * kTileDoubles + size_t(r) * kTile + 16 * part;
+    const double* __restrict__ xj = x + size_t(kTile) * J + 16 * part;
+    const int valid = n - (kTile * J + 16 * part);
+#pragma unroll
+    for (int c = 0; c < 16; ++c) s += (c < valid) ? row[c] * xj[c] : 0.0;
+  }
+  s += __shfl_xor(s, 1, 64);
+  s += __shfl_xor(s, 2, 64);
+  if (part == 0) {
+    const double yv = W[size_t(q1) * kTileDoubles + size_t(r) * kTile] - s;
+    if (r < NB) y1[r] = r < kb1 ? yv : 0.0;
+    else y2[r - NB] = (r - NB) < kb2 ? yv : 0.0;
+  }
+  __syncthreads();
+  const double* __restrict__ D = W + size_t(q0) * kTileDoubles;
+  const double* __restrict__ ui1 = uinv + size_t(2 * I) * NB * NB;
+  if (kb2 > 0) {
+    sp_gemv32(ui1 + NB * NB, NB, y2, x2, NB, NB);
+    __syncthreads();
+    sp_gemv32(D + NB, kTile, x2, tmp, kb1, kb2);  // U12 x2
+    __syncthreads();
+    if (t < NB) y1[t] -= tmp[t];
+  } else if (t < NB) {
+    x2[t] = 0.0;
+  }
+  __syncthreads();
+  sp_gemv32(ui1, NB, y1, x1, NB, NB);
+  __syncthreads();
+  if (t < 64) {
+    const double v = t < NB ? x1[t] : x2[t - NB];
+    if (t < kb1 + kb2) x[k0 + t] = v;
+  }
+}
+
 // Backward substitution, one tile row (64 rows) per launch, as the dense solver's k_trsv_bwd64: every workgroup solves
 // the tile row's 64 x 64 triangular system with the stored inverses of its two diagonal blocks (x2 = U22^-1 y2,
 // x1 = U11^-1 (y1 - U12 x2)), then workgroup w subtracts (tile w of tile column I) x from that tile's 64 rows.
@@ -361,6 +586,61 @@ std::vector<int32_t> GroupMinimumDegree(int C, const std::vector<std::vector<int
   return out;
 }
 
+// Nested dissection from a linear arrangement: `seq` lists cameras in a locality-preserving order (reverse
+// Cuthill-McKee).  Cut the list in the middle; the cameras of one side that have a neighbour on the other side form
+// a vertex separator -- take the smaller of the two candidates, order both remainders recursively (they no longer
+// touch each other) and put the separator last.  Whatever a separator eliminates couples only with its own subtree and
+// with the separators above it, so the two halves are independent subtrees of the elimination tree: that is the
+// parallelism the level schedule exploits.  A hub camera that sees everything ends up in a separator by itself
+// being the smaller boundary.
+struct Dissection {
+  const std::vector<std::vector<int32_t>>& adj;
+  std::vector<int32_t> side;   // scratch: 1 / 2 = left / right half of the cut being examined, 0 otherwise
+  std::vector<int32_t> order;  // result: cameras in elimination order
+  int leaf;
+  Dissection(const std::vector<std::vector<int32_t>>& a, int leaf_size) : adj(a), side(a.size(), 0), leaf(leaf_size) { order.reserve(a.size()); }
+  void Run(std::vector<int32_t> seq) {
+    if (int(seq.size()) <= leaf) {
+      order.insert(order.end(), seq.begin(), seq.end());
+      return;
+    }
+    const size_t mid = seq.size() / 2;
+    for (size_t i = 0; i < seq.size(); ++i) side[size_t(seq[i])] = i < mid ? 1 : 2;
+    std::vector<int32_t> bl, br;  // boundary of the left / right half
+    for (size_t i = 0; i < seq.size(); ++i) {
+      const int32_t u = seq[i];
+      const int32_t other = i < mid ? 2 : 1;
+      for (int32_t v : adj[size_t(u)])
+        if (side[size_t(v)] == other) { (i < mid ? bl : br).push_back(u); break; }
+    }
+    const bool take_left = bl.size() <= br.size();
+    const std::vector<int32_t>& sep = take_left ? bl : br;
+    for (int32_t u : sep) side[size_t(u)] = 3;
+    std::vector<int32_t> left, right;
+    for (size_t i = 0; i < seq.size(); ++i)
+      if (side[size_t(seq[i])] != 3) (i < mid ? left : right).push_back(seq[i]);
+    for (int32_t u : seq) side[size_t(u)] = 0;
+    if (left.empty() || right.empty()) {  // the cut separates nothing (a clique-like piece): keep the arrangement
+      order.insert(order.end(), seq.begin(), seq.end());
+      return;
+    }
+    const std::vector<int32_t> keep(sep);
+    Run(std::move(left));
+    Run(std::move(right));
+    order.insert(order.end(), keep.begin(), keep.end());
+  }
+};
+
+std::vector<int32_t> NestedDissection(int C, const std::vector<std::vector<int32_t>>& adj, const std::vector<int32_t>& rcm_pos, int leaf) {
+  std::vector<int32_t> seq(static_cast<size_t>(C));
+  for (int c = 0; c < C; ++c) seq[size_t(rcm_pos[size_t(c)])] = c;
+  Dissection d(adj, leaf);
+  d.Run(std::move(seq));
+  std::vector<int32_t> pos(static_cast<size_t>(C));
+  for (int k = 0; k < C; ++k) pos[size_t(d.order[size_t(k)])] = k;
+  return pos;
+}
+
 // tile-level structure of the permuted S (upper) and its symbolic fill (eliminating tile row k connects every pair
 // of its later column tiles); rows as sorted lists, each closed by the right-hand-side tile T
 void TileStructure(const cx_matrix* A, const std::vector<int32_t>& pos, int T, std::vector<int32_t>* row_start,
@@ -406,11 +686,13 @@ int cxsp_build_plan(cx_matrix* A) {
     const int c1 = A->h_cell_c1[size_t(k)], c2 = A->h_cell_c2[size_t(k)];
     if (c1 != c2) { adj[size_t(c1)].push_back(c2); adj[size_t(c2)].push_back(c1); }
   }
-  // two candidate orderings, the one with fewer tiles after fill wins
+  const char* ordering_env = std::getenv("CX_SPARSE_ORDERING");
+  const bool band_ordering = ordering_env != nullptr && std::string(ordering_env) == "rcm";
   std::vector<int32_t> pos = ReverseCuthillMcKee(C, adj);
   std::vector<int32_t> row_start, row_tiles;
-  TileStructure(A, pos, T, &row_start, &row_tiles);
-  {
+  if (band_ordering) {
+    // round 1: two candidate band orderings, the one with fewer tiles after fill wins
+    TileStructure(A, pos, T, &row_start, &row_tiles);
     std::vector<int32_t> pos2 = GroupMinimumDegree(C, adj, pos), rs2, rt2;
     TileStructure(A, pos2, T, &rs2, &rt2);
     if (rt2.size() < row_tiles.size()) {
@@ -418,6 +700,10 @@ int cxsp_build_plan(cx_matrix* A) {
       row_start.swap(rs2);
       row_tiles.swap(rt2);
     }
+  } else {
+    // leaves of about 5 tile rows: below that a subtree is a chain of tile rows anyway
+    pos = NestedDissection(C, adj, pos, 36);
+    TileStructure(A, pos, T, &row_start, &row_tiles);
   }
   const int64_t num_tiles = int64_t(row_tiles.size());
   // transposed index: the tiles (Ii <= I, I) of tile column I, ascending Ii, with their pool positions
@@ -432,6 +718,88 @@ int cxsp_build_plan(cx_matrix* A) {
       for (auto& e : cols[size_t(J)]) { col_row.push_back(e.first); col_pool.push_back(e.second); }
     }
     col_start[size_t(T)] = int32_t(col_pool.size());
+  }
+  // Level schedule: the elimination tree of the TILE rows (parent = first tile right of the diagonal), tile rows
+  // grouped by height; per level the diagonal tiles, the panel tiles and, for every tile that a row of the level
+  // updates, its sources (pool indices of F(I, Ja), F(I, Jb)) in ascending I.
+  {
+    std::vector<int32_t> height(static_cast<size_t>(T), 0);
+    int max_h = 0;
+    for (int I = 0; I < T; ++I) {  // children have smaller indices: one ascending sweep pushes heights up
+      const int32_t q = row_start[size_t(I)] + 1;
+      const int32_t parent = row_tiles[size_t(q)];  // the list always ends with T, so q is valid
+      if (parent < T) height[size_t(parent)] = std::max(height[size_t(parent)], height[size_t(I)] + 1);
+      max_h = std::max(max_h, height[size_t(I)]);
+    }
+    const int L = T > 0 ? max_h + 1 : 0;
+    std::vector<int32_t> lrb(size_t(L) + 1, 0), lpb(size_t(L) + 1, 0), ltb(size_t(L) + 1, 0);
+    for (int I = 0; I < T; ++I) lrb[size_t(height[size_t(I)]) + 1]++;
+    for (int l = 0; l < L; ++l) lrb[size_t(l) + 1] += lrb[size_t(l)];
+    std::vector<int32_t> level_rows(static_cast<size_t>(T));
+    {
+      std::vector<int32_t> cur(lrb.begin(), lrb.end() - 1);
+      for (int I = 0; I < T; ++I) level_rows[size_t(cur[size_t(height[size_t(I)])]++)] = I;
+    }
+    std::vector<int32_t> panel_row, panel_pool;
+    struct Src { int32_t level, tgt, row, qa, qb; };
+    std::vector<Src> srcs;
+    for (int l = 0; l < L; ++l) {
+      lpb[size_t(l)] = int32_t(panel_row.size());
+      for (int32_t k = lrb[size_t(l)]; k < lrb[size_t(l) + 1]; ++k) {
+        const int I = level_rows[size_t(k)];
+        const int32_t q0 = row_start[size_t(I)], q1 = row_start[size_t(I) + 1];
+        for (int32_t q = q0 + 1; q < q1; ++q) { panel_row.push_back(I); panel_pool.push_back(q); }
+        for (int32_t qa = q0 + 1; qa < q1 - 1; ++qa) {  // Ja a real tile row; Jb up to the right-hand-side tile
+          const int Ja = row_tiles[size_t(qa)];
+          const auto first = row_tiles.begin() + row_start[size_t(Ja)], last = row_tiles.begin() + row_start[size_t(Ja) + 1];
+          auto it = first;
+          for (int32_t qb = qa; qb < q1; ++qb) {
+            it = std::lower_bound(it, last, row_tiles[size_t(qb)]);  // present by construction of the symbolic fill
+            srcs.push_back(Src{l, int32_t(it - row_tiles.begin()), I, qa, qb});
+          }
+        }
+      }
+    }
+    lpb[size_t(L)] = int32_t(panel_row.size());
+    std::sort(srcs.begin(), srcs.end(), [](const Src& x, const Src& y) {
+      return x.level != y.level ? x.level < y.level : (x.tgt != y.tgt ? x.tgt < y.tgt : x.row < y.row);
+    });
+    std::vector<int32_t> tgt_pool, tgt_flags, src_begin, src_a(srcs.size()), src_b(srcs.size());
+    {
+      int level = 0;
+      for (size_t i = 0; i < srcs.size(); ++i) {
+        while (level < srcs[i].level) ltb[size_t(++level)] = int32_t(tgt_pool.size());
+        if (i == 0 || srcs[i].level != srcs[i - 1].level || srcs[i].tgt != srcs[i - 1].tgt) {
+          const int32_t tq = srcs[i].tgt;
+          // which row owns pool slot tq: the row whose range contains it
+          const int Ja = int(std::upper_bound(row_start.begin(), row_start.end(), tq) - row_start.begin()) - 1;
+          const int Jb = row_tiles[size_t(tq)];
+          tgt_pool.push_back(tq);
+          tgt_flags.push_back((Jb == Ja ? 1 : 0) | (Jb == T ? 2 : 0));
+          src_begin.push_back(int32_t(i));
+        }
+        src_a[i] = srcs[i].qa;
+        src_b[i] = srcs[i].qb;
+      }
+      while (level < L) ltb[size_t(++level)] = int32_t(tgt_pool.size());
+      src_begin.push_back(int32_t(srcs.size()));
+    }
+    hipStream_t st0 = A->ctx->stream;
+    CX_TRY(A->d_sp_level_rows.upload(level_rows, st0));
+    CX_TRY(A->d_sp_panel_row.upload(panel_row, st0));
+    CX_TRY(A->d_sp_panel_pool.upload(panel_pool, st0));
+    CX_TRY(A->d_sp_tgt_pool.upload(tgt_pool, st0));
+    CX_TRY(A->d_sp_tgt_flags.upload(tgt_flags, st0));
+    CX_TRY(A->d_sp_src_begin.upload(src_begin, st0));
+    CX_TRY(A->d_sp_src_a.upload(src_a, st0));
+    CX_TRY(A->d_sp_src_b.upload(src_b, st0));
+    A->h_sp_level_row_begin = lrb;
+    A->h_sp_level_panel_begin = lpb;
+    A->h_sp_level_tgt_begin = ltb;
+    A->sp_num_levels = L;
+    if (std::getenv("CX_SPARSE_CHOLESKY_VERBOSE"))
+      std::fprintf(stderr, "[cxschur] tile-sparse Cholesky levels: %d tile rows in %d levels, %zu tile-pair updates on %zu (level, target) pairs\n",
+                   T, L, srcs.size(), tgt_pool.size());
   }
   // two pools (working copy and factor): refuse structures that would not fit comfortably
   if (double(num_tiles) * kTileDoubles * 8.0 * 2.0 > 160e9) { A->sp_state = 2; return CX_OK; }
@@ -461,16 +829,17 @@ int cxsp_factor_and_solve(cx_matrix* A, const double* Df, const double* rhs, dou
   const int C = A->C, n = 9 * C, T = A->sp_T;
   if (n == 0) return CX_OK;
   const size_t pool = size_t(A->sp_num_tiles) * kTileDoubles;
+  static const bool by_steps = std::getenv("CX_SPARSE_CHOLESKY_STEPS") != nullptr;  // round 1's numeric phase, for A/B runs
   CX_TRY(A->d_sp_W.alloc(pool));
-  CX_TRY(A->d_sp_F.alloc(pool));
+  if (by_steps) CX_TRY(A->d_sp_F.alloc(pool));
   CX_TRY(A->d_sp_x.alloc(2 * size_t(n) + size_t((n + NB - 1) / NB) * NB * NB));
   double* W = A->d_sp_W.p;
-  double* F = A->d_sp_F.p;
+  double* F = by_steps ? A->d_sp_F.p : W;
   double* xp = A->d_sp_x.p;
   double* yv = xp + n;
   double* uinv = yv + n;
   CX_HIP(hipMemsetAsync(W, 0, pool * sizeof(double), st));
-  CX_HIP(hipMemsetAsync(F, 0, pool * sizeof(double), st));
+  if (by_steps) CX_HIP(hipMemsetAsync(F, 0, pool * sizeof(double), st));
   if (A->num_cells > 0)
     hipLaunchKernelGGL(k_sp_assemble, dim3(unsigned((A->num_cells + 2) / 3)), dim3(3 * 81), 0, st, (const int32_t*)A->d_cell_c1.p,
                        (const int32_t*)A->d_cell_c2.p, (const int32_t*)A->d_cell_item_start.p, (const double*)A->d_item_partial.p,
@@ -478,20 +847,47 @@ int cxsp_factor_and_solve(cx_matrix* A, const double* Df, const double* rhs, dou
                        (const int32_t*)A->d_sp_row_tiles.p, W, A->num_cells);
   hipLaunchKernelGGL(k_sp_rhs, dim3((n + 255) / 256), dim3(256), 0, st, rhs, (const int32_t*)A->d_sp_cam_pos.p,
                      (const int32_t*)A->d_sp_row_start.p, W, C);
-  hipLaunchKernelGGL(k_sp_first, dim3(1), dim3(64), 0, st, (const double*)W, F, n, uinv, d_flag);
-  for (int k0 = 0; k0 < n; k0 += NB) {
-    const int I = k0 >> 6, half = (k0 >> 5) & 1;
-    const int m = A->h_sp_row_start[size_t(I) + 1] - A->h_sp_row_start[size_t(I)] - half;
-    hipLaunchKernelGGL(k_sp_step, dim3(unsigned(m * (m + 1) / 2)), dim3(256), 0, st, W, F, (const int32_t*)A->d_sp_row_start.p,
-                       (const int32_t*)A->d_sp_row_tiles.p, n, T, uinv, k0, d_flag);
-  }
-  CX_HIP(hipGetLastError());
-  hipLaunchKernelGGL(k_sp_gather_y, dim3((n + 255) / 256), dim3(256), 0, st, (const double*)F, (const int32_t*)A->d_sp_row_start.p, yv, n);
-  for (int I = T - 1; I >= 0; --I) {
-    const int tiles = A->h_sp_col_start[size_t(I) + 1] - A->h_sp_col_start[size_t(I)];
-    hipLaunchKernelGGL(k_sp_bwd64, dim3(unsigned(std::max(1, tiles))), dim3(256), 0, st, (const double*)F,
-                       (const int32_t*)A->d_sp_row_start.p, (const int32_t*)A->d_sp_col_start.p, (const int32_t*)A->d_sp_col_pool.p,
-                       (const int32_t*)A->d_sp_col_row.p, n, I, (const double*)uinv, yv, xp);
+  if (by_steps) {
+    hipLaunchKernelGGL(k_sp_first, dim3(1), dim3(64), 0, st, (const double*)W, F, n, uinv, d_flag);
+    for (int k0 = 0; k0 < n; k0 += NB) {
+      const int I = k0 >> 6, half = (k0 >> 5) & 1;
+      const int m = A->h_sp_row_start[size_t(I) + 1] - A->h_sp_row_start[size_t(I)] - half;
+      hipLaunchKernelGGL(k_sp_step, dim3(unsigned(m * (m + 1) / 2)), dim3(256), 0, st, W, F, (const int32_t*)A->d_sp_row_start.p,
+                         (const int32_t*)A->d_sp_row_tiles.p, n, T, uinv, k0, d_flag);
+    }
+    CX_HIP(hipGetLastError());
+    hipLaunchKernelGGL(k_sp_gather_y, dim3((n + 255) / 256), dim3(256), 0, st, (const double*)F, (const int32_t*)A->d_sp_row_start.p, yv, n);
+    for (int I = T - 1; I >= 0; --I) {
+      const int tiles = A->h_sp_col_start[size_t(I) + 1] - A->h_sp_col_start[size_t(I)];
+      hipLaunchKernelGGL(k_sp_bwd64, dim3(unsigned(std::max(1, tiles))), dim3(256), 0, st, (const double*)F,
+                         (const int32_t*)A->d_sp_row_start.p, (const int32_t*)A->d_sp_col_start.p, (const int32_t*)A->d_sp_col_pool.p,
+                         (const int32_t*)A->d_sp_col_row.p, n, I, (const double*)uinv, yv, xp);
+    }
+  } else {
+    const int L = A->sp_num_levels;
+    const int32_t* rows = A->d_sp_level_rows.p;
+    for (int l = 0; l < L; ++l) {
+      const int r0 = A->h_sp_level_row_begin[size_t(l)], nr = A->h_sp_level_row_begin[size_t(l) + 1] - r0;
+      const int p0 = A->h_sp_level_panel_begin[size_t(l)], np = A->h_sp_level_panel_begin[size_t(l) + 1] - p0;
+      const int t0 = A->h_sp_level_tgt_begin[size_t(l)], nt = A->h_sp_level_tgt_begin[size_t(l) + 1] - t0;
+      if (nr > 0)
+        hipLaunchKernelGGL(k_sp_diag, dim3(unsigned(nr)), dim3(64), 0, st, W, (const int32_t*)A->d_sp_row_start.p, rows + r0, n, uinv, d_flag);
+      if (np > 0)
+        hipLaunchKernelGGL(k_sp_panel, dim3(unsigned(np)), dim3(128), 0, st, W, (const int32_t*)A->d_sp_row_start.p,
+                           (const int32_t*)A->d_sp_row_tiles.p, (const int32_t*)A->d_sp_panel_row.p + p0,
+                           (const int32_t*)A->d_sp_panel_pool.p + p0, n, T, (const double*)uinv);
+      if (nt > 0)
+        hipLaunchKernelGGL(k_sp_update, dim3(unsigned(nt)), dim3(256), 0, st, W, (const int32_t*)A->d_sp_tgt_pool.p + t0,
+                           (const int32_t*)A->d_sp_tgt_flags.p + t0, (const int32_t*)A->d_sp_src_begin.p + t0,
+                           (const int32_t*)A->d_sp_src_a.p, (const int32_t*)A->d_sp_src_b.p);
+    }
+    CX_HIP(hipGetLastError());
+    for (int l = L - 1; l >= 0; --l) {
+      const int r0 = A->h_sp_level_row_begin[size_t(l)], nr = A->h_sp_level_row_begin[size_t(l) + 1] - r0;
+      if (nr > 0)
+        hipLaunchKernelGGL(k_sp_bwd_level, dim3(unsigned(nr)), dim3(256), 0, st, (const double*)W, (const int32_t*)A->d_sp_row_start.p,
+                           (const int32_t*)A->d_sp_row_tiles.p, rows + r0, n, (const double*)uinv, xp);
+    }
   }
   hipLaunchKernelGGL(k_sp_unpermute, dim3((n + 255) / 256), dim3(256), 0, st, (const double*)xp, (const int32_t*)A->d_sp_cam_pos.p, z, C);
   CX_HIP(hipGetLastError());
