@@ -598,7 +598,10 @@ struct Dissection {
   std::vector<int32_t> side;   // scratch: 1 / 2 = left / right half of the cut being examined, 0 otherwise
   std::vector<int32_t> order;  // result: cameras in elimination order
   int leaf;
-  Dissection(const std::vector<std::vector<int32_t>>& a, int leaf_size) : adj(a), side(a.size(), 0), leaf(leaf_size) { order.reserve(a.size()); }
+  int min_ratio;  // a cut is accepted when the piece is at least this many times larger than its separator
+  Dissection(const std::vector<std::vector<int32_t>>& a, int leaf_size, int ratio) : adj(a), side(a.size(), 0), leaf(leaf_size), min_ratio(ratio) {
+    order.reserve(a.size());
+  }
   void Run(std::vector<int32_t> seq) {
     if (int(seq.size()) <= leaf) {
       order.insert(order.end(), seq.begin(), seq.end());
@@ -615,6 +618,13 @@ struct Dissection {
     }
     const bool take_left = bl.size() <= br.size();
     const std::vector<int32_t>& sep = take_left ? bl : br;
+    if (sep.size() * size_t(min_ratio) > seq.size()) {
+      // the separator would be a large part of the piece (a band as wide as the piece is long): dissecting further only
+      // adds fill; the piece stays a chain in its arrangement order
+      for (int32_t u : seq) side[size_t(u)] = 0;
+      order.insert(order.end(), seq.begin(), seq.end());
+      return;
+    }
     for (int32_t u : sep) side[size_t(u)] = 3;
     std::vector<int32_t> left, right;
     for (size_t i = 0; i < seq.size(); ++i)
@@ -634,7 +644,8 @@ struct Dissection {
 std::vector<int32_t> NestedDissection(int C, const std::vector<std::vector<int32_t>>& adj, const std::vector<int32_t>& rcm_pos, int leaf) {
   std::vector<int32_t> seq(static_cast<size_t>(C));
   for (int c = 0; c < C; ++c) seq[size_t(rcm_pos[size_t(c)])] = c;
-  Dissection d(adj, leaf);
+  static const int ratio = [] { const char* v = std::getenv("CX_SPARSE_ND_RATIO"); return v ? std::max(2, atoi(v)) : 6; }();
+  Dissection d(adj, leaf, ratio);
   d.Run(std::move(seq));
   std::vector<int32_t> pos(static_cast<size_t>(C));
   for (int k = 0; k < C; ++k) pos[size_t(d.order[size_t(k)])] = k;
