@@ -322,8 +322,42 @@ __global__ __launch_bounds__(64) void k_sp_diag(double* __restrict__ W, const in
   cxchol::potrf_inverse_block(D22, kTile, D22, kTile, kb2, ui1 + NB * NB, not_pd, lds);
 }
 
+// operands of the panel solve X = Uinv' W (cxchol::panel_x) held in registers: A(m, r) = Uinv[r][m], B(r, c) = W[r][c]
+__device__ __forceinline__ void load_aop(const double* __restrict__ uinv, double (&aop)[8][2]) {
+  const int lane = threadIdx.x & 63, li = lane & 15, lk = lane >> 4;
+#pragma unroll
+  for (int s = 0; s < 8; ++s)
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) aop[s][mt] = uinv[(4 * s + lk) * NB + 16 * mt + li];
+}
+__device__ __forceinline__ void load_bop(const double* __restrict__ Wrow, int kb, int ncols, double (&bop)[8][2]) {
+  const int lane = threadIdx.x & 63, li = lane & 15, lk = lane >> 4;
+#pragma unroll
+  for (int s = 0; s < 8; ++s)
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+      const int r = 4 * s + lk, c = 16 * nt + li;
+      bop[s][nt] = (r < kb && c < ncols) ? Wrow[size_t(r) * kTile + c] : 0.0;
+    }
+}
+__device__ __forceinline__ void solve_x(const double (&aop)[8][2], const double (&bop)[8][2], double4_t (&X)[2][2]) {
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) X[mt][nt] = double4_t{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+  for (int s = 0; s < 8; ++s)
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt) X[mt][nt] = __builtin_amdgcn_mfma_f64_16x16x4f64(aop[s][mt], bop[s][nt], X[mt][nt], 0, 0, 0);
+}
+
 // Level, part 2: the other tiles of those rows become rows of the factor, F(I, J) = U_II^-T W(I, J), in place:
 // X1 = U11^-T W1; X2 = U22^-T (W2 - U12' X1).  One workgroup of two wavefronts per tile, wavefront q = columns 32 q ...
+// Everything the chain needs is requested up front (both inverses, U12, both halves of the tile): the result registers
+// of U12' X1 have the layout of the next product's B operand, so W2 - U12' X1 never leaves the registers -- one
+// memory round trip per tile.
 __global__ __launch_bounds__(128) void k_sp_panel(double* __restrict__ W, const int32_t* __restrict__ row_start,
                                                   const int32_t* __restrict__ row_tiles, const int32_t* __restrict__ panel_row,
                                                   const int32_t* __restrict__ panel_pool, int n, int T, const double* __restrict__ uinv) {
@@ -337,23 +371,35 @@ __global__ __launch_bounds__(128) void k_sp_panel(double* __restrict__ W, const 
   const int k0 = kTile * I;
   const int kb1 = min(NB, n - k0), kb2 = max(0, min(NB, n - k0 - NB));
   const double* ui1 = uinv + size_t(2 * I) * NB * NB;
+  double a1[8][2], a2[8][2], w1[8][2], w2[8][2];
+  double4_t U12[2][2];
+  load_aop(ui1, a1);
+  load_bop(Wt, kb1, ncols, w1);
+  if (kb2 > 0) {
+    load_aop(ui1 + NB * NB, a2);
+    load_bop(Wt + size_t(NB) * kTile, kb2, ncols, w2);
+    load_operand(D + NB, kb1, kb2, U12);
+  }
   double4_t X1[2][2];
-  cxchol::panel_x(Wt, kTile, ui1, kb1, ncols, X1);
+  solve_x(a1, w1, X1);
   store_rows(X1, Wt, kb1, ncols);
   if (kb2 <= 0) return;
-  double4_t U12[2][2], acc[2][2];
-  load_operand(D + NB, kb1, kb2, U12);
+  double4_t acc[2][2];
 #pragma unroll
   for (int a = 0; a < 2; ++a)
 #pragma unroll
     for (int b = 0; b < 2; ++b) acc[a][b] = double4_t{0.0, 0.0, 0.0, 0.0};
   mfma_atb(U12, X1, acc);
-  double* W2 = Wt + size_t(NB) * kTile;
-  subtract_block(acc, W2, kb2, ncols, false);
-  own_stores_visible();
+  // register g of acc[a][nt] holds row 16 a + (lane >> 4) + 4 g = 4 (4 a + g) + (lane >> 4): operand step s = 4 a + g
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt) w2[4 * a + g][nt] -= acc[a][nt][g];
   double4_t X2[2][2];
-  cxchol::panel_x(W2, kTile, ui1 + NB * NB, kb2, ncols, X2);
-  store_rows(X2, W2, kb2, ncols);
+  solve_x(a2, w2, X2);
+  store_rows(X2, Wt + size_t(NB) * kTile, kb2, ncols);
 }
 
 // Level, part 3: every tile that receives contributions from this level's rows: W(Ja, Jb) -= sum_I F(I, Ja)' F(I, Jb)
@@ -373,56 +419,74 @@ __global__ __launch_bounds__(256) void k_sp_update(double* __restrict__ W, const
   for (int a = 0; a < 2; ++a)
 #pragma unroll
     for (int b = 0; b < 2; ++b) acc[a][b] = double4_t{0.0, 0.0, 0.0, 0.0};
-  const int s1 = src_begin[t + 1];
-  for (int s = src_begin[t]; s < s1; ++s) {
+  // the operands of source s + 1 are requested before the products of source s are issued (two register sets)
+  struct Operands { double4_t A0[2][2], A1[2][2], B0[2][2], B1[2][2]; };
+  auto fetch = [&](int s, Operands& o) {
     const double* Fa = W + size_t(src_a[s]) * kTileDoubles + 32 * qi;
     const double* Fb = W + size_t(src_b[s]) * kTileDoubles + 32 * qj;
+    load_operand(Fb, 32, 32, o.B0);
+    load_operand(Fb + size_t(32) * kTile, 32, 32, o.B1);
+    if (Fa == Fb) {
 #pragma unroll
-    for (int half = 0; half < 2; ++half) {
-      double4_t A[2][2], B[2][2];
-      load_operand(Fb + size_t(32 * half) * kTile, 32, 32, B);
-      if (Fa == Fb) {
+      for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-          for (int nt = 0; nt < 2; ++nt) A[mt][nt] = B[mt][nt];
-      } else {
-        load_operand(Fa + size_t(32 * half) * kTile, 32, 32, A);
-      }
-      mfma_atb(A, B, acc);
+        for (int nt = 0; nt < 2; ++nt) { o.A0[mt][nt] = o.B0[mt][nt]; o.A1[mt][nt] = o.B1[mt][nt]; }
+    } else {
+      load_operand(Fa, 32, 32, o.A0);
+      load_operand(Fa + size_t(32) * kTile, 32, 32, o.A1);
     }
+  };
+  const int s0 = src_begin[t], s1 = src_begin[t + 1];
+  Operands cur, nxt;
+  fetch(s0, cur);
+  for (int s = s0; s < s1; ++s) {
+    if (s + 1 < s1) fetch(s + 1, nxt);
+    mfma_atb(cur.A0, cur.B0, acc);
+    mfma_atb(cur.A1, cur.B1, acc);
+    if (s + 1 < s1) cur = nxt;
   }
   double* dst = W + size_t(tgt_pool[t]) * kTileDoubles + size_t(32 * qi) * kTile + 32 * qj;
   subtract_block(acc, dst, 32, 32, (flags & 1) && qi == qj);
 }
 
-// Backward substitution of one level (top down): workgroup = tile row I.  y_I (column 0 of the row's last tile)
-// minus sum_J F(I, J) x_J over the row's tiles right of the diagonal, then the 64 x 64 triangular solve with the
-// kept inverses (x2 = U22^-1 y2, x1 = U11^-1 (y1 - U12 x2)).
+// Backward substitution of a level (top down), part 1: workgroup = one tile F(I, J) right of the diagonal of a row of
+// the level: partial[tile][r] = sum_c F(I, J)[r][c] x_J[c].
+__global__ __launch_bounds__(256) void k_sp_bwd_partial(const double* __restrict__ W, const int32_t* __restrict__ row_tiles,
+                                                        const int32_t* __restrict__ panel_pool, int n, int T,
+                                                        const double* __restrict__ x, double* __restrict__ partial) {
+  const int q = panel_pool[blockIdx.x];
+  const int J = row_tiles[q];
+  if (J >= T) return;  // the right-hand-side tile
+  const int t = threadIdx.x, r = t >> 2, part = t & 3;
+  const double* __restrict__ row = W + size_t(q) * kTileDoubles + size_t(r) * kTile + 16 * part;
+  const double* __restrict__ xj = x + size_t(kTile) * J + 16 * part;
+  const int valid = n - (kTile * J + 16 * part);
+  double s = 0.0;
+#pragma unroll
+  for (int c = 0; c < 16; ++c) s += (c < valid) ? row[c] * xj[c] : 0.0;
+  s += __shfl_xor(s, 1, 64);
+  s += __shfl_xor(s, 2, 64);
+  if (part == 0) partial[size_t(q) * kTile + r] = s;
+}
+
+// ... part 2: workgroup = tile row I: y_I (column 0 of the row's last tile) minus the partial sums of its tiles in
+// ascending order, then the 64 x 64 triangular solve with the kept inverses (x2 = U22^-1 y2, x1 = U11^-1 (y1 - U12 x2)).
 __global__ __launch_bounds__(256) void k_sp_bwd_level(const double* __restrict__ W, const int32_t* __restrict__ row_start,
-                                                      const int32_t* __restrict__ row_tiles, const int32_t* __restrict__ level_rows,
-                                                      int n, const double* __restrict__ uinv, double* __restrict__ x) {
+                                                      const int32_t* __restrict__ level_rows, int n, const double* __restrict__ uinv,
+                                                      const double* __restrict__ partial, double* __restrict__ x) {
   __shared__ double y1[NB], y2[NB], x1[NB], x2[NB], tmp[NB];
   const int I = level_rows[blockIdx.x];
-  const int t = threadIdx.x, r = t >> 2, part = t & 3;
+  const int t = threadIdx.x;
   const int k0 = kTile * I;
   const int kb1 = min(NB, n - k0), kb2 = max(0, min(NB, n - k0 - NB));
   const int q0 = row_start[I], q1 = row_start[I + 1] - 1;  // [q0] diagonal tile, [q1] right-hand-side tile
-  double s = 0.0;
-  for (int q = q0 + 1; q < q1; ++q) {
-    const int J = row_tiles[q];
-    const double* __restrict__ row = W + size_t(q) * kTileDoubles + size_t(r) * kTile + 16 * part;
-    const double* __restrict__ xj = x + size_t(kTile) * J + 16 * part;
-    const int valid = n - (kTile * J + 16 * part);
-#pragma unroll
-    for (int c = 0; c < 16; ++c) s += (c < valid) ? row[c] * xj[c] : 0.0;
-  }
-  s += __shfl_xor(s, 1, 64);
-  s += __shfl_xor(s, 2, 64);
-  if (part == 0) {
-    const double yv = W[size_t(q1) * kTileDoubles + size_t(r) * kTile] - s;
-    if (r < NB) y1[r] = r < kb1 ? yv : 0.0;
-    else y2[r - NB] = (r - NB) < kb2 ? yv : 0.0;
+  if (t < kTile) {
+    double s = 0.0;
+#pragma unroll 8
+    for (int q = q0 + 1; q < q1; ++q) s += partial[size_t(q) * kTile + t];
+    const double yv = W[size_t(q1) * kTileDoubles + size_t(t) * kTile] - s;
+    if (t < NB) y1[t] = t < kb1 ? yv : 0.0;
+    else y2[t - NB] = (t - NB) < kb2 ? yv : 0.0;
   }
   __syncthreads();
   const double* __restrict__ D = W + size_t(q0) * kTileDoubles;
@@ -586,67 +650,144 @@ std::vector<int32_t> GroupMinimumDegree(int C, const std::vector<std::vector<int
   return out;
 }
 
-// Nested dissection from a linear arrangement: `seq` lists cameras in a locality-preserving order (reverse
-// Cuthill-McKee).  Cut the list in the middle; the cameras of one side that have a neighbour on the other side form
-// a vertex separator -- take the smaller of the two candidates, order both remainders recursively (they no longer
-// touch each other) and put the separator last.  Whatever a separator eliminates couples only with its own subtree and
-// with the separators above it, so the two halves are independent subtrees of the elimination tree: that is the
-// parallelism the level schedule exploits.  A hub camera that sees everything ends up in a separator by itself
-// being the smaller boundary.
+// Nested dissection of the camera graph (George's automatic nested dissection): the level structure of a breadth-
+// first search from a pseudo-peripheral camera cuts a connected piece into "before", one level, and "after"; the level
+// is a vertex separator.  Both sides are ordered first (recursively), the separator last, so the two sides are
+// independent subtrees of the elimination tree -- the parallelism the level schedule of the factorisation exploits --
+// and whatever a separator eliminates couples only with its own subtree and the separators above it.  A cut is taken
+// only while the piece is at least `ratio` times larger than the separator: below that (a band as wide as the piece is
+// long) dissecting further only adds fill, and the piece is laid out as a band instead (reverse breadth-first order).
+// Work stack instead of recursion; pieces are told apart by an owner id per camera.
 struct Dissection {
   const std::vector<std::vector<int32_t>>& adj;
-  std::vector<int32_t> side;   // scratch: 1 / 2 = left / right half of the cut being examined, 0 otherwise
+  int ratio, leaf;
+  std::vector<int32_t> owner;  // piece id of a camera, -1 once ordered
+  std::vector<int32_t> dist;   // breadth-first level inside the current search, -1 otherwise
+  std::vector<int32_t> bfs;    // visit order of the last search
   std::vector<int32_t> order;  // result: cameras in elimination order
-  int leaf;
-  int min_ratio;  // a cut is accepted when the piece is at least this many times larger than its separator
-  Dissection(const std::vector<std::vector<int32_t>>& a, int leaf_size, int ratio) : adj(a), side(a.size(), 0), leaf(leaf_size), min_ratio(ratio) {
-    order.reserve(a.size());
-  }
-  void Run(std::vector<int32_t> seq) {
-    if (int(seq.size()) <= leaf) {
-      order.insert(order.end(), seq.begin(), seq.end());
-      return;
-    }
-    const size_t mid = seq.size() / 2;
-    for (size_t i = 0; i < seq.size(); ++i) side[size_t(seq[i])] = i < mid ? 1 : 2;
-    std::vector<int32_t> bl, br;  // boundary of the left / right half
-    for (size_t i = 0; i < seq.size(); ++i) {
-      const int32_t u = seq[i];
-      const int32_t other = i < mid ? 2 : 1;
+  int next_piece = 1;
+
+  Dissection(const std::vector<std::vector<int32_t>>& a, int leaf_size, int min_ratio)
+      : adj(a), ratio(min_ratio), leaf(leaf_size), owner(a.size(), 0), dist(a.size(), -1) { order.reserve(a.size()); }
+
+  int Search(int32_t start, int32_t piece) {  // fills bfs / dist, returns the number of levels
+    bfs.clear();
+    bfs.push_back(start);
+    dist[size_t(start)] = 0;
+    for (size_t h = 0; h < bfs.size(); ++h) {
+      const int32_t u = bfs[h];
       for (int32_t v : adj[size_t(u)])
-        if (side[size_t(v)] == other) { (i < mid ? bl : br).push_back(u); break; }
+        if (owner[size_t(v)] == piece && dist[size_t(v)] < 0) { dist[size_t(v)] = dist[size_t(u)] + 1; bfs.push_back(v); }
     }
-    const bool take_left = bl.size() <= br.size();
-    const std::vector<int32_t>& sep = take_left ? bl : br;
-    if (sep.size() * size_t(min_ratio) > seq.size()) {
-      // the separator would be a large part of the piece (a band as wide as the piece is long): dissecting further only
-      // adds fill; the piece stays a chain in its arrangement order
-      for (int32_t u : seq) side[size_t(u)] = 0;
-      order.insert(order.end(), seq.begin(), seq.end());
-      return;
+    return dist[size_t(bfs.back())] + 1;
+  }
+  void Forget() { for (int32_t u : bfs) dist[size_t(u)] = -1; }
+  int32_t FarLowDegree(int levels) const {  // a camera of the last level with the fewest neighbours
+    int32_t best = bfs.back();
+    for (size_t i = bfs.size(); i-- > 0 && dist[size_t(bfs[i])] == levels - 1;)
+      if (adj[size_t(bfs[i])].size() < adj[size_t(best)].size()) best = bfs[i];
+    return best;
+  }
+  void EmitBand() {  // the last search's cameras as a band: reverse breadth-first order
+    for (size_t i = bfs.size(); i-- > 0;) { order.push_back(bfs[i]); owner[size_t(bfs[i])] = -1; }
+  }
+
+  // entries of the work stack: a piece to dissect (seed >= 0: any camera of it) or a separator to emit (list)
+  struct Job { int32_t piece, seed; std::vector<int32_t> emit; };
+
+  void Run() {
+    std::vector<Job> stack;
+    // whole graph: every connected component is a piece of its own
+    const int32_t n = int32_t(adj.size());
+    for (int32_t c = n - 1; c >= 0; --c) {
+      if (owner[size_t(c)] != 0) continue;
+      const int32_t piece = next_piece++;
+      // label the component
+      owner[size_t(c)] = piece;
+      std::vector<int32_t> comp{c};
+      for (size_t h = 0; h < comp.size(); ++h)
+        for (int32_t v : adj[size_t(comp[h])]) if (owner[size_t(v)] == 0) { owner[size_t(v)] = piece; comp.push_back(v); }
+      stack.push_back(Job{piece, c, {}});
     }
-    for (int32_t u : sep) side[size_t(u)] = 3;
-    std::vector<int32_t> left, right;
-    for (size_t i = 0; i < seq.size(); ++i)
-      if (side[size_t(seq[i])] != 3) (i < mid ? left : right).push_back(seq[i]);
-    for (int32_t u : seq) side[size_t(u)] = 0;
-    if (left.empty() || right.empty()) {  // the cut separates nothing (a clique-like piece): keep the arrangement
-      order.insert(order.end(), seq.begin(), seq.end());
-      return;
+    while (!stack.empty()) {
+      Job job = std::move(stack.back());
+      stack.pop_back();
+      if (job.seed < 0) {
+        for (int32_t u : job.emit) { order.push_back(u); owner[size_t(u)] = -1; }
+        continue;
+      }
+      // pseudo-peripheral start: search again from a far, low-degree camera while the structure gets deeper
+      int levels = Search(job.seed, job.piece);
+      for (int pass = 0; pass < 3; ++pass) {
+        const int32_t far = FarLowDegree(levels);
+        Forget();
+        const int deeper = Search(far, job.piece);
+        const bool improved = deeper > levels;
+        levels = deeper;
+        if (!improved) break;
+      }
+      const int32_t size = int32_t(bfs.size());
+      if (size <= leaf || levels < 3) { EmitBand(); Forget(); continue; }
+      std::vector<int32_t> count(size_t(levels), 0);
+      for (int32_t u : bfs) count[size_t(dist[size_t(u)])]++;
+      // the thinnest level that leaves at least a quarter of the piece on either side
+      int cut = -1;
+      int32_t below = 0;
+      for (int l = 0; l < levels; ++l) {
+        const int32_t above = size - below - count[size_t(l)];
+        if (l > 0 && l < levels - 1 && 4 * below >= size && 4 * above >= size && (cut < 0 || count[size_t(l)] < count[size_t(cut)])) cut = l;
+        below += count[size_t(l)];
+      }
+      if (cut < 0 || int64_t(count[size_t(cut)]) * ratio > size) { EmitBand(); Forget(); continue; }
+      const int32_t lo = next_piece++, hi = next_piece++;
+      std::vector<int32_t> sep;
+      int32_t seed_lo = -1, seed_hi = -1;
+      for (int32_t u : bfs) {
+        const int d = dist[size_t(u)];
+        if (d < cut) { owner[size_t(u)] = lo; seed_lo = u; }
+        else if (d > cut) { owner[size_t(u)] = hi; seed_hi = u; }
+        else { owner[size_t(u)] = -2; sep.push_back(u); }
+      }
+      Forget();
+      // stack order: the separator is emitted after both sides (pushed first, popped last).  A side may fall apart into
+      // several components once the separator is gone: each becomes a piece of its own.
+      stack.push_back(Job{-1, -1, std::move(sep)});
+      const int32_t seeds[2] = {seed_lo, seed_hi};
+      const int32_t sides[2] = {lo, hi};
+      for (int k = 0; k < 2; ++k) PushComponents(sides[k], seeds[k], &stack);
     }
-    const std::vector<int32_t> keep(sep);
-    Run(std::move(left));
-    Run(std::move(right));
-    order.insert(order.end(), keep.begin(), keep.end());
+  }
+
+  // split the cameras labelled `piece` into connected components (each relabelled) and push them
+  void PushComponents(int32_t piece, int32_t any, std::vector<Job>* stack) {
+    if (any < 0) return;
+    // collect the members by a search over the piece, restarting until all are seen
+    std::vector<int32_t> members;
+    for (int32_t u = 0; u < int32_t(owner.size()); ++u) if (owner[size_t(u)] == piece) members.push_back(u);
+    for (int32_t m : members) {
+      if (owner[size_t(m)] != piece) continue;
+      const int32_t comp = next_piece++;
+      owner[size_t(m)] = comp;
+      std::vector<int32_t> q{m};
+      for (size_t h = 0; h < q.size(); ++h)
+        for (int32_t v : adj[size_t(q[h])]) if (owner[size_t(v)] == piece) { owner[size_t(v)] = comp; q.push_back(v); }
+      stack->push_back(Job{comp, m, {}});
+    }
   }
 };
 
-std::vector<int32_t> NestedDissection(int C, const std::vector<std::vector<int32_t>>& adj, const std::vector<int32_t>& rcm_pos, int leaf) {
-  std::vector<int32_t> seq(static_cast<size_t>(C));
-  for (int c = 0; c < C; ++c) seq[size_t(rcm_pos[size_t(c)])] = c;
+std::vector<int32_t> NestedDissection(int C, const std::vector<std::vector<int32_t>>& adj, int leaf) {
   static const int ratio = [] { const char* v = std::getenv("CX_SPARSE_ND_RATIO"); return v ? std::max(2, atoi(v)) : 6; }();
   Dissection d(adj, leaf, ratio);
-  d.Run(std::move(seq));
+  // hub cameras (co-visible with a large part of all cameras) would glue every level structure into two or three
+  // levels: they are taken out first and eliminated last, where their fill is unavoidable anyway
+  std::vector<int32_t> hubs;
+  if (C >= 64)
+    for (int c = 0; c < C; ++c)
+      if (adj[size_t(c)].size() * 5 > size_t(C) * 2) { d.owner[size_t(c)] = -3; hubs.push_back(c); }
+  std::stable_sort(hubs.begin(), hubs.end(), [&](int32_t u, int32_t v) { return adj[size_t(u)].size() < adj[size_t(v)].size(); });
+  d.Run();
+  d.order.insert(d.order.end(), hubs.begin(), hubs.end());
   std::vector<int32_t> pos(static_cast<size_t>(C));
   for (int k = 0; k < C; ++k) pos[size_t(d.order[size_t(k)])] = k;
   return pos;
@@ -699,9 +840,10 @@ int cxsp_build_plan(cx_matrix* A) {
   }
   const char* ordering_env = std::getenv("CX_SPARSE_ORDERING");
   const bool band_ordering = ordering_env != nullptr && std::string(ordering_env) == "rcm";
-  std::vector<int32_t> pos = ReverseCuthillMcKee(C, adj);
+  std::vector<int32_t> pos;
   std::vector<int32_t> row_start, row_tiles;
   if (band_ordering) {
+    pos = ReverseCuthillMcKee(C, adj);
     // round 1: two candidate band orderings, the one with fewer tiles after fill wins
     TileStructure(A, pos, T, &row_start, &row_tiles);
     std::vector<int32_t> pos2 = GroupMinimumDegree(C, adj, pos), rs2, rt2;
@@ -713,7 +855,7 @@ int cxsp_build_plan(cx_matrix* A) {
     }
   } else {
     // leaves of about 5 tile rows: below that a subtree is a chain of tile rows anyway
-    pos = NestedDissection(C, adj, pos, 36);
+    pos = NestedDissection(C, adj, 36);
     TileStructure(A, pos, T, &row_start, &row_tiles);
   }
   const int64_t num_tiles = int64_t(row_tiles.size());
@@ -843,7 +985,7 @@ int cxsp_factor_and_solve(cx_matrix* A, const double* Df, const double* rhs, dou
   static const bool by_steps = std::getenv("CX_SPARSE_CHOLESKY_STEPS") != nullptr;  // round 1's numeric phase, for A/B runs
   CX_TRY(A->d_sp_W.alloc(pool));
   if (by_steps) CX_TRY(A->d_sp_F.alloc(pool));
-  CX_TRY(A->d_sp_x.alloc(2 * size_t(n) + size_t((n + NB - 1) / NB) * NB * NB));
+  CX_TRY(A->d_sp_x.alloc(2 * size_t(n) + size_t((n + NB - 1) / NB) * NB * NB + size_t(A->sp_num_tiles) * kTile));
   double* W = A->d_sp_W.p;
   double* F = by_steps ? A->d_sp_F.p : W;
   double* xp = A->d_sp_x.p;
@@ -893,11 +1035,16 @@ int cxsp_factor_and_solve(cx_matrix* A, const double* Df, const double* rhs, dou
                            (const int32_t*)A->d_sp_src_a.p, (const int32_t*)A->d_sp_src_b.p);
     }
     CX_HIP(hipGetLastError());
+    double* partial = uinv + size_t((n + NB - 1) / NB) * NB * NB;  // [tiles][64] partial products of the backward sweep
     for (int l = L - 1; l >= 0; --l) {
       const int r0 = A->h_sp_level_row_begin[size_t(l)], nr = A->h_sp_level_row_begin[size_t(l) + 1] - r0;
+      const int p0 = A->h_sp_level_panel_begin[size_t(l)], np = A->h_sp_level_panel_begin[size_t(l) + 1] - p0;
+      if (np > 0)
+        hipLaunchKernelGGL(k_sp_bwd_partial, dim3(unsigned(np)), dim3(256), 0, st, (const double*)W, (const int32_t*)A->d_sp_row_tiles.p,
+                           (const int32_t*)A->d_sp_panel_pool.p + p0, n, T, (const double*)xp, partial);
       if (nr > 0)
         hipLaunchKernelGGL(k_sp_bwd_level, dim3(unsigned(nr)), dim3(256), 0, st, (const double*)W, (const int32_t*)A->d_sp_row_start.p,
-                           (const int32_t*)A->d_sp_row_tiles.p, rows + r0, n, (const double*)uinv, xp);
+                           rows + r0, n, (const double*)uinv, (const double*)partial, xp);
     }
   }
   hipLaunchKernelGGL(k_sp_unpermute, dim3((n + 255) / 256), dim3(256), 0, st, (const double*)xp, (const int32_t*)A->d_sp_cam_pos.p, z, C);
