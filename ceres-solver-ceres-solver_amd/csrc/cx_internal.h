@@ -163,9 +163,8 @@ struct cx_matrix {
   int sp_state = 0;
   int sp_T = 0;
   int64_t sp_num_tiles = 0;
-  std::vector<int32_t> h_sp_row_start, h_sp_col_start;
-  DevBuf<int32_t> d_sp_cam_pos, d_sp_row_start, d_sp_row_tiles, d_sp_col_start, d_sp_col_pool, d_sp_col_row;
-  DevBuf<double> d_sp_W, d_sp_F, d_sp_x;
+  DevBuf<int32_t> d_sp_cam_pos, d_sp_valid, d_sp_row_start, d_sp_row_tiles;  // first row of each camera; valid rows per tile row
+  DevBuf<double> d_sp_W, d_sp_x;
   // level schedule of the tile elimination tree (tile rows of one height are factored together)
   int sp_num_levels = 0;
   std::vector<int32_t> h_sp_level_row_begin, h_sp_level_panel_begin, h_sp_level_tgt_begin;  // [levels + 1]

@@ -54,16 +54,6 @@ __device__ __forceinline__ int tile_find(const int32_t* __restrict__ row_tiles, 
   return lo;
 }
 
-// (a, b), a <= b < m, number t in row-major order of the upper triangle
-__device__ __forceinline__ void pair_decode(int t, int m, int& a, int& b) {
-  int row = int((2.0 * m + 1.0 - sqrt((2.0 * m + 1.0) * (2.0 * m + 1.0) - 8.0 * t)) * 0.5);
-  row = max(0, min(m - 1, row));
-  while (row > 0 && row * m - row * (row - 1) / 2 > t) --row;
-  while ((row + 1) * m - (row + 1) * row / 2 <= t) ++row;
-  a = row;
-  b = row + (t - (row * m - row * (row - 1) / 2));
-}
-
 // S cells (gather assembly of cx_schur.hip) -> tile pool at the permuted positions; 81 threads per cell
 __global__ __launch_bounds__(3 * 81) void k_sp_assemble(const int32_t* __restrict__ cell_c1, const int32_t* __restrict__ cell_c2,
                                                         const int32_t* __restrict__ cell_item_start,
@@ -85,7 +75,7 @@ __global__ __launch_bounds__(3 * 81) void k_sp_assemble(const int32_t* __restric
       v += d * d;
     }
   }
-  int row = 9 * cam_pos[c1] + a, col = 9 * cam_pos[c2] + c;
+  int row = cam_pos[c1] + a, col = cam_pos[c2] + c;  // cam_pos: first row of the camera in the padded elimination order
   if (c1 != c2 && row > col) { const int t = row; row = col; col = t; }  // the cell lands transposed
   if (row > col) return;                                                 // lower half of a diagonal cell
   const int I = row >> 6, J = col >> 6;
@@ -99,116 +89,9 @@ __global__ void k_sp_rhs(const double* __restrict__ rhs, const int32_t* __restri
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= 9 * C) return;
   const int c = i / 9, a = i - 9 * c;
-  const int row = 9 * cam_pos[c] + a;
+  const int row = cam_pos[c] + a;
   const int I = row >> 6;
   W[size_t(row_start[I + 1] - 1) * kTileDoubles + (row & 63) * kTile] = rhs[i];
-}
-
-__global__ __launch_bounds__(64) void k_sp_first(const double* __restrict__ W, double* __restrict__ F, int n, double* __restrict__ uinv,
-                                                 int* __restrict__ not_pd) {
-  __shared__ double lds[cxchol::kPotrfLds];
-  cxchol::potrf_inverse_block(W, kTile, F, kTile, min(NB, n), uinv, not_pd, lds);
-}
-
-// One block step k0 (see the file header).  Tile row I = k0 / 64, half = upper / lower 32 rows of it.  The
-// step's column tiles are the row's list (without the diagonal tile in a lower-half step); block t owns the
-// pair (a <= b) number t of that list: target tile (L[a], L[b]), panel pieces from tiles (I, L[a]), (I, L[b]).
-__global__ __launch_bounds__(256) void k_sp_step(double* __restrict__ W, double* __restrict__ F, const int32_t* __restrict__ row_start,
-                                                 const int32_t* __restrict__ row_tiles, int n, int T, double* __restrict__ uinv,
-                                                 int k0, int* __restrict__ not_pd) {
-  __shared__ double lds[cxchol::kPotrfLds];
-  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-  const int li = lane & 15, lk = lane >> 4;
-  const int kb = min(NB, n - k0), rest = k0 + kb;
-  const int I = k0 >> 6, half = (k0 >> 5) & 1;
-  const double* ui = uinv + size_t(k0 / NB) * NB * NB;  // all block inverses are kept (backward substitution)
-  const int rs = row_start[I] + half;  // a lower-half step has left the diagonal tile behind
-  const int m = row_start[I + 1] - rs;
-  int a, b;
-  pair_decode(blockIdx.x, m, a, b);
-  const int Ji = row_tiles[rs + a], Jj = row_tiles[rs + b];
-  const int qi = wave >> 1, qj = wave & 1;
-  const size_t prow = size_t(32 * half) * kTile;  // the panel's rows inside the tiles of row I
-  // X_j = U_kk^-T W(k, columns of quadrant qj of tile Jj); the rhs tile T has one column
-  const int ncols_j = (Jj < T) ? min(32, n - (kTile * Jj + 32 * qj)) : (qj == 0 ? 1 : 0);
-  double4_t Xj[2][2];
-  cxchol::panel_x(W + size_t(rs + b) * kTileDoubles + prow + 32 * qj, kTile, ui, kb, ncols_j, Xj);
-  if (a == 0 && qi == 0) {
-    // rows k0.. of the factor; columns left of `rest` belong to U_kk itself
-    double* Frow = F + size_t(rs + b) * kTileDoubles + prow + 32 * qj;
-#pragma unroll
-    for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-      for (int nt = 0; nt < 2; ++nt)
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          const int mr = 16 * mt + lk + 4 * g;
-          const int cl = 16 * nt + li;
-          const bool ok = (Jj < T) ? (kTile * Jj + 32 * qj + cl >= rest && cl < ncols_j) : (cl < ncols_j);
-          if (mr < kb && ok) Frow[size_t(mr) * kTile + cl] = Xj[mt][nt][g];
-        }
-  }
-  if (Ji < T) {
-    double4_t Xi[2][2];
-    if (Ji == Jj && qi == qj) {
-#pragma unroll
-      for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-        for (int nt = 0; nt < 2; ++nt) Xi[mt][nt] = Xj[mt][nt];
-    } else {
-      const int ncols_i = min(32, n - (kTile * Ji + 32 * qi));
-      cxchol::panel_x(W + size_t(rs + a) * kTileDoubles + prow + 32 * qi, kTile, ui, kb, ncols_i, Xi);
-    }
-    double4_t acc[2][2];
-#pragma unroll
-    for (int x = 0; x < 2; ++x)
-#pragma unroll
-      for (int y = 0; y < 2; ++y) acc[x][y] = double4_t{0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-    for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-      for (int g = 0; g < 4; ++g)
-#pragma unroll
-        for (int x = 0; x < 2; ++x)
-#pragma unroll
-          for (int y = 0; y < 2; ++y)
-            acc[x][y] = __builtin_amdgcn_mfma_f64_16x16x4f64(Xi[mt][x][g], Xj[mt][y][g], acc[x][y], 0, 0, 0);
-    // target tile (Ji, Jj): present by construction of the symbolic fill
-    const int idx = tile_find(row_tiles, row_start[Ji], row_start[Ji + 1], Jj);
-    double* Wt = W + size_t(idx) * kTileDoubles;
-#pragma unroll
-    for (int x = 0; x < 2; ++x)
-#pragma unroll
-      for (int y = 0; y < 2; ++y)
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          const int il = 32 * qi + x * 16 + lk + 4 * g;  // local row / column inside the tile
-          const int jl = 32 * qj + y * 16 + li;
-          const int i = kTile * Ji + il;
-          const bool col_ok = (Jj < T) ? (kTile * Jj + jl < n && kTile * Jj + jl >= i) : (jl == 0);
-          if (i >= rest && i < n && col_ok) Wt[il * kTile + jl] -= acc[x][y][g];
-        }
-  }
-  if (blockIdx.x == 0 && rest < n) {
-    // look-ahead: the next diagonal block lies in the tile this workgroup has just updated, or in a
-    // tile this step does not touch
-    // owner of the next diagonal block: an upper-half step updates it as quadrant (1, 1) of the diagonal tile
-    // (wavefront 3), a lower-half step as quadrant (0, 0) of the next diagonal tile (wavefront 0) or not at all --
-    // either way one wavefront's own program order suffices (see k_chol_step)
-    if (wave == (half ? 0 : 3)) {
-      __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
-      const int In = rest >> 6, hn = (rest >> 5) & 1;
-      const size_t off = size_t(row_start[In]) * kTileDoubles + size_t(32 * hn) * kTile + 32 * hn;
-      cxchol::potrf_inverse_block(W + off, kTile, F + off, kTile, min(NB, n - rest), uinv + size_t(rest / NB) * NB * NB, not_pd, lds);
-    }
-  }
-}
-
-// y (dense, permuted order) = column 0 of every tile row's last tile of the factor (U^-T rhs)
-__global__ void k_sp_gather_y(const double* __restrict__ F, const int32_t* __restrict__ row_start, double* __restrict__ y, int n) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  y[i] = F[size_t(row_start[(i >> 6) + 1] - 1) * kTileDoubles + size_t(i & 63) * kTile];
 }
 
 // out[m] = sum_c M[m][c] v[c] for a 32 x 32 block, 8 threads per row
@@ -296,13 +179,12 @@ __device__ __forceinline__ void own_stores_visible() {
 // Level, part 1: the diagonal tiles of the level's tile rows, one wavefront each.  U11 = chol(A11) and its inverse;
 // U12 = U11^-T A12; A22 -= U12' U12; U22 = chol(A22) and its inverse.
 __global__ __launch_bounds__(64) void k_sp_diag(double* __restrict__ W, const int32_t* __restrict__ row_start,
-                                                const int32_t* __restrict__ level_rows, int n, double* __restrict__ uinv,
-                                                int* __restrict__ not_pd) {
+                                                const int32_t* __restrict__ level_rows, const int32_t* __restrict__ valid,
+                                                double* __restrict__ uinv, int* __restrict__ not_pd) {
   __shared__ double lds[cxchol::kPotrfLds];
   const int I = level_rows[blockIdx.x];
   double* D = W + size_t(row_start[I]) * kTileDoubles;
-  const int k0 = kTile * I;
-  const int kb1 = min(NB, n - k0), kb2 = max(0, min(NB, n - k0 - NB));
+  const int kb1 = min(NB, valid[I]), kb2 = max(0, min(NB, valid[I] - NB));
   double* ui1 = uinv + size_t(2 * I) * NB * NB;
   cxchol::potrf_inverse_block(D, kTile, D, kTile, kb1, ui1, not_pd, lds);
   if (kb2 <= 0) return;
@@ -360,16 +242,16 @@ __device__ __forceinline__ void solve_x(const double (&aop)[8][2], const double 
 // memory round trip per tile.
 __global__ __launch_bounds__(128) void k_sp_panel(double* __restrict__ W, const int32_t* __restrict__ row_start,
                                                   const int32_t* __restrict__ row_tiles, const int32_t* __restrict__ panel_row,
-                                                  const int32_t* __restrict__ panel_pool, int n, int T, const double* __restrict__ uinv) {
+                                                  const int32_t* __restrict__ panel_pool, const int32_t* __restrict__ valid, int T,
+                                                  const double* __restrict__ uinv) {
   const int I = panel_row[blockIdx.x], q = panel_pool[blockIdx.x];
   const int J = row_tiles[q];
   const int wave = threadIdx.x >> 6;
-  const int ncols = (J < T) ? max(0, min(32, n - (kTile * J + 32 * wave))) : (wave == 0 ? 1 : 0);
+  const int ncols = (J < T) ? max(0, min(32, valid[J] - 32 * wave)) : (wave == 0 ? 1 : 0);
   if (ncols <= 0) return;
   double* Wt = W + size_t(q) * kTileDoubles + 32 * wave;
   const double* D = W + size_t(row_start[I]) * kTileDoubles;
-  const int k0 = kTile * I;
-  const int kb1 = min(NB, n - k0), kb2 = max(0, min(NB, n - k0 - NB));
+  const int kb1 = min(NB, valid[I]), kb2 = max(0, min(NB, valid[I] - NB));
   const double* ui1 = uinv + size_t(2 * I) * NB * NB;
   double a1[8][2], a2[8][2], w1[8][2], w2[8][2];
   double4_t U12[2][2];
@@ -452,7 +334,7 @@ __global__ __launch_bounds__(256) void k_sp_update(double* __restrict__ W, const
 // Backward substitution of a level (top down), part 1: workgroup = one tile F(I, J) right of the diagonal of a row of
 // the level: partial[tile][r] = sum_c F(I, J)[r][c] x_J[c].
 __global__ __launch_bounds__(256) void k_sp_bwd_partial(const double* __restrict__ W, const int32_t* __restrict__ row_tiles,
-                                                        const int32_t* __restrict__ panel_pool, int n, int T,
+                                                        const int32_t* __restrict__ panel_pool, const int32_t* __restrict__ valid, int T,
                                                         const double* __restrict__ x, double* __restrict__ partial) {
   const int q = panel_pool[blockIdx.x];
   const int J = row_tiles[q];
@@ -460,10 +342,10 @@ __global__ __launch_bounds__(256) void k_sp_bwd_partial(const double* __restrict
   const int t = threadIdx.x, r = t >> 2, part = t & 3;
   const double* __restrict__ row = W + size_t(q) * kTileDoubles + size_t(r) * kTile + 16 * part;
   const double* __restrict__ xj = x + size_t(kTile) * J + 16 * part;
-  const int valid = n - (kTile * J + 16 * part);
+  const int nvalid = valid[J] - 16 * part;
   double s = 0.0;
 #pragma unroll
-  for (int c = 0; c < 16; ++c) s += (c < valid) ? row[c] * xj[c] : 0.0;
+  for (int c = 0; c < 16; ++c) s += (c < nvalid) ? row[c] * xj[c] : 0.0;
   s += __shfl_xor(s, 1, 64);
   s += __shfl_xor(s, 2, 64);
   if (part == 0) partial[size_t(q) * kTile + r] = s;
@@ -472,13 +354,14 @@ __global__ __launch_bounds__(256) void k_sp_bwd_partial(const double* __restrict
 // ... part 2: workgroup = tile row I: y_I (column 0 of the row's last tile) minus the partial sums of its tiles in
 // ascending order, then the 64 x 64 triangular solve with the kept inverses (x2 = U22^-1 y2, x1 = U11^-1 (y1 - U12 x2)).
 __global__ __launch_bounds__(256) void k_sp_bwd_level(const double* __restrict__ W, const int32_t* __restrict__ row_start,
-                                                      const int32_t* __restrict__ level_rows, int n, const double* __restrict__ uinv,
-                                                      const double* __restrict__ partial, double* __restrict__ x) {
+                                                      const int32_t* __restrict__ level_rows, const int32_t* __restrict__ valid,
+                                                      const double* __restrict__ uinv, const double* __restrict__ partial,
+                                                      double* __restrict__ x) {
   __shared__ double y1[NB], y2[NB], x1[NB], x2[NB], tmp[NB];
   const int I = level_rows[blockIdx.x];
   const int t = threadIdx.x;
   const int k0 = kTile * I;
-  const int kb1 = min(NB, n - k0), kb2 = max(0, min(NB, n - k0 - NB));
+  const int kb1 = min(NB, valid[I]), kb2 = max(0, min(NB, valid[I] - NB));
   const int q0 = row_start[I], q1 = row_start[I + 1] - 1;  // [q0] diagonal tile, [q1] right-hand-side tile
   if (t < kTile) {
     double s = 0.0;
@@ -505,67 +388,15 @@ __global__ __launch_bounds__(256) void k_sp_bwd_level(const double* __restrict__
   __syncthreads();
   if (t < 64) {
     const double v = t < NB ? x1[t] : x2[t - NB];
-    if (t < kb1 + kb2) x[k0 + t] = v;
+    x[k0 + t] = (t < kb1 + kb2) ? v : 0.0;  // padding rows of the tile row carry zeros
   }
-}
-
-// Backward substitution, one tile row (64 rows) per launch, as the dense solver's k_trsv_bwd64: every workgroup solves
-// the tile row's 64 x 64 triangular system with the stored inverses of its two diagonal blocks (x2 = U22^-1 y2,
-// x1 = U11^-1 (y1 - U12 x2)), then workgroup w subtracts (tile w of tile column I) x from that tile's 64 rows.
-__global__ __launch_bounds__(256) void k_sp_bwd64(const double* __restrict__ F, const int32_t* __restrict__ row_start,
-                                                  const int32_t* __restrict__ col_start, const int32_t* __restrict__ col_pool,
-                                                  const int32_t* __restrict__ col_row, int n, int I, const double* __restrict__ uinv,
-                                                  double* __restrict__ y, double* __restrict__ x) {
-  __shared__ double y1[NB], y2[NB], x1[NB], x2[NB], tmp[NB];
-  const int t = threadIdx.x;
-  const int k0 = kTile * I;
-  const int kb1 = min(NB, n - k0), kb2 = max(0, min(NB, n - k0 - NB));
-  if (t < NB) {
-    y1[t] = t < kb1 ? y[k0 + t] : 0.0;
-    y2[t] = t < kb2 ? y[k0 + NB + t] : 0.0;
-  }
-  __syncthreads();
-  const double* __restrict__ D = F + size_t(row_start[I]) * kTileDoubles;  // the diagonal tile
-  const double* __restrict__ ui1 = uinv + size_t(2 * I) * NB * NB;
-  if (kb2 > 0) {
-    sp_gemv32(ui1 + NB * NB, NB, y2, x2, NB, NB);
-    __syncthreads();
-    sp_gemv32(D + NB, kTile, x2, tmp, kb1, kb2);  // U12 x2
-    __syncthreads();
-    if (t < NB) y1[t] -= tmp[t];
-  } else if (t < NB) {
-    x2[t] = 0.0;
-  }
-  __syncthreads();
-  sp_gemv32(ui1, NB, y1, x1, NB, NB);
-  __syncthreads();
-  if (blockIdx.x == 0 && t < 64) {
-    const double v = t < NB ? x1[t] : x2[t - NB];
-    if (t < kb1 + kb2) x[k0 + t] = v;  // not into y: other workgroups still read the tile row's y
-  }
-  const int p = col_start[I] + blockIdx.x;
-  if (p >= col_start[I + 1]) return;
-  const int Ii = col_row[p];
-  if (Ii >= I) return;  // the diagonal tile's part (U12) is inside the group solve
-  const int il = t >> 2, part = t & 3;
-  const double* __restrict__ row = F + size_t(col_pool[p]) * kTileDoubles + size_t(il) * kTile + 16 * part;
-  double s = 0.0;
-#pragma unroll
-  for (int q = 0; q < 16; ++q) {
-    const int c = 16 * part + q;
-    const double xv = c < NB ? x1[c] : x2[c - NB];
-    s += c < kb1 + kb2 ? row[q] * xv : 0.0;
-  }
-  s += __shfl_xor(s, 1, 64);
-  s += __shfl_xor(s, 2, 64);
-  if (part == 0) y[kTile * Ii + il] -= s;
 }
 
 __global__ void k_sp_unpermute(const double* __restrict__ xp, const int32_t* __restrict__ cam_pos, double* __restrict__ x, int C) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= 9 * C) return;
   const int c = i / 9, a = i - 9 * c;
-  x[i] = xp[9 * cam_pos[c] + a];
+  x[i] = xp[cam_pos[c] + a];
 }
 
 // reverse Cuthill-McKee on the camera graph; returns position[camera]
@@ -665,6 +496,7 @@ struct Dissection {
   std::vector<int32_t> dist;   // breadth-first level inside the current search, -1 otherwise
   std::vector<int32_t> bfs;    // visit order of the last search
   std::vector<int32_t> order;  // result: cameras in elimination order
+  std::vector<int32_t> piece_end;  // ... cut into pieces (bands and separators): end of each piece in `order`
   int next_piece = 1;
 
   Dissection(const std::vector<std::vector<int32_t>>& a, int leaf_size, int min_ratio)
@@ -690,6 +522,7 @@ struct Dissection {
   }
   void EmitBand() {  // the last search's cameras as a band: reverse breadth-first order
     for (size_t i = bfs.size(); i-- > 0;) { order.push_back(bfs[i]); owner[size_t(bfs[i])] = -1; }
+    piece_end.push_back(int32_t(order.size()));
   }
 
   // entries of the work stack: a piece to dissect (seed >= 0: any camera of it) or a separator to emit (list)
@@ -714,6 +547,7 @@ struct Dissection {
       stack.pop_back();
       if (job.seed < 0) {
         for (int32_t u : job.emit) { order.push_back(u); owner[size_t(u)] = -1; }
+        piece_end.push_back(int32_t(order.size()));
         continue;
       }
       // pseudo-peripheral start: search again from a far, low-degree camera while the structure gets deeper
@@ -776,7 +610,33 @@ struct Dissection {
   }
 };
 
-std::vector<int32_t> NestedDissection(int C, const std::vector<std::vector<int32_t>>& adj, int leaf) {
+// Padded layout of an elimination order cut into pieces: every piece starts at a multiple of 64 rows, so that no
+// 64-row tile row holds cameras of two pieces.  (A tile row shared by the end of one subtree and the start of its
+// sibling would tie the two subtrees into one chain of the TILE elimination tree, which is the tree the level schedule
+// works on.)  The rows between the end of a piece and the next tile boundary are padding: unit diagonal, zero
+// right-hand side; valid[I] = rows of tile row I that belong to cameras (always its first rows).
+struct PaddedLayout {
+  std::vector<int32_t> cam_row;  // first row of every camera
+  std::vector<int32_t> valid;    // [T]
+  int T = 0;
+};
+
+PaddedLayout LayOut(int C, const std::vector<int32_t>& order, const std::vector<int32_t>& piece_end) {
+  PaddedLayout out;
+  out.cam_row.assign(size_t(C), 0);
+  int32_t row = 0, k = 0;
+  for (int32_t end : piece_end) {
+    row = (row + kTile - 1) / kTile * kTile;
+    for (; k < end; ++k) { out.cam_row[size_t(order[size_t(k)])] = row; row += 9; }
+  }
+  out.T = (row + kTile - 1) / kTile;
+  out.valid.assign(size_t(out.T), 0);
+  for (int c = 0; c < C; ++c)
+    for (int a = 0; a < 9; ++a) out.valid[size_t((out.cam_row[size_t(c)] + a) >> 6)]++;
+  return out;
+}
+
+PaddedLayout NestedDissection(int C, const std::vector<std::vector<int32_t>>& adj, int leaf) {
   static const int ratio = [] { const char* v = std::getenv("CX_SPARSE_ND_RATIO"); return v ? std::max(2, atoi(v)) : 6; }();
   Dissection d(adj, leaf, ratio);
   // hub cameras (co-visible with a large part of all cameras) would glue every level structure into two or three
@@ -787,24 +647,25 @@ std::vector<int32_t> NestedDissection(int C, const std::vector<std::vector<int32
       if (adj[size_t(c)].size() * 5 > size_t(C) * 2) { d.owner[size_t(c)] = -3; hubs.push_back(c); }
   std::stable_sort(hubs.begin(), hubs.end(), [&](int32_t u, int32_t v) { return adj[size_t(u)].size() < adj[size_t(v)].size(); });
   d.Run();
-  d.order.insert(d.order.end(), hubs.begin(), hubs.end());
-  std::vector<int32_t> pos(static_cast<size_t>(C));
-  for (int k = 0; k < C; ++k) pos[size_t(d.order[size_t(k)])] = k;
-  return pos;
+  if (!hubs.empty()) {
+    d.order.insert(d.order.end(), hubs.begin(), hubs.end());
+    d.piece_end.push_back(int32_t(d.order.size()));
+  }
+  return LayOut(C, d.order, d.piece_end);
 }
 
 // tile-level structure of the permuted S (upper) and its symbolic fill (eliminating tile row k connects every pair
 // of its later column tiles); rows as sorted lists, each closed by the right-hand-side tile T
-void TileStructure(const cx_matrix* A, const std::vector<int32_t>& pos, int T, std::vector<int32_t>* row_start,
+void TileStructure(const cx_matrix* A, const std::vector<int32_t>& cam_row, int T, std::vector<int32_t>* row_start,
                    std::vector<int32_t>* row_tiles) {
   std::vector<std::vector<char>> nz(static_cast<size_t>(T), std::vector<char>(static_cast<size_t>(T), 0));
-  auto mark = [&](int p1, int p2) {  // camera positions p1 <= p2
-    for (int rt = (9 * p1) >> 6; rt <= (9 * p1 + 8) >> 6; ++rt)
-      for (int ct = (9 * p2) >> 6; ct <= (9 * p2 + 8) >> 6; ++ct) nz[size_t(std::min(rt, ct))][size_t(std::max(rt, ct))] = 1;
+  auto mark = [&](int r1, int r2) {  // first rows of the two cameras, r1 <= r2
+    for (int rt = r1 >> 6; rt <= (r1 + 8) >> 6; ++rt)
+      for (int ct = r2 >> 6; ct <= (r2 + 8) >> 6; ++ct) nz[size_t(std::min(rt, ct))][size_t(std::max(rt, ct))] = 1;
   };
   for (int64_t k = 0; k < A->num_cells; ++k) {
-    const int p1 = pos[size_t(A->h_cell_c1[size_t(k)])], p2 = pos[size_t(A->h_cell_c2[size_t(k)])];
-    mark(std::min(p1, p2), std::max(p1, p2));
+    const int r1 = cam_row[size_t(A->h_cell_c1[size_t(k)])], r2 = cam_row[size_t(A->h_cell_c2[size_t(k)])];
+    mark(std::min(r1, r2), std::max(r1, r2));
   }
   for (int I = 0; I < T; ++I) nz[size_t(I)][size_t(I)] = 1;
   std::vector<int32_t> later;
@@ -832,7 +693,6 @@ int cxsp_build_plan(cx_matrix* A) {
   if (A->pairs_state != 1) { A->sp_state = 2; return CX_OK; }
   const int C = A->C;
   const int n = 9 * C;
-  const int T = (n + kTile - 1) / kTile;
   std::vector<std::vector<int32_t>> adj(static_cast<size_t>(C));
   for (int64_t k = 0; k < A->num_cells; ++k) {
     const int c1 = A->h_cell_c1[size_t(k)], c2 = A->h_cell_c2[size_t(k)];
@@ -840,38 +700,34 @@ int cxsp_build_plan(cx_matrix* A) {
   }
   const char* ordering_env = std::getenv("CX_SPARSE_ORDERING");
   const bool band_ordering = ordering_env != nullptr && std::string(ordering_env) == "rcm";
-  std::vector<int32_t> pos;
+  PaddedLayout layout;
   std::vector<int32_t> row_start, row_tiles;
   if (band_ordering) {
-    pos = ReverseCuthillMcKee(C, adj);
-    // round 1: two candidate band orderings, the one with fewer tiles after fill wins
-    TileStructure(A, pos, T, &row_start, &row_tiles);
-    std::vector<int32_t> pos2 = GroupMinimumDegree(C, adj, pos), rs2, rt2;
-    TileStructure(A, pos2, T, &rs2, &rt2);
+    // round 1's orderings: one band (reverse Cuthill-McKee), optionally minimum degree on groups of 64 cameras,
+    // whichever leaves fewer tiles after fill; one piece, no padding, the tile elimination tree is (close to) a chain
+    std::vector<int32_t> pos = ReverseCuthillMcKee(C, adj);
+    auto as_layout = [&](const std::vector<int32_t>& p) {
+      std::vector<int32_t> order(static_cast<size_t>(C));
+      for (int c = 0; c < C; ++c) order[size_t(p[size_t(c)])] = c;
+      return LayOut(C, order, std::vector<int32_t>{int32_t(C)});
+    };
+    layout = as_layout(pos);
+    TileStructure(A, layout.cam_row, layout.T, &row_start, &row_tiles);
+    std::vector<int32_t> rs2, rt2;
+    PaddedLayout layout2 = as_layout(GroupMinimumDegree(C, adj, pos));
+    TileStructure(A, layout2.cam_row, layout2.T, &rs2, &rt2);
     if (rt2.size() < row_tiles.size()) {
-      pos.swap(pos2);
+      layout = layout2;
       row_start.swap(rs2);
       row_tiles.swap(rt2);
     }
   } else {
     // leaves of about 5 tile rows: below that a subtree is a chain of tile rows anyway
-    pos = NestedDissection(C, adj, 36);
-    TileStructure(A, pos, T, &row_start, &row_tiles);
+    layout = NestedDissection(C, adj, 36);
+    TileStructure(A, layout.cam_row, layout.T, &row_start, &row_tiles);
   }
+  const int T = layout.T;
   const int64_t num_tiles = int64_t(row_tiles.size());
-  // transposed index: the tiles (Ii <= I, I) of tile column I, ascending Ii, with their pool positions
-  std::vector<int32_t> col_start(size_t(T) + 1, 0), col_pool, col_row;
-  {
-    std::vector<std::vector<std::pair<int32_t, int32_t>>> cols(static_cast<size_t>(T));
-    for (int I = 0; I < T; ++I)
-      for (int32_t q = row_start[size_t(I)]; q < (I + 1 < T ? row_start[size_t(I) + 1] : int32_t(row_tiles.size())); ++q)
-        if (row_tiles[size_t(q)] < T) cols[size_t(row_tiles[size_t(q)])].push_back({I, q});
-    for (int J = 0; J < T; ++J) {
-      col_start[size_t(J)] = int32_t(col_pool.size());
-      for (auto& e : cols[size_t(J)]) { col_row.push_back(e.first); col_pool.push_back(e.second); }
-    }
-    col_start[size_t(T)] = int32_t(col_pool.size());
-  }
   // Level schedule: the elimination tree of the TILE rows (parent = first tile right of the diagonal), tile rows
   // grouped by height; per level the diagonal tiles, the panel tiles and, for every tile that a row of the level
   // updates, its sources (pool indices of F(I, Ja), F(I, Jb)) in ascending I.
@@ -954,23 +810,19 @@ int cxsp_build_plan(cx_matrix* A) {
       std::fprintf(stderr, "[cxschur] tile-sparse Cholesky levels: %d tile rows in %d levels, %zu tile-pair updates on %zu (level, target) pairs\n",
                    T, L, srcs.size(), tgt_pool.size());
   }
-  // two pools (working copy and factor): refuse structures that would not fit comfortably
-  if (double(num_tiles) * kTileDoubles * 8.0 * 2.0 > 160e9) { A->sp_state = 2; return CX_OK; }
+  // one pool, factored in place: refuse structures that would not fit comfortably
+  if (double(num_tiles) * kTileDoubles * 8.0 > 160e9) { A->sp_state = 2; return CX_OK; }
   hipStream_t st = A->ctx->stream;
-  CX_TRY(A->d_sp_cam_pos.upload(pos, st));
+  CX_TRY(A->d_sp_cam_pos.upload(layout.cam_row, st));
+  CX_TRY(A->d_sp_valid.upload(layout.valid, st));
   CX_TRY(A->d_sp_row_start.upload(row_start, st));
   CX_TRY(A->d_sp_row_tiles.upload(row_tiles, st));
-  CX_TRY(A->d_sp_col_start.upload(col_start, st));
-  CX_TRY(A->d_sp_col_pool.upload(col_pool, st));
-  CX_TRY(A->d_sp_col_row.upload(col_row, st));
-  A->h_sp_col_start = col_start;
-  A->h_sp_row_start = row_start;
   A->sp_num_tiles = num_tiles;
   A->sp_T = T;
   A->sp_state = 1;
   if (std::getenv("CX_SPARSE_CHOLESKY_VERBOSE"))
-    std::fprintf(stderr, "[cxschur] tile-sparse Cholesky plan: %d cameras, %d tile rows, %lld tiles (%.2f GB per pool, dense would be %.2f GB)\n", C, T,
-                 (long long)num_tiles, double(num_tiles) * kTileDoubles * 8e-9, double(n) * n * 8e-9);
+    std::fprintf(stderr, "[cxschur] tile-sparse Cholesky plan: %d cameras, %d tile rows (%d rows of padding), %lld tiles (%.2f GB, dense would be %.2f GB)\n",
+                 C, T, kTile * T - n, (long long)num_tiles, double(num_tiles) * kTileDoubles * 8e-9, double(n) * n * 8e-9);
   return CX_OK;
 }
 
@@ -982,17 +834,15 @@ int cxsp_factor_and_solve(cx_matrix* A, const double* Df, const double* rhs, dou
   const int C = A->C, n = 9 * C, T = A->sp_T;
   if (n == 0) return CX_OK;
   const size_t pool = size_t(A->sp_num_tiles) * kTileDoubles;
-  static const bool by_steps = std::getenv("CX_SPARSE_CHOLESKY_STEPS") != nullptr;  // round 1's numeric phase, for A/B runs
+  const size_t npad = size_t(T) * kTile;
   CX_TRY(A->d_sp_W.alloc(pool));
-  if (by_steps) CX_TRY(A->d_sp_F.alloc(pool));
-  CX_TRY(A->d_sp_x.alloc(2 * size_t(n) + size_t((n + NB - 1) / NB) * NB * NB + size_t(A->sp_num_tiles) * kTile));
+  CX_TRY(A->d_sp_x.alloc(npad + 2 * size_t(T) * NB * NB + size_t(A->sp_num_tiles) * kTile));
   double* W = A->d_sp_W.p;
-  double* F = by_steps ? A->d_sp_F.p : W;
-  double* xp = A->d_sp_x.p;
-  double* yv = xp + n;
-  double* uinv = yv + n;
+  double* xp = A->d_sp_x.p;                            // solution in the padded elimination order
+  double* uinv = xp + npad;                            // two inverted 32 x 32 diagonal blocks per tile row
+  double* partial = uinv + 2 * size_t(T) * NB * NB;    // [tiles][64] partial products of the backward sweep
+  const int32_t* valid = A->d_sp_valid.p;
   CX_HIP(hipMemsetAsync(W, 0, pool * sizeof(double), st));
-  if (by_steps) CX_HIP(hipMemsetAsync(F, 0, pool * sizeof(double), st));
   if (A->num_cells > 0)
     hipLaunchKernelGGL(k_sp_assemble, dim3(unsigned((A->num_cells + 2) / 3)), dim3(3 * 81), 0, st, (const int32_t*)A->d_cell_c1.p,
                        (const int32_t*)A->d_cell_c2.p, (const int32_t*)A->d_cell_item_start.p, (const double*)A->d_item_partial.p,
@@ -1000,52 +850,33 @@ int cxsp_factor_and_solve(cx_matrix* A, const double* Df, const double* rhs, dou
                        (const int32_t*)A->d_sp_row_tiles.p, W, A->num_cells);
   hipLaunchKernelGGL(k_sp_rhs, dim3((n + 255) / 256), dim3(256), 0, st, rhs, (const int32_t*)A->d_sp_cam_pos.p,
                      (const int32_t*)A->d_sp_row_start.p, W, C);
-  if (by_steps) {
-    hipLaunchKernelGGL(k_sp_first, dim3(1), dim3(64), 0, st, (const double*)W, F, n, uinv, d_flag);
-    for (int k0 = 0; k0 < n; k0 += NB) {
-      const int I = k0 >> 6, half = (k0 >> 5) & 1;
-      const int m = A->h_sp_row_start[size_t(I) + 1] - A->h_sp_row_start[size_t(I)] - half;
-      hipLaunchKernelGGL(k_sp_step, dim3(unsigned(m * (m + 1) / 2)), dim3(256), 0, st, W, F, (const int32_t*)A->d_sp_row_start.p,
-                         (const int32_t*)A->d_sp_row_tiles.p, n, T, uinv, k0, d_flag);
-    }
-    CX_HIP(hipGetLastError());
-    hipLaunchKernelGGL(k_sp_gather_y, dim3((n + 255) / 256), dim3(256), 0, st, (const double*)F, (const int32_t*)A->d_sp_row_start.p, yv, n);
-    for (int I = T - 1; I >= 0; --I) {
-      const int tiles = A->h_sp_col_start[size_t(I) + 1] - A->h_sp_col_start[size_t(I)];
-      hipLaunchKernelGGL(k_sp_bwd64, dim3(unsigned(std::max(1, tiles))), dim3(256), 0, st, (const double*)F,
-                         (const int32_t*)A->d_sp_row_start.p, (const int32_t*)A->d_sp_col_start.p, (const int32_t*)A->d_sp_col_pool.p,
-                         (const int32_t*)A->d_sp_col_row.p, n, I, (const double*)uinv, yv, xp);
-    }
-  } else {
-    const int L = A->sp_num_levels;
-    const int32_t* rows = A->d_sp_level_rows.p;
-    for (int l = 0; l < L; ++l) {
-      const int r0 = A->h_sp_level_row_begin[size_t(l)], nr = A->h_sp_level_row_begin[size_t(l) + 1] - r0;
-      const int p0 = A->h_sp_level_panel_begin[size_t(l)], np = A->h_sp_level_panel_begin[size_t(l) + 1] - p0;
-      const int t0 = A->h_sp_level_tgt_begin[size_t(l)], nt = A->h_sp_level_tgt_begin[size_t(l) + 1] - t0;
-      if (nr > 0)
-        hipLaunchKernelGGL(k_sp_diag, dim3(unsigned(nr)), dim3(64), 0, st, W, (const int32_t*)A->d_sp_row_start.p, rows + r0, n, uinv, d_flag);
-      if (np > 0)
-        hipLaunchKernelGGL(k_sp_panel, dim3(unsigned(np)), dim3(128), 0, st, W, (const int32_t*)A->d_sp_row_start.p,
-                           (const int32_t*)A->d_sp_row_tiles.p, (const int32_t*)A->d_sp_panel_row.p + p0,
-                           (const int32_t*)A->d_sp_panel_pool.p + p0, n, T, (const double*)uinv);
-      if (nt > 0)
-        hipLaunchKernelGGL(k_sp_update, dim3(unsigned(nt)), dim3(256), 0, st, W, (const int32_t*)A->d_sp_tgt_pool.p + t0,
-                           (const int32_t*)A->d_sp_tgt_flags.p + t0, (const int32_t*)A->d_sp_src_begin.p + t0,
-                           (const int32_t*)A->d_sp_src_a.p, (const int32_t*)A->d_sp_src_b.p);
-    }
-    CX_HIP(hipGetLastError());
-    double* partial = uinv + size_t((n + NB - 1) / NB) * NB * NB;  // [tiles][64] partial products of the backward sweep
-    for (int l = L - 1; l >= 0; --l) {
-      const int r0 = A->h_sp_level_row_begin[size_t(l)], nr = A->h_sp_level_row_begin[size_t(l) + 1] - r0;
-      const int p0 = A->h_sp_level_panel_begin[size_t(l)], np = A->h_sp_level_panel_begin[size_t(l) + 1] - p0;
-      if (np > 0)
-        hipLaunchKernelGGL(k_sp_bwd_partial, dim3(unsigned(np)), dim3(256), 0, st, (const double*)W, (const int32_t*)A->d_sp_row_tiles.p,
-                           (const int32_t*)A->d_sp_panel_pool.p + p0, n, T, (const double*)xp, partial);
-      if (nr > 0)
-        hipLaunchKernelGGL(k_sp_bwd_level, dim3(unsigned(nr)), dim3(256), 0, st, (const double*)W, (const int32_t*)A->d_sp_row_start.p,
-                           rows + r0, n, (const double*)uinv, (const double*)partial, xp);
-    }
+  const int L = A->sp_num_levels;
+  const int32_t* rows = A->d_sp_level_rows.p;
+  for (int l = 0; l < L; ++l) {
+    const int r0 = A->h_sp_level_row_begin[size_t(l)], nr = A->h_sp_level_row_begin[size_t(l) + 1] - r0;
+    const int p0 = A->h_sp_level_panel_begin[size_t(l)], np = A->h_sp_level_panel_begin[size_t(l) + 1] - p0;
+    const int t0 = A->h_sp_level_tgt_begin[size_t(l)], nt = A->h_sp_level_tgt_begin[size_t(l) + 1] - t0;
+    if (nr > 0)
+      hipLaunchKernelGGL(k_sp_diag, dim3(unsigned(nr)), dim3(64), 0, st, W, (const int32_t*)A->d_sp_row_start.p, rows + r0, valid, uinv, d_flag);
+    if (np > 0)
+      hipLaunchKernelGGL(k_sp_panel, dim3(unsigned(np)), dim3(128), 0, st, W, (const int32_t*)A->d_sp_row_start.p,
+                         (const int32_t*)A->d_sp_row_tiles.p, (const int32_t*)A->d_sp_panel_row.p + p0,
+                         (const int32_t*)A->d_sp_panel_pool.p + p0, valid, T, (const double*)uinv);
+    if (nt > 0)
+      hipLaunchKernelGGL(k_sp_update, dim3(unsigned(nt)), dim3(256), 0, st, W, (const int32_t*)A->d_sp_tgt_pool.p + t0,
+                         (const int32_t*)A->d_sp_tgt_flags.p + t0, (const int32_t*)A->d_sp_src_begin.p + t0,
+                         (const int32_t*)A->d_sp_src_a.p, (const int32_t*)A->d_sp_src_b.p);
+  }
+  CX_HIP(hipGetLastError());
+  for (int l = L - 1; l >= 0; --l) {
+    const int r0 = A->h_sp_level_row_begin[size_t(l)], nr = A->h_sp_level_row_begin[size_t(l) + 1] - r0;
+    const int p0 = A->h_sp_level_panel_begin[size_t(l)], np = A->h_sp_level_panel_begin[size_t(l) + 1] - p0;
+    if (np > 0)
+      hipLaunchKernelGGL(k_sp_bwd_partial, dim3(unsigned(np)), dim3(256), 0, st, (const double*)W, (const int32_t*)A->d_sp_row_tiles.p,
+                         (const int32_t*)A->d_sp_panel_pool.p + p0, valid, T, (const double*)xp, partial);
+    if (nr > 0)
+      hipLaunchKernelGGL(k_sp_bwd_level, dim3(unsigned(nr)), dim3(256), 0, st, (const double*)W, (const int32_t*)A->d_sp_row_start.p,
+                         rows + r0, valid, (const double*)uinv, (const double*)partial, xp);
   }
   hipLaunchKernelGGL(k_sp_unpermute, dim3((n + 255) / 256), dim3(256), 0, st, (const double*)xp, (const int32_t*)A->d_sp_cam_pos.p, z, C);
   CX_HIP(hipGetLastError());
