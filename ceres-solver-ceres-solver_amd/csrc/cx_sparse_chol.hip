@@ -287,7 +287,8 @@ __global__ __launch_bounds__(128) void k_sp_panel(double* __restrict__ W, const 
 // Level, part 3: every tile that receives contributions from this level's rows: W(Ja, Jb) -= sum_I F(I, Ja)' F(I, Jb)
 // over its sources I of the level, ascending I.  Workgroup = target tile, wavefront = 32 x 32 quadrant.
 // flags: 1 = diagonal target (the lower-left quadrant is not needed), 2 = right-hand-side target (one column).
-__global__ __launch_bounds__(256) void k_sp_update(double* __restrict__ W, const int32_t* __restrict__ tgt_pool,
+template <int kWgPerCu>
+__global__ __launch_bounds__(256, kWgPerCu) void k_sp_update(double* __restrict__ W, const int32_t* __restrict__ tgt_pool,
                                                    const int32_t* __restrict__ tgt_flags, const int32_t* __restrict__ src_begin,
                                                    const int32_t* __restrict__ src_a, const int32_t* __restrict__ src_b) {
   const int t = blockIdx.x;
@@ -301,31 +302,28 @@ __global__ __launch_bounds__(256) void k_sp_update(double* __restrict__ W, const
   for (int a = 0; a < 2; ++a)
 #pragma unroll
     for (int b = 0; b < 2; ++b) acc[a][b] = double4_t{0.0, 0.0, 0.0, 0.0};
-  // the operands of source s + 1 are requested before the products of source s are issued (two register sets)
-  struct Operands { double4_t A0[2][2], A1[2][2], B0[2][2], B1[2][2]; };
-  auto fetch = [&](int s, Operands& o) {
+  // Most targets have one or two sources per level, so a workgroup is a short chain of memory latency -> 32 products
+  // -> memory latency; the latency is hidden by running four workgroups per CU (128 registers each: one 32-row half
+  // of the two operands at a time), not by software pipelining (a two-stage prefetch needed 300 registers and left one
+  // workgroup per CU: 45 ns per tile pair against ...).
+  const int s0 = src_begin[t], s1 = src_begin[t + 1];
+  for (int s = s0; s < s1; ++s) {
     const double* Fa = W + size_t(src_a[s]) * kTileDoubles + 32 * qi;
     const double* Fb = W + size_t(src_b[s]) * kTileDoubles + 32 * qj;
-    load_operand(Fb, 32, 32, o.B0);
-    load_operand(Fb + size_t(32) * kTile, 32, 32, o.B1);
-    if (Fa == Fb) {
 #pragma unroll
-      for (int mt = 0; mt < 2; ++mt)
+    for (int half = 0; half < 2; ++half) {
+      double4_t A[2][2], B[2][2];
+      load_operand(Fb + size_t(32 * half) * kTile, 32, 32, B);
+      if (Fa == Fb) {
 #pragma unroll
-        for (int nt = 0; nt < 2; ++nt) { o.A0[mt][nt] = o.B0[mt][nt]; o.A1[mt][nt] = o.B1[mt][nt]; }
-    } else {
-      load_operand(Fa, 32, 32, o.A0);
-      load_operand(Fa + size_t(32) * kTile, 32, 32, o.A1);
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+          for (int nt = 0; nt < 2; ++nt) A[mt][nt] = B[mt][nt];
+      } else {
+        load_operand(Fa + size_t(32 * half) * kTile, 32, 32, A);
+      }
+      mfma_atb(A, B, acc);
     }
-  };
-  const int s0 = src_begin[t], s1 = src_begin[t + 1];
-  Operands cur, nxt;
-  fetch(s0, cur);
-  for (int s = s0; s < s1; ++s) {
-    if (s + 1 < s1) fetch(s + 1, nxt);
-    mfma_atb(cur.A0, cur.B0, acc);
-    mfma_atb(cur.A1, cur.B1, acc);
-    if (s + 1 < s1) cur = nxt;
   }
   double* dst = W + size_t(tgt_pool[t]) * kTileDoubles + size_t(32 * qi) * kTile + 32 * qj;
   subtract_block(acc, dst, 32, 32, (flags & 1) && qi == qj);
@@ -862,10 +860,17 @@ int cxsp_factor_and_solve(cx_matrix* A, const double* Df, const double* rhs, dou
       hipLaunchKernelGGL(k_sp_panel, dim3(unsigned(np)), dim3(128), 0, st, W, (const int32_t*)A->d_sp_row_start.p,
                          (const int32_t*)A->d_sp_row_tiles.p, (const int32_t*)A->d_sp_panel_row.p + p0,
                          (const int32_t*)A->d_sp_panel_pool.p + p0, valid, T, (const double*)uinv);
-    if (nt > 0)
-      hipLaunchKernelGGL(k_sp_update, dim3(unsigned(nt)), dim3(256), 0, st, W, (const int32_t*)A->d_sp_tgt_pool.p + t0,
-                         (const int32_t*)A->d_sp_tgt_flags.p + t0, (const int32_t*)A->d_sp_src_begin.p + t0,
-                         (const int32_t*)A->d_sp_src_a.p, (const int32_t*)A->d_sp_src_b.p);
+    if (nt > 0) {
+      static const int occ = [] { const char* v = std::getenv("CX_SPARSE_UPDATE_OCCUPANCY"); return v ? atoi(v) : 3; }();
+#define CX_SP_UPDATE(K)                                                                                                          \
+  hipLaunchKernelGGL(k_sp_update<K>, dim3(unsigned(nt)), dim3(256), 0, st, W, (const int32_t*)A->d_sp_tgt_pool.p + t0,           \
+                     (const int32_t*)A->d_sp_tgt_flags.p + t0, (const int32_t*)A->d_sp_src_begin.p + t0,                         \
+                     (const int32_t*)A->d_sp_src_a.p, (const int32_t*)A->d_sp_src_b.p)
+      if (occ >= 4) CX_SP_UPDATE(4);
+      else if (occ == 3) CX_SP_UPDATE(3);
+      else CX_SP_UPDATE(2);
+#undef CX_SP_UPDATE
+    }
   }
   CX_HIP(hipGetLastError());
   for (int l = L - 1; l >= 0; --l) {
