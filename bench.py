@@ -269,6 +269,24 @@ def main():
         elapsed = float(tt[0])
     ms_per_step = elapsed * 1e3 / max(1, args.steps)
 
+    # ---- per-rank view of the timed solves (what a scaling curve is explained with): this rank's share of the
+    # residual blocks, its device time in the two S x kernels, and the exchange step -- collectives per solve, their
+    # payload, and the DEVICE time inside them (event pairs around every ncclAllReduce on the solve's stream)
+    nsteps = max(1, args.steps)
+    mine = {"rank": rank, "residual_blocks": int(prob.num_observations), "points": int(prob.num_points),
+            "solve_ms": phases.get("total_ms", 0.0) / nsteps,
+            "eliminate_ms": phases.get("eliminate_ms", 0.0) / nsteps, "reduced_solve_ms": phases.get("reduced_solve_ms", 0.0) / nsteps,
+            "kernel_avg_ms": {k: v[0] / max(1, v[1]) for k, v in kstats.items()},
+            "allreduce_device_ms_per_solve": phases.get("allreduce_ms", 0.0) / nsteps,
+            "allreduce_host_ms_per_solve": phases.get("allreduce_host_ms", 0.0) / nsteps,
+            "collectives_per_solve": phases.get("allreduce_calls", 0.0) / nsteps,
+            "bytes_per_collective": (phases.get("allreduce_bytes", 0.0) / max(1.0, phases.get("allreduce_calls", 0.0)))}
+    per_rank = [mine]
+    if world > 1:
+        gathered = [None] * world
+        dist.all_gather_object(gathered, mine)
+        per_rank = gathered
+
     # ---- the same solve at bundle_adjuster's tighter default (eta = 1e-2, bundle_adjuster.cc:114): many more
     # CG iterations, so this is the per-iteration cost of S x; informational, outside the timed region
     tight = None
@@ -353,6 +371,16 @@ def main():
                        "termination": int(summ.termination_type), "initial_cost": cost,
                        "sharding": "points over %d rank(s), RCCL all-reduce of camera-space sums" % world},
             "phases_ms_per_solve": {k: v / max(1, args.steps) for k, v in phases.items()},
+            "per_rank": per_rank,
+            "load_balance": {"max_over_mean_residual_blocks": max(r["residual_blocks"] for r in per_rank) * len(per_rank) /
+                             float(sum(r["residual_blocks"] for r in per_rank)),
+                             "max_over_mean_solve_ms": max(r["solve_ms"] for r in per_rank) * len(per_rank) /
+                             max(1e-12, float(sum(r["solve_ms"] for r in per_rank)))},
+            "exchange": {"transport": "gloo callback (rehearsal)" if os.environ.get("CX_BENCH_TRANSPORT") == "gloo" else
+                         ("RCCL ncclAllReduce(sum, fp64) over xGMI" if world > 1 else "none (one rank)"),
+                         "collectives_per_solve": per_rank[0]["collectives_per_solve"],
+                         "bytes_per_collective": per_rank[0]["bytes_per_collective"],
+                         "device_ms_per_solve_max_over_ranks": max(r["allreduce_device_ms_per_solve"] for r in per_rank)},
             "at_bundle_adjuster_eta": tight,
             "explicit_s": explicit_info,
             "jacobian_eval_ms": eval_ms,

@@ -87,7 +87,8 @@ class cx_summary(ctypes.Structure):
 
 class cx_solve_timing(ctypes.Structure):
     _fields_ = [(n, ctypes.c_double) for n in
-                ("setup_ms", "eliminate_ms", "reduced_solve_ms", "back_substitute_ms", "total_ms", "allreduce_ms")]
+                ("setup_ms", "eliminate_ms", "reduced_solve_ms", "back_substitute_ms", "total_ms", "allreduce_ms",
+                 "allreduce_host_ms", "allreduce_calls", "allreduce_bytes")]
 
 
 class cx_kernel_stat(ctypes.Structure):

@@ -72,22 +72,63 @@ static int AllReduce(cx_context* ctx, double* p, int64_t n, bool even_single_ran
   // with one rank the sum is the identity: skipped inside the solvers, but cx_allreduce_sum still goes through
   // RCCL when a communicator exists, so that the call path can be exercised on a one-GPU box
   if (ctx->nranks <= 1 && !(even_single_rank && ctx->comm)) return CX_OK;
+  ctx->ar_calls += 1;
+  ctx->ar_bytes += n * int64_t(sizeof(double));
   if (ctx->allreduce_cb) {
     CX_HIP(hipStreamSynchronize(ctx->stream));
+    auto t0 = std::chrono::steady_clock::now();
     if (ctx->allreduce_cb(p, n, ctx->allreduce_cb_user) != 0) {
       cx_set_error("all-reduce callback failed");
       return CX_ERR_COMM;
     }
+    ctx->allreduce_host_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     return CX_OK;
   }
   if (!ctx->comm) {
     cx_set_error("context has %d ranks but no communicator", ctx->nranks);
     return CX_ERR_COMM;
   }
+  // device time of the collective: an event pair on the stream it runs on (host enqueue time says nothing about it)
+  const bool timed = ctx->ar_timed < cx_context::kTimedCollectives;
+  if (timed) {
+    if (ctx->ar_events.empty()) {
+      ctx->ar_events.resize(2 * cx_context::kTimedCollectives);
+      for (auto& ev : ctx->ar_events) CX_HIP(hipEventCreate(&ev));
+    }
+    CX_HIP(hipEventRecord(ctx->ar_events[size_t(2 * ctx->ar_timed)], ctx->stream));
+  }
   auto t0 = std::chrono::steady_clock::now();
   int rc = g_rccl.all_reduce(p, p, size_t(n), kNcclFloat64, kNcclSum, ctx->comm, ctx->stream);
   ctx->allreduce_host_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+  if (timed) {
+    CX_HIP(hipEventRecord(ctx->ar_events[size_t(2 * ctx->ar_timed + 1)], ctx->stream));
+    ++ctx->ar_timed;
+  }
   return RcclCheck(rc, "ncclAllReduce");
+}
+
+void cx_allreduce_reset(cx_context* ctx) {
+  ctx->allreduce_host_ms = 0.0;
+  ctx->ar_timed = 0;
+  ctx->ar_calls = 0;
+  ctx->ar_bytes = 0;
+}
+
+int cx_allreduce_collect(cx_context* ctx, double* device_ms, double* host_ms, double* calls, double* bytes) {
+  double sum = 0.0;
+  for (int i = 0; i < ctx->ar_timed; ++i) {
+    float ms = 0.f;
+    CX_HIP(hipEventSynchronize(ctx->ar_events[size_t(2 * i + 1)]));
+    CX_HIP(hipEventElapsedTime(&ms, ctx->ar_events[size_t(2 * i)], ctx->ar_events[size_t(2 * i + 1)]));
+    sum += ms;
+  }
+  // more collectives than event pairs (a long CG run): the untimed ones are priced at the timed ones' mean
+  if (ctx->ar_timed > 0 && ctx->ar_calls > ctx->ar_timed) sum *= double(ctx->ar_calls) / double(ctx->ar_timed);
+  *device_ms = sum;
+  *host_ms = ctx->allreduce_host_ms;
+  *calls = double(ctx->ar_calls);
+  *bytes = double(ctx->ar_bytes);
+  return CX_OK;
 }
 
 int cx_allreduce_device(cx_context* ctx, double* p, int64_t n) { return AllReduce(ctx, p, n, false); }
@@ -129,6 +170,8 @@ void cx_context_destroy(cx_context* ctx) {
   (void)hipStreamSynchronize(ctx->stream);
   if (ctx->comm && g_rccl.comm_destroy) g_rccl.comm_destroy(ctx->comm);
   for (auto& ev : ctx->ev)
+    if (ev) (void)hipEventDestroy(ev);
+  for (auto& ev : ctx->ar_events)
     if (ev) (void)hipEventDestroy(ev);
   if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;

@@ -82,6 +82,11 @@ struct cx_context {
   int rank = 0;
   int nranks = 1;
   double allreduce_host_ms = 0.0;
+  // device-side timing of the exchange step: event pairs around the collectives since cx_allreduce_reset()
+  static constexpr int kTimedCollectives = 256;
+  std::vector<hipEvent_t> ar_events;   // 2 * kTimedCollectives, created on first use
+  int ar_timed = 0;                    // pairs recorded
+  int64_t ar_calls = 0, ar_bytes = 0;
   int num_cus = 256;
   char name[128] = {};
   DevBuf<double> chol_scratch;  // dense Cholesky work vectors (cx_cholesky.hip)
@@ -214,6 +219,10 @@ int cxk_ft_multiply(cx_matrix* A, const double* t, double* y_f, bool accumulate)
 int cxk_ft_partials(cx_matrix* A, const double* t);
 
 int cx_allreduce_device(cx_context* ctx, double* p, int64_t n);
+// statistics of the collectives since the last reset; collect waits for the recorded events (call after the stream
+// has been synchronised) and returns the device time, extrapolated when more collectives ran than were timed
+void cx_allreduce_reset(cx_context* ctx);
+int cx_allreduce_collect(cx_context* ctx, double* device_ms, double* host_ms, double* calls, double* bytes);
 
 // ---------------------------------------------------------------- evaluator (cx_eval.hip)
 struct cx_evaluator {

@@ -1266,9 +1266,10 @@ int SolveDenseSchur239(cx_solver* S, cx_matrix* A, const double* b, const double
       }
     }
   }
-  if (A->C >= 2 * kDenseSchurMaxCameras) {
-    // a dense S of this size (> 190 GB with its working copy) cannot be meant: several ranks, or a structure whose
-    // tile-sparse plan could not be built
+  if (A->C >= 2 * kDenseSchurMaxCameras || (ctx->nranks > 1 && A->C >= kDenseSchurMaxCameras)) {
+    // a dense S of this size (> 190 GB with its working copy; on several ranks every rank would hold and all-reduce
+    // its own 24+ GB copy) cannot be meant: a sharded context, where the tile-sparse factorisation is not available,
+    // or a structure whose tile-sparse plan could not be built
     cx_set_error("%s with %d cameras: the dense reduced matrix does not fit and the tile-sparse Cholesky is not available "
                  "here (sharded context or too much fill); use ITERATIVE_SCHUR", S->opt.type == CX_SPARSE_SCHUR ? "SPARSE_SCHUR" : "DENSE_SCHUR", A->C);
     return CX_ERR_UNSUPPORTED;
@@ -1426,7 +1427,7 @@ int cx_solver_solve(cx_solver* S, cx_matrix* A, const double* b, const cx_per_so
   S->timing = cx_solve_timing{};
   S->num_pending = 0;
   S->ktimer.reset();
-  ctx->allreduce_host_ms = 0.0;
+  cx_allreduce_reset(ctx);
   HostOrDevice hb(ctx), hD(ctx), hx(ctx);
   CX_TRY(hb.in(b, size_t(A->num_rows), ps->b_on_device ? CX_DEVICE : ps->memspace));
   CX_TRY(hD.in(ps->D, size_t(A->num_cols), ps->memspace));
@@ -1467,7 +1468,8 @@ int cx_solver_solve(cx_solver* S, cx_matrix* A, const double* b, const cx_per_so
     CX_HIP(hipEventElapsedTime(&f, ctx->ev[8 + 2 * i], ctx->ev[9 + 2 * i]));
     *S->pending_ms[i] = f;
   }
-  S->timing.allreduce_ms = ctx->allreduce_host_ms;
+  CX_TRY(cx_allreduce_collect(ctx, &S->timing.allreduce_ms, &S->timing.allreduce_host_ms, &S->timing.allreduce_calls,
+                              &S->timing.allreduce_bytes));
   CX_TRY(S->ktimer.collect());
   return hx.out();
 }

@@ -161,7 +161,12 @@ typedef struct {
   double reduced_solve_ms;    /* Cholesky, or the CG loop          */
   double back_substitute_ms;
   double total_ms;
-  double allreduce_ms;        /* host-side estimate of time in RCCL calls */
+  double allreduce_ms;        /* DEVICE time inside the exchange step of a sharded solve: HIP event pairs around every
+                               * ncclAllReduce on the context's stream, summed (the first 256 collectives of a solve are
+                               * timed, more are extrapolated from them); 0 on one rank */
+  double allreduce_host_ms;   /* host time spent enqueueing them (or, with the callback transport, inside the callback) */
+  double allreduce_calls;     /* collectives of the solve */
+  double allreduce_bytes;     /* payload summed over them (8 bytes per double) */
 } cx_solve_timing;
 
 /* Device time of one kernel (or short kernel sequence) of the hot loop during the

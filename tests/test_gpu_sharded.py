@@ -73,6 +73,16 @@ def _worker(rank, port, results_dir):
         err = float(np.abs(x - expect).max() / np.abs(expect).max())
         out.append((stype + "+" + pre + ("+explicit" if explicit else ""), s.termination_type == s_full.termination_type and
                     s.num_iterations == s_full.num_iterations and err < 1e-8, err, s.num_iterations, s_full.num_iterations))
+        if (stype, pre, explicit) == ("ITERATIVE_SCHUR", "JACOBI", 0):
+            # what the first real multi-GPU run will be analysed with: collectives per solve, their payload and the time
+            # in them.  One fused set-up collective (rhs + the 45 distinct values of every 9x9 block = 54 C doubles), one
+            # of 9 C doubles per S x (an extra one in every residual_reset_period-th iteration).
+            tm = S.timing()
+            it = s.num_iterations
+            calls = 1 + it + it // 10
+            ok = (tm["allreduce_calls"] == calls and tm["allreduce_bytes"] == 8.0 * (54 * C + 9 * C * (calls - 1)) and
+                  tm["allreduce_host_ms"] > 0.0 and tm["allreduce_ms"] == 0.0)   # callback transport: host time only
+            out.append(("exchange_stats", ok, tm["allreduce_calls"], tm["allreduce_bytes"], tm["allreduce_host_ms"]))
         S.close()
     # sharded trust-region loop: every rank must walk the same iterations as the unsharded oracle loop
     mo = cx.binding.minimizer_options(max_num_iterations=6)
@@ -91,6 +101,22 @@ def _worker(rank, port, results_dir):
     out.append(("minimize", same_path and summ["termination_type"] == summ_r["termination_type"] and err < 1e-4, err,
                 len(its), len(its_r)))
     S.close()
+    # SPARSE_SCHUR on several ranks has no tile-sparse factorisation and the dense reduced matrix of 6 200 cameras would
+    # be 25 GB per rank, all-reduced: refused with a message, not attempted
+    big = cx.bal.make_bal_like(6200, 7000, 21000, seed=9)
+    bb = cx.bal.partition_points(big, WORLD)
+    big_sub = cx.bal.shard(big, int(bb[rank]), int(bb[rank + 1]))
+    bs_big, _ = cx.bal.build_structure(big_sub)
+    Ab = cx.Matrix(ctx, bs_big, big_sub.num_points)
+    Ab.set_values(cx.bal.random_jacobian_values(big_sub.num_observations, 1))
+    Sb = cx.Solver(ctx, type=cx.SPARSE_SCHUR, num_eliminate_blocks=big_sub.num_points)
+    try:
+        Sb.solve(Ab, np.ones(Ab.num_rows), np.ones(Ab.num_cols))
+        out.append(("sharded_sparse_schur_refused", False, "no error"))
+    except cx.binding.CxError as e:
+        out.append(("sharded_sparse_schur_refused", "does not fit" in str(e), str(e)[:80]))
+    Sb.close()
+    Ab.close()
     with open(os.path.join(results_dir, "rank%d.txt" % rank), "w") as f:
         for o in out:
             f.write(repr(o) + "\n")
@@ -106,7 +132,7 @@ def test_two_ranks_one_gpu(tmp_path, oracle):
     mp.spawn(_worker, args=(port, str(tmp_path)), nprocs=WORLD, join=True)
     for rank in range(WORLD):
         lines = open(tmp_path / ("rank%d.txt" % rank)).read().strip().splitlines()
-        assert len(lines) == 11
+        assert len(lines) == 13
         for line in lines:
             rec = eval(line)
             assert rec[1], line
