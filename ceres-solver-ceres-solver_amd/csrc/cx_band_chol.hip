@@ -408,8 +408,38 @@ __global__ __launch_bounds__(NT) void k_band_solve_lds(const double* __restrict_
 
 }  // namespace
 
+// band or tile-sparse factorisation for this plan (see cx_vis_plan::use_sparse); CX_VISIBILITY_SPARSE=0/1 forces one
+static int cxv_use_sparse(cx_matrix* A, cx_vis_plan* plan) {
+  if (plan->use_sparse >= 0) return CX_OK;
+  const char* env = std::getenv("CX_VISIBILITY_SPARSE");
+  const int longest = plan->num_paths ? plan->path_num_blk[0] : 0;
+  bool sparse = env ? std::atoi(env) != 0 : (plan->preconditioner_type == CX_CLUSTER_TRIDIAGONAL && longest > 64);
+  if (sparse) {
+    std::vector<int32_t> c1(plan->sel_cells.size()), c2(plan->sel_cells.size());
+    for (size_t k = 0; k < plan->sel_cells.size(); ++k) {
+      c1[k] = A->h_cell_c1[size_t(plan->sel_cells[k])];
+      c2[k] = A->h_cell_c2[size_t(plan->sel_cells[k])];
+    }
+    CX_TRY(cxsp_plan_from_cells(A->ctx, A->C, c1.data(), c2.data(), int64_t(c1.size()), &plan->sp));
+    if (plan->sp.state != 1) sparse = false;
+  }
+  plan->use_sparse = sparse ? 1 : 0;
+  return CX_OK;
+}
+
 int cxv_factor(cx_matrix* A, cx_vis_plan* plan, const double* D, bool halve_offdiag, int* d_flag) {
   hipStream_t st = A->ctx->stream;
+  CX_TRY(cxv_use_sparse(A, plan));
+  if (plan->use_sparse == 1) {
+    CX_TRY(cxs_assemble_pair_items(A, D, plan->d_sel_items.p, plan->num_sel_items));
+    const bool shard = A->ctx->nranks > 1;
+    const double* Dfs = (D && (!shard || A->ctx->rank == 0)) ? D + 3 * int64_t(A->P) : nullptr;
+    CX_TRY(cxsp_assemble(A, &plan->sp, Dfs, plan->d_sel_cells.p, plan->d_sel_offdiag.p, int64_t(plan->sel_cells.size()),
+                         halve_offdiag ? 0.5 : 1.0));
+    // sharded matrix: every rank has assembled the contributions of its points into the same tile layout
+    if (shard) CX_TRY(cx_allreduce_device(A->ctx, plan->sp.d_W.p, plan->sp.num_tiles * 4096));
+    return cxsp_factor(A->ctx, &plan->sp, d_flag);
+  }
   const int N = plan->N, ld = plan->ld;
   const size_t band = size_t(N) * size_t(ld + 1);
   CX_TRY(plan->d_W.alloc(band));
@@ -440,6 +470,7 @@ int cxv_factor(cx_matrix* A, cx_vis_plan* plan, const double* D, bool halve_offd
 }
 
 int cxv_solve(cx_matrix* A, cx_vis_plan* plan, const double* r, double* z) {
+  if (plan->use_sparse == 1) return cxsp_solve(A->ctx, &plan->sp, r, z);
   const bool force_global = std::getenv("CX_BAND_SOLVE_GLOBAL") != nullptr;  // A/B switch, read per call so tests can flip it
   // 512 threads per path pay off on long paths (instruction issue of the one workgroup); the short walks of
   // CLUSTER_JACOBI (a few blocks per cluster) are quicker with 256 (72 vs 78 us on the Final shape)

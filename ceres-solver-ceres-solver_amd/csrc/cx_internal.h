@@ -92,6 +92,23 @@ struct cx_context {
   DevBuf<double> chol_scratch;  // dense Cholesky work vectors (cx_cholesky.hip)
 };
 
+// ------------------------------------------------- tile-sparse Cholesky (cx_sparse_chol.hip)
+// Plan and storage of the level-scheduled tile-sparse Cholesky of a symmetric positive definite matrix made of 9x9
+// camera blocks: the explicit Schur complement S (SPARSE_SCHUR) or a visibility based preconditioner.
+struct cx_sp_plan {
+  int state = 0;       // 0 not built, 1 ready, 2 not available (too much fill)
+  int C = 0;           // 9x9 block rows
+  int T = 0;           // tile rows (64 scalar rows each, padding included)
+  int num_levels = 0;  // heights of the tile elimination tree
+  int64_t num_tiles = 0;
+  std::vector<int32_t> h_level_row_begin, h_level_panel_begin, h_level_tgt_begin;  // [levels + 1]
+  DevBuf<int32_t> d_cam_pos, d_valid, d_row_start, d_row_tiles;  // first row of each camera; valid rows per tile row; tile lists
+  DevBuf<int32_t> d_level_rows, d_panel_row, d_panel_pool;
+  DevBuf<int32_t> d_tgt_pool, d_tgt_flags, d_src_begin, d_src_a, d_src_b;
+  DevBuf<int32_t> d_col_start, d_col_pool;  // transposed index: the tiles (K < I, I) of tile column I, ascending K (forward solves)
+  DevBuf<double> d_W, d_x;                  // tile pool (factored in place); vectors, block inverses, partial products
+};
+
 // ----------------------------------------------------------------- matrix
 // Tile of the point-major ("chunk") kernels: whole chunks, at most kTileRows rows,
 // unless a single chunk is larger than that (then the tile is that one chunk).
@@ -164,17 +181,8 @@ struct cx_matrix {
   int64_t num_items = 0;
   int64_t num_cells = 0;
   DevBuf<double> d_elim_bg0, d_elim_bg1, d_elim_bg2;  // per row B = E'F (3x9) and G = (E'E)^-1 B, 3 x 18 doubles
-  // tile-sparse Cholesky of S (cx_sparse_chol.hip): plan (0 not built, 1 ready, 2 not available) and pools
-  int sp_state = 0;
-  int sp_T = 0;
-  int64_t sp_num_tiles = 0;
-  DevBuf<int32_t> d_sp_cam_pos, d_sp_valid, d_sp_row_start, d_sp_row_tiles;  // first row of each camera; valid rows per tile row
-  DevBuf<double> d_sp_W, d_sp_x;
-  // level schedule of the tile elimination tree (tile rows of one height are factored together)
-  int sp_num_levels = 0;
-  std::vector<int32_t> h_sp_level_row_begin, h_sp_level_panel_begin, h_sp_level_tgt_begin;  // [levels + 1]
-  DevBuf<int32_t> d_sp_level_rows, d_sp_panel_row, d_sp_panel_pool;
-  DevBuf<int32_t> d_sp_tgt_pool, d_sp_tgt_flags, d_sp_src_begin, d_sp_src_a, d_sp_src_b;
+  // tile-sparse Cholesky of S (cx_sparse_chol.hip)
+  cx_sp_plan sp;
   int pairs_state = 0;                   // 0 not built, 1 ready, 2 too many pairs (atomic path)
   // visibility based preconditioners of this structure (cx_visibility.h), one plan per (preconditioner type,
   // clustering type), built on first use

@@ -27,9 +27,19 @@ int cxs_eliminate_sparse(cx_matrix* A, const double* b, const double* D, double*
 // item_ids (device, optional): only these work items are summed (the cells a visibility preconditioner keeps)
 int cxs_assemble_pair_items(cx_matrix* A, const double* D, const int32_t* item_ids = nullptr, int64_t num_selected = 0);
 int cxs_eliminate_rhs(cx_matrix* A, const double* b, double* rhs);
-// tile-sparse Cholesky of the explicit S (cx_sparse_chol.hip)
+// tile-sparse Cholesky (cx_sparse_chol.hip).  For the explicit S of a matrix: plan into A->sp, then assemble + factor
+// + solve in one call.
 int cxsp_build_plan(cx_matrix* A);
 int cxsp_factor_and_solve(cx_matrix* A, const double* Df, const double* rhs, double* z, int* d_flag);
+// The pieces, for any symmetric matrix of 9x9 camera blocks given by a subset of A's S cells (the visibility based
+// preconditioners): plan from the cells (c1 <= c2, every diagonal cell present), assembly of the selected cells
+// (sel_cells = ids into A's cell list or NULL for all; sel_offdiag / offdiag_scale as k_band_assemble), numeric
+// factorisation in place, and M^-1 r by a forward and a backward sweep over the levels (r, z in camera order).
+int cxsp_plan_from_cells(cx_context* ctx, int C, const int32_t* cell_c1, const int32_t* cell_c2, int64_t num_cells, cx_sp_plan* plan);
+int cxsp_assemble(cx_matrix* A, cx_sp_plan* plan, const double* Df, const int32_t* sel_cells, const int32_t* sel_offdiag,
+                  int64_t num_sel, double offdiag_scale);
+int cxsp_factor(cx_context* ctx, cx_sp_plan* plan, int* d_flag);
+int cxsp_solve(cx_context* ctx, cx_sp_plan* plan, const double* r, double* z);
 // y = S x with that storage (BlockRandomAccessSparseMatrix::SymmetricRightMultiplyAndAccumulate); blocks[c] = S(c,c)
 int cxs_sparse_multiply(cx_matrix* A, const double* x, double* y);
 int cxs_sparse_diagonal(cx_matrix* A, double* blocks);

@@ -1259,9 +1259,9 @@ int SolveDenseSchur239(cx_solver* S, cx_matrix* A, const double* b, const double
     const bool forced = std::getenv("CX_SPARSE_CHOLESKY") != nullptr;
     if (forced || A->C >= kSparseCholeskyMinCameras) {
       CX_TRY(cxsp_build_plan(A));
-      if (A->sp_state == 1) {
-        const int64_t T = A->sp_T, dense_tiles = T * (T + 1) / 2 + T;
-        if (forced || 2 * A->sp_num_tiles <= dense_tiles || A->C >= kDenseSchurMaxCameras)
+      if (A->sp.state == 1) {
+        const int64_t T = A->sp.T, dense_tiles = T * (T + 1) / 2 + T;
+        if (forced || 2 * A->sp.num_tiles <= dense_tiles || A->C >= kDenseSchurMaxCameras)
           return SolveSparseSchur239(S, A, b, D, x, summary);
       }
     }

@@ -60,9 +60,14 @@ __global__ __launch_bounds__(3 * 81) void k_sp_assemble(const int32_t* __restric
                                                         const double* __restrict__ item_partial, const double* __restrict__ diag,
                                                         const double* __restrict__ Df, const int32_t* __restrict__ cam_pos,
                                                         const int32_t* __restrict__ row_start, const int32_t* __restrict__ row_tiles,
-                                                        double* __restrict__ W, int64_t num_cells) {
-  const int64_t cell = int64_t(blockIdx.x) * 3 + threadIdx.x / 81;
-  if (cell >= num_cells) return;
+                                                        double* __restrict__ W, int64_t num_cells,
+                                                        const int32_t* __restrict__ sel_cells, const int32_t* __restrict__ sel_offdiag,
+                                                        double offdiag_scale) {
+  // sel_cells != NULL: only these cells of the list (a visibility based preconditioner keeps a subset of S), the ones
+  // flagged in sel_offdiag scaled (ScaleOffDiagonalCells, visibility_based_preconditioner.cc:366-393)
+  const int64_t k = int64_t(blockIdx.x) * 3 + threadIdx.x / 81;
+  if (k >= num_cells) return;
+  const int64_t cell = sel_cells ? int64_t(sel_cells[k]) : k;
   const int el = threadIdx.x % 81;
   const int c1 = cell_c1[cell], c2 = cell_c2[cell];
   const int a = el / 9, c = el - a * 9;
@@ -75,6 +80,7 @@ __global__ __launch_bounds__(3 * 81) void k_sp_assemble(const int32_t* __restric
       v += d * d;
     }
   }
+  if (sel_offdiag && sel_offdiag[k]) v *= offdiag_scale;
   int row = cam_pos[c1] + a, col = cam_pos[c2] + c;  // cam_pos: first row of the camera in the padded elimination order
   if (c1 != c2 && row > col) { const int t = row; row = col; col = t; }  // the cell lands transposed
   if (row > col) return;                                                 // lower half of a diagonal cell
@@ -354,7 +360,9 @@ __global__ __launch_bounds__(256) void k_sp_bwd_partial(const double* __restrict
 __global__ __launch_bounds__(256) void k_sp_bwd_level(const double* __restrict__ W, const int32_t* __restrict__ row_start,
                                                       const int32_t* __restrict__ level_rows, const int32_t* __restrict__ valid,
                                                       const double* __restrict__ uinv, const double* __restrict__ partial,
-                                                      double* __restrict__ x) {
+                                                      double* __restrict__ x, int y_in_x) {
+  // y_in_x: the right-hand side of the sweep is x itself (a solve with a stored factor); otherwise column 0 of the
+  // row's last tile (the right-hand side that was forward-substituted along with the factorisation)
   __shared__ double y1[NB], y2[NB], x1[NB], x2[NB], tmp[NB];
   const int I = level_rows[blockIdx.x];
   const int t = threadIdx.x;
@@ -365,7 +373,7 @@ __global__ __launch_bounds__(256) void k_sp_bwd_level(const double* __restrict__
     double s = 0.0;
 #pragma unroll 8
     for (int q = q0 + 1; q < q1; ++q) s += partial[size_t(q) * kTile + t];
-    const double yv = W[size_t(q1) * kTileDoubles + size_t(t) * kTile] - s;
+    const double yv = (y_in_x ? x[k0 + t] : W[size_t(q1) * kTileDoubles + size_t(t) * kTile]) - s;
     if (t < NB) y1[t] = t < kb1 ? yv : 0.0;
     else y2[t - NB] = (t - NB) < kb2 ? yv : 0.0;
   }
@@ -388,6 +396,93 @@ __global__ __launch_bounds__(256) void k_sp_bwd_level(const double* __restrict__
     const double v = t < NB ? x1[t] : x2[t - NB];
     x[k0 + t] = (t < kb1 + kb2) ? v : 0.0;  // padding rows of the tile row carry zeros
   }
+}
+
+// out[m] = sum_c M[c][m] v[c] (the transposed 32 x 32 block), 8 threads per output
+__device__ __forceinline__ void sp_gemv32_t(const double* __restrict__ M, int ldm, const double* __restrict__ v, double* __restrict__ out,
+                                            int rows_valid, int cols_valid) {
+  const int t = threadIdx.x, m = t >> 3, part = t & 7;
+  double s = 0.0;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int c = 4 * part + q;
+    s += (c < rows_valid && m < cols_valid) ? M[size_t(c) * ldm + m] * v[c] : 0.0;
+  }
+  s += __shfl_xor(s, 1, 64);
+  s += __shfl_xor(s, 2, 64);
+  s += __shfl_xor(s, 4, 64);
+  if (part == 0) out[m] = s;
+}
+
+// Forward substitution U' y = r with a stored factor, by levels bottom up.  Part 1, workgroup = tile row I of the level:
+// r_I minus the partial products of the tiles of COLUMN I (rows K < I, all of lower levels, ascending K), then
+// y1 = U11^-T v1, y2 = U22^-T (v2 - U12' y1) with the kept inverses.  y holds r on entry and y on exit.
+__global__ __launch_bounds__(256) void k_sp_fwd_level(const double* __restrict__ W, const int32_t* __restrict__ row_start,
+                                                      const int32_t* __restrict__ level_rows, const int32_t* __restrict__ valid,
+                                                      const double* __restrict__ uinv, const int32_t* __restrict__ col_start,
+                                                      const int32_t* __restrict__ col_pool, const double* __restrict__ partial,
+                                                      double* __restrict__ y) {
+  __shared__ double v1[NB], v2[NB], y1[NB], y2[NB], tmp[NB];
+  const int I = level_rows[blockIdx.x];
+  const int t = threadIdx.x;
+  const int k0 = kTile * I;
+  const int kb1 = min(NB, valid[I]), kb2 = max(0, min(NB, valid[I] - NB));
+  if (t < kTile) {
+    double s = 0.0;
+#pragma unroll 8
+    for (int p = col_start[I]; p < col_start[I + 1]; ++p) s += partial[size_t(col_pool[p]) * kTile + t];
+    const double v = y[k0 + t] - s;
+    if (t < NB) v1[t] = t < kb1 ? v : 0.0;
+    else v2[t - NB] = (t - NB) < kb2 ? v : 0.0;
+  }
+  __syncthreads();
+  const double* __restrict__ D = W + size_t(row_start[I]) * kTileDoubles;
+  const double* __restrict__ ui1 = uinv + size_t(2 * I) * NB * NB;
+  sp_gemv32_t(ui1, NB, v1, y1, NB, NB);  // y1 = U11^-T v1 (identity-padded inverse)
+  __syncthreads();
+  if (kb2 > 0) {
+    sp_gemv32_t(D + NB, kTile, y1, tmp, kb1, kb2);  // U12' y1
+    __syncthreads();
+    if (t < NB) v2[t] -= tmp[t];
+    __syncthreads();
+    sp_gemv32_t(ui1 + NB * NB, NB, v2, y2, NB, NB);
+    __syncthreads();
+  } else if (t < NB) {
+    y2[t] = 0.0;
+  }
+  __syncthreads();
+  if (t < 64) {
+    const double v = t < NB ? y1[t] : y2[t - NB];
+    y[k0 + t] = (t < kb1 + kb2) ? v : 0.0;
+  }
+}
+
+// ... part 2, workgroup = one tile F(K, J) right of the diagonal of a row K of the level: partial[tile][c] =
+// sum_r F(K, J)[r][c] y_K[r], gathered later by tile row J.
+__global__ __launch_bounds__(256) void k_sp_fwd_partial(const double* __restrict__ W, const int32_t* __restrict__ row_tiles,
+                                                        const int32_t* __restrict__ panel_row, const int32_t* __restrict__ panel_pool,
+                                                        int T, const double* __restrict__ y, double* __restrict__ partial) {
+  __shared__ double red[4][kTile];
+  const int q = panel_pool[blockIdx.x];
+  if (row_tiles[q] >= T) return;  // the right-hand-side tile
+  const int K = panel_row[blockIdx.x];
+  const int t = threadIdx.x, c = t & 63, part = t >> 6;
+  const double* __restrict__ F = W + size_t(q) * kTileDoubles + size_t(16 * part) * kTile + c;
+  const double* __restrict__ yk = y + size_t(kTile) * K + 16 * part;
+  double s = 0.0;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) s += F[size_t(r) * kTile] * yk[r];  // padding rows of y are zero
+  red[part][c] = s;
+  __syncthreads();
+  if (part == 0) partial[size_t(q) * kTile + c] = (red[0][c] + red[1][c]) + (red[2][c] + red[3][c]);
+}
+
+// camera order -> padded elimination order (padding rows zero: memset first)
+__global__ void k_sp_permute(const double* __restrict__ r, const int32_t* __restrict__ cam_pos, double* __restrict__ yp, int C) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= 9 * C) return;
+  const int c = i / 9, a = i - 9 * c;
+  yp[cam_pos[c] + a] = r[i];
 }
 
 __global__ void k_sp_unpermute(const double* __restrict__ xp, const int32_t* __restrict__ cam_pos, double* __restrict__ x, int C) {
@@ -654,15 +749,15 @@ PaddedLayout NestedDissection(int C, const std::vector<std::vector<int32_t>>& ad
 
 // tile-level structure of the permuted S (upper) and its symbolic fill (eliminating tile row k connects every pair
 // of its later column tiles); rows as sorted lists, each closed by the right-hand-side tile T
-void TileStructure(const cx_matrix* A, const std::vector<int32_t>& cam_row, int T, std::vector<int32_t>* row_start,
-                   std::vector<int32_t>* row_tiles) {
+void TileStructure(const int32_t* cell_c1, const int32_t* cell_c2, int64_t num_cells, const std::vector<int32_t>& cam_row, int T,
+                   std::vector<int32_t>* row_start, std::vector<int32_t>* row_tiles) {
   std::vector<std::vector<char>> nz(static_cast<size_t>(T), std::vector<char>(static_cast<size_t>(T), 0));
   auto mark = [&](int r1, int r2) {  // first rows of the two cameras, r1 <= r2
     for (int rt = r1 >> 6; rt <= (r1 + 8) >> 6; ++rt)
       for (int ct = r2 >> 6; ct <= (r2 + 8) >> 6; ++ct) nz[size_t(std::min(rt, ct))][size_t(std::max(rt, ct))] = 1;
   };
-  for (int64_t k = 0; k < A->num_cells; ++k) {
-    const int r1 = cam_row[size_t(A->h_cell_c1[size_t(k)])], r2 = cam_row[size_t(A->h_cell_c2[size_t(k)])];
+  for (int64_t k = 0; k < num_cells; ++k) {
+    const int r1 = cam_row[size_t(cell_c1[k])], r2 = cam_row[size_t(cell_c2[k])];
     mark(std::min(r1, r2), std::max(r1, r2));
   }
   for (int I = 0; I < T; ++I) nz[size_t(I)][size_t(I)] = 1;
@@ -685,15 +780,13 @@ void TileStructure(const cx_matrix* A, const std::vector<int32_t>& cam_row, int 
 
 }  // namespace
 
-int cxsp_build_plan(cx_matrix* A) {
-  if (A->sp_state != 0) return CX_OK;
-  CX_TRY(cxs_build_pair_lists(A));
-  if (A->pairs_state != 1) { A->sp_state = 2; return CX_OK; }
-  const int C = A->C;
+int cxsp_plan_from_cells(cx_context* ctx, int C, const int32_t* cell_c1, const int32_t* cell_c2, int64_t num_cells, cx_sp_plan* P) {
+  if (P->state != 0) return CX_OK;
+  P->C = C;
   const int n = 9 * C;
   std::vector<std::vector<int32_t>> adj(static_cast<size_t>(C));
-  for (int64_t k = 0; k < A->num_cells; ++k) {
-    const int c1 = A->h_cell_c1[size_t(k)], c2 = A->h_cell_c2[size_t(k)];
+  for (int64_t k = 0; k < num_cells; ++k) {
+    const int c1 = cell_c1[k], c2 = cell_c2[k];
     if (c1 != c2) { adj[size_t(c1)].push_back(c2); adj[size_t(c2)].push_back(c1); }
   }
   const char* ordering_env = std::getenv("CX_SPARSE_ORDERING");
@@ -710,10 +803,10 @@ int cxsp_build_plan(cx_matrix* A) {
       return LayOut(C, order, std::vector<int32_t>{int32_t(C)});
     };
     layout = as_layout(pos);
-    TileStructure(A, layout.cam_row, layout.T, &row_start, &row_tiles);
+    TileStructure(cell_c1, cell_c2, num_cells, layout.cam_row, layout.T, &row_start, &row_tiles);
     std::vector<int32_t> rs2, rt2;
     PaddedLayout layout2 = as_layout(GroupMinimumDegree(C, adj, pos));
-    TileStructure(A, layout2.cam_row, layout2.T, &rs2, &rt2);
+    TileStructure(cell_c1, cell_c2, num_cells, layout2.cam_row, layout2.T, &rs2, &rt2);
     if (rt2.size() < row_tiles.size()) {
       layout = layout2;
       row_start.swap(rs2);
@@ -722,105 +815,234 @@ int cxsp_build_plan(cx_matrix* A) {
   } else {
     // leaves of about 5 tile rows: below that a subtree is a chain of tile rows anyway
     layout = NestedDissection(C, adj, 36);
-    TileStructure(A, layout.cam_row, layout.T, &row_start, &row_tiles);
+    TileStructure(cell_c1, cell_c2, num_cells, layout.cam_row, layout.T, &row_start, &row_tiles);
   }
   const int T = layout.T;
   const int64_t num_tiles = int64_t(row_tiles.size());
+  // one pool, factored in place: refuse structures that would not fit comfortably
+  if (double(num_tiles) * kTileDoubles * 8.0 > 160e9) { P->state = 2; return CX_OK; }
+  hipStream_t st = ctx->stream;
   // Level schedule: the elimination tree of the TILE rows (parent = first tile right of the diagonal), tile rows
   // grouped by height; per level the diagonal tiles, the panel tiles and, for every tile that a row of the level
   // updates, its sources (pool indices of F(I, Ja), F(I, Jb)) in ascending I.
-  {
-    std::vector<int32_t> height(static_cast<size_t>(T), 0);
-    int max_h = 0;
-    for (int I = 0; I < T; ++I) {  // children have smaller indices: one ascending sweep pushes heights up
-      const int32_t q = row_start[size_t(I)] + 1;
-      const int32_t parent = row_tiles[size_t(q)];  // the list always ends with T, so q is valid
-      if (parent < T) height[size_t(parent)] = std::max(height[size_t(parent)], height[size_t(I)] + 1);
-      max_h = std::max(max_h, height[size_t(I)]);
-    }
-    const int L = T > 0 ? max_h + 1 : 0;
-    std::vector<int32_t> lrb(size_t(L) + 1, 0), lpb(size_t(L) + 1, 0), ltb(size_t(L) + 1, 0);
-    for (int I = 0; I < T; ++I) lrb[size_t(height[size_t(I)]) + 1]++;
-    for (int l = 0; l < L; ++l) lrb[size_t(l) + 1] += lrb[size_t(l)];
-    std::vector<int32_t> level_rows(static_cast<size_t>(T));
-    {
-      std::vector<int32_t> cur(lrb.begin(), lrb.end() - 1);
-      for (int I = 0; I < T; ++I) level_rows[size_t(cur[size_t(height[size_t(I)])]++)] = I;
-    }
-    std::vector<int32_t> panel_row, panel_pool;
-    struct Src { int32_t level, tgt, row, qa, qb; };
-    std::vector<Src> srcs;
-    for (int l = 0; l < L; ++l) {
-      lpb[size_t(l)] = int32_t(panel_row.size());
-      for (int32_t k = lrb[size_t(l)]; k < lrb[size_t(l) + 1]; ++k) {
-        const int I = level_rows[size_t(k)];
-        const int32_t q0 = row_start[size_t(I)], q1 = row_start[size_t(I) + 1];
-        for (int32_t q = q0 + 1; q < q1; ++q) { panel_row.push_back(I); panel_pool.push_back(q); }
-        for (int32_t qa = q0 + 1; qa < q1 - 1; ++qa) {  // Ja a real tile row; Jb up to the right-hand-side tile
-          const int Ja = row_tiles[size_t(qa)];
-          const auto first = row_tiles.begin() + row_start[size_t(Ja)], last = row_tiles.begin() + row_start[size_t(Ja) + 1];
-          auto it = first;
-          for (int32_t qb = qa; qb < q1; ++qb) {
-            it = std::lower_bound(it, last, row_tiles[size_t(qb)]);  // present by construction of the symbolic fill
-            srcs.push_back(Src{l, int32_t(it - row_tiles.begin()), I, qa, qb});
-          }
-        }
-      }
-    }
-    lpb[size_t(L)] = int32_t(panel_row.size());
-    std::sort(srcs.begin(), srcs.end(), [](const Src& x, const Src& y) {
-      return x.level != y.level ? x.level < y.level : (x.tgt != y.tgt ? x.tgt < y.tgt : x.row < y.row);
-    });
-    std::vector<int32_t> tgt_pool, tgt_flags, src_begin, src_a(srcs.size()), src_b(srcs.size());
-    {
-      int level = 0;
-      for (size_t i = 0; i < srcs.size(); ++i) {
-        while (level < srcs[i].level) ltb[size_t(++level)] = int32_t(tgt_pool.size());
-        if (i == 0 || srcs[i].level != srcs[i - 1].level || srcs[i].tgt != srcs[i - 1].tgt) {
-          const int32_t tq = srcs[i].tgt;
-          // which row owns pool slot tq: the row whose range contains it
-          const int Ja = int(std::upper_bound(row_start.begin(), row_start.end(), tq) - row_start.begin()) - 1;
-          const int Jb = row_tiles[size_t(tq)];
-          tgt_pool.push_back(tq);
-          tgt_flags.push_back((Jb == Ja ? 1 : 0) | (Jb == T ? 2 : 0));
-          src_begin.push_back(int32_t(i));
-        }
-        src_a[i] = srcs[i].qa;
-        src_b[i] = srcs[i].qb;
-      }
-      while (level < L) ltb[size_t(++level)] = int32_t(tgt_pool.size());
-      src_begin.push_back(int32_t(srcs.size()));
-    }
-    hipStream_t st0 = A->ctx->stream;
-    CX_TRY(A->d_sp_level_rows.upload(level_rows, st0));
-    CX_TRY(A->d_sp_panel_row.upload(panel_row, st0));
-    CX_TRY(A->d_sp_panel_pool.upload(panel_pool, st0));
-    CX_TRY(A->d_sp_tgt_pool.upload(tgt_pool, st0));
-    CX_TRY(A->d_sp_tgt_flags.upload(tgt_flags, st0));
-    CX_TRY(A->d_sp_src_begin.upload(src_begin, st0));
-    CX_TRY(A->d_sp_src_a.upload(src_a, st0));
-    CX_TRY(A->d_sp_src_b.upload(src_b, st0));
-    A->h_sp_level_row_begin = lrb;
-    A->h_sp_level_panel_begin = lpb;
-    A->h_sp_level_tgt_begin = ltb;
-    A->sp_num_levels = L;
-    if (std::getenv("CX_SPARSE_CHOLESKY_VERBOSE"))
-      std::fprintf(stderr, "[cxschur] tile-sparse Cholesky levels: %d tile rows in %d levels, %zu tile-pair updates on %zu (level, target) pairs\n",
-                   T, L, srcs.size(), tgt_pool.size());
+  std::vector<int32_t> height(static_cast<size_t>(T), 0);
+  int max_h = 0;
+  for (int I = 0; I < T; ++I) {  // children have smaller indices: one ascending sweep pushes heights up
+    const int32_t q = row_start[size_t(I)] + 1;
+    const int32_t parent = row_tiles[size_t(q)];  // the list always ends with T, so q is valid
+    if (parent < T) height[size_t(parent)] = std::max(height[size_t(parent)], height[size_t(I)] + 1);
+    max_h = std::max(max_h, height[size_t(I)]);
   }
-  // one pool, factored in place: refuse structures that would not fit comfortably
-  if (double(num_tiles) * kTileDoubles * 8.0 > 160e9) { A->sp_state = 2; return CX_OK; }
-  hipStream_t st = A->ctx->stream;
-  CX_TRY(A->d_sp_cam_pos.upload(layout.cam_row, st));
-  CX_TRY(A->d_sp_valid.upload(layout.valid, st));
-  CX_TRY(A->d_sp_row_start.upload(row_start, st));
-  CX_TRY(A->d_sp_row_tiles.upload(row_tiles, st));
-  A->sp_num_tiles = num_tiles;
-  A->sp_T = T;
-  A->sp_state = 1;
+  const int L = T > 0 ? max_h + 1 : 0;
+  std::vector<int32_t> lrb(size_t(L) + 1, 0), lpb(size_t(L) + 1, 0), ltb(size_t(L) + 1, 0);
+  for (int I = 0; I < T; ++I) lrb[size_t(height[size_t(I)]) + 1]++;
+  for (int l = 0; l < L; ++l) lrb[size_t(l) + 1] += lrb[size_t(l)];
+  std::vector<int32_t> level_rows(static_cast<size_t>(T));
+  {
+    std::vector<int32_t> cur(lrb.begin(), lrb.end() - 1);
+    for (int I = 0; I < T; ++I) level_rows[size_t(cur[size_t(height[size_t(I)])]++)] = I;
+  }
+  std::vector<int32_t> panel_row, panel_pool;
+  struct Src { int32_t level, tgt, row, qa, qb; };
+  std::vector<Src> srcs;
+  for (int l = 0; l < L; ++l) {
+    lpb[size_t(l)] = int32_t(panel_row.size());
+    for (int32_t k = lrb[size_t(l)]; k < lrb[size_t(l) + 1]; ++k) {
+      const int I = level_rows[size_t(k)];
+      const int32_t q0 = row_start[size_t(I)], q1 = row_start[size_t(I) + 1];
+      for (int32_t q = q0 + 1; q < q1; ++q) { panel_row.push_back(I); panel_pool.push_back(q); }
+      for (int32_t qa = q0 + 1; qa < q1 - 1; ++qa) {  // Ja a real tile row; Jb up to the right-hand-side tile
+        const int Ja = row_tiles[size_t(qa)];
+        const auto first = row_tiles.begin() + row_start[size_t(Ja)], last = row_tiles.begin() + row_start[size_t(Ja) + 1];
+        auto it = first;
+        for (int32_t qb = qa; qb < q1; ++qb) {
+          it = std::lower_bound(it, last, row_tiles[size_t(qb)]);  // present by construction of the symbolic fill
+          srcs.push_back(Src{l, int32_t(it - row_tiles.begin()), I, qa, qb});
+        }
+      }
+    }
+  }
+  lpb[size_t(L)] = int32_t(panel_row.size());
+  std::sort(srcs.begin(), srcs.end(), [](const Src& x, const Src& y) {
+    return x.level != y.level ? x.level < y.level : (x.tgt != y.tgt ? x.tgt < y.tgt : x.row < y.row);
+  });
+  std::vector<int32_t> tgt_pool, tgt_flags, src_begin, src_a(srcs.size()), src_b(srcs.size());
+  {
+    int level = 0;
+    for (size_t i = 0; i < srcs.size(); ++i) {
+      while (level < srcs[i].level) ltb[size_t(++level)] = int32_t(tgt_pool.size());
+      if (i == 0 || srcs[i].level != srcs[i - 1].level || srcs[i].tgt != srcs[i - 1].tgt) {
+        const int32_t tq = srcs[i].tgt;
+        // which row owns pool slot tq: the row whose range contains it
+        const int Ja = int(std::upper_bound(row_start.begin(), row_start.end(), tq) - row_start.begin()) - 1;
+        const int Jb = row_tiles[size_t(tq)];
+        tgt_pool.push_back(tq);
+        tgt_flags.push_back((Jb == Ja ? 1 : 0) | (Jb == T ? 2 : 0));
+        src_begin.push_back(int32_t(i));
+      }
+      src_a[i] = srcs[i].qa;
+      src_b[i] = srcs[i].qb;
+    }
+    while (level < L) ltb[size_t(++level)] = int32_t(tgt_pool.size());
+    src_begin.push_back(int32_t(srcs.size()));
+  }
+  // transposed index for forward solves with the stored factor: the tiles (K < I, I) of tile column I, ascending K
+  std::vector<int32_t> col_start(size_t(T) + 1, 0), col_pool;
+  {
+    for (int K = 0; K < T; ++K)
+      for (int32_t q = row_start[size_t(K)] + 1; q < row_start[size_t(K) + 1] - 1; ++q) col_start[size_t(row_tiles[size_t(q)]) + 1]++;
+    for (int I = 0; I < T; ++I) col_start[size_t(I) + 1] += col_start[size_t(I)];
+    col_pool.resize(size_t(col_start[size_t(T)]));
+    std::vector<int32_t> cur(col_start.begin(), col_start.end() - 1);
+    for (int K = 0; K < T; ++K)
+      for (int32_t q = row_start[size_t(K)] + 1; q < row_start[size_t(K) + 1] - 1; ++q) col_pool[size_t(cur[size_t(row_tiles[size_t(q)])]++)] = q;
+  }
+  CX_TRY(P->d_cam_pos.upload(layout.cam_row, st));
+  CX_TRY(P->d_valid.upload(layout.valid, st));
+  CX_TRY(P->d_row_start.upload(row_start, st));
+  CX_TRY(P->d_row_tiles.upload(row_tiles, st));
+  CX_TRY(P->d_level_rows.upload(level_rows, st));
+  CX_TRY(P->d_panel_row.upload(panel_row, st));
+  CX_TRY(P->d_panel_pool.upload(panel_pool, st));
+  CX_TRY(P->d_tgt_pool.upload(tgt_pool, st));
+  CX_TRY(P->d_tgt_flags.upload(tgt_flags, st));
+  CX_TRY(P->d_src_begin.upload(src_begin, st));
+  CX_TRY(P->d_src_a.upload(src_a, st));
+  CX_TRY(P->d_src_b.upload(src_b, st));
+  CX_TRY(P->d_col_start.upload(col_start, st));
+  CX_TRY(P->d_col_pool.upload(col_pool, st));
+  P->h_level_row_begin = lrb;
+  P->h_level_panel_begin = lpb;
+  P->h_level_tgt_begin = ltb;
+  P->num_levels = L;
+  P->num_tiles = num_tiles;
+  P->T = T;
+  P->state = 1;
   if (std::getenv("CX_SPARSE_CHOLESKY_VERBOSE"))
-    std::fprintf(stderr, "[cxschur] tile-sparse Cholesky plan: %d cameras, %d tile rows (%d rows of padding), %lld tiles (%.2f GB, dense would be %.2f GB)\n",
-                 C, T, kTile * T - n, (long long)num_tiles, double(num_tiles) * kTileDoubles * 8e-9, double(n) * n * 8e-9);
+    std::fprintf(stderr, "[cxschur] tile-sparse Cholesky plan: %d cameras, %d tile rows (%d rows of padding) in %d levels, %lld tiles (%.2f GB, "
+                 "dense would be %.2f GB), %zu tile-pair updates on %zu (level, target) pairs\n", C, T, kTile * T - n, L, (long long)num_tiles,
+                 double(num_tiles) * kTileDoubles * 8e-9, double(n) * n * 8e-9, srcs.size(), tgt_pool.size());
+  return CX_OK;
+}
+
+int cxsp_build_plan(cx_matrix* A) {
+  if (A->sp.state != 0) return CX_OK;
+  CX_TRY(cxs_build_pair_lists(A));
+  if (A->pairs_state != 1) { A->sp.state = 2; return CX_OK; }
+  return cxsp_plan_from_cells(A->ctx, A->C, A->h_cell_c1.data(), A->h_cell_c2.data(), A->num_cells, &A->sp);
+}
+
+namespace {
+// layout of plan->d_x: [T * 64] vector in the padded elimination order | two inverted 32 x 32 diagonal blocks per tile row |
+// [tiles][64] partial products of the sweeps
+struct Scratch { double *xp, *uinv, *partial; };
+int GetScratch(cx_sp_plan* P, Scratch* s) {
+  const size_t npad = size_t(P->T) * kTile;
+  CX_TRY(P->d_x.alloc(npad + 2 * size_t(P->T) * NB * NB + size_t(P->num_tiles) * kTile));
+  s->xp = P->d_x.p;
+  s->uinv = s->xp + npad;
+  s->partial = s->uinv + 2 * size_t(P->T) * NB * NB;
+  return CX_OK;
+}
+}  // namespace
+
+// zero the pool and scatter (the selected) S cells of the matrix into it; A's gather assembly must have run
+// (cxs_assemble_pair_items)
+int cxsp_assemble(cx_matrix* A, cx_sp_plan* P, const double* Df, const int32_t* sel_cells, const int32_t* sel_offdiag, int64_t num_sel,
+                  double offdiag_scale) {
+  hipStream_t st = A->ctx->stream;
+  const size_t pool = size_t(P->num_tiles) * kTileDoubles;
+  CX_TRY(P->d_W.alloc(pool));
+  CX_HIP(hipMemsetAsync(P->d_W.p, 0, pool * sizeof(double), st));
+  const int64_t count = sel_cells ? num_sel : A->num_cells;
+  if (count > 0)
+    hipLaunchKernelGGL(k_sp_assemble, dim3(unsigned((count + 2) / 3)), dim3(3 * 81), 0, st, (const int32_t*)A->d_cell_c1.p,
+                       (const int32_t*)A->d_cell_c2.p, (const int32_t*)A->d_cell_item_start.p, (const double*)A->d_item_partial.p,
+                       (const double*)A->d_elim_diag.p, Df, (const int32_t*)P->d_cam_pos.p, (const int32_t*)P->d_row_start.p,
+                       (const int32_t*)P->d_row_tiles.p, P->d_W.p, count, sel_cells, sel_offdiag, offdiag_scale);
+  CX_HIP(hipGetLastError());
+  return CX_OK;
+}
+
+// numeric factorisation of the assembled pool, in place, level by level; a right-hand side placed in the rows' last
+// tiles (k_sp_rhs) is forward-substituted along
+int cxsp_factor(cx_context* ctx, cx_sp_plan* P, int* d_flag) {
+  hipStream_t st = ctx->stream;
+  Scratch sc;
+  CX_TRY(GetScratch(P, &sc));
+  double* W = P->d_W.p;
+  const int32_t* valid = P->d_valid.p;
+  const int32_t* rows = P->d_level_rows.p;
+  for (int l = 0; l < P->num_levels; ++l) {
+    const int r0 = P->h_level_row_begin[size_t(l)], nr = P->h_level_row_begin[size_t(l) + 1] - r0;
+    const int p0 = P->h_level_panel_begin[size_t(l)], np = P->h_level_panel_begin[size_t(l) + 1] - p0;
+    const int t0 = P->h_level_tgt_begin[size_t(l)], nt = P->h_level_tgt_begin[size_t(l) + 1] - t0;
+    if (nr > 0)
+      hipLaunchKernelGGL(k_sp_diag, dim3(unsigned(nr)), dim3(64), 0, st, W, (const int32_t*)P->d_row_start.p, rows + r0, valid, sc.uinv, d_flag);
+    if (np > 0)
+      hipLaunchKernelGGL(k_sp_panel, dim3(unsigned(np)), dim3(128), 0, st, W, (const int32_t*)P->d_row_start.p,
+                         (const int32_t*)P->d_row_tiles.p, (const int32_t*)P->d_panel_row.p + p0,
+                         (const int32_t*)P->d_panel_pool.p + p0, valid, P->T, (const double*)sc.uinv);
+    if (nt > 0) {
+      static const int occ = [] { const char* v = std::getenv("CX_SPARSE_UPDATE_OCCUPANCY"); return v ? atoi(v) : 3; }();
+#define CX_SP_UPDATE(K)                                                                                                          \
+  hipLaunchKernelGGL(k_sp_update<K>, dim3(unsigned(nt)), dim3(256), 0, st, W, (const int32_t*)P->d_tgt_pool.p + t0,              \
+                     (const int32_t*)P->d_tgt_flags.p + t0, (const int32_t*)P->d_src_begin.p + t0,                               \
+                     (const int32_t*)P->d_src_a.p, (const int32_t*)P->d_src_b.p)
+      if (occ >= 4) CX_SP_UPDATE(4);
+      else if (occ == 3) CX_SP_UPDATE(3);
+      else CX_SP_UPDATE(2);
+#undef CX_SP_UPDATE
+    }
+  }
+  CX_HIP(hipGetLastError());
+  return CX_OK;
+}
+
+namespace {
+// backward sweep U x = y by levels, top down; y_in_x: y is sc.xp itself, otherwise the rows' right-hand-side tiles
+int BackwardSweep(cx_context* ctx, cx_sp_plan* P, const Scratch& sc, int y_in_x) {
+  hipStream_t st = ctx->stream;
+  const int32_t* rows = P->d_level_rows.p;
+  for (int l = P->num_levels - 1; l >= 0; --l) {
+    const int r0 = P->h_level_row_begin[size_t(l)], nr = P->h_level_row_begin[size_t(l) + 1] - r0;
+    const int p0 = P->h_level_panel_begin[size_t(l)], np = P->h_level_panel_begin[size_t(l) + 1] - p0;
+    if (np > 0)
+      hipLaunchKernelGGL(k_sp_bwd_partial, dim3(unsigned(np)), dim3(256), 0, st, (const double*)P->d_W.p, (const int32_t*)P->d_row_tiles.p,
+                         (const int32_t*)P->d_panel_pool.p + p0, (const int32_t*)P->d_valid.p, P->T, (const double*)sc.xp, sc.partial);
+    if (nr > 0)
+      hipLaunchKernelGGL(k_sp_bwd_level, dim3(unsigned(nr)), dim3(256), 0, st, (const double*)P->d_W.p, (const int32_t*)P->d_row_start.p,
+                         rows + r0, (const int32_t*)P->d_valid.p, (const double*)sc.uinv, (const double*)sc.partial, sc.xp, y_in_x);
+  }
+  CX_HIP(hipGetLastError());
+  return CX_OK;
+}
+}  // namespace
+
+// z = M^-1 r with the stored factor M = U'U (r, z in camera order): U' y = r bottom up, U x = y top down
+int cxsp_solve(cx_context* ctx, cx_sp_plan* P, const double* r, double* z) {
+  hipStream_t st = ctx->stream;
+  const int C = P->C, n = 9 * C;
+  if (n == 0) return CX_OK;
+  Scratch sc;
+  CX_TRY(GetScratch(P, &sc));
+  CX_HIP(hipMemsetAsync(sc.xp, 0, size_t(P->T) * kTile * sizeof(double), st));
+  hipLaunchKernelGGL(k_sp_permute, dim3((n + 255) / 256), dim3(256), 0, st, r, (const int32_t*)P->d_cam_pos.p, sc.xp, C);
+  const int32_t* rows = P->d_level_rows.p;
+  for (int l = 0; l < P->num_levels; ++l) {
+    const int r0 = P->h_level_row_begin[size_t(l)], nr = P->h_level_row_begin[size_t(l) + 1] - r0;
+    const int p0 = P->h_level_panel_begin[size_t(l)], np = P->h_level_panel_begin[size_t(l) + 1] - p0;
+    if (nr > 0)
+      hipLaunchKernelGGL(k_sp_fwd_level, dim3(unsigned(nr)), dim3(256), 0, st, (const double*)P->d_W.p, (const int32_t*)P->d_row_start.p,
+                         rows + r0, (const int32_t*)P->d_valid.p, (const double*)sc.uinv, (const int32_t*)P->d_col_start.p,
+                         (const int32_t*)P->d_col_pool.p, (const double*)sc.partial, sc.xp);
+    if (np > 0)
+      hipLaunchKernelGGL(k_sp_fwd_partial, dim3(unsigned(np)), dim3(256), 0, st, (const double*)P->d_W.p, (const int32_t*)P->d_row_tiles.p,
+                         (const int32_t*)P->d_panel_row.p + p0, (const int32_t*)P->d_panel_pool.p + p0, P->T, (const double*)sc.xp, sc.partial);
+  }
+  CX_TRY(BackwardSweep(ctx, P, sc, 1));
+  hipLaunchKernelGGL(k_sp_unpermute, dim3((n + 255) / 256), dim3(256), 0, st, (const double*)sc.xp, (const int32_t*)P->d_cam_pos.p, z, C);
+  CX_HIP(hipGetLastError());
   return CX_OK;
 }
 
@@ -829,61 +1051,17 @@ int cxsp_build_plan(cx_matrix* A) {
 int cxsp_factor_and_solve(cx_matrix* A, const double* Df, const double* rhs, double* z, int* d_flag) {
   cx_context* ctx = A->ctx;
   hipStream_t st = ctx->stream;
-  const int C = A->C, n = 9 * C, T = A->sp_T;
+  cx_sp_plan* P = &A->sp;
+  const int C = A->C, n = 9 * C;
   if (n == 0) return CX_OK;
-  const size_t pool = size_t(A->sp_num_tiles) * kTileDoubles;
-  const size_t npad = size_t(T) * kTile;
-  CX_TRY(A->d_sp_W.alloc(pool));
-  CX_TRY(A->d_sp_x.alloc(npad + 2 * size_t(T) * NB * NB + size_t(A->sp_num_tiles) * kTile));
-  double* W = A->d_sp_W.p;
-  double* xp = A->d_sp_x.p;                            // solution in the padded elimination order
-  double* uinv = xp + npad;                            // two inverted 32 x 32 diagonal blocks per tile row
-  double* partial = uinv + 2 * size_t(T) * NB * NB;    // [tiles][64] partial products of the backward sweep
-  const int32_t* valid = A->d_sp_valid.p;
-  CX_HIP(hipMemsetAsync(W, 0, pool * sizeof(double), st));
-  if (A->num_cells > 0)
-    hipLaunchKernelGGL(k_sp_assemble, dim3(unsigned((A->num_cells + 2) / 3)), dim3(3 * 81), 0, st, (const int32_t*)A->d_cell_c1.p,
-                       (const int32_t*)A->d_cell_c2.p, (const int32_t*)A->d_cell_item_start.p, (const double*)A->d_item_partial.p,
-                       (const double*)A->d_elim_diag.p, Df, (const int32_t*)A->d_sp_cam_pos.p, (const int32_t*)A->d_sp_row_start.p,
-                       (const int32_t*)A->d_sp_row_tiles.p, W, A->num_cells);
-  hipLaunchKernelGGL(k_sp_rhs, dim3((n + 255) / 256), dim3(256), 0, st, rhs, (const int32_t*)A->d_sp_cam_pos.p,
-                     (const int32_t*)A->d_sp_row_start.p, W, C);
-  const int L = A->sp_num_levels;
-  const int32_t* rows = A->d_sp_level_rows.p;
-  for (int l = 0; l < L; ++l) {
-    const int r0 = A->h_sp_level_row_begin[size_t(l)], nr = A->h_sp_level_row_begin[size_t(l) + 1] - r0;
-    const int p0 = A->h_sp_level_panel_begin[size_t(l)], np = A->h_sp_level_panel_begin[size_t(l) + 1] - p0;
-    const int t0 = A->h_sp_level_tgt_begin[size_t(l)], nt = A->h_sp_level_tgt_begin[size_t(l) + 1] - t0;
-    if (nr > 0)
-      hipLaunchKernelGGL(k_sp_diag, dim3(unsigned(nr)), dim3(64), 0, st, W, (const int32_t*)A->d_sp_row_start.p, rows + r0, valid, uinv, d_flag);
-    if (np > 0)
-      hipLaunchKernelGGL(k_sp_panel, dim3(unsigned(np)), dim3(128), 0, st, W, (const int32_t*)A->d_sp_row_start.p,
-                         (const int32_t*)A->d_sp_row_tiles.p, (const int32_t*)A->d_sp_panel_row.p + p0,
-                         (const int32_t*)A->d_sp_panel_pool.p + p0, valid, T, (const double*)uinv);
-    if (nt > 0) {
-      static const int occ = [] { const char* v = std::getenv("CX_SPARSE_UPDATE_OCCUPANCY"); return v ? atoi(v) : 3; }();
-#define CX_SP_UPDATE(K)                                                                                                          \
-  hipLaunchKernelGGL(k_sp_update<K>, dim3(unsigned(nt)), dim3(256), 0, st, W, (const int32_t*)A->d_sp_tgt_pool.p + t0,           \
-                     (const int32_t*)A->d_sp_tgt_flags.p + t0, (const int32_t*)A->d_sp_src_begin.p + t0,                         \
-                     (const int32_t*)A->d_sp_src_a.p, (const int32_t*)A->d_sp_src_b.p)
-      if (occ >= 4) CX_SP_UPDATE(4);
-      else if (occ == 3) CX_SP_UPDATE(3);
-      else CX_SP_UPDATE(2);
-#undef CX_SP_UPDATE
-    }
-  }
-  CX_HIP(hipGetLastError());
-  for (int l = L - 1; l >= 0; --l) {
-    const int r0 = A->h_sp_level_row_begin[size_t(l)], nr = A->h_sp_level_row_begin[size_t(l) + 1] - r0;
-    const int p0 = A->h_sp_level_panel_begin[size_t(l)], np = A->h_sp_level_panel_begin[size_t(l) + 1] - p0;
-    if (np > 0)
-      hipLaunchKernelGGL(k_sp_bwd_partial, dim3(unsigned(np)), dim3(256), 0, st, (const double*)W, (const int32_t*)A->d_sp_row_tiles.p,
-                         (const int32_t*)A->d_sp_panel_pool.p + p0, valid, T, (const double*)xp, partial);
-    if (nr > 0)
-      hipLaunchKernelGGL(k_sp_bwd_level, dim3(unsigned(nr)), dim3(256), 0, st, (const double*)W, (const int32_t*)A->d_sp_row_start.p,
-                         rows + r0, valid, (const double*)uinv, (const double*)partial, xp);
-  }
-  hipLaunchKernelGGL(k_sp_unpermute, dim3((n + 255) / 256), dim3(256), 0, st, (const double*)xp, (const int32_t*)A->d_sp_cam_pos.p, z, C);
+  CX_TRY(cxsp_assemble(A, P, Df, nullptr, nullptr, 0, 1.0));
+  hipLaunchKernelGGL(k_sp_rhs, dim3((n + 255) / 256), dim3(256), 0, st, rhs, (const int32_t*)P->d_cam_pos.p,
+                     (const int32_t*)P->d_row_start.p, P->d_W.p, C);
+  CX_TRY(cxsp_factor(ctx, P, d_flag));
+  Scratch sc;
+  CX_TRY(GetScratch(P, &sc));
+  CX_TRY(BackwardSweep(ctx, P, sc, 0));
+  hipLaunchKernelGGL(k_sp_unpermute, dim3((n + 255) / 256), dim3(256), 0, st, (const double*)sc.xp, (const int32_t*)P->d_cam_pos.p, z, C);
   CX_HIP(hipGetLastError());
   return CX_OK;
 }

@@ -38,6 +38,12 @@ struct cx_vis_plan {
   // ---- device
   DevBuf<int32_t> d_sel_cells, d_sel_items, d_sel_offdiag, d_cam_row, d_row_src, d_path_first_blk, d_path_num_blk, d_blk_cend;
   DevBuf<double> d_W, d_F, d_uinv, d_y;
+  // ---- alternative to the band: the level-scheduled tile-sparse Cholesky (cx_sparse_chol.hip) on the same cells.
+  // Chosen (cxv_use_sparse) when a path of the cluster forest is long: the band walk is then a chain of thousands of
+  // dependent block steps per application, while nested dissection of a path gives an elimination tree of logarithmic
+  // depth -- block cyclic reduction in effect.  -1 undecided, 0 band, 1 tile-sparse.
+  int use_sparse = -1;
+  cx_sp_plan sp;
 };
 
 // builds (or returns the cached) plan; CX_ERR_UNSUPPORTED with a message when it cannot be built

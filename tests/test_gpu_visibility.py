@@ -79,6 +79,62 @@ def test_solve_matches_oracle(ctx, oracle, C, P, O, seed, pre, clustering):
     A.close()
 
 
+@pytest.mark.parametrize("clustering", CLUSTERING)
+@pytest.mark.parametrize("pre", PRE)
+@pytest.mark.parametrize("C,P,O,seed", PROBLEMS[1:])
+def test_tile_sparse_factorisation_of_the_preconditioner(ctx, oracle, monkeypatch, C, P, O, seed, pre, clustering):
+    """The preconditioner matrix factored by the level-scheduled tile-sparse Cholesky (cx_sparse_chol.hip) instead of the
+    band -- the default for CLUSTER_TRIDIAGONAL when the cluster forest has a long path, forced here on small problems
+    (CX_VISIBILITY_SPARSE=1): M^-1 r is the same operator, so iteration counts equal the oracle's and the band path's,
+    solutions agree to 1e-8, and two solves give the same bits."""
+    prob, bs, vals, b, D = make(oracle, C, P, O, seed)
+    kw = dict(type=cx.ITERATIVE_SCHUR, preconditioner_type=getattr(cx, pre), num_eliminate_blocks=P,
+              visibility_clustering_type=getattr(cx, clustering), max_num_iterations=300)
+    eta = 1e-3 if C >= 400 else 0.1
+    monkeypatch.setenv("CX_VISIBILITY_SPARSE", "1")
+    A = cx.Matrix(ctx, bs, P)
+    A.set_values(vals)
+    S = cx.Solver(ctx, **kw)
+    x, s = S.solve(A, b, D, r_tolerance=-1.0, q_tolerance=eta)
+    x2, s2 = S.solve(A, b, D, r_tolerance=-1.0, q_tolerance=eta)
+    S.close()
+    A.close()
+    monkeypatch.setenv("CX_VISIBILITY_SPARSE", "0")
+    A = cx.Matrix(ctx, bs, P)
+    A.set_values(vals)
+    S = cx.Solver(ctx, **kw)
+    xb, sb = S.solve(A, b, D, r_tolerance=-1.0, q_tolerance=eta)
+    S.close()
+    A.close()
+    oo = oracle.make_options(type=oracle.ITERATIVE_SCHUR, preconditioner_type=getattr(oracle, pre), num_eliminate_blocks=P,
+                             visibility_clustering_type=getattr(oracle, clustering), max_num_iterations=300)
+    xr, sr = oracle.solve(bs, vals, b, D, oo, r_tolerance=-1.0, q_tolerance=eta)
+    assert s.termination_type == sr.termination_type == 0, (s.message, sr.message)
+    assert s.num_iterations == sr.num_iterations == sb.num_iterations, (s.message, sr.message, sb.message)
+    assert relerr(x, xr) < 1e-7 and relerr(x, xb) < 1e-8
+    assert np.array_equal(x, x2)
+
+
+def test_tile_sparse_retry_and_failure_paths(ctx, oracle, monkeypatch):
+    """The CLUSTER_TRIDIAGONAL retry (indefinite until the off-diagonal cluster cells are halved) through the tile-sparse
+    factorisation: same outcome as the band path and the oracle."""
+    monkeypatch.setenv("CX_VISIBILITY_SPARSE", "1")
+    prob, bs, vals, b, D, P = crafted_indefinite_tridiagonal(0)
+    A = cx.Matrix(ctx, bs, P)
+    A.set_values(vals)
+    S = cx.Solver(ctx, type=cx.ITERATIVE_SCHUR, preconditioner_type=cx.CLUSTER_TRIDIAGONAL, num_eliminate_blocks=P,
+                  visibility_clustering_type=cx.SINGLE_LINKAGE, max_num_iterations=100)
+    x, s = S.solve(A, b, D, r_tolerance=-1.0, q_tolerance=0.01)
+    oo = oracle.make_options(type=oracle.ITERATIVE_SCHUR, preconditioner_type=oracle.CLUSTER_TRIDIAGONAL, num_eliminate_blocks=P,
+                             visibility_clustering_type=oracle.SINGLE_LINKAGE, max_num_iterations=100)
+    xr, sr = oracle.solve(bs, vals, b, D, oo, r_tolerance=-1.0, q_tolerance=0.01)
+    assert s.termination_type == sr.termination_type == 0, (s.message, sr.message)
+    assert s.num_iterations == sr.num_iterations
+    assert relerr(x, xr) < 1e-4
+    S.close()
+    A.close()
+
+
 def test_global_memory_walk_agrees(ctx, oracle, monkeypatch):
     """k_band_solve (vector in global memory, used when the band does not fit the LDS window) and
     k_band_solve_lds do the same arithmetic (the backward dot products are grouped differently: 1e-12)."""
