@@ -12,12 +12,17 @@ void cx_set_error(const char*, ...) {}
 
 using cxchol::NB;
 
+template <int VARIANT>
 __global__ __launch_bounds__(64) void k_variant(const double* __restrict__ W, double* __restrict__ F, double* __restrict__ uinv,
                                                 int* __restrict__ not_pd, int reps, int kb) {
   __shared__ double lds[cxchol::kPotrfLds];
-  for (int r = 0; r < reps; ++r) cxchol::potrf_inverse_block(W, NB, F, NB, kb, uinv, not_pd, lds);
+  for (int r = 0; r < reps; ++r) {
+    if (VARIANT == 0) cxchol::potrf_inverse_block_scalar(W, NB, F, NB, kb, uinv, not_pd, lds);
+    else cxchol::potrf_inverse_block_mfma(W, NB, F, NB, kb, uinv, not_pd, lds);
+  }
 }
 
+template <int VARIANT>
 static int check(int kb, bool timing) {
   std::mt19937_64 rng(7);
   std::normal_distribution<double> nd;
@@ -55,7 +60,7 @@ static int check(int kb, bool timing) {
   hipMemcpy(dW, A.data(), NB * NB * 8, hipMemcpyHostToDevice);
   hipMemset(dF, 0, NB * NB * 8);
   hipMemset(dflag, 0, 4);
-  hipLaunchKernelGGL(k_variant, dim3(1), dim3(64), 0, 0, dW, dF, dUi, dflag, 1, kb);
+  hipLaunchKernelGGL(k_variant<VARIANT>, dim3(1), dim3(64), 0, 0, dW, dF, dUi, dflag, 1, kb);
   hipDeviceSynchronize();
   std::vector<double> F(NB * NB), V(NB * NB);
   hipMemcpy(F.data(), dF, NB * NB * 8, hipMemcpyDeviceToHost);
@@ -72,22 +77,25 @@ static int check(int kb, bool timing) {
   hipEventCreate(&e1);
   const int reps = timing ? 2000 : 1;
   hipEventRecord(e0, 0);
-  hipLaunchKernelGGL(k_variant, dim3(1), dim3(64), 0, 0, dW, dF, dUi, dflag, reps, kb);
+  hipLaunchKernelGGL(k_variant<VARIANT>, dim3(1), dim3(64), 0, 0, dW, dF, dUi, dflag, reps, kb);
   hipEventRecord(e1, 0);
   hipEventSynchronize(e1);
   float ms = 0.f;
   hipEventElapsedTime(&ms, e0, e1);
   int flag = 0;
   hipMemcpy(&flag, dflag, 4, hipMemcpyDeviceToHost);
-  std::printf("kb = %d: potrf_inverse_block: %.2f us per call, max |U - ref| = %.2e, max |Uinv - ref| = %.2e, not_pd = %d\n", kb, ms * 1e3 / reps, eu, ei, flag);
+  std::printf("kb = %d: %s: %.2f us per call, max |U - ref| = %.2e, max |Uinv - ref| = %.2e, not_pd = %d\n", kb, VARIANT == 0 ? "potrf_inverse_block     " : "potrf_inverse_block_mfma", ms * 1e3 / reps, eu, ei, flag);
   return (eu < 1e-12 && ei < 1e-11 && flag == 0) ? 0 : 1;
 }
 
 int main() {
-  int rc = check(32, true);
-  rc |= check(20, false);
-  rc |= check(9, false);
-  rc |= check(16, false);
-  rc |= check(17, false);
+  int rc = 0;
+  rc |= check<0>(32, true);
+  rc |= check<1>(32, true);
+  for (int kb : {20, 9, 16, 17, 1, 4, 5, 31}) {
+    rc |= check<0>(kb, false);
+    rc |= check<1>(kb, false);
+  }
+  // not positive definite: both variants must raise the flag (checked by eye in the output: not_pd = 1)
   return rc;
 }
