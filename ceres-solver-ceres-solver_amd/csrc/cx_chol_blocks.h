@@ -236,6 +236,40 @@ __device__ __forceinline__ void potrf_group4(double4_t (&T)[2][2], bool& ok, dou
   }
 }
 
+// the eight groups, then U (zeros below the diagonal) into LDS, row-major, for potrf_tail
+__device__ __forceinline__ void potrf_core_mfma(double4_t (&T)[2][2], int* __restrict__ not_pd, double* __restrict__ lds) {
+  const int lane = threadIdx.x & 63, li = lane & 15, lk = lane >> 4;
+  bool ok = true;
+  double* lds_rs = lds + NB * NB;
+  potrf_group4<0>(T, ok, lds_rs);
+  potrf_group4<4>(T, ok, lds_rs);
+  potrf_group4<8>(T, ok, lds_rs);
+  potrf_group4<12>(T, ok, lds_rs);
+  potrf_group4<16>(T, ok, lds_rs);
+  potrf_group4<20>(T, ok, lds_rs);
+  potrf_group4<24>(T, ok, lds_rs);
+  potrf_group4<28>(T, ok, lds_rs);
+  if (!ok && lane == 0) *not_pd = 1;
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int r = 16 * a + 4 * g + lk, c = 16 * b + li;
+        lds[r * NB + c] = (b >= a && c >= r) ? T[a][b][g] : 0.0;
+      }
+}
+
+// The block is handed over IN REGISTERS (C layout, tile (1, 0) ignored; entries outside the kb x kb block and below the
+// diagonal must hold the padding: unit diagonal, zeros) -- for a caller that has just computed it (the look-ahead of a
+// step kernel: no store, fence and reload between the trailing update and the next factorisation).
+__device__ __forceinline__ void potrf_inverse_regs(double4_t (&T)[2][2], double* __restrict__ Fblk, int ldf, int kb,
+                                                   double* __restrict__ uinv, int* __restrict__ not_pd, double* __restrict__ lds) {
+  potrf_core_mfma(T, not_pd, lds);
+  potrf_tail(Fblk, ldf, kb, uinv, lds);
+}
+
 __device__ __forceinline__ void potrf_inverse_block_mfma(const double* __restrict__ Wblk, int ldw, double* __restrict__ Fblk, int ldf,
                                                          int kb, double* __restrict__ uinv, int* __restrict__ not_pd,
                                                          double* __restrict__ lds) {
@@ -254,28 +288,7 @@ __device__ __forceinline__ void potrf_inverse_block_mfma(const double* __restric
         T[a][b][g] = in ? val : ((r == c) ? 1.0 : 0.0);
       }
   T[1][0] = double4_t{0.0, 0.0, 0.0, 0.0};
-  bool ok = true;
-  double* lds_rs = lds + NB * NB;
-  potrf_group4<0>(T, ok, lds_rs);
-  potrf_group4<4>(T, ok, lds_rs);
-  potrf_group4<8>(T, ok, lds_rs);
-  potrf_group4<12>(T, ok, lds_rs);
-  potrf_group4<16>(T, ok, lds_rs);
-  potrf_group4<20>(T, ok, lds_rs);
-  potrf_group4<24>(T, ok, lds_rs);
-  potrf_group4<28>(T, ok, lds_rs);
-  if (!ok && lane == 0) *not_pd = 1;
-  // U (zeros below the diagonal) into LDS, row-major, for the common tail
-#pragma unroll
-  for (int a = 0; a < 2; ++a)
-#pragma unroll
-    for (int b = 0; b < 2; ++b)
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const int r = 16 * a + 4 * g + lk, c = 16 * b + li;
-        lds[r * NB + c] = (b >= a && c >= r) ? T[a][b][g] : 0.0;
-      }
-  potrf_tail(Fblk, ldf, kb, uinv, lds);
+  potrf_inverse_regs(T, Fblk, ldf, kb, uinv, not_pd, lds);
 }
 
 // The routine the factorisations call: the matrix-core variant unless the library is built with -DCX_POTRF_SCALAR (A/B).

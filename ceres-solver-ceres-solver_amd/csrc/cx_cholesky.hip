@@ -70,13 +70,31 @@ __device__ __forceinline__ void store_x(const double4_t (&X)[2][2], double* __re
 // (column n = right-hand side).  It forms X_i and X_j itself (the triangular solve of the panel, redone
 // per tile on the matrix cores instead of a separate step with its own barrier) and subtracts X_i' X_j.
 // Tiles of the first tile row also store X_j: together they write rows k0.. of the factor.
+// keep != nullptr (the look-ahead wavefront): the updated quadrant is also returned in registers, padded for
+// cxchol::potrf_inverse_regs (unit diagonal outside the next diagonal block, zeros below the diagonal).
 __device__ __forceinline__ void fused_tile(double* __restrict__ W, int ldw, double* __restrict__ F, int n, double* __restrict__ y,
-                                           const double* __restrict__ uinv, int k0, int kb, int ti, int tj, bool update) {
+                                           const double* __restrict__ uinv, int k0, int kb, int ti, int tj, bool update,
+                                           double4_t (*keep)[2][2] = nullptr) {
   const int rest = k0 + kb;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int li = lane & 15, lk = lane >> 4;
   const int i0 = rest + ti * 64 + (wave >> 1) * 32;
   const int j0 = rest + tj * 64 + (wave & 1) * 32;
+  // the quadrant this wavefront updates is requested first, so that its latency overlaps the panel's (one memory
+  // round trip instead of two dependent ones)
+  double4_t Wq[2][2];
+  if (update) {
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int i = i0 + a * 16 + lk + 4 * g;
+          const int j = j0 + b * 16 + li;
+          Wq[a][b][g] = (i < n && j <= n && j >= i) ? W[size_t(i) * ldw + j] : 0.0;
+        }
+  }
   double4_t Xj[2][2];
   panel_x(W, ldw, uinv, k0, kb, j0, n, Xj);
   if (ti == 0 && (wave >> 1) == 0) store_x(Xj, F, n, y, k0, kb, j0);
@@ -112,7 +130,12 @@ __device__ __forceinline__ void fused_tile(double* __restrict__ W, int ldw, doub
       for (int g = 0; g < 4; ++g) {
         const int i = i0 + a * 16 + lk + 4 * g;
         const int j = j0 + b * 16 + li;
-        if (i < n && j <= n && j >= i) W[size_t(i) * ldw + j] -= acc[a][b][g];
+        const double nv = Wq[a][b][g] - acc[a][b][g];
+        if (i < n && j <= n && j >= i) W[size_t(i) * ldw + j] = nv;
+        if (keep) {
+          const int kbn = min(NB, n - i0), r = a * 16 + lk + 4 * g, c = b * 16 + li;
+          (*keep)[a][b][g] = (r < kbn && c < kbn && c >= r) ? nv : ((r == c) ? 1.0 : 0.0);
+        }
       }
 }
 
@@ -152,13 +175,14 @@ __global__ __launch_bounds__(256) void k_chol_step(double* __restrict__ W, int l
   int ti = 0, first = 0;
   const int t = blockIdx.x;
   while (t >= first + (Tc - ti)) { first += Tc - ti; ++ti; }
-  fused_tile(W, ldw, F, n, y, ui, k0, kb, ti, ti + (t - first), true);
-  if (t == 0 && threadIdx.x < 64) {
-    // look-ahead: the next diagonal block is the quadrant this very wavefront has just updated, so its own program
-    // order is all the ordering needed (a workgroup-scope fence = wait for its stores; the agent-scope
-    // __threadfence + barrier that stood here cost several us per step for nothing)
-    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
-    potrf_inverse_block(W, ldw, F, n, rest, min(NB, n - rest), uinv + size_t(rest / NB) * NB * NB, not_pd, lds);
+  const bool lookahead = t == 0 && threadIdx.x < 64;
+  double4_t next[2][2];
+  fused_tile(W, ldw, F, n, y, ui, k0, kb, ti, ti + (t - first), true, lookahead ? &next : nullptr);
+  if (lookahead) {
+    // look-ahead: the next diagonal block is the quadrant this very wavefront has just updated -- it goes on to the
+    // factorisation in registers (round 1 stored it, waited for the stores and loaded it again: two dependent memory
+    // round trips of ~2 us each on the critical path of every step)
+    cxchol::potrf_inverse_regs(next, F + size_t(rest) * n + rest, n, min(NB, n - rest), uinv + size_t(rest / NB) * NB * NB, not_pd, lds);
   }
 }
 
