@@ -24,7 +24,9 @@ __device__ __forceinline__ double readlane_f64(double v, int l) {
 
 // Second half of the diagonal-block routines below: U (upper, row-major, zeros below the diagonal) and 1 / diag(U) are in
 // LDS (lds[r * NB + c], lds[NB * NB + j]); store U into the factor and form U^-1 (see potrf_inverse_block).
-__device__ __forceinline__ void potrf_tail(double* __restrict__ Fblk, int ldf, int kb, double* __restrict__ uinv, double* __restrict__ lds) {
+// uinv_lds (optional, NB * NB doubles of LDS outside `lds`): a second copy of the inverse for a caller that goes on to use it.
+__device__ __forceinline__ void potrf_tail(double* __restrict__ Fblk, int ldf, int kb, double* __restrict__ uinv, double* __restrict__ lds,
+                                           double* __restrict__ uinv_lds = nullptr) {
   const int lane = threadIdx.x & 63;
   // (single wavefront: its LDS writes are ordered before its LDS reads, no barrier needed)
   // U into the factor from the LDS copy, two rows per store instruction (all 64 lanes) instead of one
@@ -68,10 +70,17 @@ __device__ __forceinline__ void potrf_tail(double* __restrict__ Fblk, int ldf, i
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
       const int r = lk + 4 * g;
-      uinv[r * NB + li] = Vs[r * 16 + li];
-      uinv[r * NB + 16 + li] = -X[g];
+      const double v11 = Vs[r * 16 + li], v12 = -X[g], v22 = Vs[256 + r * 16 + li];
+      uinv[r * NB + li] = v11;
+      uinv[r * NB + 16 + li] = v12;
       uinv[(16 + r) * NB + li] = 0.0;
-      uinv[(16 + r) * NB + 16 + li] = Vs[256 + r * 16 + li];
+      uinv[(16 + r) * NB + 16 + li] = v22;
+      if (uinv_lds) {
+        uinv_lds[r * NB + li] = v11;
+        uinv_lds[r * NB + 16 + li] = v12;
+        uinv_lds[(16 + r) * NB + li] = 0.0;
+        uinv_lds[(16 + r) * NB + 16 + li] = v22;
+      }
     }
   }
 }
@@ -265,9 +274,10 @@ __device__ __forceinline__ void potrf_core_mfma(double4_t (&T)[2][2], int* __res
 // diagonal must hold the padding: unit diagonal, zeros) -- for a caller that has just computed it (the look-ahead of a
 // step kernel: no store, fence and reload between the trailing update and the next factorisation).
 __device__ __forceinline__ void potrf_inverse_regs(double4_t (&T)[2][2], double* __restrict__ Fblk, int ldf, int kb,
-                                                   double* __restrict__ uinv, int* __restrict__ not_pd, double* __restrict__ lds) {
+                                                   double* __restrict__ uinv, int* __restrict__ not_pd, double* __restrict__ lds,
+                                                   double* __restrict__ uinv_lds = nullptr) {
   potrf_core_mfma(T, not_pd, lds);
-  potrf_tail(Fblk, ldf, kb, uinv, lds);
+  potrf_tail(Fblk, ldf, kb, uinv, lds, uinv_lds);
 }
 
 __device__ __forceinline__ void potrf_inverse_block_mfma(const double* __restrict__ Wblk, int ldw, double* __restrict__ Fblk, int ldf,

@@ -182,34 +182,6 @@ __device__ __forceinline__ void own_stores_visible() {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
-// Level, part 1: the diagonal tiles of the level's tile rows, one wavefront each.  U11 = chol(A11) and its inverse;
-// U12 = U11^-T A12; A22 -= U12' U12; U22 = chol(A22) and its inverse.
-__global__ __launch_bounds__(64) void k_sp_diag(double* __restrict__ W, const int32_t* __restrict__ row_start,
-                                                const int32_t* __restrict__ level_rows, const int32_t* __restrict__ valid,
-                                                double* __restrict__ uinv, int* __restrict__ not_pd) {
-  __shared__ double lds[cxchol::kPotrfLds];
-  const int I = level_rows[blockIdx.x];
-  double* D = W + size_t(row_start[I]) * kTileDoubles;
-  const int kb1 = min(NB, valid[I]), kb2 = max(0, min(NB, valid[I] - NB));
-  double* ui1 = uinv + size_t(2 * I) * NB * NB;
-  cxchol::potrf_inverse_block(D, kTile, D, kTile, kb1, ui1, not_pd, lds);
-  if (kb2 <= 0) return;
-  own_stores_visible();
-  double4_t X[2][2];
-  cxchol::panel_x(D + NB, kTile, ui1, kb1, kb2, X);
-  store_rows(X, D + NB, kb1, kb2);
-  double4_t acc[2][2];
-#pragma unroll
-  for (int a = 0; a < 2; ++a)
-#pragma unroll
-    for (int b = 0; b < 2; ++b) acc[a][b] = double4_t{0.0, 0.0, 0.0, 0.0};
-  mfma_atb(X, X, acc);
-  double* D22 = D + size_t(NB) * kTile + NB;
-  subtract_block(acc, D22, kb2, kb2, true);
-  own_stores_visible();
-  cxchol::potrf_inverse_block(D22, kTile, D22, kTile, kb2, ui1 + NB * NB, not_pd, lds);
-}
-
 // operands of the panel solve X = Uinv' W (cxchol::panel_x) held in registers: A(m, r) = Uinv[r][m], B(r, c) = W[r][c]
 __device__ __forceinline__ void load_aop(const double* __restrict__ uinv, double (&aop)[8][2]) {
   const int lane = threadIdx.x & 63, li = lane & 15, lk = lane >> 4;
@@ -239,6 +211,66 @@ __device__ __forceinline__ void solve_x(const double (&aop)[8][2], const double 
     for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
       for (int nt = 0; nt < 2; ++nt) X[mt][nt] = __builtin_amdgcn_mfma_f64_16x16x4f64(aop[s][mt], bop[s][nt], X[mt][nt], 0, 0, 0);
+}
+
+// Level, part 1: the diagonal tiles of the level's tile rows, one wavefront each.  U11 = chol(A11) and its inverse;
+// U12 = U11^-T A12; A22 -= U12' U12; U22 = chol(A22) and its inverse.  The whole tile is requested up front and the chain
+// runs in registers (the 32 x 32 routine takes and leaves its block in the MFMA C layout, U11^-1 stays in LDS for the
+// panel product): one memory round trip instead of the four of a store / wait / reload between the stages (27 -> ... us).
+__global__ __launch_bounds__(64) void k_sp_diag(double* __restrict__ W, const int32_t* __restrict__ row_start,
+                                                const int32_t* __restrict__ level_rows, const int32_t* __restrict__ valid,
+                                                double* __restrict__ uinv, int* __restrict__ not_pd) {
+  __shared__ double lds[cxchol::kPotrfLds];
+  __shared__ double inv1[NB * NB];
+  const int I = level_rows[blockIdx.x];
+  double* D = W + size_t(row_start[I]) * kTileDoubles;
+  const int kb1 = min(NB, valid[I]), kb2 = max(0, min(NB, valid[I] - NB));
+  double* ui1 = uinv + size_t(2 * I) * NB * NB;
+  const int lane = threadIdx.x & 63, li = lane & 15, lk = lane >> 4;
+  // A11 and A22 in the C layout, padded (unit diagonal outside the valid block, zeros below the diagonal); A12 as the
+  // B operand of the panel product
+  double4_t T1[2][2], T2[2][2];
+  double a12[8][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = a; b < 2; ++b)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int r = 16 * a + 4 * g + lk, c = 16 * b + li;
+        const double v1 = D[size_t(min(r, kb1 - 1)) * kTile + min(c, kb1 - 1)];
+        T1[a][b][g] = (r < kb1 && c < kb1 && c >= r) ? v1 : ((r == c) ? 1.0 : 0.0);
+        const int k2 = max(kb2, 1);
+        const double v2 = D[size_t(NB + min(r, k2 - 1)) * kTile + NB + min(c, k2 - 1)];
+        T2[a][b][g] = (r < kb2 && c < kb2 && c >= r) ? v2 : ((r == c) ? 1.0 : 0.0);
+      }
+  T1[1][0] = double4_t{0.0, 0.0, 0.0, 0.0};
+  T2[1][0] = double4_t{0.0, 0.0, 0.0, 0.0};
+  load_bop(D + NB, kb1, kb2, a12);
+  cxchol::potrf_inverse_regs(T1, D, kTile, kb1, ui1, not_pd, lds, inv1);
+  if (kb2 <= 0) return;
+  double a1[8][2];
+  load_aop(inv1, a1);  // this wavefront's own LDS writes: ordered before its LDS reads
+  double4_t X[2][2];
+  solve_x(a1, a12, X);
+  store_rows(X, D + NB, kb1, kb2);
+  double4_t acc[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b) acc[a][b] = double4_t{0.0, 0.0, 0.0, 0.0};
+  mfma_atb(X, X, acc);
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = a; b < 2; ++b)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int r = 16 * a + 4 * g + lk, c = 16 * b + li;
+        if (r < kb2 && c < kb2 && c >= r) T2[a][b][g] -= acc[a][b][g];
+      }
+  double* D22 = D + size_t(NB) * kTile + NB;
+  cxchol::potrf_inverse_regs(T2, D22, kTile, kb2, ui1 + NB * NB, not_pd, lds);
 }
 
 // Level, part 2: the other tiles of those rows become rows of the factor, F(I, J) = U_II^-T W(I, J), in place:
