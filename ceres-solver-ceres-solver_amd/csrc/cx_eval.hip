@@ -224,16 +224,18 @@ __device__ __forceinline__ void snavely_jet(const double* camv, const double* pt
   for (int i = 0; i < 3; ++i) { jp[i] = px.v[9 + i]; jp[3 + i] = py.v[9 + i]; }
 }
 
-// The same residual and Jacobian cells in closed form (round 2).  The dual-number path above is 13 x the scalar work
-// (~1 900 fp64 instructions per wavefront: the kernel was bound by fp64 issue, 0.43 of the HBM peak); differentiating by
-// hand block by block costs ~250 flops per residual block:
+// The same residual and Jacobian cells in closed form (round 2, an experiment: build with -DCX_EVAL_CLOSED_FORM).  The
+// dual-number path above is 13 x the scalar work (1 891 fp64 instructions in the kernel's ISA against 1 380 with this
+// form, most of the rest being sin / cos), and the kernel sits at 0.43 of the HBM peak with no excess traffic, so fp64
+// issue was the suspect.  It is not: this form ran 2.03 ms against 1.93-2.05 ms for the dual numbers on the Final shape
+// (same box, all 255 parity tests green with either).  The default therefore stays with the arithmetic that follows the
+// reference's autodiff operation by operation.  Differentiating by hand block by block:
 //   p = R(w) X + t;  dp/dX = R = c I + s [k]x + (1 - c) k k',  k = w / |w|;
 //   dp/dw = -[R X]x J_l(w),  J_l = (s / th) I + ((1 - c) / th) [k]x + (1 - s / th) k k'   (left Jacobian of SO(3));
 //   |w| = 0 exactly (the reference's first-order branch, rotation.h:836-856): R X = X + w x X, dp/dw = -[X]x, dp/dX = I + [w]x;
 //   (xp, yp) = -(p0, p1) / p2;  r = f d (xp, yp) - obs,  d = 1 + r2 (k1 + k2 r2);  chain rule through the 2 x 2 and 2 x 3 blocks.
 // Same function, other rounding: against the oracle's dual numbers 3e-14 relative for |w| ~ 1, 1e-13 at 1e-3, 1e-16 / |w|
 // below (the dual numbers divide by |w| where this form has no cancellation) -- inside the 1e-11 the parity tests state.
-// -DCX_EVAL_JETS builds the dual-number path instead (A/B).
 __device__ __forceinline__ void snavely_closed_form(const double* cam, const double* X, double ox, double oy, double& r0, double& r1,
                                                     double (&jc)[18], double (&jp)[6]) {
   const double w0 = cam[0], w1 = cam[1], w2 = cam[2];
@@ -420,10 +422,10 @@ __global__ __launch_bounds__(kBlock) void k_bal_evaluate(const double* __restric
     for (int i = 0; i < 3; ++i) pt[i] = pp[i];
     const double2 o = reinterpret_cast<const double2*>(obs)[r];
     if constexpr (MODEL == CX_CAMERA_ANGLE_AXIS) {
-#ifdef CX_EVAL_JETS
-      if (WITH_J) snavely_jet(cam, pt, o.x, o.y, res0, res1, jc, jp);
-#else
+#ifdef CX_EVAL_CLOSED_FORM
       if (WITH_J) snavely_closed_form(cam, pt, o.x, o.y, res0, res1, jc, jp);
+#else
+      if (WITH_J) snavely_jet(cam, pt, o.x, o.y, res0, res1, jc, jp);
 #endif
       else snavely_value(cam, pt, o.x, o.y, res0, res1);
     } else {
