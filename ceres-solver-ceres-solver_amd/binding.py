@@ -38,7 +38,7 @@ EXPORTED_SYMBOLS = [
     "cx_implicit_schur_multiply", "cx_dense_cholesky_solve", "cx_evaluator_create_bal", "cx_evaluator_destroy",
     "cx_evaluator_jacobian", "cx_evaluator_row_of_observation", "cx_evaluator_evaluate", "cx_evaluator_set_loss", "cx_minimizer_default_options", "cx_minimize", "cx_schur_sparse_structure", "cx_visibility_structure", "cx_visibility_clusters_host",
     "cx_evaluator_set_camera_model", "cx_evaluator_num_parameters", "cx_evaluator_num_effective_parameters", "cx_evaluator_plus",
-    "cx_evaluator_last_kernel_ms", "cx_evaluator_device_residuals", "cx_evaluator_set_emit_camera_major", "cx_detect_structure", "cx_partition_points", "cx_stable_schur_ordering",
+    "cx_evaluator_last_kernel_ms", "cx_evaluator_device_residuals", "cx_evaluator_set_emit_camera_major", "cx_sparse_cholesky_plan_host", "cx_detect_structure", "cx_partition_points", "cx_stable_schur_ordering",
 ]
 
 
@@ -591,6 +591,27 @@ def minimize(evaluator, solver, state, options=None, max_summaries=None):
                                its, cap))
     n = min(cap, summ.num_iterations)
     return out, _summary_dict(summ), [_summary_dict(its[i]) for i in range(n)]
+
+
+def sparse_cholesky_plan_host(num_cameras, cell_row, cell_col):
+    """Host half of the tile-sparse Cholesky plan (no device): dict with camera_first_row, num_tile_rows, num_levels,
+    num_tiles, num_tile_pair_updates, tile_row_level, tile_row_start, tile_cols."""
+    lib = load_library()
+    r = np.ascontiguousarray(cell_row, dtype=np.int32)
+    c = np.ascontiguousarray(cell_col, dtype=np.int32)
+    T, L = ctypes.c_int32(), ctypes.c_int32()
+    nt, npairs = ctypes.c_int64(), ctypes.c_int64()
+    first = np.zeros(num_cameras, dtype=np.int32)
+    _check(lib.cx_sparse_cholesky_plan_host(int(num_cameras), _ptr(r), _ptr(c), ctypes.c_int64(r.size), _ptr(first), ctypes.byref(T),
+                                            ctypes.byref(L), ctypes.byref(nt), ctypes.byref(npairs), None, None, 0, None, ctypes.c_int64(0)))
+    level = np.zeros(T.value, dtype=np.int32)
+    start = np.zeros(T.value + 1, dtype=np.int32)
+    cols = np.zeros(nt.value, dtype=np.int32)
+    _check(lib.cx_sparse_cholesky_plan_host(int(num_cameras), _ptr(r), _ptr(c), ctypes.c_int64(r.size), _ptr(first), ctypes.byref(T),
+                                            ctypes.byref(L), ctypes.byref(nt), ctypes.byref(npairs), _ptr(level), _ptr(start), T.value,
+                                            _ptr(cols), ctypes.c_int64(nt.value)))
+    return dict(camera_first_row=first, num_tile_rows=T.value, num_levels=L.value, num_tiles=nt.value,
+                num_tile_pair_updates=npairs.value, tile_row_level=level, tile_row_start=start, tile_cols=cols)
 
 
 def schur_sparse_structure(A):

@@ -812,10 +812,18 @@ void TileStructure(const int32_t* cell_c1, const int32_t* cell_c2, int64_t num_c
 
 }  // namespace
 
-int cxsp_plan_from_cells(cx_context* ctx, int C, const int32_t* cell_c1, const int32_t* cell_c2, int64_t num_cells, cx_sp_plan* P) {
-  if (P->state != 0) return CX_OK;
-  P->C = C;
-  const int n = 9 * C;
+namespace {
+// Everything of the plan that needs no device: layout, tile structure after fill, level schedule, update lists.
+struct HostPlan {
+  PaddedLayout layout;
+  std::vector<int32_t> row_start, row_tiles, height, level_rows, lrb, lpb, ltb, panel_row, panel_pool;
+  std::vector<int32_t> tgt_pool, tgt_flags, src_begin, src_a, src_b, col_start, col_pool;
+  int T = 0, L = 0;
+  int64_t num_tiles = 0;
+  bool fits = true;
+};
+
+void BuildHostPlan(int C, const int32_t* cell_c1, const int32_t* cell_c2, int64_t num_cells, HostPlan* H) {
   std::vector<std::vector<int32_t>> adj(static_cast<size_t>(C));
   for (int64_t k = 0; k < num_cells; ++k) {
     const int c1 = cell_c1[k], c2 = cell_c2[k];
@@ -823,8 +831,9 @@ int cxsp_plan_from_cells(cx_context* ctx, int C, const int32_t* cell_c1, const i
   }
   const char* ordering_env = std::getenv("CX_SPARSE_ORDERING");
   const bool band_ordering = ordering_env != nullptr && std::string(ordering_env) == "rcm";
-  PaddedLayout layout;
-  std::vector<int32_t> row_start, row_tiles;
+  PaddedLayout& layout = H->layout;
+  std::vector<int32_t>& row_start = H->row_start;
+  std::vector<int32_t>& row_tiles = H->row_tiles;
   if (band_ordering) {
     // round 1's orderings: one band (reverse Cuthill-McKee), optionally minimum degree on groups of 64 cameras,
     // whichever leaves fewer tiles after fill; one piece, no padding, the tile elimination tree is (close to) a chain
@@ -851,13 +860,15 @@ int cxsp_plan_from_cells(cx_context* ctx, int C, const int32_t* cell_c1, const i
   }
   const int T = layout.T;
   const int64_t num_tiles = int64_t(row_tiles.size());
+  H->T = T;
+  H->num_tiles = num_tiles;
   // one pool, factored in place: refuse structures that would not fit comfortably
-  if (double(num_tiles) * kTileDoubles * 8.0 > 160e9) { P->state = 2; return CX_OK; }
-  hipStream_t st = ctx->stream;
+  if (double(num_tiles) * kTileDoubles * 8.0 > 160e9) { H->fits = false; return; }
   // Level schedule: the elimination tree of the TILE rows (parent = first tile right of the diagonal), tile rows
   // grouped by height; per level the diagonal tiles, the panel tiles and, for every tile that a row of the level
   // updates, its sources (pool indices of F(I, Ja), F(I, Jb)) in ascending I.
-  std::vector<int32_t> height(static_cast<size_t>(T), 0);
+  std::vector<int32_t>& height = H->height;
+  height.assign(static_cast<size_t>(T), 0);
   int max_h = 0;
   for (int I = 0; I < T; ++I) {  // children have smaller indices: one ascending sweep pushes heights up
     const int32_t q = row_start[size_t(I)] + 1;
@@ -866,15 +877,20 @@ int cxsp_plan_from_cells(cx_context* ctx, int C, const int32_t* cell_c1, const i
     max_h = std::max(max_h, height[size_t(I)]);
   }
   const int L = T > 0 ? max_h + 1 : 0;
-  std::vector<int32_t> lrb(size_t(L) + 1, 0), lpb(size_t(L) + 1, 0), ltb(size_t(L) + 1, 0);
+  H->L = L;
+  std::vector<int32_t>&lrb = H->lrb, &lpb = H->lpb, &ltb = H->ltb;
+  lrb.assign(size_t(L) + 1, 0);
+  lpb.assign(size_t(L) + 1, 0);
+  ltb.assign(size_t(L) + 1, 0);
   for (int I = 0; I < T; ++I) lrb[size_t(height[size_t(I)]) + 1]++;
   for (int l = 0; l < L; ++l) lrb[size_t(l) + 1] += lrb[size_t(l)];
-  std::vector<int32_t> level_rows(static_cast<size_t>(T));
+  std::vector<int32_t>& level_rows = H->level_rows;
+  level_rows.assign(static_cast<size_t>(T), 0);
   {
     std::vector<int32_t> cur(lrb.begin(), lrb.end() - 1);
     for (int I = 0; I < T; ++I) level_rows[size_t(cur[size_t(height[size_t(I)])]++)] = I;
   }
-  std::vector<int32_t> panel_row, panel_pool;
+  std::vector<int32_t>&panel_row = H->panel_row, &panel_pool = H->panel_pool;
   struct Src { int32_t level, tgt, row, qa, qb; };
   std::vector<Src> srcs;
   for (int l = 0; l < L; ++l) {
@@ -898,7 +914,9 @@ int cxsp_plan_from_cells(cx_context* ctx, int C, const int32_t* cell_c1, const i
   std::sort(srcs.begin(), srcs.end(), [](const Src& x, const Src& y) {
     return x.level != y.level ? x.level < y.level : (x.tgt != y.tgt ? x.tgt < y.tgt : x.row < y.row);
   });
-  std::vector<int32_t> tgt_pool, tgt_flags, src_begin, src_a(srcs.size()), src_b(srcs.size());
+  std::vector<int32_t>&tgt_pool = H->tgt_pool, &tgt_flags = H->tgt_flags, &src_begin = H->src_begin, &src_a = H->src_a, &src_b = H->src_b;
+  src_a.assign(srcs.size(), 0);
+  src_b.assign(srcs.size(), 0);
   {
     int level = 0;
     for (size_t i = 0; i < srcs.size(); ++i) {
@@ -919,7 +937,8 @@ int cxsp_plan_from_cells(cx_context* ctx, int C, const int32_t* cell_c1, const i
     src_begin.push_back(int32_t(srcs.size()));
   }
   // transposed index for forward solves with the stored factor: the tiles (K < I, I) of tile column I, ascending K
-  std::vector<int32_t> col_start(size_t(T) + 1, 0), col_pool;
+  std::vector<int32_t>&col_start = H->col_start, &col_pool = H->col_pool;
+  col_start.assign(size_t(T) + 1, 0);
   {
     for (int K = 0; K < T; ++K)
       for (int32_t q = row_start[size_t(K)] + 1; q < row_start[size_t(K) + 1] - 1; ++q) col_start[size_t(row_tiles[size_t(q)]) + 1]++;
@@ -929,6 +948,23 @@ int cxsp_plan_from_cells(cx_context* ctx, int C, const int32_t* cell_c1, const i
     for (int K = 0; K < T; ++K)
       for (int32_t q = row_start[size_t(K)] + 1; q < row_start[size_t(K) + 1] - 1; ++q) col_pool[size_t(cur[size_t(row_tiles[size_t(q)])]++)] = q;
   }
+}
+}  // namespace
+
+int cxsp_plan_from_cells(cx_context* ctx, int C, const int32_t* cell_c1, const int32_t* cell_c2, int64_t num_cells, cx_sp_plan* P) {
+  if (P->state != 0) return CX_OK;
+  P->C = C;
+  const int n = 9 * C;
+  HostPlan H;
+  BuildHostPlan(C, cell_c1, cell_c2, num_cells, &H);
+  if (!H.fits) { P->state = 2; return CX_OK; }
+  hipStream_t st = ctx->stream;
+  const int T = H.T, L = H.L;
+  const int64_t num_tiles = H.num_tiles;
+  const PaddedLayout& layout = H.layout;
+  const std::vector<int32_t>&row_start = H.row_start, &row_tiles = H.row_tiles, &level_rows = H.level_rows, &panel_row = H.panel_row,
+      &panel_pool = H.panel_pool, &tgt_pool = H.tgt_pool, &tgt_flags = H.tgt_flags, &src_begin = H.src_begin, &src_a = H.src_a,
+      &src_b = H.src_b, &col_start = H.col_start, &col_pool = H.col_pool, &lrb = H.lrb, &lpb = H.lpb, &ltb = H.ltb;
   CX_TRY(P->d_cam_pos.upload(layout.cam_row, st));
   CX_TRY(P->d_valid.upload(layout.valid, st));
   CX_TRY(P->d_row_start.upload(row_start, st));
@@ -953,7 +989,7 @@ int cxsp_plan_from_cells(cx_context* ctx, int C, const int32_t* cell_c1, const i
   if (std::getenv("CX_SPARSE_CHOLESKY_VERBOSE"))
     std::fprintf(stderr, "[cxschur] tile-sparse Cholesky plan: %d cameras, %d tile rows (%d rows of padding) in %d levels, %lld tiles (%.2f GB, "
                  "dense would be %.2f GB), %zu tile-pair updates on %zu (level, target) pairs\n", C, T, kTile * T - n, L, (long long)num_tiles,
-                 double(num_tiles) * kTileDoubles * 8e-9, double(n) * n * 8e-9, srcs.size(), tgt_pool.size());
+                 double(num_tiles) * kTileDoubles * 8e-9, double(n) * n * 8e-9, src_a.size(), tgt_pool.size());
   return CX_OK;
 }
 
@@ -1095,5 +1131,33 @@ int cxsp_factor_and_solve(cx_matrix* A, const double* Df, const double* rhs, dou
   CX_TRY(BackwardSweep(ctx, P, sc, 0));
   hipLaunchKernelGGL(k_sp_unpermute, dim3((n + 255) / 256), dim3(256), 0, st, (const double*)sc.xp, (const int32_t*)P->d_cam_pos.p, z, C);
   CX_HIP(hipGetLastError());
+  return CX_OK;
+}
+
+// Host half of the plan on its own (no device): the CPU test suite checks the layout, the symbolic fill and the level
+// schedule through this entry point.
+extern "C" int cx_sparse_cholesky_plan_host(int32_t num_cameras, const int32_t* cell_row, const int32_t* cell_col, int64_t num_cells,
+                                            int32_t* camera_first_row, int32_t* num_tile_rows, int32_t* num_levels,
+                                            int64_t* num_tiles, int64_t* num_tile_pair_updates, int32_t* tile_row_level,
+                                            int32_t* tile_row_start, int32_t capacity_rows, int32_t* tile_cols,
+                                            int64_t capacity_tiles) {
+  CX_CHECK_ARG(num_cameras > 0 && cell_row && cell_col && num_cells >= num_cameras && num_tile_rows && num_levels && num_tiles &&
+               num_tile_pair_updates);
+  for (int64_t k = 0; k < num_cells; ++k)
+    CX_CHECK_ARG(cell_row[k] >= 0 && cell_row[k] <= cell_col[k] && cell_col[k] < num_cameras);
+  HostPlan H;
+  BuildHostPlan(num_cameras, cell_row, cell_col, num_cells, &H);
+  *num_tile_rows = H.T;
+  *num_levels = H.L;
+  *num_tiles = H.num_tiles;
+  *num_tile_pair_updates = int64_t(H.src_a.size());
+  if (!H.fits) {
+    cx_set_error("the tile-sparse Cholesky of this structure would need more than 160 GB");
+    return CX_ERR_UNSUPPORTED;
+  }
+  if (camera_first_row) std::copy(H.layout.cam_row.begin(), H.layout.cam_row.end(), camera_first_row);
+  if (tile_row_level && capacity_rows >= H.T) std::copy(H.height.begin(), H.height.end(), tile_row_level);
+  if (tile_row_start && capacity_rows >= H.T) std::copy(H.row_start.begin(), H.row_start.end(), tile_row_start);
+  if (tile_cols && capacity_tiles >= H.num_tiles) std::copy(H.row_tiles.begin(), H.row_tiles.end(), tile_cols);
   return CX_OK;
 }

@@ -462,6 +462,18 @@ int cx_detect_structure(const cx_block_structure* bs, int32_t num_eliminate_bloc
 int cx_stable_schur_ordering(int32_t num_cameras, int32_t num_points, int64_t num_observations,
                              const int32_t* camera_index, const int32_t* point_index,
                              int32_t* ordering, int32_t* independent_set_size);
+/* Host half of the plan of the tile-sparse Cholesky that stands in for SuiteSparse in SPARSE_SCHUR
+ * (schur_complement_solver.cc:292-335, suitesparse.cc:218-279, 397-469) -- no device needed.  Input: the upper cells
+ * (cell_row <= cell_col, every diagonal cell present) of a symmetric matrix of num_cameras 9x9 blocks, e.g. the
+ * InitStorage cell list (cx_schur_sparse_structure).  Output: the padded nested-dissection layout (first scalar row of
+ * every camera; pieces start at multiples of 64 rows), the number of 64-row tile rows, of levels of the tile elimination
+ * tree, of tiles after symbolic fill and of tile-pair updates; per tile row its level and its list of column tiles
+ * (tile_row_start[num_tile_rows + 1] into tile_cols; every list is closed by the pseudo tile `num_tile_rows` that
+ * carries the right-hand side).  Arrays may be NULL; they are filled when their capacity suffices. */
+int cx_sparse_cholesky_plan_host(int32_t num_cameras, const int32_t* cell_row, const int32_t* cell_col, int64_t num_cells,
+                                 int32_t* camera_first_row, int32_t* num_tile_rows, int32_t* num_levels, int64_t* num_tiles,
+                                 int64_t* num_tile_pair_updates, int32_t* tile_row_level, int32_t* tile_row_start,
+                                 int32_t capacity_rows, int32_t* tile_cols, int64_t capacity_tiles);
 /* Partition the first num_eliminate_blocks column blocks (points) into nranks
  * contiguous ranges holding about equal numbers of non-zeros -- the balancing
  * PartitionRangeForParallelFor does on cumulative_nnz

@@ -132,3 +132,55 @@ def test_visibility_clusters_host_fuzz(oracle, seed):
             m, k, cp = cx.binding.visibility_clusters_host(bs, P, getattr(cx, pre), getattr(cx, clustering))
             mr, kr, cpr, _ = oracle.visibility_structure(bs, P, getattr(oracle, pre), getattr(oracle, clustering))
             assert k == kr and np.array_equal(m, mr) and np.array_equal(cp, cpr), (seed, pre, clustering)
+
+
+def _plan_checks(oracle, C, P, O, seed):
+    """Host half of the tile-sparse Cholesky plan (no device) on the InitStorage cell list of a synthetic scene."""
+    prob = cx.bal.make_bal_like(C, P, O, seed)
+    bs, _ = cx.bal.build_structure(prob)
+    r, c = oracle.schur_sparse_structure(bs, P)
+    plan = cx.binding.sparse_cholesky_plan_host(C, r, c)
+    T, first = plan["num_tile_rows"], plan["camera_first_row"]
+    # layout: every camera owns 9 rows of its own inside the padded range
+    rows = (first[:, None] + np.arange(9)[None, :]).ravel()
+    assert rows.min() >= 0 and rows.max() < 64 * T and np.unique(rows).size == 9 * C
+    # symbolic fill, recomputed with dense booleans at tile level
+    nz = np.zeros((T, T), dtype=bool)
+    for c1, c2 in zip(r, c):
+        a, b = sorted((first[c1], first[c2]))
+        nz[np.ix_(np.arange(a >> 6, ((a + 8) >> 6) + 1), np.arange(b >> 6, ((b + 8) >> 6) + 1))] = True
+    nz = np.triu(nz | nz.T) | np.eye(T, dtype=bool)
+    for k in range(T):
+        later = np.nonzero(nz[k, k + 1:])[0] + k + 1
+        nz[np.ix_(later, later)] |= later[:, None] <= later[None, :]
+    start, cols, level = plan["tile_row_start"], plan["tile_cols"], plan["tile_row_level"]
+    assert start[-1] == plan["num_tiles"] == cols.size
+    pairs = 0
+    for i in range(T):
+        lst = cols[start[i]:start[i + 1]]
+        assert lst[-1] == T                                     # the right-hand-side tile closes every row
+        assert np.array_equal(lst[:-1], np.nonzero(nz[i])[0])   # diagonal first, then the filled row, ascending
+        m = lst.size - 1                                        # real tiles incl. the diagonal
+        pairs += (m - 1) * m // 2 + (m - 1)                      # (Ja <= Jb) right of the diagonal + the right-hand side column
+        # a tile row is factored after every row that updates it
+        for j in lst[1:-1]:
+            assert level[j] > level[i]
+    assert pairs == plan["num_tile_pair_updates"]
+    assert plan["num_levels"] == level.max() + 1
+    again = cx.binding.sparse_cholesky_plan_host(C, r, c)
+    assert np.array_equal(again["camera_first_row"], first) and np.array_equal(again["tile_cols"], cols)
+    return plan
+
+
+@pytest.mark.parametrize("C,P,O,seed", [(6, 40, 130, 1), (49, 7776, 31843, 49), (400, 9000, 40000, 4)])
+def test_sparse_cholesky_plan_host(oracle, C, P, O, seed):
+    _plan_checks(oracle, C, P, O, seed)
+
+
+def test_sparse_cholesky_plan_host_dissects_a_long_scene(oracle):
+    """3 000 cameras on the generator's ring with a narrow visibility window: the dissection must find independent subtrees
+    (levels well below the number of tile rows) without blowing up the fill."""
+    plan = _plan_checks(oracle, 3000, 60000, 260000, 5)
+    T = plan["num_tile_rows"]
+    assert T >= 3000 * 9 // 64
+    assert plan["num_levels"] < T // 2, (plan["num_levels"], T)
