@@ -469,13 +469,33 @@ __global__ __launch_bounds__(kBlock) void k_bal_evaluate(const double* __restric
   }
 }
 
-// deterministic final sum of the per-workgroup cost partials
-__global__ __launch_bounds__(256) void k_sum_partials(const double* __restrict__ partial, int64_t n, double* __restrict__ out) {
+// deterministic sum of the per-workgroup cost partials, two stages: 256 workgroups add contiguous slices (each in a
+// fixed order), the last of them to finish -- told by an agent-scope ticket -- adds the 256 slice sums in index order.
+// (One workgroup walking 113 k partials alone took 183 us per evaluation on the Final shape.)
+__global__ __launch_bounds__(256) void k_sum_partials(const double* __restrict__ partial, int64_t n, double* __restrict__ slice_sum,
+                                                      unsigned* __restrict__ ticket, double* __restrict__ out) {
   __shared__ double red[4];
+  __shared__ int is_last;
+  const int64_t per = (n + gridDim.x - 1) / gridDim.x;
+  const int64_t lo = per * blockIdx.x, hi = min(n, lo + per);
   double s[1] = {0.0};
-  for (int64_t i = threadIdx.x; i < n; i += 256) s[0] += partial[i];
+  for (int64_t i = lo + threadIdx.x; i < hi; i += 256) s[0] += partial[i];
   block_sum<1>(s, red);
-  if (threadIdx.x == 0) *out = s[0];
+  if (threadIdx.x == 0) {
+    __hip_atomic_store(&slice_sum[blockIdx.x], s[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the slice sum is complete before the ticket is drawn (cx_solver.hip: dot2_finish)
+    const unsigned t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    is_last = (t == gridDim.x - 1) ? 1 : 0;
+  }
+  __syncthreads();
+  if (!is_last) return;
+  double v[1] = {0.0};
+  for (int i = threadIdx.x; i < int(gridDim.x); i += 256) v[0] += __hip_atomic_load(&slice_sum[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  block_sum<1>(v, red);
+  if (threadIdx.x == 0) {
+    *out = v[0];
+    __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
 }
 
 // Evaluator::Plus (program_evaluator.h:306-320): out = x + sign * delta on Euclidean blocks ...
@@ -570,7 +590,8 @@ int cx_evaluator_create_bal(cx_context* ctx, int32_t C, int32_t P, int64_t O, co
     rc = CX_ERR_UNSUPPORTED;
   }
   if (rc == CX_OK) rc = e->d_obs.upload(obs_rows, ctx->stream);
-  if (rc == CX_OK) rc = e->d_partial.alloc(size_t((O + kBlock - 1) / kBlock) + 1);
+  if (rc == CX_OK) rc = e->d_partial.alloc(size_t((O + kBlock - 1) / kBlock) + 1 + 256 + 1);
+  if (rc == CX_OK && hipMemset(e->d_partial.p, 0, e->d_partial.n * sizeof(double)) != hipSuccess) rc = CX_ERR_HIP;
   if (rc != CX_OK) {
     if (e->J) cx_matrix_destroy(e->J);
     delete e;
@@ -645,7 +666,12 @@ int cx_evaluator_evaluate(cx_evaluator* e, const double* state, double* cost, do
     else CX_LAUNCH_EVAL(false, CX_CAMERA_QUATERNION_MANIFOLD);
   }
 #undef CX_LAUNCH_EVAL
-  if (cost) hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(256), 0, st, (const double*)e->d_partial.p, int64_t(grid), e->d_partial.p + grid);
+  if (cost) {
+    // layout of d_partial: [grid] per-workgroup costs | total | [256] slice sums | ticket (kept zero between launches)
+    const int slices = std::min(256, grid);
+    hipLaunchKernelGGL(k_sum_partials, dim3(slices), dim3(256), 0, st, (const double*)e->d_partial.p, int64_t(grid),
+                       e->d_partial.p + grid + 1, reinterpret_cast<unsigned*>(e->d_partial.p + grid + 1 + 256), e->d_partial.p + grid);
+  }
   CX_HIP(hipGetLastError());
   CX_HIP(hipEventRecord(ctx->ev[7], st));
   if (with_j) { A->ft_valid = ft_out != nullptr; A->f32_valid = false; }
