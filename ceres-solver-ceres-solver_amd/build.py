@@ -14,6 +14,11 @@ FLAGS = ["-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-Wall", "-Wno-u
     os.environ.get("CX_EXTRA_HIPCC_FLAGS", "").split()   # e.g. -DCX_POTRF_SCALAR for an A/B build
 
 
+# cx_eval.hip: the persistent evaluator loop must not have the literal constants of its sin / cos / exp expansions
+# hoisted into (and spilled from) vector registers
+PER_FILE_FLAGS = {"cx_eval.hip": ["-mllvm", "-disable-machine-licm"]}
+
+
 def _stale(target, deps):
     if not os.path.exists(target):
         return True
@@ -31,7 +36,7 @@ def build_library(force=False, verbose=False):
         o = os.path.join(CSRC, os.path.splitext(src)[0] + ".o")
         objs.append(o)
         if force or _stale(o, [s] + hdrs):
-            cmd = [HIPCC] + FLAGS + ["-x", "hip", "-c", s, "-o", o]
+            cmd = [HIPCC] + FLAGS + PER_FILE_FLAGS.get(src, []) + ["-x", "hip", "-c", s, "-o", o]
             if verbose:
                 print(" ".join(cmd), flush=True)
             procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))

@@ -5,23 +5,24 @@
 // A (n x n, row-major, upper triangle valid) = U'U, blocked right-looking with 32-wide panels on a
 // working copy W that carries the right-hand side as column n (so the forward substitution happens
 // inside the factorisation).  The factorisation is a chain of n / 32 dependent steps, each far too
-// short to amortise several kernel launches (~12 us per dependent launch on this part), so a step is
-// ONE launch, k_chol_step:
+// short to amortise several kernel launches (a dependent kernel boundary costs 1.5-1.9 us and every launch
+// re-reads its operands from L2/HBM), so a step is ONE launch, k_chol_step:
 //   * every workgroup owns a 64x64 tile of the trailing matrix (32x32 per wavefront) and first forms
 //     the panel rows it needs itself, X = U_kk^-T W(k, .), as an MFMA product with the explicit
 //     inverse of the 32x32 diagonal block (v_mfma_f64_16x16x4_f64; the result registers are already
 //     in the operand layout of the next product), then subtracts X_i' X_j -- the one genuinely
 //     dense, MFMA-bound piece;
 //   * tiles of the first tile row store X: together they write rows k.. of the factor;
-//   * the workgroup of tile (0,0) goes on to factor and invert the next diagonal block (look-ahead).
+//   * the workgroup of tile (0,0) goes on to factor and invert the next diagonal block (look-ahead): its updated
+//     quadrant stays in registers and feeds the MFMA potrf (cxchol::potrf_inverse_regs) directly.
 // Backward substitution follows, one launch per two blocks (k_trsv_bwd64).
 //
 // Measured alternatives (n = 3204, Dubrovnik-356): five kernels per step (potrf, per-column trsm,
 // syrk, blocked forward/backward substitution) 8.2 ms; the whole solve as one cooperative kernel with
 // grid barriers 10.2 ms (one workgroup per CU cannot hide the memory latency of its tiles after every
-// barrier's L2 invalidation); this file 3.3 ms (2.9 ms factor + 0.4 ms backward substitution; 4.6 ms while an
+// barrier's L2 invalidation); this file 2.3 ms (2.0 ms factor + 0.3 ms backward substitution; 4.6 ms while an
 // agent-scope fence and a barrier stood in front of the look-ahead and the backward substitution took one launch
-// per 32-row block).
+// per 32-row block; 2.9 ms with the scalar diagonal-block kernel and a store/reload between update and look-ahead).
 #include <cstdlib>
 
 #include "cx_chol_blocks.h"

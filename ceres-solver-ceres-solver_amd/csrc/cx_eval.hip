@@ -224,11 +224,11 @@ __device__ __forceinline__ void snavely_jet(const double* camv, const double* pt
   for (int i = 0; i < 3; ++i) { jp[i] = px.v[9 + i]; jp[3 + i] = py.v[9 + i]; }
 }
 
-// The same residual and Jacobian cells in closed form (round 2, an experiment: build with -DCX_EVAL_CLOSED_FORM).  The
-// dual-number path above is 13 x the scalar work (1 891 fp64 instructions in the kernel's ISA against 1 380 with this
-// form, most of the rest being sin / cos), and the kernel sits at 0.43 of the HBM peak with no excess traffic, so fp64
-// issue was the suspect.  It is not: this form ran 2.03 ms against 1.93-2.05 ms for the dual numbers on the Final shape
-// (same box, all 255 parity tests green with either).  The default therefore stays with the arithmetic that follows the
+// The same residual and Jacobian cells in closed form (round 2; the default with the Jacobian, CX_EVAL_VARIANT=1 selects the
+// dual numbers above).  The dual-number path is 13 x the scalar work (1 891 fp64 instructions in the kernel's ISA against
+// 1 380 with this form, most of the rest being sin / cos) and needs 172 VGPRs inside the pipelined loop of k_bal_evaluate
+// against 133: three workgroups per CU instead of two, 1.55 against 1.91 ms on the Final shape (in round 1's one-tile kernel,
+// bound by its gathers, the two ran the same 2.0 ms).  All parity tests are green with either; the dual numbers follow the
 // reference's autodiff operation by operation.  Differentiating by hand block by block:
 //   p = R(w) X + t;  dp/dX = R = c I + s [k]x + (1 - c) k k',  k = w / |w|;
 //   dp/dw = -[R X]x J_l(w),  J_l = (s / th) I + ((1 - c) / th) [k]x + (1 - s / th) k k'   (left Jacobian of SO(3));
@@ -390,82 +390,189 @@ __device__ __forceinline__ void snavely_jet_quat(const double* camv, const doubl
   for (int i = 0; i < 3; ++i) { jp[i] = px.v[10 + i]; jp[3 + i] = py.v[10 + i]; }
 }
 
-template <bool WITH_J, int MODEL>
-__global__ __launch_bounds__(kBlock) void k_bal_evaluate(const double* __restrict__ state,
+// Tile k of this workgroup under the XCD-aware map of a grid that may be smaller than the number of tiles
+// (gridDim.x a multiple of 8): XCD x = blockIdx % 8 owns the contiguous tiles [x * per, (x + 1) * per), its
+// workgroups take them round-robin.  With gridDim.x >= 8 * per every workgroup has exactly one tile (xcd_segment).
+__device__ __forceinline__ int eval_tile(int k, int num_tiles) {
+  const int per = (num_tiles + 7) >> 3;
+  const int j = int(blockIdx.x >> 3) + k * int(gridDim.x >> 3);
+  const int t = int(blockIdx.x & 7) * per + j;
+  return (j < per && t < num_tiles) ? t : -1;
+}
+
+// One residual block per thread, kBlock per tile; 232 bytes per residual block, 208 of them written.
+// Round 2, what bounds it (Final shape, tools/eval_ab.py, profiles/r02_evaluator_probes.json).  Round 1's kernel (one tile
+// per workgroup, dual numbers, every lane gathering its own camera) took 1.9 ms.  Probes of that kernel: the arithmetic
+// alone 1.07 ms (0.59 ms in closed form), the stores alone 1.02 ms (5.5 TB/s), every load and store WITHOUT the
+// arithmetic 1.8 ms -- it is bound by its memory requests, and more by their number than by their bytes: a lane-per-camera
+// gather is 64 cache-line requests per load instruction, 340 of the kernel's 450 requests per wavefront.  Hence
+//   * the cooperative gather (gather_by_row): 1.8 -> 1.5 ms for the loads and stores alone;
+//   * the closed-form Jacobian (snavely_closed_form) as the default: 133 instead of 172 VGPRs, three workgroups per CU;
+//   * a PERSISTENT, SOFTWARE-PIPELINED loop: a workgroup walks over its tiles and issues the gather of tile t + 1 and the
+//     index load of tile t + 2 before the arithmetic of tile t, and waits for them after the arithmetic, before it issues
+//     the stores of tile t (a CU's loads queue behind its stores): 1.73 -> 1.55 ms.
+// 1.9 -> 1.55 ms with the Jacobian, 0.53 -> 0.46 ms for values and residuals.
+// VARIANT (A/B, CX_EVAL_VARIANT): bit 0 dual numbers (Jet<12>) instead of the closed-form Jacobian, bit 2 plain instead of
+// cooperative camera gather, bit 1 probe: every load and store, no arithmetic.
+template <bool WITH_J, int MODEL, int VARIANT = 0>
+__global__ __launch_bounds__(kBlock, !WITH_J ? 4 : ((MODEL == CX_CAMERA_ANGLE_AXIS && !(VARIANT & 1)) ? 3 : 2)) void k_bal_evaluate(const double* __restrict__ state,
                                                          const double* __restrict__ obs,
                                                          const int32_t* __restrict__ row_pt,
                                                          const int32_t* __restrict__ row_cam, int64_t O,
                                                          int64_t cam_off, double* __restrict__ residuals,
                                                          double* __restrict__ E, double* __restrict__ F,
-                                                         double* __restrict__ cost_partial, LossParams loss,
+                                                         double* __restrict__ cost_partial, LossParams loss_in,
                                                          double* __restrict__ Ft, const int32_t* __restrict__ cam_pos,
                                                          int num_tiles) {
-  __shared__ double lds[kBlock * 18];
+  constexpr bool kClosed = (VARIANT & 1) == 0;
+  constexpr bool kCoop = (VARIANT & 4) == 0 && MODEL == CX_CAMERA_ANGLE_AXIS;  // (64 x 9 doubles per wavefront = the LDS buffer)
+  constexpr int kCam = (MODEL == CX_CAMERA_ANGLE_AXIS) ? 9 : 10;
+  __shared__ double lds[kBlock * 9];
   __shared__ double red[4];
-  // num_tiles > 0: XCD-aware tile map, see k_scale_239 (cx_matrix.hip)
-  const int tile = num_tiles > 0 ? xcd_segment(num_tiles) : int(blockIdx.x);
+  __shared__ int cpos[kBlock];
+  const int tid0 = threadIdx.x;
+  int tid = tid0;
+  int tile = eval_tile(0, num_tiles);
   if (tile < 0) return;
-  const int64_t r0i = int64_t(tile) * kBlock;
-  const int nvalid = int(min(int64_t(kBlock), O - r0i));
-  const int tid = threadIdx.x;
-  const int64_t r = r0i + tid;
-  double res0 = 0.0, res1 = 0.0, cost_term = 0.0;
-  double jc[18], jp[6];
-  if (tid < nvalid) {
-    constexpr int kCam = (MODEL == CX_CAMERA_ANGLE_AXIS) ? 9 : 10;
+  // prologue: indices and parameters of the first tile, indices of the second
+  int32_t ci = 0, pi = 0, cp_n = 0;  // cp_n: position of the row's F cell in the camera-major copy
+  {
+    const int64_t r = int64_t(tile) * kBlock + tid;
+    if (r < O) {
+      ci = row_cam[r];
+      pi = row_pt[r];
+      if (WITH_J && Ft != nullptr) cp_n = cam_pos[r];
+    }
+  }
+  double cam_n[kCam], pt_n[3];
+  double2 o_n = make_double2(0.0, 0.0);
+  {
+    gather_by_row<kCam, kCoop>(state + cam_off, ci, tid0 & 63, cam_n);  // (rows past O read block 0: valid memory, never used)
+    const double* pp = state + 3 * int64_t(pi);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) pt_n[i] = pp[i];
+    const int64_t r = int64_t(tile) * kBlock + tid;
+    if (r < O) o_n = reinterpret_cast<const double2*>(obs)[r];
+  }
+  int tile1 = eval_tile(1, num_tiles);
+  ci = 0; pi = 0;
+  if (tile1 >= 0) {
+    const int64_t r = int64_t(tile1) * kBlock + tid;
+    if (r < O) { ci = row_cam[r]; pi = row_pt[r]; }
+  }
+  // (nothing of the prologue is left in flight at the loop's entry: the compiler merges what is pending on the two
+  // edges into the loop header, and a load pending on the entry edge became a vmcnt wait at the top of every
+  // iteration -- behind the previous iteration's stores)
+#pragma unroll
+  for (int i = 0; i < kCam; ++i) asm volatile("" : "+v"(cam_n[i]));
+#pragma unroll
+  for (int i = 0; i < 3; ++i) asm volatile("" : "+v"(pt_n[i]));
+  asm volatile("" : "+v"(o_n.x), "+v"(o_n.y), "+v"(ci), "+v"(pi), "+v"(cp_n));
+  for (int k = 0; tile >= 0; ++k) {
+    // the thread index and the loss parameters pass through an opaque statement per tile.  Left visible as loop
+    // invariants, everything derived from them (LDS and global addresses, the index arithmetic of the stores; every
+    // uniform subexpression of every loss type) is hoisted out of the loop and kept in vector registers: 62 -> 175
+    // VGPRs for the value-only kernel, 138 -> 292 with the Jacobian.  (cx_eval.hip is also compiled with
+    // -mllvm -disable-machine-licm: the literal constants of sin / cos were hoisted into 77 more.)
+    tid = tid0;
+    asm volatile("" : "+v"(tid));
+    const int64_t r0i = int64_t(tile) * kBlock;
+    const int nvalid = int(min(int64_t(kBlock), O - r0i));
+    const int64_t r = r0i + tid;
     double cam[kCam], pt[3];
-    const double* cp = state + cam_off + kCam * int64_t(row_cam[r]);
-    const double* pp = state + 3 * int64_t(row_pt[r]);
 #pragma unroll
-    for (int i = 0; i < kCam; ++i) cam[i] = cp[i];
+    for (int i = 0; i < kCam; ++i) cam[i] = cam_n[i];
 #pragma unroll
-    for (int i = 0; i < 3; ++i) pt[i] = pp[i];
-    const double2 o = reinterpret_cast<const double2*>(obs)[r];
-    if constexpr (MODEL == CX_CAMERA_ANGLE_AXIS) {
-#ifdef CX_EVAL_CLOSED_FORM
-      if (WITH_J) snavely_closed_form(cam, pt, o.x, o.y, res0, res1, jc, jp);
-#else
-      if (WITH_J) snavely_jet(cam, pt, o.x, o.y, res0, res1, jc, jp);
-#endif
-      else snavely_value(cam, pt, o.x, o.y, res0, res1);
-    } else {
-      if (WITH_J) snavely_jet_quat(cam, pt, o.x, o.y, res0, res1, jc, jp);
-      else snavely_value_quat(cam, pt, o.x, o.y, res0, res1);
+    for (int i = 0; i < 3; ++i) pt[i] = pt_n[i];
+    const double2 o = o_n;
+    const int32_t cp = cp_n;
+    if constexpr (kCoop) {
+      transpose_gathered<kCam>(lds + (tid >> 6) * 64 * kCam, tid & 63, cam);
+      __syncthreads();  // the slices are the staging buffer of the stores below
     }
-    const double sq = res0 * res0 + res1 * res1;
-    cost_term = 0.5 * sq;
-    if (loss.type != CX_LOSS_NONE) {
-      // residual_block.cc:165-196 with Corrector (corrector.cc:41-116): Jacobians first, with
-      // the uncorrected residuals, then the residuals
-      double rho[3];
-      loss_evaluate(loss, sq, rho);
-      cost_term = 0.5 * rho[0];
-      const double sqrt_rho1 = sqrt(rho[1]);
-      double residual_scaling = sqrt_rho1, alpha_sq_norm = 0.0;
-      if (sq != 0.0 && rho[2] > 0.0) {
-        const double D = 1.0 + 2.0 * sq * rho[2] / rho[1];
-        const double alpha = 1.0 - sqrt(D);
-        residual_scaling = sqrt_rho1 / (1 - alpha);
-        alpha_sq_norm = alpha / sq;
+    // requests of the tiles to come, in front of this tile's stores
+    const int tile2 = eval_tile(k + 2, num_tiles);
+    if (tile1 >= 0) {
+      gather_by_row<kCam, kCoop>(state + cam_off, ci, tid & 63, cam_n);
+      const double* pp = state + 3 * int64_t(pi);
+#pragma unroll
+      for (int i = 0; i < 3; ++i) pt_n[i] = pp[i];
+      const int64_t r1 = int64_t(tile1) * kBlock + tid;
+      if (r1 < O) {
+        o_n = reinterpret_cast<const double2*>(obs)[r1];
+        if (WITH_J && Ft != nullptr) cp_n = cam_pos[r1];
       }
-      if (WITH_J) {
-        correct_jacobian<9>(sqrt_rho1, alpha_sq_norm, res0, res1, jc);
-        correct_jacobian<3>(sqrt_rho1, alpha_sq_norm, res0, res1, jp);
+      ci = 0; pi = 0;
+      if (tile2 >= 0) {
+        const int64_t r2 = int64_t(tile2) * kBlock + tid;
+        if (r2 < O) { ci = row_cam[r2]; pi = row_pt[r2]; }
       }
-      res0 *= residual_scaling;
-      res1 *= residual_scaling;
     }
-    if (residuals) reinterpret_cast<double2*>(residuals)[r] = make_double2(res0, res1);
-  }
-  if (WITH_J) {
-    // F cells: row-major run and (Ft != nullptr) the camera-major copy in the same pass, see unstage_f_cells_two
-    unstage_f_cells_two(F + 18 * r0i, Ft, cam_pos + r0i, nvalid, lds, jc);
-    unstage_cells<6>(E + 6 * r0i, nvalid, lds, jp);
-  }
-  if (cost_partial) {
-    double c[1] = {cost_term};
-    block_sum<1>(c, red);
-    if (tid == 0) cost_partial[tile] = c[0];
+    double res0 = 0.0, res1 = 0.0, cost_term = 0.0;
+    double jc[18], jp[6];
+    LossParams loss = loss_in;
+    asm volatile("" : "+s"(loss.type), "+s"(loss.a), "+s"(loss.b));
+    if (tid < nvalid) {
+      if constexpr ((VARIANT & 2) != 0) {  // probe: every load and store of the kernel, no arithmetic
+        res0 = o.x; res1 = o.y;
+#pragma unroll
+        for (int i = 0; i < 18; ++i) jc[i] = cam[i % kCam] + double(i);
+#pragma unroll
+        for (int i = 0; i < 6; ++i) jp[i] = pt[i % 3] + double(i);
+      } else if constexpr (MODEL == CX_CAMERA_ANGLE_AXIS) {
+        if (WITH_J && kClosed) snavely_closed_form(cam, pt, o.x, o.y, res0, res1, jc, jp);
+        else if (WITH_J) snavely_jet(cam, pt, o.x, o.y, res0, res1, jc, jp);
+        else snavely_value(cam, pt, o.x, o.y, res0, res1);
+      } else {
+        if (WITH_J) snavely_jet_quat(cam, pt, o.x, o.y, res0, res1, jc, jp);
+        else snavely_value_quat(cam, pt, o.x, o.y, res0, res1);
+      }
+      const double sq = res0 * res0 + res1 * res1;
+      cost_term = 0.5 * sq;
+      if (loss.type != CX_LOSS_NONE) {
+        // residual_block.cc:165-196 with Corrector (corrector.cc:41-116): Jacobians first, with
+        // the uncorrected residuals, then the residuals
+        double rho[3];
+        loss_evaluate(loss, sq, rho);
+        cost_term = 0.5 * rho[0];
+        const double sqrt_rho1 = sqrt(rho[1]);
+        double residual_scaling = sqrt_rho1, alpha_sq_norm = 0.0;
+        if (sq != 0.0 && rho[2] > 0.0) {
+          const double D = 1.0 + 2.0 * sq * rho[2] / rho[1];
+          const double alpha = 1.0 - sqrt(D);
+          residual_scaling = sqrt_rho1 / (1 - alpha);
+          alpha_sq_norm = alpha / sq;
+        }
+        if (WITH_J) {
+          correct_jacobian<9>(sqrt_rho1, alpha_sq_norm, res0, res1, jc);
+          correct_jacobian<3>(sqrt_rho1, alpha_sq_norm, res0, res1, jp);
+        }
+        res0 *= residual_scaling;
+        res1 *= residual_scaling;
+      }
+    }
+    // The requests of the next tiles are waited for HERE, before this tile's stores are issued: vmcnt counts loads and
+    // stores in one in-order counter, and the number of stores below depends on nvalid, so a wait placed after them
+    // (where the values are first read, at the top of the next iteration) could only be vmcnt(0) -- the loads would
+    // wait for this tile's stores to reach memory, which is the serialisation the loop exists to remove.
+#pragma unroll
+    for (int i = 0; i < kCam; ++i) asm volatile("" : "+v"(cam_n[i]));
+#pragma unroll
+    for (int i = 0; i < 3; ++i) asm volatile("" : "+v"(pt_n[i]));
+    asm volatile("" : "+v"(o_n.x), "+v"(o_n.y), "+v"(ci), "+v"(pi), "+v"(cp_n));
+    if (residuals && tid < nvalid) reinterpret_cast<double2*>(residuals)[r] = make_double2(res0, res1);
+    if (WITH_J) {
+      // F cells: row-major run and (Ft != nullptr) the camera-major copy in the same pass, see unstage_f_cells_two
+      unstage_cells_halves<18>(F + 18 * r0i, Ft, cp, cpos, nvalid, lds, jc, tid);
+      unstage_cells<6>(E + 6 * r0i, nvalid, lds, jp, tid);
+    }
+    if (cost_partial) {
+      double c[1] = {cost_term};
+      block_sum<1>(c, red, tid);
+      if (tid == 0) cost_partial[tile] = c[0];
+    }
+    tile = tile1;
+    tile1 = tile2;
   }
 }
 
@@ -649,23 +756,38 @@ int cx_evaluator_evaluate(cx_evaluator* e, const double* state, double* cost, do
     CX_TRY(A->d_Ft.alloc(size_t(A->O) * 18));
     ft_out = A->d_Ft.p;
   }
-  static const bool xcd_env = std::getenv("CX_NO_XCD_TILES") == nullptr;
-  const bool xcd_tiles = xcd_env && ft_out != nullptr;
-  const int launch_grid = xcd_tiles ? xcd_grid(grid) : grid;
+  // persistent grid: as many workgroups as the chip holds at once (a multiple of 8, see eval_tile); CX_EVAL_PERSISTENT=0
+  // launches one workgroup per tile instead (round 1's form, kept for the A/B of tools/eval_ab.py)
+  static const bool persistent = !(std::getenv("CX_EVAL_PERSISTENT") && std::atoi(std::getenv("CX_EVAL_PERSISTENT")) == 0);
+  static const int variant = std::getenv("CX_EVAL_VARIANT") ? std::atoi(std::getenv("CX_EVAL_VARIANT")) : 0;  // A/B switch
   CX_HIP(hipEventRecord(ctx->ev[6], st));
-#define CX_LAUNCH_EVAL(WJ, MODEL)                                                                                      \
-  hipLaunchKernelGGL((k_bal_evaluate<WJ, MODEL>), dim3(launch_grid), dim3(kBlock), 0, st, (const double*)hs.dptr,       \
-                     (const double*)e->d_obs.p, (const int32_t*)A->d_row_pt.p, (const int32_t*)A->d_row_cam.p, e->O,    \
-                     3 * int64_t(e->P), res_dev, E, F, cost ? e->d_partial.p : nullptr, loss, ft_out,                  \
-                     (const int32_t*)A->d_cam_pos.p, xcd_tiles ? grid : 0)
+#define CX_LAUNCH_EVAL_V(WJ, MODEL, V)                                                                                 \
+  do {                                                                                                                 \
+    static int occ = 0;                                                                                                \
+    if (occ == 0) {                                                                                                    \
+      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_bal_evaluate<WJ, MODEL, V>, kBlock, 0) != hipSuccess || occ < 1) occ = 1; \
+    }                                                                                                                  \
+    const int resident = std::max(8, (ctx->num_cus * occ) / 8 * 8);                                                    \
+    const int launch_grid = persistent ? std::min(xcd_grid(grid), resident) : xcd_grid(grid);                          \
+    hipLaunchKernelGGL((k_bal_evaluate<WJ, MODEL, V>), dim3(launch_grid), dim3(kBlock), 0, st, (const double*)hs.dptr,  \
+                       (const double*)e->d_obs.p, (const int32_t*)A->d_row_pt.p, (const int32_t*)A->d_row_cam.p, e->O,  \
+                       3 * int64_t(e->P), res_dev, E, F, cost ? e->d_partial.p : nullptr, loss, ft_out,                \
+                       (const int32_t*)A->d_cam_pos.p, grid);                                                          \
+  } while (0)
+#define CX_LAUNCH_EVAL(WJ, MODEL) CX_LAUNCH_EVAL_V(WJ, MODEL, 0)
   if (e->camera_model == CX_CAMERA_ANGLE_AXIS) {
-    if (with_j) CX_LAUNCH_EVAL(true, CX_CAMERA_ANGLE_AXIS);
+    if (with_j && variant == 1) CX_LAUNCH_EVAL_V(true, CX_CAMERA_ANGLE_AXIS, 1);
+    else if (with_j && variant == 2) CX_LAUNCH_EVAL_V(true, CX_CAMERA_ANGLE_AXIS, 2);
+    else if (with_j && variant == 4) CX_LAUNCH_EVAL_V(true, CX_CAMERA_ANGLE_AXIS, 4);
+    else if (with_j && variant == 5) CX_LAUNCH_EVAL_V(true, CX_CAMERA_ANGLE_AXIS, 5);
+    else if (with_j) CX_LAUNCH_EVAL(true, CX_CAMERA_ANGLE_AXIS);
     else CX_LAUNCH_EVAL(false, CX_CAMERA_ANGLE_AXIS);
   } else {
     if (with_j) CX_LAUNCH_EVAL(true, CX_CAMERA_QUATERNION_MANIFOLD);
     else CX_LAUNCH_EVAL(false, CX_CAMERA_QUATERNION_MANIFOLD);
   }
 #undef CX_LAUNCH_EVAL
+#undef CX_LAUNCH_EVAL_V
   if (cost) {
     // layout of d_partial: [grid] per-workgroup costs | total | [256] slice sums | ticket (kept zero between launches)
     const int slices = std::min(256, grid);

@@ -123,14 +123,21 @@ __device__ __forceinline__ void stage_cells(const double* __restrict__ base, int
 // then the second.  Two more barriers, but an 18 KB instead of a 36 KB workgroup lets twice as many
 // wavefronts share a CU (the streaming kernels are bound by loads in flight).
 template <int DPR>
+__device__ __forceinline__ void exchange_cells_halves(const double2 (&v)[DPR / 2], double* __restrict__ lds, double (&out)[DPR]);
+template <int DPR>
 __device__ __forceinline__ void stage_cells_halves(const double* __restrict__ base, int nvalid,
                                                    double* __restrict__ lds, double (&out)[DPR]) {
   constexpr int kPieces = DPR / 2;
-  constexpr int kHalf = kBlock * kPieces / 2;
   static_assert((kBlock * kPieces) % 2 == 0, "the run splits into two equal halves");
-  const int tid = threadIdx.x;
   double2 v[kPieces];
   load_cells<DPR>(base, nvalid, v);
+  exchange_cells_halves<DPR>(v, lds, out);
+}
+template <int DPR>
+__device__ __forceinline__ void exchange_cells_halves(const double2 (&v)[DPR / 2], double* __restrict__ lds, double (&out)[DPR]) {
+  constexpr int kPieces = DPR / 2;
+  constexpr int kHalf = kBlock * kPieces / 2;
+  const int tid = threadIdx.x;
   double2* l2 = reinterpret_cast<double2*>(lds);
 #pragma unroll
   for (int i = 0; i < kPieces; ++i) {
@@ -181,11 +188,12 @@ template <> struct FStage<float> {
 
 // reverse of stage_cells: every thread hands in its own cell, the workgroup stores
 // the nvalid cells as one contiguous run of 16-byte pieces
+// (tid is a parameter for callers inside a loop that hide the thread index from the optimiser per iteration, so that
+// what derives from it -- addresses, index arithmetic -- is not hoisted out of the loop into registers: k_bal_evaluate)
 template <int DPR>
 __device__ __forceinline__ void unstage_cells(double* __restrict__ base, int nvalid, double* __restrict__ lds,
-                                              const double (&in)[DPR]) {
+                                              const double (&in)[DPR], int tid) {
   constexpr int kPieces = DPR / 2;
-  const int tid = threadIdx.x;
   double2* l2 = reinterpret_cast<double2*>(lds);
 #pragma unroll
   for (int i = 0; i < kPieces; ++i) l2[tid * kPieces + i] = make_double2(in[2 * i], in[2 * i + 1]);
@@ -198,6 +206,12 @@ __device__ __forceinline__ void unstage_cells(double* __restrict__ base, int nva
     if (idx < total) dst[idx] = l2[idx];
   }
   __syncthreads();
+}
+
+template <int DPR>
+__device__ __forceinline__ void unstage_cells(double* __restrict__ base, int nvalid, double* __restrict__ lds,
+                                              const double (&in)[DPR]) {
+  unstage_cells<DPR>(base, nvalid, lds, in, int(threadIdx.x));
 }
 
 // unstage_cells for the F cells with a second destination: the camera-major copy Ft (cx_matrix.hip).  The
@@ -236,6 +250,87 @@ __device__ __forceinline__ void unstage_f_cells_two(double* __restrict__ base, d
   __syncthreads();
 }
 
+// unstage_cells / unstage_f_cells_two with half the LDS (kBlock * DPR / 2 doubles): the cells of threads
+// 0 .. kBlock/2-1 go out in a first round, those of the other half in a second.  Two more barriers, but a producer
+// kernel holds its workgroup slot while its stores drain, so that the number of workgroups a CU can hold -- not the
+// arithmetic and not the write rate -- sets its speed (k_bal_evaluate: compute alone 1.07 ms, stores alone 1.02 ms,
+// together 1.91 ms with 36 KB workgroups).  ft == nullptr: no second destination.
+// The second destination's cell numbers come from the callers' registers (own_cam_pos = cam_pos of the thread's own row,
+// loaded early) through cpos (kBlock ints of LDS): a global load between the stores would wait for them (vmcnt).
+template <int DPR>
+__device__ __forceinline__ void unstage_cells_halves(double* __restrict__ base, double* __restrict__ ft,
+                                                     int own_cam_pos, int* __restrict__ cpos, int nvalid,
+                                                     double* __restrict__ lds, const double (&in)[DPR], int tid) {
+  constexpr int kPieces = DPR / 2;
+  constexpr int kHalfRows = kBlock / 2;
+  constexpr int kHalfPieces = kHalfRows * kPieces;
+  constexpr int kIter = (kHalfPieces + kBlock - 1) / kBlock;
+  double2* l2 = reinterpret_cast<double2*>(lds);
+  double2* dst = reinterpret_cast<double2*>(base);
+  double2* dft = reinterpret_cast<double2*>(ft);
+  if (ft != nullptr) cpos[tid] = own_cam_pos;
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    if ((tid >= kHalfRows) == (h == 1)) {
+      const int lt = tid - h * kHalfRows;
+#pragma unroll
+      for (int i = 0; i < kPieces; ++i) l2[lt * kPieces + i] = make_double2(in[2 * i], in[2 * i + 1]);
+    }
+    __syncthreads();
+    const int total = max(0, min(kHalfRows, nvalid - h * kHalfRows)) * kPieces;
+    double2 v[kIter];  // (read unconditionally from a clamped index: a conditionally filled array went to scratch memory)
+#pragma unroll
+    for (int i = 0; i < kIter; ++i) v[i] = l2[min(i * kBlock + tid, kHalfPieces - 1)];
+#pragma unroll
+    for (int i = 0; i < kIter; ++i) {
+      const int idx = i * kBlock + tid;
+      if (idx < total) dst[h * kHalfPieces + idx] = v[i];
+    }
+    if (ft != nullptr) {
+#pragma unroll
+      for (int i = 0; i < kIter; ++i) {
+        const int idx = i * kBlock + tid;
+        if (idx < total) {
+          const int cell = idx / kPieces;
+          const int part = idx - cell * kPieces;
+          dft[int64_t(cpos[h * kHalfRows + cell]) * kPieces + part] = v[i];
+        }
+      }
+    }
+    __syncthreads();
+  }
+}
+
+// N consecutive doubles per row, gathered by a per-row index (camera parameters, column scales of a camera block) for
+// the 64 rows of a wavefront.  Plain form: lane l reads the N values of its own row's block -- 64 different cache
+// lines per load instruction.  Cooperative form (kCoop): value number f = l + 64 j of the wavefront's [row][N] array is
+// read by lane l, so that consecutive lanes read consecutive words of one block (64 / N blocks, about as many lines,
+// per instruction: a third of the L2 requests of the whole evaluation kernel); transpose_gathered then hands every lane
+// its own row through the wavefront's slice of LDS (64 * N doubles).
+template <int N, bool kCoop>
+__device__ __forceinline__ void gather_by_row(const double* __restrict__ blocks, int32_t block_of_row, int lane, double (&out)[N]) {
+  if constexpr (kCoop) {
+#pragma unroll
+    for (int j = 0; j < N; ++j) {
+      const int f = lane + 64 * j;
+      const int row = f / N;
+      const int c = __shfl(block_of_row, row, 64);
+      out[j] = blocks[N * int64_t(c) + (f - row * N)];
+    }
+  } else {
+    const double* cp = blocks + N * int64_t(block_of_row);
+#pragma unroll
+    for (int i = 0; i < N; ++i) out[i] = cp[i];
+  }
+}
+template <int N>
+__device__ __forceinline__ void transpose_gathered(double* __restrict__ wave_slice, int lane, double (&v)[N]) {
+#pragma unroll
+  for (int j = 0; j < N; ++j) wave_slice[lane + 64 * j] = v[j];
+#pragma unroll
+  for (int k = 0; k < N; ++k) v[k] = wave_slice[lane * N + k];
+}
+
 // XCD-aware block -> work item map for camera-major kernels.  Workgroups are dealt round-robin
 // over the 8 XCDs (blockIdx % 8 picks the XCD), so giving XCD x the contiguous range
 // [x*per, (x+1)*per) of segments makes workgroups that run at the same time on one XCD work on
@@ -260,8 +355,8 @@ __device__ __forceinline__ double wave_sum(double v) {
 // wave results are added in wave order.  scratch: N*4 doubles of LDS.  Result in
 // every thread.  Contains two block barriers.
 template <int N>
-__device__ __forceinline__ void block_sum(double (&v)[N], double* scratch) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+__device__ __forceinline__ void block_sum(double (&v)[N], double* scratch, int tid) {
+  const int lane = tid & 63, wave = tid >> 6;
 #pragma unroll
   for (int i = 0; i < N; ++i) {
     const double s = wave_sum(v[i]);
@@ -271,6 +366,11 @@ __device__ __forceinline__ void block_sum(double (&v)[N], double* scratch) {
 #pragma unroll
   for (int i = 0; i < N; ++i) v[i] = ((scratch[i * 4] + scratch[i * 4 + 1]) + scratch[i * 4 + 2]) + scratch[i * 4 + 3];
   __syncthreads();
+}
+
+template <int N>
+__device__ __forceinline__ void block_sum(double (&v)[N], double* scratch) {
+  block_sum<N>(v, scratch, int(threadIdx.x));
 }
 
 // Same reduction, but the N sums are stored to out[0..N) by threads 0..N-1 (no

@@ -246,6 +246,9 @@ __global__ __launch_bounds__(kBlock) void k_cam_sqnorm(const double* __restrict_
 // registers, out through LDS -- coalesced both ways (416 B per residual block incl. ids).  The scaled F cells
 // also go to their places in the camera-major copy Ft (+148 B per residual block), which is therefore current
 // when the kernel ends: the LM iteration needs no k_permute_ft pass (292 B per residual block) afterwards.
+// (Round 2 A/B: issuing every load of the tile before the first store, the cooperative gather of the camera block's
+// scales (gather_by_row), half-size staging and cell numbers passed through LDS -- what sped up k_bal_evaluate -- left
+// this kernel at the same 3.45 ms on the Final shape: 15.6 GB at 4.5 TB/s, against 4.7 TB/s for a plain copy.)
 __global__ __launch_bounds__(kBlock) void k_scale_239(double* __restrict__ E, double* __restrict__ F,
                                                       const int32_t* __restrict__ row_pt,
                                                       const int32_t* __restrict__ row_cam,

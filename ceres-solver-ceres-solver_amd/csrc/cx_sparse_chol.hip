@@ -176,12 +176,6 @@ __device__ __forceinline__ void subtract_block(const double4_t (&acc)[2][2], dou
       }
 }
 
-// same-wavefront read-after-write through global memory (see k_chol_step's look-ahead): wait for the stores
-__device__ __forceinline__ void own_stores_visible() {
-  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-}
-
 // operands of the panel solve X = Uinv' W (cxchol::panel_x) held in registers: A(m, r) = Uinv[r][m], B(r, c) = W[r][c]
 __device__ __forceinline__ void load_aop(const double* __restrict__ uinv, double (&aop)[8][2]) {
   const int lane = threadIdx.x & 63, li = lane & 15, lk = lane >> 4;
