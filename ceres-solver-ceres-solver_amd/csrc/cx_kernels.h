@@ -173,16 +173,27 @@ __device__ __forceinline__ void exchange_cells_halves(const double2 (&v)[DPR / 2
 
 // The F cells (18 values) of a tile: fp64 through the half-size buffer, fp32 through the plain one.
 template <typename T> struct FStage;
+// (load + exchange = run, for kernels that put other requests in flight between the two)
 template <> struct FStage<double> {
   static constexpr int kLdsDoubles = kBlock * 9;
+  struct Pieces { double2 v[9]; };
   static __device__ __forceinline__ void run(const double* __restrict__ base, int nvalid, double* __restrict__ lds, double (&out)[18]) {
     stage_cells_halves<18>(base, nvalid, lds, out);
+  }
+  static __device__ __forceinline__ void load(const double* __restrict__ base, int nvalid, Pieces& p) { load_cells<18>(base, nvalid, p.v); }
+  static __device__ __forceinline__ void exchange(const Pieces& p, double* __restrict__ lds, double (&out)[18]) {
+    exchange_cells_halves<18>(p.v, lds, out);
   }
 };
 template <> struct FStage<float> {
   static constexpr int kLdsDoubles = kBlock * 18;
+  struct Pieces { float4_u v[5]; };
   static __device__ __forceinline__ void run(const float* __restrict__ base, int nvalid, double* __restrict__ lds, double (&out)[18]) {
     stage_cells<18>(base, nvalid, lds, out);
+  }
+  static __device__ __forceinline__ void load(const float* __restrict__ base, int nvalid, Pieces& p) { load_cells<18>(base, nvalid, p.v); }
+  static __device__ __forceinline__ void exchange(const Pieces& p, double* __restrict__ lds, double (&out)[18]) {
+    exchange_cells<18>(p.v, lds, out);
   }
 };
 

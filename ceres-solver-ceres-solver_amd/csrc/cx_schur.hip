@@ -189,7 +189,11 @@ __global__ __launch_bounds__(kBlock) void k_chunk_pass(const T* __restrict__ E,
     const int nvalid = r1 - r0;
     const int r = r0 + tid;
     // F is staged and consumed before E is requested: measured 12 % faster on MI355X than
-    // requesting everything up front (fewer live registers, see DESIGN.md "A/B notes")
+    // requesting everything up front (fewer live registers, see DESIGN.md "A/B notes").
+    // Round 2 A/B: the cooperative camera gather that sped up k_bal_evaluate (gather_by_row, cx_kernels.h; issued while
+    // the F cells are in flight, transposed through the staging buffer) made this kernel no faster -- 1.133 against
+    // 1.111 ms on the same box; it reads 212 bytes per row where the evaluator reads 24, the gather's requests hide
+    // behind the cell stream -- and is not kept here.
     const bool live = tid < nvalid;
     const int lp = (MODE != 2 && live) ? row_pt[r] - p0 : 0;
     double e[6];
