@@ -62,12 +62,13 @@ struct DevBuf {
     n = count;
     return CX_OK;
   }
-  int upload(const std::vector<T>& h, hipStream_t s) {
-    CX_TRY(alloc(h.size()));
-    if (!h.empty()) CX_HIP(hipMemcpyAsync(p, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice, s));
+  int upload(const T* h, size_t count, hipStream_t s) {
+    CX_TRY(alloc(count));
+    if (count > 0) CX_HIP(hipMemcpyAsync(p, h, count * sizeof(T), hipMemcpyHostToDevice, s));
     CX_HIP(hipStreamSynchronize(s));
     return CX_OK;
   }
+  int upload(const std::vector<T>& h, hipStream_t s) { return upload(h.data(), h.size(), s); }
 };
 
 // ---------------------------------------------------------------- context

@@ -19,6 +19,8 @@
 #include "cx_schur.h"
 
 #include <algorithm>
+#include <chrono>
+#include <memory>
 #include <thread>
 #include <cstdlib>
 
@@ -808,6 +810,13 @@ constexpr int kPairItem = kPairGroups * 8;  // pairs per work item
 
 int cxs_build_pair_lists(cx_matrix* A) {
   if (A->pairs_state != 0) return CX_OK;
+  const bool verbose = std::getenv("CX_SPARSE_CHOLESKY_VERBOSE") != nullptr;
+  auto t_last = std::chrono::steady_clock::now();
+  auto lap = [&](const char* what) {
+    const auto now = std::chrono::steady_clock::now();
+    if (verbose) std::fprintf(stderr, "[cxschur] pair lists: %s %.3f s\n", what, std::chrono::duration<double>(now - t_last).count());
+    t_last = now;
+  };
   const int C = A->C;
   const int64_t O = A->O;
   int64_t total = 0;
@@ -830,35 +839,73 @@ int cxs_build_pair_lists(cx_matrix* A) {
     return CX_OK;
   }
   auto cam_of = [&](int64_t r) { return A->cells[2 * r + 1].block_id - A->P; };
-  // 1. bucket the pairs by their smaller camera c1 (stable: chunk order inside a bucket)
+  // 1. bucket the pairs by their smaller camera c1 (stable: chunk order inside a bucket).  Worker threads take
+  //    contiguous ranges of points balanced by pair count; thread t's pairs of a bucket go behind those of threads
+  //    < t, which is the chunk order (one thread walking 164 M pairs of the Final shape twice took 1.1 s of the
+  //    1.9 s one-time set-up of SPARSE_SCHUR).
   struct Pair { int32_t c2, ri, rj; };
-  std::vector<int64_t> bucket(size_t(C) + 1, 0);
-  for (int p = 0; p < A->P; ++p)
-    for (int64_t i = start[p]; i < start[p + 1]; ++i)
-      for (int64_t j = i; j < start[p + 1]; ++j) bucket[size_t(std::min(cam_of(i), cam_of(j))) + 1]++;
-  for (int c = 0; c < C; ++c) bucket[c + 1] += bucket[c];
-  std::vector<Pair> tmp(static_cast<size_t>(total));
+  const unsigned hw = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
+  std::vector<int> range(size_t(hw) + 1, A->P);
   {
-    std::vector<int64_t> fill(bucket.begin(), bucket.end() - 1);
-    for (int p = 0; p < A->P; ++p)
-      for (int64_t i = start[p]; i < start[p + 1]; ++i)
-        for (int64_t j = i; j < start[p + 1]; ++j) {
-          const int ci = cam_of(i), cj = cam_of(j);
-          Pair& q = tmp[size_t(fill[std::min(ci, cj)]++)];
-          q.c2 = std::max(ci, cj);
-          q.ri = int32_t(ci <= cj ? i : j);
-          q.rj = int32_t(ci <= cj ? j : i);
-        }
+    range[0] = 0;
+    int64_t acc = 0;
+    unsigned t = 1;
+    for (int p = 0; p < A->P && t < hw; ++p) {
+      const int64_t k = start[p + 1] - start[p];
+      acc += k * (k + 1) / 2;
+      if (acc * int64_t(hw) >= total * int64_t(t)) range[t++] = p + 1;
+    }
   }
+  std::vector<std::vector<int64_t>> count(hw, std::vector<int64_t>(size_t(C), 0));  // then: fill cursors
+  {
+    std::vector<std::thread> workers;
+    for (unsigned t = 0; t < hw; ++t)
+      workers.emplace_back([&, t]() {
+        std::vector<int64_t>& cnt = count[t];
+        for (int p = range[t]; p < range[t + 1]; ++p)
+          for (int64_t i = start[p]; i < start[p + 1]; ++i)
+            for (int64_t j = i; j < start[p + 1]; ++j) cnt[size_t(std::min(cam_of(i), cam_of(j)))]++;
+      });
+    for (auto& w : workers) w.join();
+  }
+  std::vector<int64_t> bucket(size_t(C) + 1, 0);
+  for (int c = 0; c < C; ++c) {
+    int64_t acc = bucket[c];
+    for (unsigned t = 0; t < hw; ++t) {
+      const int64_t n = count[t][size_t(c)];
+      count[t][size_t(c)] = acc;
+      acc += n;
+    }
+    bucket[c + 1] = acc;
+  }
+  // (not a std::vector: its value-initialisation would touch the 2 GB from one thread before the workers fill them)
+  std::unique_ptr<Pair[]> tmp(new Pair[static_cast<size_t>(std::max<int64_t>(total, 1))]);
+  {
+    std::vector<std::thread> workers;
+    for (unsigned t = 0; t < hw; ++t)
+      workers.emplace_back([&, t]() {
+        std::vector<int64_t>& fill = count[t];
+        for (int p = range[t]; p < range[t + 1]; ++p)
+          for (int64_t i = start[p]; i < start[p + 1]; ++i)
+            for (int64_t j = i; j < start[p + 1]; ++j) {
+              const int ci = cam_of(i), cj = cam_of(j);
+              Pair& q = tmp[size_t(fill[size_t(std::min(ci, cj))]++)];
+              q.c2 = std::max(ci, cj);
+              q.ri = int32_t(ci <= cj ? i : j);
+              q.rj = int32_t(ci <= cj ? j : i);
+            }
+      });
+    for (auto& w : workers) w.join();
+  }
+  lap("bucket by first camera");
   // 2. inside every bucket a stable counting sort by c2 gives the cells of block row c1 in order, each with
   //    its pairs in chunk order; the diagonal cell (c1, c1) exists even without pairs.  Buckets are
   //    independent: worker threads take them round-robin.
   std::vector<int32_t> row_cells(size_t(C) + 1, 0);  // cells per block row, then prefix sums
-  std::vector<int32_t> pairs(static_cast<size_t>(2 * total));
+  std::unique_ptr<int32_t[]> pairs(new int32_t[static_cast<size_t>(std::max<int64_t>(2 * total, 1))]);
   std::vector<std::vector<int32_t>> row_c2(static_cast<size_t>(C));     // c2 of the row's cells
   std::vector<std::vector<int64_t>> row_begin(static_cast<size_t>(C));  // first pair of each of them
   {
-    const unsigned hw = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
     std::vector<std::thread> workers;
     for (unsigned t = 0; t < hw; ++t)
       workers.emplace_back([&, t]() {
@@ -889,7 +936,8 @@ int cxs_build_pair_lists(cx_matrix* A) {
       });
     for (auto& w : workers) w.join();
   }
-  std::vector<Pair>().swap(tmp);
+  tmp.reset();
+  lap("sort by second camera");
   for (int c = 0; c < C; ++c) row_cells[size_t(c) + 1] = row_cells[size_t(c)] + int32_t(row_c2[size_t(c)].size());
   const int64_t ncell = row_cells[size_t(C)];
   A->h_cell_c1.resize(size_t(ncell));
@@ -923,8 +971,9 @@ int cxs_build_pair_lists(cx_matrix* A) {
     for (int64_t cell = 0; cell < ncell; ++cell)
       if (A->h_cell_c1[size_t(cell)] != A->h_cell_c2[size_t(cell)]) col_cells[size_t(fill[size_t(A->h_cell_c2[size_t(cell)])]++)] = int32_t(cell);
   }
+  lap("cell and item index");
   hipStream_t st = A->ctx->stream;
-  CX_TRY(A->d_pair_rows.upload(pairs, st));
+  CX_TRY(A->d_pair_rows.upload(pairs.get(), static_cast<size_t>(2 * total), st));
   CX_TRY(A->d_item_begin.upload(item_begin, st));
   CX_TRY(A->d_cell_item_start.upload(cell_item_start, st));
   A->h_cell_item_start = cell_item_start;
@@ -937,6 +986,7 @@ int cxs_build_pair_lists(cx_matrix* A) {
   A->num_pairs = total;
   A->num_cells = ncell;
   A->pairs_state = 1;
+  lap("uploads");
   return CX_OK;
 }
 

@@ -28,6 +28,7 @@
 // CX_SPARSE_CHOLESKY_STEPS=1 runs round 1's numeric phase instead (one launch per 32-column block step in
 // elimination order, look-ahead of the next diagonal block), kept for A/B runs.
 #include <algorithm>
+#include <chrono>
 #include <cstdlib>
 #include <queue>
 #include <string>
@@ -989,9 +990,15 @@ int cxsp_plan_from_cells(cx_context* ctx, int C, const int32_t* cell_c1, const i
 
 int cxsp_build_plan(cx_matrix* A) {
   if (A->sp.state != 0) return CX_OK;
+  const auto t0 = std::chrono::steady_clock::now();
   CX_TRY(cxs_build_pair_lists(A));
   if (A->pairs_state != 1) { A->sp.state = 2; return CX_OK; }
-  return cxsp_plan_from_cells(A->ctx, A->C, A->h_cell_c1.data(), A->h_cell_c2.data(), A->num_cells, &A->sp);
+  const auto t1 = std::chrono::steady_clock::now();
+  const int rc = cxsp_plan_from_cells(A->ctx, A->C, A->h_cell_c1.data(), A->h_cell_c2.data(), A->num_cells, &A->sp);
+  if (std::getenv("CX_SPARSE_CHOLESKY_VERBOSE"))
+    std::fprintf(stderr, "[cxschur] one-time structure analysis: pair lists %.3f s, ordering + symbolic factorisation + plan %.3f s\n",
+                 std::chrono::duration<double>(t1 - t0).count(), std::chrono::duration<double>(std::chrono::steady_clock::now() - t1).count());
+  return rc;
 }
 
 namespace {

@@ -36,7 +36,10 @@ def bench(args, eta):
 
 
 def main():
-    path = os.path.join(ROOT, "profiles", "r%s_config_runs.jsonl" % os.environ.get("CX_ROUND", "02"))
+    # (through gpurun only gpurun_out/ travels back from the GPU box: copy the file into profiles/ afterwards)
+    out_dir = os.path.join(ROOT, "gpurun_out") if os.environ.get("GRAFT_REPO_ROOT") else os.path.join(ROOT, "profiles")
+    os.makedirs(out_dir, exist_ok=True)
+    path = os.path.join(out_dir, "r%s_config_runs.jsonl" % os.environ.get("CX_ROUND", "02"))
     with open(path, "w") as f:
         for args in RUNS:
             a = bench(args, 0.1)
