@@ -1038,10 +1038,15 @@ __global__ __launch_bounds__(kBlock) void k_pair_items(const int32_t* __restrict
                                                        const int64_t* __restrict__ item_begin,
                                                        const int32_t* __restrict__ item_ids,
                                                        const double* __restrict__ bg0, const double* __restrict__ bg1,
-                                                       const double* __restrict__ bg2, double* __restrict__ item_partial) {
+                                                       const double* __restrict__ bg2, double* __restrict__ item_partial,
+                                                       int num_launch_items) {
   __shared__ double part[kPairGroups * 81];
   const int tid = threadIdx.x;
-  const int64_t item = item_ids ? int64_t(item_ids[blockIdx.x]) : int64_t(blockIdx.x);  // a selection, or all items
+  // num_launch_items > 0: XCD-aware map (xcd_segment) -- the items of one block row of S (pairs whose first rows all belong
+  // to one camera) run on ONE XCD, whose L2 then serves the B halves of those rows to every cell of the block row
+  const int slot = num_launch_items > 0 ? xcd_segment(num_launch_items) : int(blockIdx.x);
+  if (slot < 0) return;
+  const int64_t item = item_ids ? int64_t(item_ids[slot]) : int64_t(slot);  // a selection, or all items
   const int64_t p0 = item_begin[item], p1 = item_begin[item + 1];
   const int g = tid / 9, sub = tid - g * 9;
   const int a0 = 3 * (sub / 3), c0 = 3 * (sub - 3 * (sub / 3));
@@ -1261,10 +1266,12 @@ int cxs_assemble_pair_items(cx_matrix* A, const double* D, const int32_t* item_i
                        (const double*)A->d_elim_ete.p, A->O, A->d_elim_bg0.p, A->d_elim_bg1.p, A->d_elim_bg2.p);
   CX_TRY(cxs_camera_block_diagonal(A, A->d_elim_diag.p));
   const int64_t launch_items = item_ids ? num_selected : A->num_items;
+  static const bool xcd_items = std::getenv("CX_NO_XCD_ITEMS") == nullptr;  // A/B switch
   if (launch_items > 0)
-    hipLaunchKernelGGL(k_pair_items, dim3(unsigned(launch_items)), dim3(kBlock), 0, st, (const int32_t*)A->d_pair_rows.p,
-                       (const int64_t*)A->d_item_begin.p, item_ids, (const double*)A->d_elim_bg0.p, (const double*)A->d_elim_bg1.p,
-                       (const double*)A->d_elim_bg2.p, A->d_item_partial.p);
+    hipLaunchKernelGGL(k_pair_items, dim3(unsigned(xcd_items ? xcd_grid(int(launch_items)) : launch_items)), dim3(kBlock), 0, st,
+                       (const int32_t*)A->d_pair_rows.p, (const int64_t*)A->d_item_begin.p, item_ids, (const double*)A->d_elim_bg0.p,
+                       (const double*)A->d_elim_bg1.p, (const double*)A->d_elim_bg2.p, A->d_item_partial.p,
+                       xcd_items ? int(launch_items) : 0);
   CX_HIP(hipGetLastError());
   return CX_OK;
 }

@@ -263,6 +263,24 @@ def test_evaluator(ctx, oracle, C, P, O, seed):
     ev.close()
 
 
+@pytest.mark.parametrize("env", [{}, {"CX_EVAL_VARIANT": "1"}, {"CX_EVAL_VARIANT": "4"}, {"CX_EVAL_PERSISTENT": "0"}],
+                         ids=["default", "dual-numbers", "plain-gather", "one-tile-per-workgroup"])
+def test_evaluator_variants(env):
+    """k_bal_evaluate's variants (closed-form Jacobian / dual numbers, cooperative / plain camera gather, persistent /
+    one tile per workgroup) against the oracle on a problem with more tiles than resident workgroups; each in its own
+    process because the switches are read once (tests/evaluator_variant_check.py)."""
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    child_env = dict(os.environ)
+    for k in ("CX_EVAL_VARIANT", "CX_EVAL_PERSISTENT"):
+        child_env.pop(k, None)
+    child_env.update(env)
+    out = subprocess.run([sys.executable, os.path.join(here, "evaluator_variant_check.py")], env=child_env,
+                         stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
+    assert out.returncode == 0 and "EVALUATOR_VARIANT_OK" in out.stdout, out.stdout[-2000:]
+
+
 @pytest.mark.parametrize("loss", [(cx.binding.LOSS_HUBER, 1.0, 0.0), (cx.binding.LOSS_HUBER, 0.25, 0.0),
                                   (cx.binding.LOSS_SOFT_L_ONE, 0.7, 0.0), (cx.binding.LOSS_CAUCHY, 1.3, 0.0),
                                   (cx.binding.LOSS_ARCTAN, 0.7, 0.0), (cx.binding.LOSS_TOLERANT, 0.7, 0.4),
