@@ -335,6 +335,14 @@ __global__ __launch_bounds__(256, kWgPerCu) void k_sp_update(double* __restrict_
   for (int a = 0; a < 2; ++a)
 #pragma unroll
     for (int b = 0; b < 2; ++b) acc[a][b] = double4_t{0.0, 0.0, 0.0, 0.0};
+  // Round 2 measurements on the Final shape (rocprofv3 per launch, FETCH_SIZE per launch, tools/pmc_sparse.sh): the first 70 of
+  // the 190 levels hold 15-22 k targets each (1.06 sources per target) and take 28 of the kernel's 34 ms at 24 ns per
+  // target, i.e. 18 us per workgroup with three on a CU, for 1.7 us of products; HBM delivers 1.9 TB/s, the matrix cores run
+  // at 29 %.  A/B, same box: both source tiles staged once per workgroup through LDS with 16-byte loads, the target
+  // requested first and the next source's tiles requested before the current products (73 KB of LDS, two workgroups
+  // per CU): reduced solve 60.0 against 45.0 ms, bitwise the same result -- not kept; an XCD-aware target map: 45.1
+  // against 45.0 ms -- not kept; a probe without the operand loads: 33.2 ms -- two thirds of the time is what a
+  // one-source workgroup costs around its products (dispatch, index chain, the target's read-modify-write and drain).
   // Most targets have one or two sources per level, so a workgroup is a short chain of memory latency -> 32 products
   // -> memory latency; the latency is hidden by running four workgroups per CU (128 registers each: one 32-row half
   // of the two operands at a time), not by software pipelining (a two-stage prefetch needed 300 registers and left one
