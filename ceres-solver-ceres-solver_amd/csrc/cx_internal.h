@@ -108,6 +108,11 @@ struct cx_sp_plan {
   DevBuf<int32_t> d_tgt_pool, d_tgt_flags, d_src_begin, d_src_a, d_src_b;
   DevBuf<int32_t> d_col_start, d_col_pool;  // transposed index: the tiles (K < I, I) of tile column I, ascending K (forward solves)
   DevBuf<double> d_W, d_x;                  // tile pool (factored in place); vectors, block inverses, partial products
+  // sharded matrix (points over ranks): the plan is built from the UNION of the ranks' S cells; a rank scatters its own
+  // cell values into the common cell-major array, which is summed over the ranks and assembled into the pool
+  int64_t num_union_cells = 0;
+  DevBuf<int32_t> d_union_c1, d_union_c2, d_local_to_union;
+  DevBuf<double> d_union_values;
 };
 
 // ----------------------------------------------------------------- matrix

@@ -31,6 +31,11 @@ int cxs_eliminate_rhs(cx_matrix* A, const double* b, double* rhs);
 // + solve in one call.
 int cxsp_build_plan(cx_matrix* A);
 int cxsp_factor_and_solve(cx_matrix* A, const double* Df, const double* rhs, double* z, int* d_flag);
+// Sharded matrix (A->ctx->nranks > 1): the same plan on every rank, from the union of the ranks' cells (one dense
+// presence exchange, at most 16 384 cameras); per solve A->d_S (this rank's cell values, cxs_eliminate_sparse) is summed
+// over the ranks in the union's cell order and the factorisation and the triangular solves are replicated.
+int cxsp_build_plan_sharded(cx_matrix* A);
+int cxsp_factor_and_solve_sharded(cx_matrix* A, const double* Df, const double* rhs, double* z, int* d_flag);
 // The pieces, for any symmetric matrix of 9x9 camera blocks given by a subset of A's S cells (the visibility based
 // preconditioners): plan from the cells (c1 <= c2, every diagonal cell present), assembly of the selected cells
 // (sel_cells = ids into A's cell list or NULL for all; sel_offdiag / offdiag_scale as k_band_assemble), numeric

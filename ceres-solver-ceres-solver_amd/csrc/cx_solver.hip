@@ -1227,15 +1227,24 @@ int SolveSparseSchur239(cx_solver* S, cx_matrix* A, const double* b, const doubl
   CX_TRY(S->flag.alloc(1));
   CX_HIP(hipMemsetAsync(S->flag.p, 0, sizeof(int), st));
   CX_TRY(sw.start());
-  CX_TRY(cxs_assemble_pair_items(A, D));
-  CX_TRY(cxs_eliminate_rhs(A, b, S->v_rhs.p));
+  const bool sharded = ctx->nranks > 1;
+  if (sharded) {
+    // every rank eliminates its own points into its own S cells; the cells (in the order of the ranks' common cell
+    // list) and the right-hand side are summed over the ranks, factorisation and triangular solves are replicated
+    CX_TRY(cxs_eliminate_sparse(A, b, D, S->v_rhs.p));
+    CX_TRY(cx_allreduce_device(ctx, S->v_rhs.p, nf));
+  } else {
+    CX_TRY(cxs_assemble_pair_items(A, D));
+    CX_TRY(cxs_eliminate_rhs(A, b, S->v_rhs.p));
+  }
   CX_TRY(sw.stop(&S->timing.eliminate_ms));
   CX_TRY(sw.start());
   double* z = x + ne;
   summary->num_iterations = 1;
   summary->termination_type = CX_SUCCESS;
   std::snprintf(summary->message, sizeof(summary->message), "Success.");
-  CX_TRY(cxsp_factor_and_solve(A, D ? D + ne : nullptr, S->v_rhs.p, z, S->flag.p));
+  if (sharded) CX_TRY(cxsp_factor_and_solve_sharded(A, D ? D + ne : nullptr, S->v_rhs.p, z, S->flag.p));
+  else CX_TRY(cxsp_factor_and_solve(A, D ? D + ne : nullptr, S->v_rhs.p, z, S->flag.p));
   bool failed = false;
   CX_TRY(CheckFlag(S, "Sparse Cholesky factorization failed: the reduced camera matrix is not positive definite.", summary, &failed));
   if (failed) {
@@ -1253,12 +1262,14 @@ int SolveDenseSchur239(cx_solver* S, cx_matrix* A, const double* b, const double
   cx_context* ctx = S->ctx;
   hipStream_t st = ctx->stream;
   const int64_t nf = 9 * int64_t(A->C), ne = 3 * int64_t(A->P);
-  if (S->opt.type == CX_SPARSE_SCHUR && ctx->nranks == 1) {
+  if (S->opt.type == CX_SPARSE_SCHUR) {
     // tile-sparse factorisation when it stores less than half of the dense upper triangle, or when the dense
-    // matrix (and its working copy) would not be reasonable any more; small problems stay dense (fewer steps)
+    // matrix (and its working copy) would not be reasonable any more; small problems stay dense (fewer steps).
+    // On a sharded matrix the plan comes from the union of the ranks' cells, so every rank decides the same.
     const bool forced = std::getenv("CX_SPARSE_CHOLESKY") != nullptr;
     if (forced || A->C >= kSparseCholeskyMinCameras) {
-      CX_TRY(cxsp_build_plan(A));
+      if (ctx->nranks > 1) CX_TRY(cxsp_build_plan_sharded(A));
+      else CX_TRY(cxsp_build_plan(A));
       if (A->sp.state == 1) {
         const int64_t T = A->sp.T, dense_tiles = T * (T + 1) / 2 + T;
         if (forced || 2 * A->sp.num_tiles <= dense_tiles || A->C >= kDenseSchurMaxCameras)
@@ -1268,10 +1279,9 @@ int SolveDenseSchur239(cx_solver* S, cx_matrix* A, const double* b, const double
   }
   if (A->C >= 2 * kDenseSchurMaxCameras || (ctx->nranks > 1 && A->C >= kDenseSchurMaxCameras)) {
     // a dense S of this size (> 190 GB with its working copy; on several ranks every rank would hold and all-reduce
-    // its own 24+ GB copy) cannot be meant: a sharded context, where the tile-sparse factorisation is not available,
-    // or a structure whose tile-sparse plan could not be built
+    // its own 24+ GB copy) cannot be meant: DENSE_SCHUR, or a structure whose tile-sparse plan could not be built
     cx_set_error("%s with %d cameras: the dense reduced matrix does not fit and the tile-sparse Cholesky is not available "
-                 "here (sharded context or too much fill); use ITERATIVE_SCHUR", S->opt.type == CX_SPARSE_SCHUR ? "SPARSE_SCHUR" : "DENSE_SCHUR", A->C);
+                 "here (DENSE_SCHUR, or too much fill); use ITERATIVE_SCHUR", S->opt.type == CX_SPARSE_SCHUR ? "SPARSE_SCHUR" : "DENSE_SCHUR", A->C);
     return CX_ERR_UNSUPPORTED;
   }
   Stopwatch sw{S, st};

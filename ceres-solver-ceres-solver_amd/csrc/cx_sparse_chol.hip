@@ -1143,6 +1143,131 @@ int cxsp_factor_and_solve(cx_matrix* A, const double* Df, const double* rhs, dou
   return CX_OK;
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Sharded matrix: points over ranks.  Every rank sees the cells its own points create; the plan
+// must be the same everywhere, so it is built from the union of the ranks' cells.
+namespace {
+__global__ void k_sp_mark_cells(const int32_t* __restrict__ c1, const int32_t* __restrict__ c2, int64_t num_cells, int C,
+                                double* __restrict__ present) {
+  const int64_t k = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (k < num_cells) present[int64_t(c1[k]) * C + c2[k]] = 1.0;
+}
+// this rank's cell values into their slots of the union's cell-major array (81 doubles per cell)
+__global__ void k_sp_scatter_cells(const double* __restrict__ local, const int32_t* __restrict__ local_to_union, int64_t num_cells,
+                                   double* __restrict__ values) {
+  const int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i >= num_cells * 81) return;
+  const int64_t cell = i / 81;
+  values[int64_t(local_to_union[cell]) * 81 + (i - cell * 81)] = local[i];
+}
+// k_sp_assemble for cell values that are already summed (over items and over ranks): D_f^2 is added here, once
+__global__ __launch_bounds__(3 * 81) void k_sp_assemble_values(const int32_t* __restrict__ cell_c1, const int32_t* __restrict__ cell_c2,
+                                                               const double* __restrict__ values, const double* __restrict__ Df,
+                                                               const int32_t* __restrict__ cam_pos, const int32_t* __restrict__ row_start,
+                                                               const int32_t* __restrict__ row_tiles, double* __restrict__ W,
+                                                               int64_t num_cells) {
+  const int64_t cell = int64_t(blockIdx.x) * 3 + threadIdx.x / 81;
+  if (cell >= num_cells) return;
+  const int el = threadIdx.x % 81;
+  const int c1 = cell_c1[cell], c2 = cell_c2[cell];
+  const int a = el / 9, c = el - a * 9;
+  double v = values[cell * 81 + el];
+  if (c1 == c2 && Df && a == c) {
+    const double d = Df[9 * int64_t(c1) + a];
+    v += d * d;
+  }
+  int row = cam_pos[c1] + a, col = cam_pos[c2] + c;
+  if (c1 != c2 && row > col) { const int t = row; row = col; col = t; }
+  if (row > col) return;
+  const int I = row >> 6, J = col >> 6;
+  const int idx = tile_find(row_tiles, row_start[I], row_start[I + 1], J);
+  W[size_t(idx) * kTileDoubles + (row & 63) * kTile + (col & 63)] = v;
+}
+}  // namespace
+
+int cxsp_build_plan_sharded(cx_matrix* A) {
+  cx_sp_plan* P = &A->sp;
+  if (P->state != 0) return CX_OK;
+  cx_context* ctx = A->ctx;
+  hipStream_t st = ctx->stream;
+  const int C = A->C;
+  CX_TRY(cxs_build_pair_lists(A));
+  // (every rank takes part in the exchange below, whatever its own structure allowed)
+  if (int64_t(C) > 16384) {
+    cx_set_error("SPARSE_SCHUR on a sharded matrix is limited to 16384 cameras (dense exchange of the cell structure)");
+    return CX_ERR_UNSUPPORTED;
+  }
+  DevBuf<double> present;
+  CX_TRY(present.alloc(size_t(C) * C + 1));
+  CX_HIP(hipMemsetAsync(present.p, 0, (size_t(C) * C + 1) * sizeof(double), st));
+  if (A->pairs_state == 1 && A->num_cells > 0)
+    hipLaunchKernelGGL(k_sp_mark_cells, dim3(unsigned((A->num_cells + 255) / 256)), dim3(256), 0, st, (const int32_t*)A->d_cell_c1.p,
+                       (const int32_t*)A->d_cell_c2.p, A->num_cells, C, present.p);
+  if (A->pairs_state != 1) {  // a rank whose pair list does not fit tells the others: nobody builds a plan
+    const double one = 1.0;
+    CX_HIP(hipMemcpyAsync(present.p + size_t(C) * C, &one, sizeof(double), hipMemcpyHostToDevice, st));
+  }
+  CX_HIP(hipGetLastError());
+  CX_TRY(cx_allreduce_device(ctx, present.p, int64_t(C) * C + 1));
+  std::vector<double> h(size_t(C) * C + 1);
+  CX_HIP(hipMemcpyAsync(h.data(), present.p, h.size() * sizeof(double), hipMemcpyDeviceToHost, st));
+  CX_HIP(hipStreamSynchronize(st));
+  if (h[size_t(C) * C] > 0.0) { P->state = 2; return CX_OK; }
+  std::vector<int32_t> u1, u2, local_to_union(size_t(A->num_cells), 0);
+  {
+    size_t k = 0;  // this rank's cells are sorted the same way (block row, then block column)
+    for (int c1 = 0; c1 < C; ++c1)
+      for (int c2 = c1; c2 < C; ++c2)
+        if (c2 == c1 || h[size_t(c1) * C + c2] > 0.0) {
+          if (k < size_t(A->num_cells) && A->h_cell_c1[k] == c1 && A->h_cell_c2[k] == c2) local_to_union[k++] = int32_t(u1.size());
+          u1.push_back(c1);
+          u2.push_back(c2);
+        }
+    if (k != size_t(A->num_cells)) {
+      cx_set_error("internal: this rank's S cells are not a subset of the union");
+      return CX_ERR_INVALID_ARGUMENT;
+    }
+  }
+  std::vector<double>().swap(h);
+  P->num_union_cells = int64_t(u1.size());
+  CX_TRY(P->d_union_c1.upload(u1, st));
+  CX_TRY(P->d_union_c2.upload(u2, st));
+  CX_TRY(P->d_local_to_union.upload(local_to_union, st));
+  return cxsp_plan_from_cells(ctx, C, u1.data(), u2.data(), P->num_union_cells, P);
+}
+
+int cxsp_factor_and_solve_sharded(cx_matrix* A, const double* Df, const double* rhs, double* z, int* d_flag) {
+  cx_context* ctx = A->ctx;
+  hipStream_t st = ctx->stream;
+  cx_sp_plan* P = &A->sp;
+  const int C = A->C, n = 9 * C;
+  if (n == 0) return CX_OK;
+  const size_t count = size_t(P->num_union_cells) * 81;
+  CX_TRY(P->d_union_values.alloc(count));
+  CX_HIP(hipMemsetAsync(P->d_union_values.p, 0, count * sizeof(double), st));
+  if (A->num_cells > 0)
+    hipLaunchKernelGGL(k_sp_scatter_cells, dim3(unsigned((A->num_cells * 81 + 255) / 256)), dim3(256), 0, st, (const double*)A->d_S.p,
+                       (const int32_t*)P->d_local_to_union.p, A->num_cells, P->d_union_values.p);
+  CX_HIP(hipGetLastError());
+  CX_TRY(cx_allreduce_device(ctx, P->d_union_values.p, int64_t(count)));
+  const size_t pool = size_t(P->num_tiles) * kTileDoubles;
+  CX_TRY(P->d_W.alloc(pool));
+  CX_HIP(hipMemsetAsync(P->d_W.p, 0, pool * sizeof(double), st));
+  hipLaunchKernelGGL(k_sp_assemble_values, dim3(unsigned((P->num_union_cells + 2) / 3)), dim3(3 * 81), 0, st,
+                     (const int32_t*)P->d_union_c1.p, (const int32_t*)P->d_union_c2.p, (const double*)P->d_union_values.p, Df,
+                     (const int32_t*)P->d_cam_pos.p, (const int32_t*)P->d_row_start.p, (const int32_t*)P->d_row_tiles.p, P->d_W.p,
+                     P->num_union_cells);
+  hipLaunchKernelGGL(k_sp_rhs, dim3((n + 255) / 256), dim3(256), 0, st, rhs, (const int32_t*)P->d_cam_pos.p,
+                     (const int32_t*)P->d_row_start.p, P->d_W.p, C);
+  CX_TRY(cxsp_factor(ctx, P, d_flag));
+  Scratch sc;
+  CX_TRY(GetScratch(P, &sc));
+  CX_TRY(BackwardSweep(ctx, P, sc, 0));
+  hipLaunchKernelGGL(k_sp_unpermute, dim3((n + 255) / 256), dim3(256), 0, st, (const double*)sc.xp, (const int32_t*)P->d_cam_pos.p, z, C);
+  CX_HIP(hipGetLastError());
+  return CX_OK;
+}
+
 // Host half of the plan on its own (no device): the CPU test suite checks the layout, the symbolic fill and the level
 // schedule through this entry point.
 extern "C" int cx_sparse_cholesky_plan_host(int32_t num_cameras, const int32_t* cell_row, const int32_t* cell_col, int64_t num_cells,

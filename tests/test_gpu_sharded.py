@@ -101,20 +101,60 @@ def _worker(rank, port, results_dir):
     out.append(("minimize", same_path and summ["termination_type"] == summ_r["termination_type"] and err < 1e-4, err,
                 len(its), len(its_r)))
     S.close()
-    # SPARSE_SCHUR on several ranks has no tile-sparse factorisation and the dense reduced matrix of 6 200 cameras would
-    # be 25 GB per rank, all-reduced: refused with a message, not attempted
+    # SPARSE_SCHUR on several ranks: the tile-sparse factorisation on the union of the ranks' S cells (plan from a dense
+    # presence exchange, cell values summed over the ranks, factorisation replicated).  700 cameras take that path by
+    # themselves (>= 512); the 14-camera problem is forced onto it.
+    mid = cx.bal.make_bal_like(700, 5000, 26000, seed=8)
+    Cm, Pm = mid.num_cameras, mid.num_points
+    bs_mid, order_mid = cx.bal.build_structure(mid)
+    bm = cx.bal.partition_points(mid, WORLD)
+    lo_m, hi_m = int(bm[rank]), int(bm[rank + 1])
+    mid_sub = cx.bal.shard(mid, lo_m, hi_m)
+    _, res_m, _, vals_m = orc.bal_evaluate(bs_mid, Cm, Pm, mid.camera_index, mid.point_index, mid.observations, order_mid,
+                                           mid.state())
+    D_mid = np.random.default_rng(4).uniform(0.5, 2.0, 3 * Pm + 9 * Cm) * 1e-2 * np.sqrt(np.abs(vals_m).mean())
+    o_mid = orc.make_options(type=orc.SPARSE_SCHUR, num_eliminate_blocks=Pm)
+    x_mid, s_mid = orc.solve(bs_mid, vals_m, res_m, D_mid, o_mid, r_tolerance=-1.0, q_tolerance=0.1)
+    ev_m = cx.Evaluator(ctx, mid_sub)
+    _, res_sub, _ = ev_m.evaluate(mid_sub.state())
+    Sm = cx.Solver(ctx, type=cx.SPARSE_SCHUR, num_eliminate_blocks=mid_sub.num_points)
+    xm, sm = Sm.solve(ev_m.jacobian(), res_sub, np.concatenate([D_mid[3 * lo_m:3 * hi_m], D_mid[3 * Pm:]]),
+                      r_tolerance=-1.0, q_tolerance=0.1)
+    expect = np.concatenate([x_mid[3 * lo_m:3 * hi_m], x_mid[3 * Pm:]])
+    err = float(np.abs(xm - expect).max() / np.abs(expect).max())
+    first_calls = Sm.timing()["allreduce_calls"]      # the structure exchange + right-hand side + cell values
+    xm2, _ = Sm.solve(ev_m.jacobian(), res_sub, np.concatenate([D_mid[3 * lo_m:3 * hi_m], D_mid[3 * Pm:]]),
+                      r_tolerance=-1.0, q_tolerance=0.1)
+    tm = Sm.timing()
+    out.append(("sharded_sparse_schur_700", sm.termination_type == s_mid.termination_type and err < 1e-8 and
+                first_calls == 3 and tm["allreduce_calls"] == 2 and np.array_equal(xm, xm2), err, first_calls,
+                tm["allreduce_calls"], tm["allreduce_bytes"]))
+    Sm.close()
+    ev_m.close()
+    os.environ["CX_SPARSE_CHOLESKY"] = "1"
+    o_full = orc.make_options(type=orc.SPARSE_SCHUR, num_eliminate_blocks=P)
+    x_full, s_full = orc.solve(bs_full, vals_f, res_f, D_full, o_full, r_tolerance=-1.0, q_tolerance=0.1)
+    Sf = cx.Solver(ctx, type=cx.SPARSE_SCHUR, num_eliminate_blocks=sub.num_points)
+    _, res, _ = ev.evaluate(sub.state())   # (the minimisation above left the Jacobian of its last state in A)
+    xs, ss = Sf.solve(A, res, D, r_tolerance=-1.0, q_tolerance=0.1)
+    del os.environ["CX_SPARSE_CHOLESKY"]
+    expect = np.concatenate([x_full[3 * lo:3 * hi], x_full[3 * P:]])
+    err = float(np.abs(xs - expect).max() / np.abs(expect).max())
+    out.append(("sharded_sparse_schur_forced", ss.termination_type == s_full.termination_type and err < 1e-8, err))
+    Sf.close()
+    # DENSE_SCHUR with 6 200 cameras would be a 25 GB matrix per rank, all-reduced: refused with a message, not attempted
     big = cx.bal.make_bal_like(6200, 7000, 21000, seed=9)
     bb = cx.bal.partition_points(big, WORLD)
     big_sub = cx.bal.shard(big, int(bb[rank]), int(bb[rank + 1]))
     bs_big, _ = cx.bal.build_structure(big_sub)
     Ab = cx.Matrix(ctx, bs_big, big_sub.num_points)
     Ab.set_values(cx.bal.random_jacobian_values(big_sub.num_observations, 1))
-    Sb = cx.Solver(ctx, type=cx.SPARSE_SCHUR, num_eliminate_blocks=big_sub.num_points)
+    Sb = cx.Solver(ctx, type=cx.DENSE_SCHUR, num_eliminate_blocks=big_sub.num_points)
     try:
         Sb.solve(Ab, np.ones(Ab.num_rows), np.ones(Ab.num_cols))
-        out.append(("sharded_sparse_schur_refused", False, "no error"))
+        out.append(("sharded_dense_schur_refused", False, "no error"))
     except cx.binding.CxError as e:
-        out.append(("sharded_sparse_schur_refused", "does not fit" in str(e), str(e)[:80]))
+        out.append(("sharded_dense_schur_refused", "does not fit" in str(e), str(e)[:80]))
     Sb.close()
     Ab.close()
     with open(os.path.join(results_dir, "rank%d.txt" % rank), "w") as f:
@@ -132,7 +172,7 @@ def test_two_ranks_one_gpu(tmp_path, oracle):
     mp.spawn(_worker, args=(port, str(tmp_path)), nprocs=WORLD, join=True)
     for rank in range(WORLD):
         lines = open(tmp_path / ("rank%d.txt" % rank)).read().strip().splitlines()
-        assert len(lines) == 13
+        assert len(lines) == 15
         for line in lines:
             rec = eval(line)
             assert rec[1], line
