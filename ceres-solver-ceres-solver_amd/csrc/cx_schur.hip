@@ -1085,6 +1085,125 @@ __global__ __launch_bounds__(kBlock) void k_pair_items(const int32_t* __restrict
   }
 }
 
+// Stage 1 with the operands staged through LDS (round 2, the default).  k_pair_items above issues 18 eight-byte loads
+// per thread and pair -- 4 536 lane loads for the 28 pairs of a step, every value fetched by three threads.  Here the
+// workgroup fetches the 27 + 27 doubles of a pair once, as 28 sixteen-byte pieces (the two operands start on 16-byte
+// boundaries when ten doubles of the shared middle record are taken instead of nine), one step ahead of the products,
+// and the threads read their 3 + 3 triples from LDS.  Same pairs per group in the same order: bitwise the same sums.
+// Measured (Final shape, 164 M pairs, same box): elimination 20.4 -> 19.1 ms, i.e. this kernel 14.4 -> 13.1 ms -- the
+// load instructions were not the limit either (nor the XCD placement of the items: 2 %); what remains is 32.8 GB
+// (FETCH_SIZE) of 216-byte records read from random places of a 12.5 GB table, one record per pair, at 2.5 TB/s.
+constexpr int kPairOperand = 28;  // staged doubles per operand: B = bg0[0..18) | bg1[0..10), G = bg1[8..18) | bg2[0..18)
+constexpr int kPairPieces = kPairGroups * 28;  // 16-byte pieces per step
+__global__ __launch_bounds__(kBlock) void k_pair_items_staged(const int32_t* __restrict__ pair_rows,
+                                                              const int64_t* __restrict__ item_begin,
+                                                              const int32_t* __restrict__ item_ids,
+                                                              const double* __restrict__ bg0, const double* __restrict__ bg1,
+                                                              const double* __restrict__ bg2, double* __restrict__ item_partial,
+                                                              int num_launch_items) {
+  constexpr int kStage = kPairGroups * 2 * kPairOperand;  // doubles per buffer
+  __shared__ double lds[(2 * kStage > kPairGroups * 81) ? 2 * kStage : kPairGroups * 81];
+  const int tid = threadIdx.x;
+  const int slot = num_launch_items > 0 ? xcd_segment(num_launch_items) : int(blockIdx.x);
+  if (slot < 0) return;
+  const int64_t item = item_ids ? int64_t(item_ids[slot]) : int64_t(slot);
+  const int64_t p0 = item_begin[item], p1 = item_begin[item + 1];
+  const int steps = int((p1 - p0 + kPairGroups - 1) / kPairGroups);
+  // the (up to four) pieces this thread moves per step: pair slot, source array and offset, place in the buffer
+  int pg[4], dst[4], off[4], sel[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int q = tid + i * kBlock;
+    const int g = q / 28, w = q - g * 28;
+    const int operand = w / 14, pc = w - operand * 14;
+    pg[i] = q < kPairPieces ? g : -1;
+    // B: pieces 0..8 of bg0, then 0..4 of bg1;  G: pieces 4..8 of bg1 (from double 8), then 0..8 of bg2
+    const int first = operand == 0 ? 9 : 5;
+    sel[i] = 2 * operand + (pc < first ? 0 : 1);                          // 0 bg0, 1 bg1 (front), 2 bg1 (back), 3 bg2
+    off[i] = pc < first ? (operand == 0 ? 2 * pc : 8 + 2 * pc) : 2 * (pc - first);
+    dst[i] = (g * 2 + operand) * kPairOperand + 2 * pc;
+  }
+  // (macros, not lambdas: arrays captured by reference went to scratch memory)
+#define CX_PAIR_ROW(i, step, out)                                                                     \
+  do {                                                                                                \
+    const int64_t k_ = p0 + int64_t(step) * kPairGroups + pg[i];                                      \
+    out = (pg[i] >= 0 && k_ < p1) ? pair_rows[2 * k_ + (sel[i] >> 1)] : -1;                           \
+  } while (0)
+#define CX_PAIR_FETCH(i, row, out)                                                                    \
+  do {                                                                                                \
+    const double* base_ = sel[i] == 0 ? bg0 : (sel[i] == 3 ? bg2 : bg1);                              \
+    out = (row) < 0 ? make_double2(0.0, 0.0)                                                          \
+                    : *reinterpret_cast<const double2*>(base_ + 18 * int64_t(row) + off[i]);         \
+  } while (0)
+  int32_t rows_next[4];
+  double2 v[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) CX_PAIR_ROW(i, 0, rows_next[i]);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) CX_PAIR_FETCH(i, rows_next[i], v[i]);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    if (steps > 1) CX_PAIR_ROW(i, 1, rows_next[i]);
+    else rows_next[i] = -1;
+  }
+  const int g = tid / 9, sub = tid - g * 9;
+  const int a0 = 3 * (sub / 3), c0 = 3 * (sub - 3 * (sub / 3));
+  double acc[9];
+#pragma unroll
+  for (int k = 0; k < 9; ++k) acc[k] = 0.0;
+  for (int s = 0; s < steps; ++s) {
+    double* buf = lds + (s & 1) * kStage;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      if (pg[i] >= 0) *reinterpret_cast<double2*>(buf + dst[i]) = v[i];
+    __syncthreads();
+    if (s + 1 < steps) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) CX_PAIR_FETCH(i, rows_next[i], v[i]);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        if (s + 2 < steps) CX_PAIR_ROW(i, s + 2, rows_next[i]);
+        else rows_next[i] = -1;
+      }
+    }
+    if (g < kPairGroups && p0 + int64_t(s) * kPairGroups + g < p1) {
+      const double* Bop = buf + (g * 2) * kPairOperand;
+      const double* Gop = Bop + kPairOperand;
+      double B[9], G[9];
+#pragma unroll
+      for (int i = 0; i < 3; ++i) {
+        B[i] = Bop[a0 + i];
+        B[3 + i] = Bop[9 + a0 + i];
+        B[6 + i] = Bop[18 + a0 + i];
+        G[i] = Gop[1 + c0 + i];
+        G[3 + i] = Gop[10 + c0 + i];
+        G[6 + i] = Gop[19 + c0 + i];
+      }
+#pragma unroll
+      for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) acc[i * 3 + j] += (B[i] * G[j] + B[3 + i] * G[3 + j]) + B[6 + i] * G[6 + j];
+    }
+  }
+  __syncthreads();  // the staging buffers become the groups' partial sums
+  double* part = lds;
+  if (g < kPairGroups) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+      for (int j = 0; j < 3; ++j) part[g * 81 + (a0 + i) * 9 + c0 + j] = acc[i * 3 + j];
+  }
+  __syncthreads();
+  if (tid < 81) {
+    double v81 = 0.0;
+#pragma unroll 4
+    for (int q = 0; q < kPairGroups; ++q) v81 += part[q * 81 + tid];
+    item_partial[item * 81 + tid] = v81;
+  }
+#undef CX_PAIR_ROW
+#undef CX_PAIR_FETCH
+}
+
 // Stage 2, 81 threads per non-zero cell (c1 <= c2): [c1 == c2] F'F - sum of the cell's items, written either
 // into the dense row-major lhs (pre-zeroed; D_f^2 added on the diagonal -- the reference's dense S) or
 // into the cell-major sparse value array (81 contiguous doubles per cell, D_f^2 NOT added: the sparse
@@ -1267,8 +1386,9 @@ int cxs_assemble_pair_items(cx_matrix* A, const double* D, const int32_t* item_i
   CX_TRY(cxs_camera_block_diagonal(A, A->d_elim_diag.p));
   const int64_t launch_items = item_ids ? num_selected : A->num_items;
   static const bool xcd_items = std::getenv("CX_NO_XCD_ITEMS") == nullptr;  // A/B switch
+  static const bool staged = std::getenv("CX_PAIR_ITEMS_DIRECT") == nullptr;  // A/B switch: round 1's k_pair_items
   if (launch_items > 0)
-    hipLaunchKernelGGL(k_pair_items, dim3(unsigned(xcd_items ? xcd_grid(int(launch_items)) : launch_items)), dim3(kBlock), 0, st,
+    hipLaunchKernelGGL(staged ? k_pair_items_staged : k_pair_items, dim3(unsigned(xcd_items ? xcd_grid(int(launch_items)) : launch_items)), dim3(kBlock), 0, st,
                        (const int32_t*)A->d_pair_rows.p, (const int64_t*)A->d_item_begin.p, item_ids, (const double*)A->d_elim_bg0.p,
                        (const double*)A->d_elim_bg1.p, (const double*)A->d_elim_bg2.p, A->d_item_partial.p,
                        xcd_items ? int(launch_items) : 0);
