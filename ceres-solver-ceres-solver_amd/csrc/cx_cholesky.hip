@@ -75,7 +75,7 @@ __device__ __forceinline__ void store_x(const double4_t (&X)[2][2], double* __re
 // cxchol::potrf_inverse_regs (unit diagonal outside the next diagonal block, zeros below the diagonal).
 __device__ __forceinline__ void fused_tile(double* __restrict__ W, int ldw, double* __restrict__ F, int n, double* __restrict__ y,
                                            const double* __restrict__ uinv, int k0, int kb, int ti, int tj, bool update,
-                                           double4_t (*keep)[2][2] = nullptr) {
+                                           double4_t (*keep)[2][2] = nullptr, double* __restrict__ xshare = nullptr) {
   const int rest = k0 + kb;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int li = lane & 15, lk = lane >> 4;
@@ -96,18 +96,52 @@ __device__ __forceinline__ void fused_tile(double* __restrict__ W, int ldw, doub
           Wq[a][b][g] = (i < n && j <= n && j >= i) ? W[size_t(i) * ldw + j] : 0.0;
         }
   }
-  double4_t Xj[2][2];
-  panel_x(W, ldw, uinv, k0, kb, j0, n, Xj);
-  if (ti == 0 && (wave >> 1) == 0) store_x(Xj, F, n, y, k0, kb, j0);
-  if (!update) return;
-  double4_t Xi[2][2];
-  if (i0 == j0) {
+  double4_t Xj[2][2], Xi[2][2];
+  if (xshare != nullptr && update) {
+    // The panel solve X = U_kk^-T W(k, .) of the tile's four 32-column blocks -- two of its columns, two of its rows --
+    // is done ONCE per workgroup: wavefront w solves block w (0, 1: the column blocks, which the first tile row also
+    // stores as rows of the factor; 2, 3: the row blocks, equal to the column blocks on a diagonal tile) and the
+    // others pick it up from LDS, where the result registers ARE the operand layout.  64 instead of 96 matrix
+    // instructions per wavefront and step: at 105 cycles each (tools/mfma_peak.hip) they were two thirds of an early
+    // step's time.
+    const bool diag_tile = ti == tj;
+    const int c0 = wave < 2 ? rest + tj * 64 + 32 * wave : rest + ti * 64 + 32 * (wave - 2);
+    double* mine = xshare + wave * 1024;
+    if (wave < 2 || !diag_tile) {
+      double4_t X[2][2];
+      panel_x(W, ldw, uinv, k0, kb, c0, n, X);
+      if (ti == 0 && wave < 2) store_x(X, F, n, y, k0, kb, c0);
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+          for (int g = 0; g < 4; ++g) mine[((mt * 2 + nt) * 4 + g) * 64 + lane] = X[mt][nt][g];
+    }
+    __syncthreads();
+    const double* pj = xshare + (wave & 1) * 1024;
+    const double* pi = xshare + ((diag_tile ? 0 : 2) + (wave >> 1)) * 1024;
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-      for (int nt = 0; nt < 2; ++nt) Xi[mt][nt] = Xj[mt][nt];
+      for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          Xj[mt][nt][g] = pj[((mt * 2 + nt) * 4 + g) * 64 + lane];
+          Xi[mt][nt][g] = pi[((mt * 2 + nt) * 4 + g) * 64 + lane];
+        }
   } else {
-    panel_x(W, ldw, uinv, k0, kb, i0, n, Xi);
+    panel_x(W, ldw, uinv, k0, kb, j0, n, Xj);
+    if (ti == 0 && (wave >> 1) == 0) store_x(Xj, F, n, y, k0, kb, j0);
+    if (!update) return;
+    if (i0 == j0) {
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) Xi[mt][nt] = Xj[mt][nt];
+    } else {
+      panel_x(W, ldw, uinv, k0, kb, i0, n, Xi);
+    }
   }
   double4_t acc[2][2];
 #pragma unroll
@@ -161,8 +195,9 @@ __global__ __launch_bounds__(64) void k_chol_first(const double* __restrict__ W,
 // 0 owns tile (0,0) and the look-ahead.  Tr == 0 (last block step): only the right-hand side is left.
 __global__ __launch_bounds__(256) void k_chol_step(double* __restrict__ W, int ldw, double* __restrict__ F, int n,
                                                    double* __restrict__ y, double* __restrict__ uinv, int k0,
-                                                   int* __restrict__ not_pd) {
+                                                   int* __restrict__ not_pd, int share_panel) {
   __shared__ double lds[cxchol::kPotrfLds];
+  __shared__ double xshare[4 * 1024];  // the four 32 x 32 panel blocks of the tile (fused_tile)
   const int kb = min(NB, n - k0);
   const int rest = k0 + kb;
   const int rem = n - rest;
@@ -178,7 +213,7 @@ __global__ __launch_bounds__(256) void k_chol_step(double* __restrict__ W, int l
   while (t >= first + (Tc - ti)) { first += Tc - ti; ++ti; }
   const bool lookahead = t == 0 && threadIdx.x < 64;
   double4_t next[2][2];
-  fused_tile(W, ldw, F, n, y, ui, k0, kb, ti, ti + (t - first), true, lookahead ? &next : nullptr);
+  fused_tile(W, ldw, F, n, y, ui, k0, kb, ti, ti + (t - first), true, lookahead ? &next : nullptr, share_panel ? xshare : nullptr);
   if (lookahead) {
     // look-ahead: the next diagonal block is the quadrant this very wavefront has just updated -- it goes on to the
     // factorisation in registers (round 1 stored it, waited for the stores and loaded it again: two dependent memory
@@ -268,11 +303,12 @@ int cxd_cholesky_solve(cx_context* ctx, int n, double* a, const double* rhs, dou
   double* uinv = y + n;  // one inverted diagonal block per 32 rows
   hipLaunchKernelGGL(k_chol_augment, dim3((n + 1 + 255) / 256, n), dim3(256), 0, st, (const double*)a, rhs, n, ldw, W);
   hipLaunchKernelGGL(k_chol_first, dim3(1), dim3(64), 0, st, (const double*)W, ldw, a, n, uinv, d_flag);
+  static const bool share_panel = std::getenv("CX_CHOL_NO_PANEL_SHARING") == nullptr;  // A/B switch
   for (int k0 = 0; k0 < n; k0 += NB) {
     const int rem = n - std::min(n, k0 + NB);
     const int Tr = (rem + 63) / 64, Tc = (rem + 1 + 63) / 64;
     const int NT = Tr == 0 ? 1 : Tr * Tc - Tr * (Tr - 1) / 2;
-    hipLaunchKernelGGL(k_chol_step, dim3(NT), dim3(256), 0, st, W, ldw, a, n, y, uinv, k0, d_flag);
+    hipLaunchKernelGGL(k_chol_step, dim3(NT), dim3(256), 0, st, W, ldw, a, n, y, uinv, k0, d_flag, share_panel ? 1 : 0);
   }
   CX_HIP(hipGetLastError());
   const int last = ((n - 1) / 64) * 64;
