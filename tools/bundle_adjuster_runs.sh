@@ -1,0 +1,15 @@
+#!/bin/bash
+# The end-to-end runs of profiles/rNN_bundle_adjuster_runs.log (whole minimisations on the device, cx_minimize).
+set -o pipefail
+R=${CX_ROUND:-02}
+OUT=$GRAFT_REPO_ROOT/gpurun_out/r${R}_bundle_adjuster_runs.log
+BA="python $GRAFT_REPO_ROOT/ceres-solver-ceres-solver_amd/examples/bundle_adjuster.py"
+: > $OUT
+run() { echo "### bundle_adjuster.py $*" >> $OUT; $BA "$@" >> $OUT 2>&1; }
+run --preset final13682 --num_iterations 8 --preconditioner jacobi
+run --preset final13682 --num_iterations 8 --preconditioner cluster_jacobi
+run --preset final13682 --num_iterations 8 --preconditioner cluster_tridiagonal
+run --preset final13682 --num_iterations 8 --preconditioner schur_jacobi --explicit_schur_complement
+run --preset final13682 --num_iterations 8 --linear_solver sparse_schur
+run --preset dubrovnik356 --linear_solver dense_schur
+grep -n "^###\|^Time\|Minimizer iterations" $OUT
