@@ -343,6 +343,9 @@ __global__ __launch_bounds__(256, kWgPerCu) void k_sp_update(double* __restrict_
   // per CU): reduced solve 60.0 against 45.0 ms, bitwise the same result -- not kept; an XCD-aware target map: 45.1
   // against 45.0 ms -- not kept; a probe without the operand loads: 33.2 ms -- two thirds of the time is what a
   // one-source workgroup costs around its products (dispatch, index chain, the target's read-modify-write and drain).
+  // Last A/B: the one-source targets (94 %) grouped into tasks by (source row, left tile), the left operand kept in
+  // registers over 2 / 4 / 8 / 16 targets (190 registers, two workgroups per CU): 48.5 / 49.6 / 53.3 / 60.4 ms against
+  // 45.0 -- a target costs the same inside a loop as in a workgroup of its own, and long tasks add a serial tail.
   // Most targets have one or two sources per level, so a workgroup is a short chain of memory latency -> 32 products
   // -> memory latency; the latency is hidden by running four workgroups per CU (128 registers each: one 32-row half
   // of the two operands at a time), not by software pipelining (a two-stage prefetch needed 300 registers and left one
