@@ -373,6 +373,70 @@ __global__ __launch_bounds__(256, kWgPerCu) void k_sp_update(double* __restrict_
   subtract_block(acc, dst, 32, 32, (flags & 1) && qi == qj);
 }
 
+// k_sp_update with the operands in SLICES of the 64-row K dimension (kSteps x 4 rows: 4 kSteps registers per operand), the
+// next slice requested before the current one's 4 kSteps products (round 2, the default with 8-row slices).  The kernel is
+// bound by what one target costs at the occupancy its registers allow (see k_sp_update): 76 instead of 162 registers put
+// five workgroups on a CU instead of three, and every product has the next slice's loads in flight behind it.  Same
+// products in the same order: bitwise the results of k_sp_update.  Final shape, same box, reduced solve: 45.0 ms
+// (k_sp_update, halves of 32 rows) -> 41.1 (16-row slices, 4 per CU) -> 38.6 (8 rows, 5 per CU; 6 per CU the same) ->
+// 39.1 (4 rows); requesting two or three slices ahead: 40.2-41.2 (the register shuffle costs more than it hides).
+template <int kSteps>
+__device__ __forceinline__ void load_slice(const double* __restrict__ src, double (&X)[2][kSteps]) {
+  const int lane = threadIdx.x & 63, li = lane & 15, lk = lane >> 4;
+#pragma unroll
+  for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+    for (int g = 0; g < kSteps; ++g) X[nt][g] = src[size_t(lk + 4 * g) * kTile + 16 * nt + li];
+}
+template <int kSteps>
+__device__ __forceinline__ void mfma_slice(const double (&A)[2][kSteps], const double (&B)[2][kSteps], double4_t (&acc)[2][2]) {
+#pragma unroll
+  for (int g = 0; g < kSteps; ++g)
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int b = 0; b < 2; ++b) acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(A[a][g], B[b][g], acc[a][b], 0, 0, 0);
+}
+template <int kSteps, int kWgPerCu>
+__global__ __launch_bounds__(256, kWgPerCu) void k_sp_update_slices(double* __restrict__ W, const int32_t* __restrict__ tgt_pool,
+                                                                    const int32_t* __restrict__ tgt_flags, const int32_t* __restrict__ src_begin,
+                                                                    const int32_t* __restrict__ src_a, const int32_t* __restrict__ src_b) {
+  constexpr int kSlices = 16 / kSteps;  // per source: 64 rows of K
+  const int t = blockIdx.x;
+  const int wave = threadIdx.x >> 6;
+  const int qi = wave >> 1, qj = wave & 1;
+  const int flags = tgt_flags[t];
+  if ((flags & 1) && qi == 1 && qj == 0) return;
+  if ((flags & 2) && qj == 1) return;
+  double4_t acc[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b) acc[a][b] = double4_t{0.0, 0.0, 0.0, 0.0};
+  const int s0 = src_begin[t], s1 = src_begin[t + 1];
+  const int nq = kSlices * (s1 - s0);
+  double A[2][kSteps], B[2][kSteps], An[2][kSteps], Bn[2][kSteps];
+#define CX_SP_REQUEST(q, a, b)                                                                     \
+  do {                                                                                             \
+    const int s_ = s0 + (q) / kSlices;                                                             \
+    const size_t row_ = size_t(4 * kSteps * ((q) % kSlices)) * kTile;                              \
+    load_slice<kSteps>(W + size_t(src_b[s_]) * kTileDoubles + 32 * qj + row_, b);                 \
+    load_slice<kSteps>(W + size_t(src_a[s_]) * kTileDoubles + 32 * qi + row_, a);                 \
+  } while (0)
+  if (nq > 0) CX_SP_REQUEST(0, A, B);
+  for (int q = 0; q < nq; ++q) {
+    if (q + 1 < nq) CX_SP_REQUEST(q + 1, An, Bn);
+    mfma_slice<kSteps>(A, B, acc);
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int g = 0; g < kSteps; ++g) { A[i][g] = An[i][g]; B[i][g] = Bn[i][g]; }
+  }
+#undef CX_SP_REQUEST
+  double* dst = W + size_t(tgt_pool[t]) * kTileDoubles + size_t(32 * qi) * kTile + 32 * qj;
+  subtract_block(acc, dst, 32, 32, (flags & 1) && qi == qj);
+}
+
 // Backward substitution of a level (top down), part 1: workgroup = one tile F(I, J) right of the diagonal of a row of
 // the level: partial[tile][r] = sum_c F(I, J)[r][c] x_J[c].
 __global__ __launch_bounds__(256) void k_sp_bwd_partial(const double* __restrict__ W, const int32_t* __restrict__ row_tiles,
@@ -1069,10 +1133,19 @@ int cxsp_factor(cx_context* ctx, cx_sp_plan* P, int* d_flag) {
   hipLaunchKernelGGL(k_sp_update<K>, dim3(unsigned(nt)), dim3(256), 0, st, W, (const int32_t*)P->d_tgt_pool.p + t0,              \
                      (const int32_t*)P->d_tgt_flags.p + t0, (const int32_t*)P->d_src_begin.p + t0,                               \
                      (const int32_t*)P->d_src_a.p, (const int32_t*)P->d_src_b.p)
-      if (occ >= 4) CX_SP_UPDATE(4);
+      static const int slices = std::getenv("CX_SPARSE_UPDATE_SLICES") ? atoi(std::getenv("CX_SPARSE_UPDATE_SLICES")) : 8;  // rows; 0: k_sp_update
+#define CX_SP_SLICES(S, K)                                                                                                      \
+  hipLaunchKernelGGL((k_sp_update_slices<S, K>), dim3(unsigned(nt)), dim3(256), 0, st, W, (const int32_t*)P->d_tgt_pool.p + t0,  \
+                     (const int32_t*)P->d_tgt_flags.p + t0, (const int32_t*)P->d_src_begin.p + t0,                               \
+                     (const int32_t*)P->d_src_a.p, (const int32_t*)P->d_src_b.p)
+      if (slices == 16) CX_SP_SLICES(4, 4);
+      else if (slices == 8) CX_SP_SLICES(2, 5);
+      else if (slices == 4) CX_SP_SLICES(1, 6);
+      else if (occ >= 4) CX_SP_UPDATE(4);
       else if (occ == 3) CX_SP_UPDATE(3);
       else CX_SP_UPDATE(2);
 #undef CX_SP_UPDATE
+#undef CX_SP_SLICES
     }
   }
   CX_HIP(hipGetLastError());
