@@ -73,6 +73,7 @@ __device__ __forceinline__ void store_x(const double4_t (&X)[2][2], double* __re
 // Tiles of the first tile row also store X_j: together they write rows k0.. of the factor.
 // keep != nullptr (the look-ahead wavefront): the updated quadrant is also returned in registers, padded for
 // cxchol::potrf_inverse_regs (unit diagonal outside the next diagonal block, zeros below the diagonal).
+template <bool SHARE>
 __device__ __forceinline__ void fused_tile(double* __restrict__ W, int ldw, double* __restrict__ F, int n, double* __restrict__ y,
                                            const double* __restrict__ uinv, int k0, int kb, int ti, int tj, bool update,
                                            double4_t (*keep)[2][2] = nullptr, double* __restrict__ xshare = nullptr) {
@@ -97,7 +98,7 @@ __device__ __forceinline__ void fused_tile(double* __restrict__ W, int ldw, doub
         }
   }
   double4_t Xj[2][2], Xi[2][2];
-  if (xshare != nullptr && update) {
+  if constexpr (SHARE) {
     // The panel solve X = U_kk^-T W(k, .) of the tile's four 32-column blocks -- two of its columns, two of its rows --
     // is done ONCE per workgroup: wavefront w solves block w (0, 1: the column blocks, which the first tile row also
     // stores as rows of the factor; 2, 3: the row blocks, equal to the column blocks on a diagonal tile) and the
@@ -193,9 +194,10 @@ __global__ __launch_bounds__(64) void k_chol_first(const double* __restrict__ W,
 // One block step (see the file header).  Block b > 0 owns tile number b of the upper block trapezoid of
 // the trailing matrix (row ti has Tc - ti tiles; the last column tile holds the right-hand side); block
 // 0 owns tile (0,0) and the look-ahead.  Tr == 0 (last block step): only the right-hand side is left.
+template <bool SHARE>
 __global__ __launch_bounds__(256) void k_chol_step(double* __restrict__ W, int ldw, double* __restrict__ F, int n,
                                                    double* __restrict__ y, double* __restrict__ uinv, int k0,
-                                                   int* __restrict__ not_pd, int share_panel) {
+                                                   int* __restrict__ not_pd) {
   __shared__ double lds[cxchol::kPotrfLds];
   __shared__ double xshare[4 * 1024];  // the four 32 x 32 panel blocks of the tile (fused_tile)
   const int kb = min(NB, n - k0);
@@ -205,7 +207,7 @@ __global__ __launch_bounds__(256) void k_chol_step(double* __restrict__ W, int l
   const int Tr = (rem + 63) / 64;
   const int Tc = (rem + 1 + 63) / 64;
   if (Tr == 0) {
-    fused_tile(W, ldw, F, n, y, ui, k0, kb, 0, 0, false);
+    fused_tile<false>(W, ldw, F, n, y, ui, k0, kb, 0, 0, false);
     return;
   }
   int ti = 0, first = 0;
@@ -213,7 +215,7 @@ __global__ __launch_bounds__(256) void k_chol_step(double* __restrict__ W, int l
   while (t >= first + (Tc - ti)) { first += Tc - ti; ++ti; }
   const bool lookahead = t == 0 && threadIdx.x < 64;
   double4_t next[2][2];
-  fused_tile(W, ldw, F, n, y, ui, k0, kb, ti, ti + (t - first), true, lookahead ? &next : nullptr, share_panel ? xshare : nullptr);
+  fused_tile<SHARE>(W, ldw, F, n, y, ui, k0, kb, ti, ti + (t - first), true, lookahead ? &next : nullptr, xshare);
   if (lookahead) {
     // look-ahead: the next diagonal block is the quadrant this very wavefront has just updated -- it goes on to the
     // factorisation in registers (round 1 stored it, waited for the stores and loaded it again: two dependent memory
@@ -308,7 +310,10 @@ int cxd_cholesky_solve(cx_context* ctx, int n, double* a, const double* rhs, dou
     const int rem = n - std::min(n, k0 + NB);
     const int Tr = (rem + 63) / 64, Tc = (rem + 1 + 63) / 64;
     const int NT = Tr == 0 ? 1 : Tr * Tc - Tr * (Tr - 1) / 2;
-    hipLaunchKernelGGL(k_chol_step, dim3(NT), dim3(256), 0, st, W, ldw, a, n, y, uinv, k0, d_flag, share_panel ? 1 : 0);
+    // (A/B: capping the kernel at 168 registers -- three instead of two workgroups per CU, no spills -- changed nothing:
+    // reduced solve 2.13 ms either way on Dubrovnik-356)
+    if (share_panel) hipLaunchKernelGGL(k_chol_step<true>, dim3(NT), dim3(256), 0, st, W, ldw, a, n, y, uinv, k0, d_flag);
+    else hipLaunchKernelGGL(k_chol_step<false>, dim3(NT), dim3(256), 0, st, W, ldw, a, n, y, uinv, k0, d_flag);
   }
   CX_HIP(hipGetLastError());
   const int last = ((n - 1) / 64) * 64;
