@@ -340,7 +340,7 @@ def main():
         abytes = 212.0 * Ol + 72.0 * Pl + 72.0 * C
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tpath):
+        if os.path.exists(tpath) and world == 1:   # the PMC passes were collected on the unsharded workload
             try:
                 traffic = json.load(open(tpath)).get(args.workload, {}).get(dom)
             except Exception:
