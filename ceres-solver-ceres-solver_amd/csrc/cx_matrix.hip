@@ -164,21 +164,38 @@ __global__ __launch_bounds__(kBlock) void k_cam_ft(const T* __restrict__ Ft,
                                                    const double* __restrict__ t,
                                                    double* __restrict__ partial, const int* __restrict__ stop,
                                                    int num_segs) {
-  __shared__ double lds[kBlock * 18];
+  __shared__ double lds[FStage<T>::kLdsDoubles];
   __shared__ double red[9 * 4];
   if (stop && *stop) return;
-  const int s = xcd_segment(num_segs), tid = threadIdx.x;
+  const int s = xcd_segment(num_segs < 0 ? -num_segs : num_segs), tid = threadIdx.x;  // (num_segs < 0: A/B, the unpipelined loop)
   if (s < 0) return;
   const int b = seg_begin[s], e = seg_begin[s + 1];
   double acc[9];
 #pragma unroll
   for (int k = 0; k < 9; ++k) acc[k] = 0.0;
+  // Software pipeline over the segment's passes (round 2, as in k_cam_init): the cells of pass k + 1, its row ids and the
+  // t' values they point to (a two-hop chain) are requested before the arithmetic of pass k.
+  typename FStage<T>::Pieces v;
+  double2 tv_next = make_double2(0.0, 0.0);
+  const bool pipe = num_segs > 0;
+  if (pipe) {
+    FStage<T>::load(Ft + 18 * int64_t(b), min(kBlock, e - b), v);
+    if (b + tid < e) tv_next = reinterpret_cast<const double2*>(t)[cam_rows[b + tid]];
+  }
   for (int k0 = b; k0 < e; k0 += kBlock) {
     const int nvalid = min(kBlock, e - k0);
     double f[18];
-    stage_cells<18>(Ft + 18 * int64_t(k0), nvalid, lds, f);
+    if (!pipe) {
+      FStage<T>::load(Ft + 18 * int64_t(k0), nvalid, v);
+    }
+    FStage<T>::exchange(v, lds, f);
+    if (!pipe && tid < nvalid) tv_next = reinterpret_cast<const double2*>(t)[cam_rows[k0 + tid]];
+    const double2 tv = tv_next;
+    if (pipe && k0 + kBlock < e) {
+      FStage<T>::load(Ft + 18 * int64_t(k0 + kBlock), min(kBlock, e - k0 - kBlock), v);
+      if (k0 + kBlock + tid < e) tv_next = reinterpret_cast<const double2*>(t)[cam_rows[k0 + kBlock + tid]];
+    }
     if (tid < nvalid) {
-      const double2 tv = reinterpret_cast<const double2*>(t)[cam_rows[k0 + tid]];
 #pragma unroll
       for (int k = 0; k < 9; ++k) acc[k] += f[k] * tv.x + f[9 + k] * tv.y;
     }
@@ -546,12 +563,14 @@ int cxk_ft_partials(cx_matrix* A, const double* t) {
   CX_TRY(cx_matrix_ensure_ft(A));
   hipStream_t st = A->ctx->stream;
   if (A->num_segs > 0) {
+    static const bool plain = std::getenv("CX_CAM_FT_PLAIN") != nullptr;  // A/B switch: the unpipelined loop
+    const int segs = plain ? -A->num_segs : A->num_segs;
     if (A->use_f32)
       hipLaunchKernelGGL(k_cam_ft<float>, dim3(xcd_grid(A->num_segs)), dim3(kBlock), 0, st, (const float*)A->d_Ft32.p,
-                         A->d_cam_rows.p, A->d_seg_begin.p, t, A->d_partials.p, A->stop, A->num_segs);
+                         A->d_cam_rows.p, A->d_seg_begin.p, t, A->d_partials.p, A->stop, segs);
     else
       hipLaunchKernelGGL(k_cam_ft<double>, dim3(xcd_grid(A->num_segs)), dim3(kBlock), 0, st, (const double*)A->d_Ft.p,
-                         A->d_cam_rows.p, A->d_seg_begin.p, t, A->d_partials.p, A->stop, A->num_segs);
+                         A->d_cam_rows.p, A->d_seg_begin.p, t, A->d_partials.p, A->stop, segs);
   }
   CX_HIP(hipGetLastError());
   return CX_OK;

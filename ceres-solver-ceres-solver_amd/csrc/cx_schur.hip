@@ -488,12 +488,43 @@ __global__ __launch_bounds__(kBlock) void k_cam_init(const double* __restrict__ 
   for (int k = 0; k < 45; ++k) acc[k] = 0.0;
 #pragma unroll
   for (int k = 0; k < 9; ++k) acc9[k] = 0.0;
+  // Software pipeline over the segment's passes of kBlock rows (round 2): the cells, the row ids and the gathered t' of pass
+  // k + 1 are requested before the arithmetic of pass k.  With 178 registers for the 54 accumulators only two workgroups
+  // fit on a CU, too few to hide a pass's load -> gather chain by themselves; the 40 registers of the prefetch are free
+  // (the kernel stays under 256).
+  // (the variant with the Schur terms has 234 registers already and keeps the plain loop)
+  constexpr bool kPrefetch = !WITH_SCHUR;
+  double2 v[9];
+  int r_next = 0;
+  double2 tv_next = make_double2(0.0, 0.0);
+  if (kPrefetch) {
+    load_cells<18>(Ft + 18 * int64_t(b0), min(kBlock, e0 - b0), v);
+    if (b0 + tid < e0) {
+      r_next = cam_rows[b0 + tid];
+      if (tprime) tv_next = reinterpret_cast<const double2*>(tprime)[r_next];
+    }
+  }
   for (int k0 = b0; k0 < e0; k0 += kBlock) {
     const int nvalid = min(kBlock, e0 - k0);
     double f[18];
-    stage_cells<18>(Ft + 18 * int64_t(k0), nvalid, lds, f);
+    if (!kPrefetch) {
+      load_cells<18>(Ft + 18 * int64_t(k0), nvalid, v);
+      if (tid < nvalid) {
+        r_next = cam_rows[k0 + tid];
+        if (tprime) tv_next = reinterpret_cast<const double2*>(tprime)[r_next];
+      }
+    }
+    exchange_cells<18>(v, lds, f);
+    const int r = r_next;
+    const double2 tv = tv_next;
+    if (kPrefetch && k0 + kBlock < e0) {
+      load_cells<18>(Ft + 18 * int64_t(k0 + kBlock), min(kBlock, e0 - k0 - kBlock), v);
+      if (k0 + kBlock + tid < e0) {
+        r_next = cam_rows[k0 + kBlock + tid];
+        if (tprime) tv_next = reinterpret_cast<const double2*>(tprime)[r_next];
+      }
+    }
     if (tid < nvalid) {
-      const int r = cam_rows[k0 + tid];
 #pragma unroll
       for (int a = 0; a < 9; ++a)
 #pragma unroll
@@ -522,12 +553,10 @@ __global__ __launch_bounds__(kBlock) void k_cam_init(const double* __restrict__ 
             acc[a * 9 - a * (a - 1) / 2 + c - a] -= B[a] * G[c] + B[9 + a] * G[9 + c] + B[18 + a] * G[18 + c];
       }
       if (tprime) {
-        const double2 tv = reinterpret_cast<const double2*>(tprime)[r];
 #pragma unroll
         for (int k = 0; k < 9; ++k) acc9[k] += f[k] * tv.x + f[9 + k] * tv.y;
       }
     }
-    __syncthreads();
   }
   block_sum_store<45>(acc, red, partial45 + int64_t(sgm) * 45);
   if (tprime) block_sum_store<9>(acc9, red, partial9 + int64_t(sgm) * 9);
