@@ -101,20 +101,32 @@ __global__ void k_sp_rhs(const double* __restrict__ rhs, const int32_t* __restri
   W[size_t(row_start[I + 1] - 1) * kTileDoubles + (row & 63) * kTile] = rhs[i];
 }
 
-// out[m] = sum_c M[m][c] v[c] for a 32 x 32 block, 8 threads per row
-__device__ __forceinline__ void sp_gemv32(const double* __restrict__ M, int ldm, const double* __restrict__ v, double* __restrict__ out,
-                                          int rows_valid, int cols_valid) {
+// out[m] = sum_c M[m][c] v[c] for a 32 x 32 block, 8 threads per row.  In two halves, so that a kernel can request the
+// matrix entries of all its products up front (they do not depend on the vectors) and only the LDS-resident vectors are
+// left on its chain of dependent steps.
+__device__ __forceinline__ void sp_gemv32_load(const double* __restrict__ M, int ldm, int rows_valid, int cols_valid, double (&a)[4]) {
   const int t = threadIdx.x, m = t >> 3, part = t & 7;
-  double s = 0.0;
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
     const int c = 4 * part + q;
-    s += (m < rows_valid && c < cols_valid) ? M[size_t(m) * ldm + c] * v[c] : 0.0;
+    a[q] = (m < rows_valid && c < cols_valid) ? M[size_t(m) * ldm + c] : 0.0;
   }
+}
+__device__ __forceinline__ void sp_gemv32_apply(const double (&a)[4], const double* __restrict__ v, double* __restrict__ out) {
+  const int t = threadIdx.x, m = t >> 3, part = t & 7;
+  double s = 0.0;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) s += a[q] * v[4 * part + q];
   s += __shfl_xor(s, 1, 64);
   s += __shfl_xor(s, 2, 64);
   s += __shfl_xor(s, 4, 64);
   if (part == 0) out[m] = s;
+}
+__device__ __forceinline__ void sp_gemv32(const double* __restrict__ M, int ldm, const double* __restrict__ v, double* __restrict__ out,
+                                          int rows_valid, int cols_valid) {
+  double a[4];
+  sp_gemv32_load(M, ldm, rows_valid, cols_valid, a);
+  sp_gemv32_apply(a, v, out);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -471,6 +483,14 @@ __global__ __launch_bounds__(256) void k_sp_bwd_level(const double* __restrict__
   const int k0 = kTile * I;
   const int kb1 = min(NB, valid[I]), kb2 = max(0, min(NB, valid[I] - NB));
   const int q0 = row_start[I], q1 = row_start[I + 1] - 1;  // [q0] diagonal tile, [q1] right-hand-side tile
+  const double* __restrict__ D = W + size_t(q0) * kTileDoubles;
+  const double* __restrict__ ui1 = uinv + size_t(2 * I) * NB * NB;
+  // the entries of the three 32 x 32 products are requested before the row's partial sums are gathered: five dependent
+  // steps of global-memory latency per level become two
+  double a22[4], a12[4], a11[4];
+  sp_gemv32_load(ui1 + NB * NB, NB, NB, NB, a22);
+  sp_gemv32_load(D + NB, kTile, kb1, kb2, a12);
+  sp_gemv32_load(ui1, NB, NB, NB, a11);
   if (t < kTile) {
     double s = 0.0;
 #pragma unroll 8
@@ -480,19 +500,17 @@ __global__ __launch_bounds__(256) void k_sp_bwd_level(const double* __restrict__
     else y2[t - NB] = (t - NB) < kb2 ? yv : 0.0;
   }
   __syncthreads();
-  const double* __restrict__ D = W + size_t(q0) * kTileDoubles;
-  const double* __restrict__ ui1 = uinv + size_t(2 * I) * NB * NB;
   if (kb2 > 0) {
-    sp_gemv32(ui1 + NB * NB, NB, y2, x2, NB, NB);
+    sp_gemv32_apply(a22, y2, x2);
     __syncthreads();
-    sp_gemv32(D + NB, kTile, x2, tmp, kb1, kb2);  // U12 x2
+    sp_gemv32_apply(a12, x2, tmp);  // U12 x2
     __syncthreads();
     if (t < NB) y1[t] -= tmp[t];
   } else if (t < NB) {
     x2[t] = 0.0;
   }
   __syncthreads();
-  sp_gemv32(ui1, NB, y1, x1, NB, NB);
+  sp_gemv32_apply(a11, y1, x1);
   __syncthreads();
   if (t < 64) {
     const double v = t < NB ? x1[t] : x2[t - NB];
@@ -500,20 +518,15 @@ __global__ __launch_bounds__(256) void k_sp_bwd_level(const double* __restrict__
   }
 }
 
-// out[m] = sum_c M[c][m] v[c] (the transposed 32 x 32 block), 8 threads per output
-__device__ __forceinline__ void sp_gemv32_t(const double* __restrict__ M, int ldm, const double* __restrict__ v, double* __restrict__ out,
-                                            int rows_valid, int cols_valid) {
+// out[m] = sum_c M[c][m] v[c] (the transposed 32 x 32 block), 8 threads per output: the load half (the apply half is
+// sp_gemv32_apply)
+__device__ __forceinline__ void sp_gemv32_t_load(const double* __restrict__ M, int ldm, int rows_valid, int cols_valid, double (&a)[4]) {
   const int t = threadIdx.x, m = t >> 3, part = t & 7;
-  double s = 0.0;
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
     const int c = 4 * part + q;
-    s += (c < rows_valid && m < cols_valid) ? M[size_t(c) * ldm + m] * v[c] : 0.0;
+    a[q] = (c < rows_valid && m < cols_valid) ? M[size_t(c) * ldm + m] : 0.0;
   }
-  s += __shfl_xor(s, 1, 64);
-  s += __shfl_xor(s, 2, 64);
-  s += __shfl_xor(s, 4, 64);
-  if (part == 0) out[m] = s;
 }
 
 // Forward substitution U' y = r with a stored factor, by levels bottom up.  Part 1, workgroup = tile row I of the level:
@@ -529,6 +542,12 @@ __global__ __launch_bounds__(256) void k_sp_fwd_level(const double* __restrict__
   const int t = threadIdx.x;
   const int k0 = kTile * I;
   const int kb1 = min(NB, valid[I]), kb2 = max(0, min(NB, valid[I] - NB));
+  const double* __restrict__ D = W + size_t(row_start[I]) * kTileDoubles;
+  const double* __restrict__ ui1 = uinv + size_t(2 * I) * NB * NB;
+  double a11[4], a12[4], a22[4];  // (requested before the partial sums are gathered, see k_sp_bwd_level)
+  sp_gemv32_t_load(ui1, NB, NB, NB, a11);
+  sp_gemv32_t_load(D + NB, kTile, kb1, kb2, a12);
+  sp_gemv32_t_load(ui1 + NB * NB, NB, NB, NB, a22);
   if (t < kTile) {
     double s = 0.0;
 #pragma unroll 8
@@ -538,16 +557,14 @@ __global__ __launch_bounds__(256) void k_sp_fwd_level(const double* __restrict__
     else v2[t - NB] = (t - NB) < kb2 ? v : 0.0;
   }
   __syncthreads();
-  const double* __restrict__ D = W + size_t(row_start[I]) * kTileDoubles;
-  const double* __restrict__ ui1 = uinv + size_t(2 * I) * NB * NB;
-  sp_gemv32_t(ui1, NB, v1, y1, NB, NB);  // y1 = U11^-T v1 (identity-padded inverse)
+  sp_gemv32_apply(a11, v1, y1);  // y1 = U11^-T v1 (identity-padded inverse)
   __syncthreads();
   if (kb2 > 0) {
-    sp_gemv32_t(D + NB, kTile, y1, tmp, kb1, kb2);  // U12' y1
+    sp_gemv32_apply(a12, y1, tmp);  // U12' y1
     __syncthreads();
     if (t < NB) v2[t] -= tmp[t];
     __syncthreads();
-    sp_gemv32_t(ui1 + NB * NB, NB, v2, y2, NB, NB);
+    sp_gemv32_apply(a22, v2, y2);
     __syncthreads();
   } else if (t < NB) {
     y2[t] = 0.0;
@@ -1160,6 +1177,9 @@ int BackwardSweep(cx_context* ctx, cx_sp_plan* P, const Scratch& sc, int y_in_x)
   for (int l = P->num_levels - 1; l >= 0; --l) {
     const int r0 = P->h_level_row_begin[size_t(l)], nr = P->h_level_row_begin[size_t(l) + 1] - r0;
     const int p0 = P->h_level_panel_begin[size_t(l)], np = P->h_level_panel_begin[size_t(l) + 1] - p0;
+    // (A/B, round 2: both parts of a level in one launch -- the workgroup that finishes a row's last tile, told by an arrival
+    // counter, going on with the row's part 2 -- took the same time: 3.474 against 3.472 ms per CG iteration with
+    // CLUSTER_TRIDIAGONAL on the Final shape; the ticket costs what the kernel boundary cost.  Not kept.)
     if (np > 0)
       hipLaunchKernelGGL(k_sp_bwd_partial, dim3(unsigned(np)), dim3(256), 0, st, (const double*)P->d_W.p, (const int32_t*)P->d_row_tiles.p,
                          (const int32_t*)P->d_panel_pool.p + p0, (const int32_t*)P->d_valid.p, P->T, (const double*)sc.xp, sc.partial);
