@@ -186,7 +186,9 @@ template <> struct FStage<double> {
   }
 };
 template <> struct FStage<float> {
-  static constexpr int kLdsDoubles = kBlock * 18;
+  // 5 sixteen-byte pieces per thread: 20 KB (round 1 declared the fp64 size, 36 KB, and left the fp32 kernels at four
+  // workgroups per CU)
+  static constexpr int kLdsDoubles = kBlock * 10;
   struct Pieces { float4_u v[5]; };
   static __device__ __forceinline__ void run(const float* __restrict__ base, int nvalid, double* __restrict__ lds, double (&out)[18]) {
     stage_cells<18>(base, nvalid, lds, out);
