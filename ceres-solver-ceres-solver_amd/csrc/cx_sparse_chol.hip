@@ -391,7 +391,9 @@ __global__ __launch_bounds__(256, kWgPerCu) void k_sp_update(double* __restrict_
 // five workgroups on a CU instead of three, and every product has the next slice's loads in flight behind it.  Same
 // products in the same order: bitwise the results of k_sp_update.  Final shape, same box, reduced solve: 45.0 ms
 // (k_sp_update, halves of 32 rows) -> 41.1 (16-row slices, 4 per CU) -> 38.6 (8 rows, 5 per CU; 6 per CU the same) ->
-// 39.1 (4 rows); requesting two or three slices ahead: 40.2-41.2 (the register shuffle costs more than it hides).
+// 39.1 (4 rows); requesting two or three slices ahead: 40.2-41.2 (the register shuffle costs more than it hides); one
+// 32-byte record per target (pool slot, flags, source range, first source's tiles: one scalar load instead of a chain of
+// two): 38.6, no change.
 template <int kSteps>
 __device__ __forceinline__ void load_slice(const double* __restrict__ src, double (&X)[2][kSteps]) {
   const int lane = threadIdx.x & 63, li = lane & 15, lk = lane >> 4;
