@@ -1122,6 +1122,8 @@ __global__ __launch_bounds__(kBlock) void k_pair_items(const int32_t* __restrict
 // Measured (Final shape, 164 M pairs, same box): elimination 20.4 -> 19.1 ms, i.e. this kernel 14.4 -> 13.1 ms -- the
 // load instructions were not the limit either (nor the XCD placement of the items: 2 %); what remains is 32.8 GB
 // (FETCH_SIZE) of 216-byte records read from random places of a 12.5 GB table, one record per pair, at 2.5 TB/s.
+// More A/B: the items launched in 8 x 8 blocks of the cell grid (both operands shared by eight cells close together on one
+// XCD): 19.05 against 19.12 ms; two, three, four steps of operands in flight instead of one: 22.6 / 23.4 / 23.9 ms.
 constexpr int kPairOperand = 28;  // staged doubles per operand: B = bg0[0..18) | bg1[0..10), G = bg1[8..18) | bg2[0..18)
 constexpr int kPairPieces = kPairGroups * 28;  // 16-byte pieces per step
 __global__ __launch_bounds__(kBlock) void k_pair_items_staged(const int32_t* __restrict__ pair_rows,
