@@ -130,3 +130,26 @@ def test_sparse_schur_solves_the_normal_equations(final):
     assert np.array_equal(x, x2)
     J.close()
     S.close()
+
+
+def test_mixed_precision_schur_cg_at_full_size(final):
+    """use_mixed_precision_solves on the Final-13682 shape (the `--mixed` line of DESIGN.md section 7): S x inside CG streams
+    fp32 copies of the 29 M cells; against the fp64 solve the LM-style truncated step takes the same number of iterations
+    (to one) and differs at the level of the fp32 rounding of J, not more."""
+    ctx, prob, ev, A, res, cost = final
+    P = prob.num_points
+    b = res.to_host()
+    sq = A.squared_column_norm()
+    D = np.sqrt(np.clip(sq, 1e-6, 1e32) / 1e2)
+    kw = dict(type=cx.ITERATIVE_SCHUR, preconditioner_type=cx.JACOBI, num_eliminate_blocks=P, max_num_iterations=500)
+    S64 = cx.Solver(ctx, **kw)
+    Smix = cx.Solver(ctx, use_mixed_precision_solves=1, **kw)
+    for q in (0.1, 1e-2):
+        x64, s64 = S64.solve(A, b, D, r_tolerance=-1.0, q_tolerance=q)
+        xm, sm = Smix.solve(A, b, D, r_tolerance=-1.0, q_tolerance=q)
+        assert sm.termination_type == cx.SUCCESS and s64.termination_type == cx.SUCCESS
+        assert abs(sm.num_iterations - s64.num_iterations) <= 1, (sm.num_iterations, s64.num_iterations)
+        err = np.abs(xm - x64).max() / np.abs(x64).max()
+        assert 0.0 < err < (1e-4 if sm.num_iterations == s64.num_iterations else 1e-2), err
+    S64.close()
+    Smix.close()
