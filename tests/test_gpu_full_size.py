@@ -153,3 +153,28 @@ def test_mixed_precision_schur_cg_at_full_size(final):
         assert 0.0 < err < (1e-4 if sm.num_iterations == s64.num_iterations else 1e-2), err
     S64.close()
     Smix.close()
+
+
+@pytest.mark.parametrize("stype", ["ITERATIVE_SCHUR", "SPARSE_SCHUR"])
+def test_minimizer_at_full_size_descends_and_repeats(final, stype):
+    """cx_minimize (TrustRegionMinimizer + LevenbergMarquardtStrategy on the device) on the Final-13682 shape: three LM
+    iterations from the perturbed start, with the exact (SPARSE_SCHUR) and with the truncated (ITERATIVE_SCHUR, eta = 0.1)
+    step, reduce the cost in every step, by more than a factor of 100 in all, and a second run walks the same path to the
+    last bit (nothing in the loop depends on atomics or timing)."""
+    ctx, prob, ev, A, res, cost = final
+    P = prob.num_points
+    kw = dict(type=getattr(cx, stype), num_eliminate_blocks=P, max_num_iterations=500)
+    if stype == "ITERATIVE_SCHUR":
+        kw["preconditioner_type"] = cx.JACOBI
+    runs = []
+    for _ in range(2):
+        S = cx.Solver(ctx, **kw)
+        x, summ, its = cx.binding.minimize(ev, S, prob.state(), cx.binding.minimizer_options(max_num_iterations=3))
+        S.close()
+        runs.append((x, [it["cost"] for it in its], [it["step_is_successful"] for it in its]))
+    x, costs, ok = runs[0]
+    assert len(costs) == 4 and all(ok[1:])
+    assert all(costs[i + 1] < costs[i] for i in range(3)), costs
+    assert costs[-1] < 1e-2 * costs[0]
+    assert costs == runs[1][1] and np.array_equal(x, runs[1][0])
+    ev.evaluate(prob.state())   # leave the fixture's Jacobian as the other tests expect it
