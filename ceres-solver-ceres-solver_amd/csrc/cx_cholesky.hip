@@ -230,17 +230,24 @@ __global__ __launch_bounds__(256) void k_chol_step(double* __restrict__ W, int l
 // (three 32 x 32 matrix-vector products; workgroup 0 stores x), then workgroup w subtracts U(i, group) x from the
 // 64 rows i = 64 w .. above the group.  Half as many dependent launches as one block per launch (a launch of this
 // size is ~10 us of dispatch and drain around ~5 us of work) and no 32-step substitution chain.
-__device__ __forceinline__ void gemv32(const double* __restrict__ M, int ldm, bool upper_only, const double* __restrict__ v,
-                                       double* __restrict__ out, int rows_valid, int cols_valid) {
-  // out[m] = sum_c M[m][c] v[c]; 8 threads per row, 4 columns each
+// out[m] = sum_c M[m][c] v[c]; 8 threads per row, 4 columns each.  In two halves: the matrix entries do not depend on the
+// vectors, so a kernel requests those of all its products up front and only LDS-resident vectors are left on its chain of
+// dependent steps.
+__device__ __forceinline__ void gemv32_load(const double* __restrict__ M, int ldm, bool upper_only, int rows_valid, int cols_valid,
+                                            double (&a)[4]) {
   const int t = threadIdx.x, m = t >> 3, part = t & 7;
-  double s = 0.0;
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
     const int c = 4 * part + q;
     const bool in = m < rows_valid && c < cols_valid && (!upper_only || c >= m);
-    s += in ? M[size_t(m) * ldm + c] * v[c] : 0.0;
+    a[q] = in ? M[size_t(m) * ldm + c] : 0.0;
   }
+}
+__device__ __forceinline__ void gemv32_apply(const double (&a)[4], const double* __restrict__ v, double* __restrict__ out) {
+  const int t = threadIdx.x, m = t >> 3, part = t & 7;
+  double s = 0.0;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) s += a[q] * v[4 * part + q];
   s += __shfl_xor(s, 1, 64);
   s += __shfl_xor(s, 2, 64);
   s += __shfl_xor(s, 4, 64);
@@ -252,23 +259,29 @@ __global__ __launch_bounds__(256) void k_trsv_bwd64(const double* __restrict__ A
   __shared__ double y1[NB], y2[NB], x1[NB], x2[NB], tmp[NB];
   const int t = threadIdx.x;
   const int kb1 = min(NB, n - k0), kb2 = max(0, min(NB, n - k0 - NB));
+  double a22[4], a12[4], a11[4];  // (requested before the right-hand side is read: three dependent steps of memory latency less)
+  {
+    const double* __restrict__ ui = uinv + size_t(k0 / NB) * NB * NB;
+    gemv32_load(ui + NB * NB, NB, true, kb2 > 0 ? NB : 0, NB, a22);
+    gemv32_load(A + size_t(k0) * n + k0 + NB, n, false, kb1, kb2, a12);
+    gemv32_load(ui, NB, true, NB, NB, a11);
+  }
   if (t < NB) {
     y1[t] = t < kb1 ? x[k0 + t] : 0.0;
     y2[t] = t < kb2 ? x[k0 + NB + t] : 0.0;
   }
   __syncthreads();
-  const double* __restrict__ ui1 = uinv + size_t(k0 / NB) * NB * NB;
   if (kb2 > 0) {
-    gemv32(ui1 + NB * NB, NB, true, y2, x2, NB, NB);                       // x2 = U22^-1 y2 (identity-padded inverse)
+    gemv32_apply(a22, y2, x2);                                              // x2 = U22^-1 y2 (identity-padded inverse)
     __syncthreads();
-    gemv32(A + size_t(k0) * n + k0 + NB, n, false, x2, tmp, kb1, kb2);     // U12 x2
+    gemv32_apply(a12, x2, tmp);                                             // U12 x2
     __syncthreads();
     if (t < NB) y1[t] -= tmp[t];
   } else if (t < NB) {
     x2[t] = 0.0;
   }
   __syncthreads();
-  gemv32(ui1, NB, true, y1, x1, NB, NB);                                    // x1 = U11^-1 (y1 - U12 x2)
+  gemv32_apply(a11, y1, x1);                                                // x1 = U11^-1 (y1 - U12 x2)
   __syncthreads();
   if (blockIdx.x == 0 && t < 64) {
     const double v = t < NB ? x1[t] : x2[t - NB];
