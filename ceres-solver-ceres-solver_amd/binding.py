@@ -169,7 +169,7 @@ def load_library():
                  "cx_matrix_num_rows", "cx_matrix_num_cols", "cx_matrix_num_nonzeros", "cx_matrix_is_static_239",
                  "cx_matrix_device_values", "cx_matrix_last_kernel_ms", "cx_evaluator_jacobian",
                  "cx_evaluator_last_kernel_ms", "cx_evaluator_device_residuals", "cx_context_stream", "cx_context_rank",
-                 "cx_context_num_ranks"):
+                 "cx_context_num_ranks", "cx_context_num_shards"):
         getattr(lib, name).argtypes = [ctypes.c_void_p]
     _lib = lib
     return lib
@@ -203,11 +203,22 @@ def _f64(a):
 
 
 class Context:
-    def __init__(self, device=0):
+    def __init__(self, device=0, devices=None):
+        """device: one GPU.  devices = [d0, d1, ...]: several shards behind one set of handles in this process
+        (cx_context_create_multi) -- distinct devices exchange through RCCL, a repeated device id means logical
+        shards on that GPU with the in-process sum."""
         lib = load_library()
         self._h = ctypes.c_void_p()
-        _check(lib.cx_context_create(int(device), ctypes.byref(self._h)))
+        if devices is None:
+            _check(lib.cx_context_create(int(device), ctypes.byref(self._h)))
+        else:
+            ids = (ctypes.c_int * len(devices))(*[int(d) for d in devices])
+            _check(lib.cx_context_create_multi(len(devices), ids, ctypes.byref(self._h)))
         self.lib = lib
+
+    @property
+    def num_shards(self):
+        return self.lib.cx_context_num_shards(self._h)
 
     def close(self):
         if self._h:
@@ -344,6 +355,12 @@ class Matrix:
     num_nonzeros = property(lambda s: s.lib.cx_matrix_num_nonzeros(s._h))
     is_static_239 = property(lambda s: bool(s.lib.cx_matrix_is_static_239(s._h)))
     last_kernel_ms = property(lambda s: s.lib.cx_matrix_last_kernel_ms(s._h))
+
+    def shard_layout(self):
+        """(e-block bounds, row-block bounds) of the shards of a matrix on a multi-shard context, n + 1 entries each."""
+        eb, rb = np.zeros(17, dtype=np.int32), np.zeros(17, dtype=np.int32)
+        n = self.lib.cx_matrix_shard_layout(self._h, _ptr(eb), _ptr(rb), 17)
+        return eb[:n + 1].copy(), rb[:n + 1].copy()
 
     def set_values(self, values):
         values = _f64(values)

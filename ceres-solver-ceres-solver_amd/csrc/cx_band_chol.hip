@@ -420,6 +420,13 @@ static int cxv_use_sparse(cx_matrix* A, cx_vis_plan* plan) {
       c1[k] = A->h_cell_c1[size_t(plan->sel_cells[k])];
       c2[k] = A->h_cell_c2[size_t(plan->sel_cells[k])];
     }
+    if (A->ctx->nranks > 1) {
+      // Sharded matrix: the tile pool is summed over the ranks entry by entry (cxv_factor), so every rank must hold the
+      // SAME dissection order and tile list -- planned from the block pairs of all ranks, not from this rank's cells
+      // (which come from its own points only and differ from rank to rank).
+      c1 = plan->global_pair_c1;
+      c2 = plan->global_pair_c2;
+    }
     CX_TRY(cxsp_plan_from_cells(A->ctx, A->C, c1.data(), c2.data(), int64_t(c1.size()), &plan->sp));
     if (plan->sp.state != 1) sparse = false;
   }

@@ -166,6 +166,7 @@ int cx_context_create(int device_id, cx_context** out) {
 
 void cx_context_destroy(cx_context* ctx) {
   if (!ctx) return;
+  if (cxm_is_front(ctx) || ctx->group) cxm_context_destroy_shards(ctx);
   (void)hipSetDevice(ctx->device);
   (void)hipStreamSynchronize(ctx->stream);
   if (ctx->comm && g_rccl.comm_destroy) g_rccl.comm_destroy(ctx->comm);

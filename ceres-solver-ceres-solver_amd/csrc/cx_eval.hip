@@ -662,6 +662,7 @@ int cx_evaluator_create_bal(cx_context* ctx, int32_t C, int32_t P, int64_t O, co
   CX_CHECK_ARG(ctx && out && C > 0 && P > 0 && O > 0 && cam && pt && obs);
   CX_CHECK_ARG(24 * O < (int64_t(1) << 31));  // int32 cell positions (block_jacobian_writer.cc:95-99,157-161)
   for (int64_t i = 0; i < O; ++i) CX_CHECK_ARG(cam[i] >= 0 && cam[i] < C && pt[i] >= 0 && pt[i] < P);
+  if (cxm_is_front(ctx)) return cxm_evaluator_create_bal(ctx, C, P, O, cam, pt, obs, out);
   // LexicographicallyOrderResidualBlocks (reorder_program.cc:256-338): bucket by point,
   // every bucket filled from its back, so a chunk lists its residuals in reverse input order
   std::vector<int64_t> offsets(size_t(P) + 1, 0), order(O);
@@ -710,6 +711,7 @@ int cx_evaluator_create_bal(cx_context* ctx, int32_t C, int32_t P, int64_t O, co
 
 void cx_evaluator_destroy(cx_evaluator* e) {
   if (!e) return;
+  if (!e->parts.empty() || cxm_is_front(e->ctx)) return cxm_evaluator_destroy(e);
   cx_matrix_destroy(e->J);
   delete e;
 }
@@ -725,6 +727,7 @@ int cx_evaluator_row_of_observation(const cx_evaluator* e, int64_t* out) {
 int cx_evaluator_evaluate(cx_evaluator* e, const double* state, double* cost, double* residuals, double* gradient,
                           int32_t evaluate_jacobian, int32_t memspace) {
   CX_CHECK_ARG(e && state);
+  if (!e->parts.empty()) return cxm_evaluator_evaluate(e, state, cost, residuals, gradient, evaluate_jacobian, memspace);
   cx_context* ctx = e->ctx;
   cx_matrix* A = e->J;
   hipStream_t st = ctx->stream;
@@ -743,7 +746,9 @@ int cx_evaluator_evaluate(cx_evaluator* e, const double* state, double* cost, do
     CX_TRY(e->d_res.alloc(size_t(nrows)));
     res_dev = e->d_res.p;
   }
-  if (residuals != nullptr) e->res_valid = res_to_host;
+  // d_res is "the residuals last handed out in host memory" only when this call hands some out; a gradient-only call
+  // borrows it as scratch for the residuals of ITS state, after which the copy no longer matches the caller's host array
+  if (residuals != nullptr || res_dev == e->d_res.p) e->res_valid = res_to_host;
   const int grid = int((e->O + kBlock - 1) / kBlock);
   double* E = A->d_values.p;
   double* F = A->d_values.p + 6 * e->O;
@@ -815,18 +820,21 @@ int cx_evaluator_evaluate(cx_evaluator* e, const double* state, double* cost, do
   return CX_OK;
 }
 
-const double* cx_evaluator_device_residuals(const cx_evaluator* e) { return (e && e->res_valid) ? e->d_res.p : nullptr; }
+const double* cx_evaluator_device_residuals(const cx_evaluator* e) {
+  if (e && !e->parts.empty()) return cxm_evaluator_device_residuals(e);
+  return (e && e->res_valid) ? e->d_res.p : nullptr;
+}
 
 int cx_evaluator_set_emit_camera_major(cx_evaluator* e, int32_t on) {
   CX_CHECK_ARG(e != nullptr);
   e->emit_ft = on != 0;
-  return CX_OK;
+  return e->parts.empty() ? CX_OK : cxm_evaluator_forward_settings(e);
 }
 
 int cx_evaluator_set_camera_model(cx_evaluator* e, int32_t camera_model) {
   CX_CHECK_ARG(e != nullptr && (camera_model == CX_CAMERA_ANGLE_AXIS || camera_model == CX_CAMERA_QUATERNION_MANIFOLD));
   e->camera_model = camera_model;
-  return CX_OK;
+  return e->parts.empty() ? CX_OK : cxm_evaluator_forward_settings(e);
 }
 
 int64_t cx_evaluator_num_parameters(const cx_evaluator* e) {
@@ -838,6 +846,7 @@ int64_t cx_evaluator_num_effective_parameters(const cx_evaluator* e) { return e 
 
 int cx_evaluator_plus(cx_evaluator* e, const double* x, const double* delta, double* x_plus_delta, int32_t memspace) {
   CX_CHECK_ARG(e && x && delta && x_plus_delta);
+  if (!e->parts.empty()) return cxm_evaluator_plus(e, x, delta, x_plus_delta, memspace);
   cx_context* ctx = e->ctx;
   CX_HIP(hipSetDevice(ctx->device));
   HostOrDevice hx(ctx), hd(ctx), ho(ctx);
@@ -857,9 +866,12 @@ int cx_evaluator_set_loss(cx_evaluator* e, int32_t loss_type, double a, double b
   e->loss_type = loss_type;
   e->loss_a = a;
   e->loss_b = b;
-  return CX_OK;
+  return e->parts.empty() ? CX_OK : cxm_evaluator_forward_settings(e);
 }
 
-double cx_evaluator_last_kernel_ms(const cx_evaluator* e) { return e ? double(e->last_ms) : 0.0; }
+double cx_evaluator_last_kernel_ms(const cx_evaluator* e) {
+  if (e && !e->parts.empty()) return cxm_evaluator_last_kernel_ms(e);
+  return e ? double(e->last_ms) : 0.0;
+}
 
 }  // extern "C"

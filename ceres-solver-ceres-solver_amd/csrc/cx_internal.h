@@ -91,6 +91,10 @@ struct cx_context {
   int num_cus = 256;
   char name[128] = {};
   DevBuf<double> chol_scratch;  // dense Cholesky work vectors (cx_cholesky.hip)
+  // ---- front of several shards driven from ONE process (cx_context_create_multi, cx_multi.hip): shards[i] is an ordinary
+  // context with rank i of shards.size(); the front itself stays a plain context on the first device
+  std::vector<cx_context*> shards;
+  struct cx_shard_group* group = nullptr;  // worker threads (one per shard) + the in-process exchange step
 };
 
 // ------------------------------------------------- tile-sparse Cholesky (cx_sparse_chol.hip)
@@ -200,6 +204,18 @@ struct cx_matrix {
   float last_ms = 0.f;
   // when set, the product kernels return at once if *stop != 0 (CG termination flag)
   const int* stop = nullptr;
+
+  // ---- front of a matrix on a multi-shard context (cx_multi.hip): the e-blocks (points) are cut into contiguous ranges,
+  // parts[i] lives on shard i and holds the rows of its range with columns [its e-blocks | all f-blocks]; the front keeps
+  // no device data of its own
+  std::vector<cx_matrix*> parts;
+  bool parts_owned = true;                  // false: the parts belong to the shards' evaluators
+  std::vector<int32_t> part_e0;             // [n + 1] first e-block of each shard
+  std::vector<int32_t> part_rowblk0;        // [n + 1] first row block
+  std::vector<int64_t> part_row0;           // [n + 1] first scalar row
+  std::vector<int64_t> part_ecol0;          // [n + 1] first scalar column of the e part
+  struct ValueRun { int64_t global, local, len; };
+  std::vector<std::vector<ValueRun>> part_runs;  // where the values of part i sit in the front's (reference layout) value array
 };
 
 // upload/download helpers for the (memspace) convention
@@ -253,8 +269,37 @@ struct cx_evaluator {
   int32_t loss_type = CX_LOSS_NONE;
   double loss_a = 0.0, loss_b = 0.0;
   int32_t camera_model = CX_CAMERA_ANGLE_AXIS;
+  std::vector<cx_evaluator*> parts;  // front on a multi-shard context (cx_multi.hip): the evaluator of each shard's points
 };
 // out = Plus(x, sign * delta) on device pointers (Evaluator::Plus), enqueued on the context stream
 int cxe_plus(cx_evaluator* e, const double* x, const double* delta, double sign, double* out);
+
+
+// ------------------------------------------- multi-shard fronts (cx_multi.hip)
+// The public entry points hand a front object (ctx->shards / A->parts / S->parts / e->parts non-empty) to these.
+struct cx_solver;
+bool cxm_is_front(const cx_context* ctx);
+void cxm_context_destroy_shards(cx_context* front);
+int cxm_matrix_create(cx_context* ctx, const cx_block_structure* bs, int32_t nelim, cx_matrix** out);
+void cxm_matrix_destroy(cx_matrix* A);
+int cxm_matrix_set_values(cx_matrix* A, const double* src, int32_t memspace);
+int cxm_matrix_get_values(const cx_matrix* A, double* dst);
+int cxm_matrix_set_zero(cx_matrix* A);
+int cxm_matrix_values_changed(cx_matrix* A);
+// op 0: y += A x, 1: y += A'x, 2: y = diag(A'A), 3: A <- A diag(x)
+int cxm_matrix_op(cx_matrix* A, int op, const double* x, double* y, int32_t memspace);
+int cxm_solver_solve(cx_solver* S, cx_matrix* A, const double* b, const cx_per_solve_options* ps, double* x, cx_summary* summary);
+void cxm_solver_destroy(cx_solver* S);
+int cxm_evaluator_create_bal(cx_context* ctx, int32_t C, int32_t P, int64_t O, const int32_t* cam, const int32_t* pt,
+                             const double* obs, cx_evaluator** out);
+void cxm_evaluator_destroy(cx_evaluator* e);
+int cxm_evaluator_evaluate(cx_evaluator* e, const double* state, double* cost, double* residuals, double* gradient,
+                           int32_t evaluate_jacobian, int32_t memspace);
+int cxm_evaluator_plus(cx_evaluator* e, const double* x, const double* delta, double* x_plus_delta, int32_t memspace);
+int cxm_evaluator_forward_settings(cx_evaluator* e);  // loss, camera model, emit_ft of the front -> its parts
+const double* cxm_evaluator_device_residuals(const cx_evaluator* e);
+double cxm_evaluator_last_kernel_ms(const cx_evaluator* e);
+int cxm_minimize(cx_evaluator* e, cx_solver* s, const cx_minimizer_options* options, double* state, int32_t memspace,
+                 cx_minimizer_summary* summary, cx_iteration_summary* iterations, int32_t capacity);
 
 #endif

@@ -716,6 +716,7 @@ int cx_matrix_create(cx_context* ctx, const cx_block_structure* bs, int32_t neli
   CX_CHECK_ARG(ctx && bs && out);
   CX_CHECK_ARG(bs->num_row_blocks >= 0 && bs->num_col_blocks >= 0);
   CX_CHECK_ARG(nelim >= 0 && nelim <= bs->num_col_blocks);
+  if (cxm_is_front(ctx)) return cxm_matrix_create(ctx, bs, nelim, out);
   CX_HIP(hipSetDevice(ctx->device));
   auto A = new cx_matrix;
   A->ctx = ctx;
@@ -781,6 +782,7 @@ int cx_matrix_create(cx_context* ctx, const cx_block_structure* bs, int32_t neli
 
 void cx_matrix_destroy(cx_matrix* A) {
   if (!A) return;
+  if (!A->parts.empty() || cxm_is_front(A->ctx)) return cxm_matrix_destroy(A);
   (void)hipSetDevice(A->ctx->device);
   (void)hipStreamSynchronize(A->ctx->stream);
   delete A;
@@ -790,10 +792,11 @@ int64_t cx_matrix_num_rows(const cx_matrix* A) { return A ? A->num_rows : 0; }
 int64_t cx_matrix_num_cols(const cx_matrix* A) { return A ? A->num_cols : 0; }
 int64_t cx_matrix_num_nonzeros(const cx_matrix* A) { return A ? A->nnz : 0; }
 int cx_matrix_is_static_239(const cx_matrix* A) { return A && A->is239 ? 1 : 0; }
-double* cx_matrix_device_values(cx_matrix* A) { return A ? A->d_values.p : nullptr; }
+double* cx_matrix_device_values(cx_matrix* A) { return A ? A->d_values.p : nullptr; }  // NULL for a multi-shard front
 
 int cx_matrix_values_changed(cx_matrix* A) {
   CX_CHECK_ARG(A);
+  if (!A->parts.empty()) return cxm_matrix_values_changed(A);
   A->ft_valid = false;
   A->f32_valid = false;
   return CX_OK;
@@ -801,6 +804,7 @@ int cx_matrix_values_changed(cx_matrix* A) {
 
 int cx_matrix_set_values(cx_matrix* A, const double* src, int32_t memspace) {
   CX_CHECK_ARG(A && (src || A->nnz == 0));
+  if (!A->parts.empty()) return cxm_matrix_set_values(A, src, memspace);
   if (A->nnz)
     CX_HIP(hipMemcpyAsync(A->d_values.p, src, size_t(A->nnz) * sizeof(double),
                           memspace == CX_HOST ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice, A->ctx->stream));
@@ -812,6 +816,7 @@ int cx_matrix_set_values(cx_matrix* A, const double* src, int32_t memspace) {
 
 int cx_matrix_get_values(const cx_matrix* A, double* dst) {
   CX_CHECK_ARG(A && (dst || A->nnz == 0));
+  if (!A->parts.empty()) return cxm_matrix_get_values(A, dst);
   if (A->nnz) CX_HIP(hipMemcpyAsync(dst, A->d_values.p, size_t(A->nnz) * sizeof(double), hipMemcpyDeviceToHost, A->ctx->stream));
   CX_HIP(hipStreamSynchronize(A->ctx->stream));
   return CX_OK;
@@ -819,6 +824,7 @@ int cx_matrix_get_values(const cx_matrix* A, double* dst) {
 
 int cx_matrix_set_zero(cx_matrix* A) {
   CX_CHECK_ARG(A);
+  if (!A->parts.empty()) return cxm_matrix_set_zero(A);
   if (A->nnz) CX_HIP(hipMemsetAsync(A->d_values.p, 0, size_t(A->nnz) * sizeof(double), A->ctx->stream));
   A->ft_valid = false;
   A->f32_valid = false;
@@ -827,6 +833,7 @@ int cx_matrix_set_zero(cx_matrix* A) {
 
 int cx_matrix_right_multiply(cx_matrix* A, const double* x, double* y, int32_t memspace) {
   CX_CHECK_ARG(A && x && y);
+  if (!A->parts.empty()) return cxm_matrix_op(A, 0, x, y, memspace);
   HostOrDevice hx(A->ctx), hy(A->ctx);
   CX_TRY(hx.in(x, size_t(A->num_cols), memspace));
   CX_TRY(hy.inout(y, size_t(A->num_rows), memspace, true));
@@ -836,6 +843,7 @@ int cx_matrix_right_multiply(cx_matrix* A, const double* x, double* y, int32_t m
 
 int cx_matrix_left_multiply(cx_matrix* A, const double* x, double* y, int32_t memspace) {
   CX_CHECK_ARG(A && x && y);
+  if (!A->parts.empty()) return cxm_matrix_op(A, 1, x, y, memspace);
   HostOrDevice hx(A->ctx), hy(A->ctx);
   CX_TRY(hx.in(x, size_t(A->num_rows), memspace));
   CX_TRY(hy.inout(y, size_t(A->num_cols), memspace, true));
@@ -846,6 +854,7 @@ int cx_matrix_left_multiply(cx_matrix* A, const double* x, double* y, int32_t me
 
 int cx_matrix_squared_column_norm(cx_matrix* A, double* x, int32_t memspace) {
   CX_CHECK_ARG(A && x);
+  if (!A->parts.empty()) return cxm_matrix_op(A, 2, nullptr, x, memspace);
   HostOrDevice hx(A->ctx);
   CX_TRY(hx.inout(x, size_t(A->num_cols), memspace, false));
   CX_TRY(cx_matrix_ensure_ft(A));
@@ -855,6 +864,7 @@ int cx_matrix_squared_column_norm(cx_matrix* A, double* x, int32_t memspace) {
 
 int cx_matrix_scale_columns(cx_matrix* A, const double* scale, int32_t memspace) {
   CX_CHECK_ARG(A && scale);
+  if (!A->parts.empty()) return cxm_matrix_op(A, 3, scale, nullptr, memspace);
   HostOrDevice hs(A->ctx);
   CX_TRY(hs.in(scale, size_t(A->num_cols), memspace));
   CX_TRY(Timed(A, [&] { return cxk_scale_columns(A, hs.dptr); }));
@@ -864,6 +874,10 @@ int cx_matrix_scale_columns(cx_matrix* A, const double* scale, int32_t memspace)
 // PartitionedMatrixView products: part 1 = E, 2 = F
 static int PartitionedMultiply(cx_matrix* A, int part, bool transpose, const double* x, double* y, int32_t memspace) {
   CX_CHECK_ARG(A && x && y && A->nelim > 0);
+  if (!A->parts.empty()) {
+    cx_set_error("the PartitionedMatrixView products are not offered on a multi-shard front");
+    return CX_ERR_UNSUPPORTED;
+  }
   const size_t ncol = size_t(part == 1 ? A->num_cols_e : A->num_cols_f);
   HostOrDevice hx(A->ctx), hy(A->ctx);
   CX_TRY(hx.in(x, transpose ? size_t(A->num_rows) : ncol, memspace));

@@ -553,6 +553,10 @@ void cx_minimizer_default_options(cx_minimizer_options* o) {
 int cx_minimize(cx_evaluator* e, cx_solver* s, const cx_minimizer_options* options, double* state, int32_t memspace,
                 cx_minimizer_summary* summary, cx_iteration_summary* iterations, int32_t capacity) {
   CX_CHECK_ARG(e && s && options && state && summary);
+  if (!e->parts.empty() || cxm_is_front(s->ctx)) {
+    CX_CHECK_ARG(capacity >= 0 && (iterations != nullptr || capacity == 0));
+    return cxm_minimize(e, s, options, state, memspace, summary, iterations, capacity);
+  }
   CX_CHECK_ARG(s->ctx == e->ctx);
   CX_CHECK_ARG(memspace == CX_HOST || memspace == CX_DEVICE);
   CX_CHECK_ARG(capacity >= 0 && (iterations != nullptr || capacity == 0));

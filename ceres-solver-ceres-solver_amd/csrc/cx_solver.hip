@@ -1397,6 +1397,7 @@ int cx_solver_create(cx_context* ctx, const cx_solver_options* options, cx_solve
 
 void cx_solver_destroy(cx_solver* s) {
   if (!s) return;
+  if (!s->parts.empty()) cxm_solver_destroy(s);
   (void)hipSetDevice(s->ctx->device);
   (void)hipStreamSynchronize(s->ctx->stream);
   if (s->ring_h) (void)hipHostFree(s->ring_h);
@@ -1405,6 +1406,7 @@ void cx_solver_destroy(cx_solver* s) {
 
 int cx_solver_kernel_stats(const cx_solver* s, cx_kernel_stat* out, int32_t capacity, int32_t* count) {
   CX_CHECK_ARG(s && out && count && capacity >= 0);
+  if (!s->parts.empty()) return cx_solver_kernel_stats(s->parts[0], out, capacity, count);  // shard 0 of a multi-shard front
   int n = 0;
   for (int i = 0; i < KernelTimer::kSlots && n < capacity; ++i) {
     if (s->ktimer.launches[i] == 0) continue;
@@ -1428,6 +1430,7 @@ int cx_solver_last_timing(const cx_solver* s, cx_solve_timing* out) {
 int cx_solver_solve(cx_solver* S, cx_matrix* A, const double* b, const cx_per_solve_options* ps, double* x,
                     cx_summary* summary) {
   CX_CHECK_ARG(S && A && b && ps && x && summary);
+  if (cxm_is_front(S->ctx) || !A->parts.empty()) return cxm_solver_solve(S, A, b, ps, x, summary);
   CX_CHECK_ARG(S->ctx == A->ctx);
   cx_context* ctx = S->ctx;
   CX_HIP(hipSetDevice(ctx->device));

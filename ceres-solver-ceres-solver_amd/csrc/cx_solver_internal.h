@@ -109,6 +109,9 @@ struct cx_solver {
   // phase timings are read back once, at the end of the solve (no synchronisation between the phases)
   double* pending_ms[4] = {};
   int num_pending = 0;
+  // front on a multi-shard context (cx_multi.hip): one solver per shard, created at the first solve of a matrix
+  std::vector<cx_solver*> parts;
+  const cx_matrix* parts_for = nullptr;
 };
 
 // ConjugateGradientsSolver (conjugate_gradients_solver.h:107-305) on device vectors of

@@ -333,6 +333,18 @@ int ComputeClusters(const cx_cell* cells, int C, int P, int64_t O, cx_context* c
   for (int c = 0; c < C; ++c) sizes[size_t(c)] = size_t(cam_pts.start[size_t(c) + 1] - cam_pts.start[size_t(c)]);
   if (sharded) CX_TRY(SumCountsOverRanks(ctx, C, &upper, &sizes));
   const Graph graph = SchurComplementGraph(C, upper, sizes);
+  plan->global_pair_c1.clear();
+  plan->global_pair_c2.clear();
+  if (sharded) {  // the S cells of the whole matrix: every diagonal cell and every co-visible pair (filtered in BuildPlan)
+    for (int c1 = 0; c1 < C; ++c1) {
+      plan->global_pair_c1.push_back(c1);
+      plan->global_pair_c2.push_back(c1);
+      for (const auto& e : upper[size_t(c1)]) {
+        plan->global_pair_c1.push_back(c1);
+        plan->global_pair_c2.push_back(e.first);
+      }
+    }
+  }
   PairCounts().swap(upper);
   // ClusterCameras
   std::vector<int32_t> raw;
@@ -398,6 +410,18 @@ int BuildPlan(cx_matrix* A, int preconditioner_type, int clustering_type, cx_vis
     for (int32_t it = A->h_cell_item_start[size_t(cell)]; it < A->h_cell_item_start[size_t(cell) + 1]; ++it) sel_items.push_back(it);
   }
   plan->num_sel_items = int64_t(sel_items.size());
+  if (!plan->global_pair_c1.empty()) {  // sharded: the same filter on the cells of all ranks
+    size_t kept = 0;
+    for (size_t k = 0; k < plan->global_pair_c1.size(); ++k) {
+      const int32_t k1 = plan->membership[size_t(plan->global_pair_c1[k])], k2 = plan->membership[size_t(plan->global_pair_c2[k])];
+      if (k1 != k2 && partner[size_t(k1)][0] != k2 && partner[size_t(k1)][1] != k2) continue;
+      plan->global_pair_c1[kept] = plan->global_pair_c1[k];
+      plan->global_pair_c2[kept] = plan->global_pair_c2[k];
+      ++kept;
+    }
+    plan->global_pair_c1.resize(kept);
+    plan->global_pair_c2.resize(kept);
+  }
 
   // ---- paths of the forest, longest first
   struct Path { std::vector<int32_t> clusters; int64_t rows = 0; };

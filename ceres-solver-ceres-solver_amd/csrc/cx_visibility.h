@@ -18,6 +18,10 @@ struct cx_vis_plan {
   std::vector<int32_t> membership;                            // cluster_membership_[camera]
   std::vector<std::pair<int32_t, int32_t>> cluster_pairs;     // cluster_pairs_ (c1 <= c2), lexicographic
   std::vector<int32_t> sel_cells;                             // block_pairs_: ids into the matrix' S cell list, ascending
+  // sharded matrix only: the block pairs of ALL ranks (c1 <= c2, lexicographic; from the summed co-visibility counts), the
+  // same list on every rank -- what the tile-sparse factorisation has to be planned from, because a rank's own cells
+  // (sel_cells) differ from rank to rank while the tile pool is summed over the ranks entry by entry
+  std::vector<int32_t> global_pair_c1, global_pair_c2;
   // ---- band layout of the preconditioner matrix M
   // Cameras are ordered path by path of the cluster forest, cluster by cluster along a path, so M is block
   // tridiagonal in cluster blocks: every row r has its non-zeros in columns [r, col_end(r)).  Stored

@@ -210,6 +210,27 @@ int cx_context_num_ranks(const cx_context* ctx);
 /* sum-all-reduce of n doubles in place on the context's stream (exposed for tests) */
 int cx_allreduce_sum(cx_context* ctx, double* device_ptr, int64_t n);
 
+/* Several GPUs behind ONE set of handles in ONE process -- how a Solver::Solve caller (one process, one ContextImpl,
+ * context_impl.h:74-83; LinearSolver::Solve and Evaluator::Evaluate called with whole vectors, linear_solver.h:363-390,
+ * evaluator.h:120-150) reaches the sharded path.  device_ids[num_shards] names either distinct devices (one shard per
+ * GPU; the shards' exchange step is ncclAllReduce on one RCCL communicator per device, each driven by its own worker
+ * thread) or the same device throughout (logical shards on one GPU with an in-process sum: the configuration the
+ * one-GPU test boxes run).  On such a context
+ *   cx_matrix_create        cuts the e-blocks (points) into num_shards contiguous ranges of about equal non-zeros
+ *                           (cx_partition_points) and gives every shard the rows of its range;
+ *   cx_evaluator_create_bal does the same with the observations;
+ *   cx_solver_solve / cx_evaluator_evaluate / cx_minimize / the matrix products take and return WHOLE vectors in host
+ *                           memory (memspace must be CX_HOST; per_solve.b_on_device accepts the token of
+ *                           cx_evaluator_device_residuals), scatter them, run the per-rank solvers of the shards side by
+ *                           side and gather the result;
+ * everything else of the ABI (cx_malloc, the parity-test entry points, ...) addresses the first device only.
+ * At most 16 shards. */
+int cx_context_create_multi(int num_shards, const int* device_ids, cx_context** out);
+int cx_context_num_shards(const cx_context* ctx);   /* 1 for a plain context */
+/* How a matrix on a multi-shard context is cut: returns the number of shards n and, when capacity >= n + 1, the first
+ * e-block and the first row block of every shard (n + 1 entries each; either array may be NULL). */
+int cx_matrix_shard_layout(const cx_matrix* A, int32_t* e_block_bounds, int32_t* row_block_bounds, int32_t capacity);
+
 int cx_malloc(cx_context* ctx, size_t bytes, void** device_ptr);
 int cx_free(cx_context* ctx, void* device_ptr);
 int cx_memcpy_h2d(cx_context* ctx, void* dst_device, const void* src_host, size_t bytes);

@@ -7,7 +7,9 @@ C ABI on the GPU:
   config 5  synthetic10M  fp32-stored Jacobian, fp64 accumulation: size-independent properties (the oracle does not finish
                           a 10 M residual-block solve in test time) -- adjointness of the fp32 operator pair, agreement with
                           the fp64 operator to fp32 rounding, normal equations after refinement
-(config 1, Ladybug-16 CPU plumbing: tests/test_oracle_sparse_schur.py; config 4, Final-13682: tests/test_gpu_full_size.py)"""
+  config 1  ladybug16     SPARSE_SCHUR / DENSE_SCHUR exact steps against the oracle's SPARSE_SCHUR (the reference documents this
+                          config as a CPU run; tests/test_oracle_sparse_schur.py runs the oracle alone on it)
+(config 4, Final-13682: tests/test_gpu_full_size.py)"""
 import os
 
 import numpy as np
@@ -41,6 +43,38 @@ def lm_system(oracle, preset):
     vals = oracle.scale_columns(bs, vals, scale)
     D = np.sqrt(np.clip(oracle.squared_column_norm(bs, vals), 1e-6, 1e32) / 1e4)
     return prob, bs, vals, b, D
+
+
+# ------------------------------------------------------------------------------------------------ config 1
+@pytest.mark.parametrize("variant", ["SPARSE_SCHUR", "DENSE_SCHUR", "SPARSE_SCHUR tile-sparse"])
+def test_config_1_ladybug16_schur(ctx, oracle, variant):
+    """BASELINE config 1 (Ladybug-16: 16 cameras, 22 106 points, 83 718 residual blocks; the reference documents it as a
+    CPU SPARSE_SCHUR run, installation.rst:198-216) on the device: DetectStructure reports <2,3,9> as the reference's log
+    does (installation.rst:211-216, "Eliminate group 2,3,9"), and the exact step of SPARSE_SCHUR (144 x 144 reduced system:
+    dense storage; the tile-sparse factorisation forced onto it as a third variant) and DENSE_SCHUR equals the oracle's
+    SPARSE_SCHUR step to 1e-8 and |dx| / n < 1e-10 (schur_complement_solver_test.cc:186-227)."""
+    prob, bs, vals, b, D = lm_system(oracle, "ladybug16")
+    P = prob.num_points
+    assert cx.binding.detect_structure(bs, P) == (2, 3, 9)
+    xr, sr = oracle.solve(bs, vals, b, D, oracle.make_options(type=oracle.SPARSE_SCHUR, num_eliminate_blocks=P))
+    assert sr.termination_type == 0
+    A = cx.Matrix(ctx, bs, P)
+    assert A.is_static_239
+    A.set_values(vals)
+    forced = variant.endswith("tile-sparse")
+    if forced:
+        os.environ["CX_SPARSE_CHOLESKY"] = "1"
+    try:
+        S = cx.Solver(ctx, type=getattr(cx, variant.split()[0]), num_eliminate_blocks=P)
+        x, s = S.solve(A, b, D)
+    finally:
+        if forced:
+            del os.environ["CX_SPARSE_CHOLESKY"]
+    assert s.termination_type == cx.SUCCESS and s.num_iterations == 1
+    assert np.linalg.norm(x - xr) / x.size < 1e-10
+    assert relerr(x, xr) < 1e-8
+    S.close()
+    A.close()
 
 
 # ------------------------------------------------------------------------------------------------ config 2
@@ -190,3 +224,29 @@ def test_config_5_synthetic10M_products(synthetic10M):
         e[j] = 1.0
         col = A.right_multiply(e)
         assert abs(float(col @ col) - sq[j]) <= 1e-12 * max(sq[j], 1e-300)
+
+
+@pytest.mark.parametrize("shards", [2, 4, 8])
+def test_config_5_synthetic10M_cgnr_on_shards(synthetic10M, shards):
+    """BASELINE config 5 ("1 -> 8 GPU scaling sweep") on 2 / 4 / 8 logical shards of the one GPU: CGNR + JACOBI with fp64
+    and with fp32-stored J equals the unsharded device solve -- same iteration count, x to 1e-8 (the point part of every
+    CGNR dot product is a sum over the shards, so the last bits may differ)."""
+    ctx, prob, ev, A, b, D = synthetic10M
+    vals = A.get_values()                      # the Jacobi-scaled values of the fixture, handed over as a host matrix
+    bs, _ = cx.bal.build_structure(prob)
+    mctx = cx.Context(devices=[0] * shards)
+    MA = cx.Matrix(mctx, bs, prob.num_points)
+    MA.set_values(vals)
+    for mixed in (0, 1):
+        kw = dict(type=cx.CGNR, preconditioner_type=cx.JACOBI, max_num_iterations=500, use_mixed_precision_solves=mixed)
+        S1 = cx.Solver(ctx, num_eliminate_blocks=0, **kw)
+        MS = cx.Solver(mctx, num_eliminate_blocks=prob.num_points, **kw)
+        x1, s1 = S1.solve(A, b, D, r_tolerance=-1.0, q_tolerance=0.01)
+        xm, sm = MS.solve(MA, b, D, r_tolerance=-1.0, q_tolerance=0.01)
+        assert sm.termination_type == s1.termination_type == cx.SUCCESS, (sm.message, s1.message)
+        assert sm.num_iterations == s1.num_iterations, (shards, mixed, sm.num_iterations, s1.num_iterations)
+        assert relerr(xm, x1) < 1e-8
+        S1.close()
+        MS.close()
+    MA.close()
+    mctx.close()

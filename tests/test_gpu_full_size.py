@@ -178,3 +178,78 @@ def test_minimizer_at_full_size_descends_and_repeats(final, stype):
     assert costs[-1] < 1e-2 * costs[0]
     assert costs == runs[1][1] and np.array_equal(x, runs[1][0])
     ev.evaluate(prob.state())   # leave the fixture's Jacobian as the other tests expect it
+
+
+# ----------------------------------------------------------------------- config 4 on shards (BASELINE: "sharded over 8 x MI355X")
+def _lm_diagonal(A):
+    return np.sqrt(np.clip(A.squared_column_norm(), 1e-6, 1e32) / 1e4)      # levenberg_marquardt_strategy.cc:81-98, radius 1e4
+
+
+@pytest.mark.parametrize("shards", [2, 4, 8])
+def test_config_4_final13682_on_shards_equals_the_unsharded_solve(final, shards):
+    """BASELINE config 4 at its full size on 2 / 4 / 8 shards (logical shards of the one GPU of the test box, in-process
+    exchange step; partitioning, scatter / gather and the per-rank sharded solvers are the production code): the front's
+    solve equals the unsharded DEVICE solve -- the same CG iteration count, x to 1e-8 -- at LM's eta = 0.1 and at
+    bundle_adjuster's 1e-2; the exchange step is what DESIGN.md section 5 predicts (1 + it + it // 10 collectives: 54 C
+    doubles once, then 9 C each); the cut balances residual blocks to 2 %."""
+    ctx, prob, ev, A, res, cost = final
+    C, P, O = prob.num_cameras, prob.num_points, prob.num_observations
+    b = res.to_host()
+    D = _lm_diagonal(A)
+    kw = dict(type=cx.ITERATIVE_SCHUR, preconditioner_type=cx.JACOBI, num_eliminate_blocks=P, max_num_iterations=500)
+    S1 = cx.Solver(ctx, **kw)
+    mctx = cx.Context(devices=[0] * shards)
+    mev = cx.Evaluator(mctx, prob)
+    mcost, mres, mgrad = mev.evaluate(prob.state())
+    assert abs(mcost - cost) <= 1e-12 * cost
+    assert np.array_equal(mres, b)                                   # the same kernel on the same rows: the same bits
+    MA = mev.jacobian()
+    eb, rb = MA.shard_layout()
+    assert eb.size == shards + 1 and eb[0] == 0 and eb[-1] == P and rb[-1] == O
+    blocks = np.diff(rb)
+    assert blocks.max() * shards / blocks.sum() < 1.02               # load_balance.max_over_mean_residual_blocks
+    assert np.abs(_lm_diagonal(MA) - D).max() <= 1e-12 * D.max()
+    g1 = A.left_multiply(b)
+    assert np.abs(mgrad - g1).max() <= 1e-11 * np.abs(g1).max()       # J'r: camera part summed over the shards
+    MS = cx.Solver(mctx, **kw)
+    for q in (0.1, 0.01):
+        x1, s1 = S1.solve(A, b, D, r_tolerance=-1.0, q_tolerance=q)
+        xm, sm = MS.solve(MA, mres, D, r_tolerance=-1.0, q_tolerance=q)
+        assert sm.termination_type == s1.termination_type == cx.SUCCESS, (sm.message, s1.message)
+        assert sm.num_iterations == s1.num_iterations, (shards, q, sm.num_iterations, s1.num_iterations)
+        assert np.abs(xm - x1).max() <= 1e-8 * np.abs(x1).max()
+        tm, it = MS.timing(), sm.num_iterations
+        calls = 1 + it + it // 10
+        assert tm["allreduce_calls"] == calls and tm["allreduce_bytes"] == 8.0 * (54 * C + 9 * C * (calls - 1))
+    MS.close()
+    S1.close()
+    mev.close()
+    mctx.close()
+
+
+def test_config_4_final13682_sparse_schur_on_shards(final):
+    """Sharded SPARSE_SCHUR at 13 682 cameras (4 shards): the plan comes from the union of the shards' S cells (one dense
+    C x C presence exchange, 1.5 GB per shard), cell values and right-hand side are summed over the shards, the
+    factorisation is replicated -- the step equals the unsharded tile-sparse solve to 1e-8."""
+    ctx, prob, ev, A, res, cost = final
+    P = prob.num_points
+    b = res.to_host()
+    D = _lm_diagonal(A)
+    S1 = cx.Solver(ctx, type=cx.SPARSE_SCHUR, num_eliminate_blocks=P)
+    x1, s1 = S1.solve(A, b, D)
+    S1.close()
+    mctx = cx.Context(devices=[0] * 4)
+    mev = cx.Evaluator(mctx, prob)
+    _, mres, _ = mev.evaluate(prob.state(), want_gradient=False)
+    MS = cx.Solver(mctx, type=cx.SPARSE_SCHUR, num_eliminate_blocks=P)
+    xm, sm = MS.solve(mev.jacobian(), mres, D)
+    first = MS.timing()
+    xm2, _ = MS.solve(mev.jacobian(), mres, D)
+    tm = MS.timing()
+    assert sm.termination_type == s1.termination_type == cx.SUCCESS, (sm.message, s1.message)
+    assert np.abs(xm - x1).max() <= 1e-8 * np.abs(x1).max()
+    assert np.array_equal(xm, xm2)
+    assert first["allreduce_calls"] == 3 and tm["allreduce_calls"] == 2      # presence exchange once; values + rhs per solve
+    MS.close()
+    mev.close()
+    mctx.close()
