@@ -30,7 +30,7 @@
 
 namespace ceres::internal {
 
-cx_context* CxSharedContext(int device);  // cx_linear_solver.h
+cx_context* CxSharedContext();  // cx_linear_solver.h: the context of the configured device list
 
 // A bundle-adjustment program in the order the Schur preprocessing leaves it (reorder_program.cc:446-540):
 // parameter blocks = points 0..P-1 then cameras 0..C-1, residual blocks grouped by point in ascending point order.
@@ -54,7 +54,7 @@ class CxBalEvaluator final : public Evaluator {
         return nullptr;
       }
     }
-    cx_context* ctx = CxSharedContext(0);
+    cx_context* ctx = CxSharedContext();
     if (ctx == nullptr) {
       *error = std::string("cxschur: ") + cx_last_error();
       return nullptr;

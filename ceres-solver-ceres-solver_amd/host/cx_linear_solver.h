@@ -15,8 +15,10 @@
 #ifndef CX_LINEAR_SOLVER_H_
 #define CX_LINEAR_SOLVER_H_
 
+#include <cstdlib>
 #include <cstring>
 #include <map>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -30,15 +32,53 @@
 
 namespace ceres::internal {
 
-// One process-wide device context, the analogue of ContextImpl::InitCuda (context_impl.cc:125-203).
-// nullptr (and cx_last_error()) when there is no usable gfx950 device; the adapters turn that into FATAL_ERROR.
-inline cx_context* CxSharedContext(int device = 0) {
-  static cx_context* ctx = nullptr;
-  static bool tried = false;
-  if (!tried) {
-    tried = true;
-    if (cx_context_create(device, &ctx) != CX_OK) ctx = nullptr;
+// The process-wide device context(s), the analogue of ContextImpl::InitCuda (context_impl.cc:125-203): one context per
+// device list, created on first use, shared by every adapter object, never destroyed (as ContextImpl's CUDA half lives
+// as long as the ceres::Context).  The list names the GPUs a Solver::Solve may use:
+//   {d}              one device (default {0}),
+//   {d0, d1, ...}    one shard per device, RCCL all-reduce of the camera-space sums between them,
+//   {d, d, ...}      logical shards on one device (how one-GPU machines exercise the sharded path),
+// set by CxSetDevices() -- the hook for a Solver::Options / ContextImpl field in a Ceres tree -- or by the environment
+// variable CX_DEVICES ("0,1,2,3") read on first use.  Thread-safe.  nullptr (and cx_last_error()) when the devices are
+// not usable; the adapters turn that into FATAL_ERROR.
+struct CxContextRegistry {
+  std::mutex mutex;
+  std::vector<int> devices;  // empty: not configured yet
+  std::map<std::vector<int>, cx_context*> contexts;
+  static CxContextRegistry& Get() {
+    static CxContextRegistry registry;
+    return registry;
   }
+};
+
+inline void CxSetDevices(const std::vector<int>& devices) {
+  CxContextRegistry& r = CxContextRegistry::Get();
+  std::lock_guard<std::mutex> lock(r.mutex);
+  r.devices = devices;
+}
+
+inline cx_context* CxSharedContext() {
+  CxContextRegistry& r = CxContextRegistry::Get();
+  std::lock_guard<std::mutex> lock(r.mutex);
+  if (r.devices.empty()) {
+    if (const char* env = std::getenv("CX_DEVICES")) {
+      for (const char* p = env; *p != '\0';) {
+        char* end = nullptr;
+        const long d = std::strtol(p, &end, 10);
+        if (end == p) break;
+        r.devices.push_back(int(d));
+        p = (*end == ',') ? end + 1 : end;
+      }
+    }
+    if (r.devices.empty()) r.devices.push_back(0);
+  }
+  auto it = r.contexts.find(r.devices);
+  if (it != r.contexts.end()) return it->second;
+  cx_context* ctx = nullptr;
+  const int rc = r.devices.size() == 1 ? cx_context_create(r.devices[0], &ctx)
+                                       : cx_context_create_multi(int(r.devices.size()), r.devices.data(), &ctx);
+  if (rc != CX_OK) return nullptr;  // not cached: a later call may succeed (or report again)
+  r.contexts.emplace(r.devices, ctx);
   return ctx;
 }
 
@@ -105,14 +145,21 @@ class CxLinearSolver final : public LinearSolver {
     if (A == nullptr || b == nullptr || x == nullptr) return Fatal(&summary, "null argument");  // CHECKs in the reference (:369-371)
     if (per_solve_options.preconditioner != nullptr)
       return Fatal(&summary, "a user-supplied preconditioner operator cannot be applied on the device");
-    cx_context* ctx = CxSharedContext();
+    // a device-resident Jacobian brings its context along (the evaluator that owns it chose the devices); a host
+    // Jacobian goes to the context of the configured device list, fixed at the first Solve like the rest of the
+    // per-structure state
+    auto* device_jacobian = dynamic_cast<CxDeviceJacobian*>(A);
+    if (ctx_ == nullptr) ctx_ = device_jacobian != nullptr ? device_jacobian->handle()->ctx : CxSharedContext();
+    cx_context* ctx = ctx_;
     if (ctx == nullptr) return Fatal(&summary);
+    if (device_jacobian != nullptr && device_jacobian->handle()->ctx != ctx)
+      return Fatal(&summary, "the Jacobian lives on another device context than the one this solver was first used with");
     const int num_eliminate_blocks =
         (options_.type == CGNR || options_.elimination_groups.empty()) ? 0 : options_.elimination_groups[0];
 
     cx_matrix* matrix = nullptr;
     const double* device_b = nullptr;
-    if (auto* device_jacobian = dynamic_cast<CxDeviceJacobian*>(A)) {
+    if (device_jacobian != nullptr) {
       matrix = device_jacobian->device_matrix();  // values are in HBM already
       if (alias_evaluator_residuals_ && device_jacobian->handle()->last_residuals_host == b)
         device_b = cx_evaluator_device_residuals(device_jacobian->handle()->evaluator);
@@ -205,6 +252,7 @@ class CxLinearSolver final : public LinearSolver {
   }
 
   LinearSolver::Options options_;
+  cx_context* ctx_ = nullptr;          // shared, not owned (CxSharedContext)
   cx_matrix* owned_matrix_ = nullptr;  // only for host BlockSparseMatrix Jacobians
   cx_solver* solver_ = nullptr;
   cx_solve_timing timing_{};

@@ -661,9 +661,78 @@ static void TestEvaluatorToSolverThroughTheInterfaces() {
   EXPECT(IsArrayValid(jacobian->num_cols(), norms.data()), "Jacobian usable after the evaluator is gone");
 }
 
+// the N-GPU path behind the boundary.  The same unmodified trust-region loop, written against the
+// abstract Evaluator / SparseMatrix / LinearSolver interfaces only, on 1, 2 and 4 shards (CxSetDevices: logical shards
+// of device 0 on a one-GPU box, one shard per GPU with RCCL where there are several): the caller still is ONE process
+// passing whole vectors (context_impl.h:74-83, linear_solver.h:363-390); costs equal the 1-shard run to 1e-9, CG
+// iteration counts are equal, J is never copied to or from the host.
+static void TestShardsBehindTheInterfaces() {
+  const int kCameras = 24, kPoints = 1500, kIterations = 6;
+  const double kEta = 1e-2;
+  BalProgram bal(kCameras, kPoints, 0.35, 11u);
+  Evaluator::Options evaluator_options;
+  evaluator_options.linear_solver_type = ITERATIVE_SCHUR;
+  evaluator_options.num_eliminate_blocks = kPoints;
+  LinearSolver::Options solver_options;
+  solver_options.type = ITERATIVE_SCHUR;
+  solver_options.preconditioner_type = JACOBI;
+  solver_options.elimination_groups = {kPoints, kCameras};
+  solver_options.min_num_iterations = 0;
+  solver_options.max_num_iterations = 500;
+  const std::vector<double> x0 = bal.StateVector();
+  LmTrace one;
+  for (int shards : {1, 2, 4}) {
+    CxSetDevices(std::vector<int>(size_t(shards), 0));
+    cx_context* ctx = CxSharedContext();
+    EXPECT(ctx != nullptr && cx_context_num_shards(ctx) == shards, "context of %d shard(s): %s", shards, cx_last_error());
+    if (ctx == nullptr) break;
+    std::string why;
+    std::unique_ptr<Evaluator> evaluator = CxBalEvaluator::TryCreate(evaluator_options, &bal.program, &why);
+    EXPECT(evaluator != nullptr, "TryCreate on %d shards declined: %s", shards, why.c_str());
+    if (!evaluator) break;
+    std::unique_ptr<SparseMatrix> jacobian = evaluator->CreateJacobian();
+    auto* device_jacobian = dynamic_cast<CxDeviceJacobian*>(jacobian.get());
+    CxLinearSolver solver(solver_options);
+    solver.set_alias_evaluator_residuals(shards == 4);  // the residual token of a front: every shard reads its own rows in HBM
+    LmTrace t = RunTrustRegionLoop(evaluator.get(), jacobian.get(), &solver, x0, kIterations, kEta);
+    EXPECT(t.ok && t.num_successful >= 3, "%d shard(s): %d successful steps", shards, t.num_successful);
+    EXPECT(device_jacobian != nullptr && device_jacobian->num_downloads() == 0 && device_jacobian->num_uploads() == 0,
+           "%d shard(s): J must stay in HBM", shards);
+    if (shards == 4) EXPECT(solver.last_solve_aliased_residuals(), "residual aliasing on a front was not taken");
+    if (shards == 1) {
+      one = t;
+    } else {
+      EXPECT(t.costs.size() == one.costs.size() && t.linear_iterations == one.linear_iterations,
+             "%d shards take the steps of one (%zu vs %zu accepted)", shards, t.costs.size(), one.costs.size());
+      for (size_t k = 0; k < std::min(t.costs.size(), one.costs.size()); ++k)
+        EXPECT(std::abs(t.costs[k] - one.costs[k]) <= 1e-9 * one.costs[k], "%d shards, cost %zu: %.12e vs %.12e", shards, k, t.costs[k],
+               one.costs[k]);
+      double worst = 0.0, scale = 0.0;
+      for (size_t i = 0; i < one.final_state.size(); ++i) {
+        worst = std::max(worst, std::abs(t.final_state[i] - one.final_state[i]));
+        scale = std::max(scale, std::abs(one.final_state[i]));
+      }
+      EXPECT(worst <= 1e-7 * scale, "%d shards, final state differs by %.3e", shards, worst);
+      // the reference-style path on shards: a host BlockSparseMatrix is cut, uploaded and solved by the same front
+      HostJacobianEvaluator host_evaluator(evaluator.get());
+      std::unique_ptr<SparseMatrix> host_jacobian = host_evaluator.CreateJacobian();
+      CxLinearSolver host_solver(solver_options);
+      LmTrace h = RunTrustRegionLoop(&host_evaluator, host_jacobian.get(), &host_solver, x0, kIterations, kEta);
+      EXPECT(h.ok && h.linear_iterations == one.linear_iterations, "%d shards, host Jacobian: same CG iterations", shards);
+      for (size_t k = 0; k < std::min(h.costs.size(), one.costs.size()); ++k)
+        EXPECT(std::abs(h.costs[k] - one.costs[k]) <= 1e-9 * one.costs[k], "%d shards, host Jacobian, cost %zu", shards, k);
+    }
+    std::printf("LM through Evaluator/LinearSolver on %d shard(s): cost %.9e -> %.9e, CG iterations", shards, t.costs.front(), t.costs.back());
+    for (int n : t.linear_iterations) std::printf(" %d", n);
+    std::printf("\n");
+  }
+  CxSetDevices({0});
+}
+
 int main() {
   TestSolversOnHostJacobian();
   TestEvaluatorToSolverThroughTheInterfaces();
+  TestShardsBehindTheInterfaces();
   std::printf("%s\n", failures ? "FAILED" : "ALL OK");
   return failures ? 1 : 0;
 }
