@@ -9,8 +9,10 @@ max_num_iterations = 500, on the Jacobi-scaled Jacobian of a synthetic problem w
 the public BAL Final-13682 header sizes (no BAL file exists offline).  Inputs
 (J values, residuals, D) are resident in HBM before the timed region.
 
-N > 1: launched by torch.distributed.run, one rank per GPU.  Points (and with them
-residual blocks) are sharded over the ranks, camera-space sums go through RCCL
+N > 1: one rank per GPU, launched by torch.distributed.run -- by the caller, or, when
+`python bench.py --gpus N` is started plainly (no WORLD_SIZE in the environment), by this
+script itself as a child process before anything here touches a GPU.  Points (and with
+them residual blocks) are sharded over the ranks, camera-space sums go through RCCL
 all-reduce inside the library (strong scaling of the fixed problem).
 
 Prints ONE JSON line on rank 0.
@@ -19,6 +21,8 @@ import argparse
 import importlib.util
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -179,9 +183,22 @@ def main():
     ap.add_argument("--cpu-threads", type=int, default=0)
     ap.add_argument("--cpu-sample-fraction", type=float, default=1.0,
                     help="part of the points the CPU baseline solves (1.0: the whole workload, ~10 s on 16 threads)")
+    ap.add_argument("--no-sparse-schur", action="store_true",
+                    help="skip the SPARSE_SCHUR solve + its CPU baseline that the default Final-13682 line carries (north star: "
+                         ">= 10x lower linear-solve ms than host SPARSE_SCHUR)")
     args = ap.parse_args()
     global ETA
     ETA = args.eta
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # started plainly: start the N ranks as fresh child processes (nothing in this process has touched a GPU yet --
+        # no torch import, no HIP call) and relay rank 0's JSON line, which the children print to the inherited stdout
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0))
+            port = s.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        raise SystemExit(subprocess.call(cmd))
 
     import torch  # first, so that libcxschur shares torch's HIP runtime instance
     import torch.distributed as dist
@@ -349,7 +366,28 @@ def main():
                 "unit": "GB/s", "frac": abytes / avg_ms / 1e6 / HBM_PEAK_GBPS,
                 "frac_of_measured_copy_peak": abytes / avg_ms / 1e6 / HBM_COPY_GBPS,
                 "avg_launch_ms": avg_ms, "launches_sampled": kstats[dom][1], "algorithmic_bytes_per_launch": abytes,
-                "traffic": traffic}
+                "traffic": traffic,
+                "traffic_source": "profiles/traffic.json (PMC passes of a builder run of this command under rocprofv3 --pmc; "
+                                  "not measured in this run)" if traffic is not None else None}
+
+    # ---- the north star's own comparison, in the same run: one SPARSE_SCHUR solve of the same system (exact Newton step;
+    # tile-sparse level-scheduled Cholesky in CHOLMOD's place) and, on rank 0 below, the oracle's SPARSE_SCHUR beside it
+    sparse = None
+    if (world == 1 and args.workload == "final13682" and args.solver == "iterative_schur" and args.preconditioner == "jacobi"
+            and not args.mixed and not args.explicit_schur and not args.no_sparse_schur):
+        SS = cx.Solver(ctx, type=cx.SPARSE_SCHUR, num_eliminate_blocks=prob.num_points)
+        SS.solve(A, b, D, x=x)           # first solve: structure analysis (pair lists, dissection, plan)
+        reps = []
+        for _ in range(3):
+            barrier()
+            t1 = time.perf_counter()
+            _, summ_s = SS.solve(A, b, D, x=x)
+            barrier()
+            reps.append((time.perf_counter() - t1) * 1e3)
+        tm = SS.timing()
+        sparse = {"ms": float(np.median(reps)), "termination": int(summ_s.termination_type),
+                  "phases_ms": {k: tm[k] for k in ("eliminate_ms", "reduced_solve_ms", "back_substitute_ms", "total_ms")}}
+        SS.close()
 
     out = None
     if rank == 0:
@@ -359,6 +397,9 @@ def main():
             cpu = cpu_baseline(cx, full, solver_kw, threads, args.cpu_sample_fraction)
         elif world == 1 and not args.no_cpu_baseline and args.solver == "sparse_schur":
             cpu = cpu_baseline(cx, full, solver_kw, threads, args.cpu_sample_fraction, solver="sparse_schur")
+        if sparse is not None and not args.no_cpu_baseline:
+            sparse["cpu_baseline"] = cpu_baseline(cx, full, solver_kw, threads, 1.0, solver="sparse_schur")
+            sparse["speedup_vs_cpu_baseline"] = sparse["cpu_baseline"]["value"] / sparse["ms"]
         out = {
             "metric": "linear_solve_ms_per_iter", "value": ms_per_step, "unit": "ms",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
@@ -385,6 +426,10 @@ def main():
             "explicit_s": explicit_info,
             "jacobian_eval_ms": eval_ms,
             "values_update_per_lm_iteration": values_update,
+            # what one LM iteration costs on the device: the evaluation of r and J, the Jacobi scaling of J (both also
+            # keep the camera-major copy of F current, work that round 1 did inside the solve) and the timed solve
+            "lm_iteration_ms": values_update["jacobian_eval_ms"] + values_update["scale_columns_ms"] + ms_per_step,
+            "sparse_schur": sparse,
             "spmv": spmv,
             "kernels": {k: {"avg_ms": v[0] / max(1, v[1]), "launches_per_solve": v[2] / max(1, args.steps)} for k, v in kstats.items()},
             "roofline": roof,
