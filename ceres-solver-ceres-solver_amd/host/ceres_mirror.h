@@ -31,6 +31,7 @@
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
+#include <algorithm>
 #include <limits>
 #include <map>
 #include <memory>
@@ -95,11 +96,133 @@ class LossFunction {  // include/ceres/loss_function.h:84-88
   virtual ~LossFunction() = default;
   virtual void Evaluate(double sq_norm, double out[3]) const = 0;
 };
+// the built-in losses, include/ceres/loss_function.h:131-292 with loss_function.cc:46-144: parameters are PRIVATE, as in
+// the reference -- which is why the adapter recovers them through Evaluate (cx_loss_probe.h)
+class TrivialLoss final : public LossFunction {
+ public:
+  void Evaluate(double s, double rho[3]) const override { rho[0] = s; rho[1] = 1.0; rho[2] = 0.0; }
+};
+class HuberLoss final : public LossFunction {
+ public:
+  explicit HuberLoss(double a) : a_(a), b_(a * a) {}
+  void Evaluate(double s, double rho[3]) const override {
+    if (s > b_) {
+      const double r = std::sqrt(s);
+      rho[0] = 2.0 * a_ * r - b_;
+      rho[1] = std::max(std::numeric_limits<double>::min(), a_ / r);
+      rho[2] = -rho[1] / (2.0 * s);
+    } else {
+      rho[0] = s; rho[1] = 1.0; rho[2] = 0.0;
+    }
+  }
+ private:
+  const double a_, b_;
+};
+class SoftLOneLoss final : public LossFunction {
+ public:
+  explicit SoftLOneLoss(double a) : b_(a * a), c_(1 / b_) {}
+  void Evaluate(double s, double rho[3]) const override {
+    const double sum = 1.0 + s * c_, tmp = std::sqrt(sum);
+    rho[0] = 2.0 * b_ * (tmp - 1.0);
+    rho[1] = std::max(std::numeric_limits<double>::min(), 1.0 / tmp);
+    rho[2] = -(c_ * rho[1]) / (2.0 * sum);
+  }
+ private:
+  const double b_, c_;
+};
+class CauchyLoss final : public LossFunction {
+ public:
+  explicit CauchyLoss(double a) : b_(a * a), c_(1 / b_) {}
+  void Evaluate(double s, double rho[3]) const override {
+    const double sum = 1.0 + s * c_, inv = 1.0 / sum;
+    rho[0] = b_ * std::log(sum);
+    rho[1] = std::max(std::numeric_limits<double>::min(), inv);
+    rho[2] = -c_ * (inv * inv);
+  }
+ private:
+  const double b_, c_;
+};
+class ArctanLoss final : public LossFunction {
+ public:
+  explicit ArctanLoss(double a) : a_(a), b_(1 / (a * a)) {}
+  void Evaluate(double s, double rho[3]) const override {
+    const double sum = 1 + s * s * b_, inv = 1 / sum;
+    rho[0] = a_ * std::atan2(s, a_);
+    rho[1] = std::max(std::numeric_limits<double>::min(), inv);
+    rho[2] = -2.0 * s * b_ * (inv * inv);
+  }
+ private:
+  const double a_, b_;
+};
+class TolerantLoss final : public LossFunction {
+ public:
+  TolerantLoss(double a, double b) : a_(a), b_(b), c_(b * std::log(1.0 + std::exp(-a / b))) {}
+  void Evaluate(double s, double rho[3]) const override {
+    const double x = (s - a_) / b_;
+    if (x > 36.7) {
+      rho[0] = s - a_ - c_; rho[1] = 1.0; rho[2] = 0.0;
+    } else {
+      const double e_x = std::exp(x);
+      rho[0] = b_ * std::log(1.0 + e_x) - c_;
+      rho[1] = std::max(std::numeric_limits<double>::min(), e_x / (1.0 + e_x));
+      rho[2] = 0.5 / (b_ * (1.0 + std::cosh(x)));
+    }
+  }
+ private:
+  const double a_, b_, c_;
+};
+class TukeyLoss final : public LossFunction {
+ public:
+  explicit TukeyLoss(double a) : a_squared_(a * a) {}
+  void Evaluate(double s, double rho[3]) const override {
+    if (s <= a_squared_) {
+      const double value = 1.0 - s / a_squared_, value_sq = value * value;
+      rho[0] = a_squared_ / 3.0 * (1.0 - value_sq * value);
+      rho[1] = value_sq;
+      rho[2] = -2.0 / a_squared_ * value;
+    } else {
+      rho[0] = a_squared_ / 3.0; rho[1] = 0.0; rho[2] = 0.0;
+    }
+  }
+ private:
+  const double a_squared_;
+};
+class ScaledLoss final : public LossFunction {  // :329-350 (a loss the device does not offer: must be declined)
+ public:
+  ScaledLoss(const LossFunction* rho, double a) : rho_(rho), a_(a) {}
+  void Evaluate(double s, double rho[3]) const override {
+    if (rho_ == nullptr) { rho[0] = a_ * s; rho[1] = a_; rho[2] = 0.0; return; }
+    rho_->Evaluate(s, rho);
+    rho[0] *= a_; rho[1] *= a_; rho[2] *= a_;
+  }
+ private:
+  std::unique_ptr<const LossFunction> rho_;
+  const double a_;
+};
 class Manifold {  // include/ceres/manifold.h:126-222 (only AmbientSize / TangentSize are read)
  public:
   virtual ~Manifold() = default;
   virtual int AmbientSize() const = 0;
   virtual int TangentSize() const = 0;
+};
+// the manifold types bundle_adjuster --use_quaternions --use_manifolds composes (bundle_adjuster.cc:337-345;
+// include/ceres/manifold.h:224-300, 310-345, product_manifold.h:67-120): identified by type, arithmetic on the device
+template <int Size>
+class EuclideanManifold final : public Manifold {
+ public:
+  int AmbientSize() const override { return Size; }
+  int TangentSize() const override { return Size; }
+};
+class QuaternionManifold final : public Manifold {
+ public:
+  int AmbientSize() const override { return 4; }
+  int TangentSize() const override { return 3; }
+};
+template <typename Manifold0, typename Manifold1, typename... ManifoldN>
+class ProductManifold final : public Manifold {
+ public:
+  int AmbientSize() const override { return (Manifold0().AmbientSize() + Manifold1().AmbientSize()) + (0 + ... + ManifoldN().AmbientSize()); }
+  int TangentSize() const override { return (Manifold0().TangentSize() + Manifold1().TangentSize()) + (0 + ... + ManifoldN().TangentSize()); }
 };
 // include/ceres/autodiff_cost_function.h:151-240: owns the functor, exposes it through functor()
 template <typename CostFunctor, int kNumResiduals, int... Ns>
@@ -117,6 +240,12 @@ namespace examples {
 // examples/snavely_reprojection_error.h:53-104 (the data members; operator() lives on the device, cx_eval.hip)
 struct SnavelyReprojectionError {
   SnavelyReprojectionError(double observed_x_, double observed_y_) : observed_x(observed_x_), observed_y(observed_y_) {}
+  double observed_x;
+  double observed_y;
+};
+// :111-170, the 10-parameter camera (quaternion w x y z, translation, focal, k1, k2)
+struct SnavelyReprojectionErrorWithQuaternions {
+  SnavelyReprojectionErrorWithQuaternions(double observed_x_, double observed_y_) : observed_x(observed_x_), observed_y(observed_y_) {}
   double observed_x;
   double observed_y;
 };

@@ -18,7 +18,10 @@
 #include <vector>
 
 #include "cx_device_jacobian.h"
+#include "cx_loss_probe.h"
 #ifdef CX_USE_CERES_HEADERS
+#include "ceres/manifold.h"
+#include "ceres/product_manifold.h"
 #include "ceres/autodiff_cost_function.h"
 #include "ceres/evaluator.h"
 #include "ceres/execution_summary.h"
@@ -41,6 +44,11 @@ struct CxBalProblemView {
   const int32_t* camera_index = nullptr;    // [num_observations], residual-block order
   const int32_t* point_index = nullptr;     // [num_observations], non-decreasing
   const double* observations_xy = nullptr;  // [2 * num_observations]
+  // cx_camera_model: CX_CAMERA_ANGLE_AXIS (9 parameters) or CX_CAMERA_QUATERNION_MANIFOLD (10 ambient, 9 tangent)
+  int32_t camera_model = CX_CAMERA_ANGLE_AXIS;
+  // the robust loss every residual block carries (cx_loss_type and its constructor arguments)
+  int32_t loss_type = CX_LOSS_NONE;
+  double loss_a = 0.0, loss_b = 0.0;
 };
 
 class CxBalEvaluator final : public Evaluator {
@@ -92,18 +100,33 @@ class CxBalEvaluator final : public Evaluator {
         return nullptr;
       }
     }
+    if (cx_evaluator_set_camera_model(handle->evaluator, view.camera_model) != CX_OK) {
+      *error = std::string("cxschur: ") + cx_last_error();
+      return nullptr;
+    }
     std::unique_ptr<CxBalEvaluator> e(new CxBalEvaluator(options, std::move(handle), view));
+    if (view.loss_type != CX_LOSS_NONE && !e->SetLoss(view.loss_type, view.loss_a, view.loss_b)) {
+      *error = std::string("cxschur: ") + cx_last_error();
+      return nullptr;
+    }
     return e;
   }
 
   // The factory hook: a CxBalEvaluator when `program` is a bundle-adjustment program the device kernels cover,
-  // nullptr (with the reason in *why_not) otherwise.  Covered: a Schur-type linear solver with
-  // num_eliminate_blocks = number of points > 0; every residual block is
-  // AutoDiffCostFunction<SnavelyReprojectionError, 2, 9, 3> on (camera, point) with no loss function; all point
-  // blocks come first (size 3, Euclidean), then all camera blocks (size 9, Euclidean); no constant blocks (the
-  // preprocessor has removed them, trust_region_preprocessor.cc:95-120), no bounds, no evaluation callback.
+  // nullptr (with the reason in *why_not) otherwise.  Covered -- the programs examples/bundle_adjuster.cc:306-346
+  // builds: a Schur-type linear solver with num_eliminate_blocks = number of points > 0; all point blocks first (size 3,
+  // Euclidean), then all camera blocks, which are either
+  //   * size 9, Euclidean, with AutoDiffCostFunction<SnavelyReprojectionError, 2, 9, 3> residual blocks, or
+  //   * size 10 on ProductManifold<QuaternionManifold, EuclideanManifold<6>> (--use_quaternions --use_manifolds) with
+  //     AutoDiffCostFunction<SnavelyReprojectionErrorWithQuaternions, 2, 10, 3> residual blocks;
+  // every residual block on (camera, point) with no loss function or with ONE built-in loss (the same type and
+  // arguments on all blocks; --robustify: HuberLoss(1.0)), recovered through LossFunction::Evaluate (cx_loss_probe.h);
+  // no constant blocks (the preprocessor has removed them, trust_region_preprocessor.cc:95-120), no bounds, no
+  // evaluation callback.
   static std::unique_ptr<Evaluator> TryCreate(const Evaluator::Options& options, Program* program, std::string* why_not) {
     using Snavely = AutoDiffCostFunction<examples::SnavelyReprojectionError, 2, 9, 3>;
+    using SnavelyQuaternion = AutoDiffCostFunction<examples::SnavelyReprojectionErrorWithQuaternions, 2, 10, 3>;
+    using CameraManifold = ProductManifold<QuaternionManifold, EuclideanManifold<6>>;
     auto no = [&](const char* why) { *why_not = why; return std::unique_ptr<Evaluator>(); };
     if (options.linear_solver_type != DENSE_SCHUR && options.linear_solver_type != SPARSE_SCHUR &&
         options.linear_solver_type != ITERATIVE_SCHUR)
@@ -114,31 +137,68 @@ class CxBalEvaluator final : public Evaluator {
     const std::vector<ParameterBlock*>& blocks = program->parameter_blocks();
     const int C = int(blocks.size()) - P;
     if (P <= 0 || C <= 0) return no("no e-blocks or no f-blocks");
+    const bool quaternion = blocks[size_t(P)]->Size() == 10;
+    const int camera_size = quaternion ? 10 : 9;
     for (int j = 0; j < P + C; ++j) {
       const ParameterBlock* b = blocks[size_t(j)];
-      const int want = j < P ? 3 : 9;
-      if (b->Size() != want || b->TangentSize() != want || b->manifold() != nullptr) return no("parameter block is not a Euclidean 3-point / 9-camera");
+      if (j < P || !quaternion) {
+        const int want = j < P ? 3 : 9;
+        if (b->Size() != want || b->TangentSize() != want || b->manifold() != nullptr) return no("parameter block is not a Euclidean 3-point / 9-camera");
+      } else if (b->Size() != 10 || b->TangentSize() != 9 || dynamic_cast<const CameraManifold*>(b->manifold()) == nullptr) {
+        return no("10-parameter camera is not on ProductManifold<QuaternionManifold, EuclideanManifold<6>>");
+      }
       if (b->IsConstant()) return no("constant parameter block");
       if (b->lower_bounds() != nullptr || b->upper_bounds() != nullptr) return no("bounds");
-      if (b->index() != j || b->state_offset() != (j < P ? 3 * j : 3 * P + 9 * (j - P))) return no("parameter offsets are not those of [points | cameras]");
+      if (b->index() != j || b->state_offset() != (j < P ? 3 * j : 3 * P + camera_size * (j - P)) ||
+          b->delta_offset() != (j < P ? 3 * j : 3 * P + 9 * (j - P)))
+        return no("parameter offsets are not those of [points | cameras]");
     }
     const std::vector<ResidualBlock*>& residual_blocks = program->residual_blocks();
     const int64_t O = int64_t(residual_blocks.size());
     std::vector<int32_t> cam(static_cast<size_t>(O)), pt(static_cast<size_t>(O));
     std::vector<double> obs(static_cast<size_t>(2 * O));
+    // the loss: identified once, then every other block's object must behave like the first (bundle_adjuster news a
+    // HuberLoss per residual block) -- compared on three abscissae around the loss's own scale
+    const LossFunction* first_loss = O > 0 ? residual_blocks[0]->loss_function() : nullptr;
+    int32_t loss_type = CX_LOSS_NONE;
+    double loss_a = 0.0, loss_b = 0.0;
+    if (!CxIdentifyLoss(first_loss, &loss_type, &loss_a, &loss_b)) return no("loss function is not one of the built-in losses the device evaluates");
+    const double probe_scale = loss_type == CX_LOSS_NONE ? 1.0 : std::max(loss_a * loss_a, loss_b);
+    double first_rho[3][3];
+    if (first_loss != nullptr)
+      for (int k = 0; k < 3; ++k) first_loss->Evaluate((k == 0 ? 0.3 : (k == 1 ? 1.7 : 40.0)) * probe_scale, first_rho[k]);
     for (int64_t i = 0; i < O; ++i) {
       const ResidualBlock* rb = residual_blocks[size_t(i)];
-      const auto* cost = dynamic_cast<const Snavely*>(rb->cost_function());
-      if (cost == nullptr) return no("cost function is not AutoDiffCostFunction<SnavelyReprojectionError, 2, 9, 3>");
-      if (rb->loss_function() != nullptr) return no("loss function present");
+      if (quaternion) {
+        const auto* cost = dynamic_cast<const SnavelyQuaternion*>(rb->cost_function());
+        if (cost == nullptr) return no("cost function is not AutoDiffCostFunction<SnavelyReprojectionErrorWithQuaternions, 2, 10, 3>");
+        obs[size_t(2 * i)] = cost->functor().observed_x;
+        obs[size_t(2 * i + 1)] = cost->functor().observed_y;
+      } else {
+        const auto* cost = dynamic_cast<const Snavely*>(rb->cost_function());
+        if (cost == nullptr) return no("cost function is not AutoDiffCostFunction<SnavelyReprojectionError, 2, 9, 3>");
+        obs[size_t(2 * i)] = cost->functor().observed_x;
+        obs[size_t(2 * i + 1)] = cost->functor().observed_y;
+      }
+      const LossFunction* loss = rb->loss_function();
+      if (loss != first_loss) {
+        if (loss == nullptr || first_loss == nullptr) return no("some residual blocks have a loss function and some have none");
+        for (int k = 0; k < 3; ++k) {
+          double rho[3];
+          loss->Evaluate((k == 0 ? 0.3 : (k == 1 ? 1.7 : 40.0)) * probe_scale, rho);
+          if (rho[0] != first_rho[k][0] || rho[1] != first_rho[k][1] || rho[2] != first_rho[k][2]) return no("residual blocks carry different loss functions");
+        }
+      }
       const int ci = rb->parameter_blocks()[0]->index(), pi = rb->parameter_blocks()[1]->index();
       if (ci < P || pi >= P) return no("residual block is not (camera, point)");
       cam[size_t(i)] = ci - P;
       pt[size_t(i)] = pi;
-      obs[size_t(2 * i)] = cost->functor().observed_x;
-      obs[size_t(2 * i + 1)] = cost->functor().observed_y;
     }
     CxBalProblemView view;
+    view.camera_model = quaternion ? CX_CAMERA_QUATERNION_MANIFOLD : CX_CAMERA_ANGLE_AXIS;
+    view.loss_type = loss_type;
+    view.loss_a = loss_a;
+    view.loss_b = loss_b;
     view.num_cameras = C;
     view.num_points = P;
     view.num_observations = O;
@@ -149,8 +209,8 @@ class CxBalEvaluator final : public Evaluator {
     return std::unique_ptr<Evaluator>(e.release());
   }
 
-  // Robust loss for programs built through Create (cx_loss_type; LossFunction objects keep their parameters private,
-  // so TryCreate declines programs that have one).
+  // Robust loss by (type, arguments): what TryCreate recovers from the program's LossFunction objects, or what a caller
+  // of Create states directly.
   bool SetLoss(int32_t loss_type, double a, double b) {
     if (cx_evaluator_set_loss(handle_->evaluator, loss_type, a, b) != CX_OK) return false;
     loss_type_ = loss_type;
@@ -206,8 +266,11 @@ class CxBalEvaluator final : public Evaluator {
   }
 
   bool Plus(const double* state, const double* delta, double* state_plus_delta) const final {
-    // all blocks Euclidean (TryCreate / the view): x + delta, the loop of program_evaluator.h:306-320.  On the host:
-    // three vectors of num_cols doubles are cheaper to add here than to send across PCIe and back.
+    // the loop of program_evaluator.h:306-320.  All blocks Euclidean: x + delta on the host (three vectors of num_cols
+    // doubles are cheaper to add here than to send across PCIe and back).  Quaternion cameras: the manifold's Plus
+    // (manifold.cc:27-59) is device code, cx_evaluator_plus.
+    if (camera_model_ == CX_CAMERA_QUATERNION_MANIFOLD)
+      return cx_evaluator_plus(handle_->evaluator, state, delta, state_plus_delta, CX_HOST) == CX_OK;
     const int64_t n = NumParameters();
     for (int64_t i = 0; i < n; ++i) state_plus_delta[i] = state[i] + delta[i];
     return true;
@@ -217,6 +280,10 @@ class CxBalEvaluator final : public Evaluator {
   int NumResiduals() const final { return int(2 * camera_index_.size()); }
   std::map<std::string, CallStatistics> Statistics() const final { return execution_summary_.statistics(); }
 
+  int32_t loss_type() const { return loss_type_; }
+  double loss_a() const { return loss_a_; }
+  double loss_b() const { return loss_b_; }
+  int32_t camera_model() const { return camera_model_; }
   // device time of the last k_bal_evaluate launch
   double last_kernel_ms() const { return cx_evaluator_last_kernel_ms(handle_->evaluator); }
   const std::shared_ptr<CxEvaluatorHandle>& handle() const { return handle_; }
@@ -225,12 +292,13 @@ class CxBalEvaluator final : public Evaluator {
   CxBalEvaluator(const Evaluator::Options& options, std::shared_ptr<CxEvaluatorHandle> handle, const CxBalProblemView& view)
       : options_(options), handle_(std::move(handle)), num_cameras_(view.num_cameras), num_points_(view.num_points),
         camera_index_(view.camera_index, view.camera_index + view.num_observations),
-        point_index_(view.point_index, view.point_index + view.num_observations) {}
+        point_index_(view.point_index, view.point_index + view.num_observations), camera_model_(view.camera_model) {}
 
   Evaluator::Options options_;
   std::shared_ptr<CxEvaluatorHandle> handle_;
   int32_t num_cameras_, num_points_;
   std::vector<int32_t> camera_index_, point_index_;
+  int32_t camera_model_ = CX_CAMERA_ANGLE_AXIS;
   int32_t loss_type_ = CX_LOSS_NONE;
   double loss_a_ = 0.0, loss_b_ = 0.0;
   ExecutionSummary execution_summary_;

@@ -15,6 +15,7 @@
 //     leaving the device.  Checked against (a) the same loop run on a host BlockSparseMatrix that holds a copy of
 //     every Jacobian (host products, values uploaded per solve) and (b) cx_minimize, the device-resident minimizer.
 // Needs a gfx950 device.  Exit code 0 = all checks passed.
+#include <functional>
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
@@ -267,11 +268,15 @@ static void TestSolversOnHostJacobian() {
 // (ApplyOrdering, reorder_program.cc:216-254), residual blocks ordered by LexicographicallyOrderResidualBlocks.
 struct BalProgram {
   using Snavely = AutoDiffCostFunction<examples::SnavelyReprojectionError, 2, 9, 3>;
+  using SnavelyQuaternion = AutoDiffCostFunction<examples::SnavelyReprojectionErrorWithQuaternions, 2, 10, 3>;
   int C = 0, P = 0;
-  std::vector<double> user_state;  // [cameras (9 each) | points (3 each)] like BALProblem (bal_problem.cc:93-108)
+  int camera_size = 9;             // 10: quaternion cameras on ProductManifold<QuaternionManifold, EuclideanManifold<6>>
+  std::unique_ptr<Manifold> camera_manifold;
+  std::vector<double> user_state;  // [cameras (9 or 10 each) | points (3 each)] like BALProblem (bal_problem.cc:93-108)
   std::vector<std::unique_ptr<ParameterBlock>> parameter_blocks;
   std::vector<std::unique_ptr<CostFunction>> cost_functions;
   std::vector<std::unique_ptr<ResidualBlock>> residual_blocks;
+  std::vector<std::unique_ptr<const LossFunction>> owned_losses;
   std::vector<int32_t> camera_index, point_index;  // input order
   std::vector<double> observations;
   Program program;
@@ -299,7 +304,41 @@ struct BalProgram {
     xy[1] = cam[6] * distortion * yp;
   }
 
-  BalProgram(int num_cameras, int num_points, double visibility, unsigned seed, const LossFunction* loss = nullptr) : C(num_cameras), P(num_points) {
+  // SnavelyReprojectionErrorWithQuaternions::operator() on doubles (snavely_reprojection_error.h:120-158,
+  // QuaternionRotatePoint rotation.h:722-760): camera = quaternion (w x y z), translation, focal, k1, k2
+  static void ProjectQuaternion(const double* cam, const double* pt, double* xy) {
+    const double scale = 1.0 / std::sqrt(cam[0] * cam[0] + cam[1] * cam[1] + cam[2] * cam[2] + cam[3] * cam[3]);
+    const double q[4] = {scale * cam[0], scale * cam[1], scale * cam[2], scale * cam[3]};
+    double uv0 = q[2] * pt[2] - q[3] * pt[1], uv1 = q[3] * pt[0] - q[1] * pt[2], uv2 = q[1] * pt[1] - q[2] * pt[0];
+    uv0 += uv0; uv1 += uv1; uv2 += uv2;
+    double p[3] = {pt[0] + q[0] * uv0 + (q[2] * uv2 - q[3] * uv1), pt[1] + q[0] * uv1 + (q[3] * uv0 - q[1] * uv2),
+                   pt[2] + q[0] * uv2 + (q[1] * uv1 - q[2] * uv0)};
+    p[0] += cam[4]; p[1] += cam[5]; p[2] += cam[6];
+    const double xp = -p[0] / p[2], yp = -p[1] / p[2];
+    const double r2 = xp * xp + yp * yp;
+    const double distortion = 1.0 + r2 * (cam[8] + cam[9] * r2);
+    xy[0] = cam[7] * distortion * xp;
+    xy[1] = cam[7] * distortion * yp;
+  }
+  void ProjectModel(const double* cam, const double* pt, double* xy) const {
+    if (camera_size == 10) ProjectQuaternion(cam, pt, xy);
+    else Project(cam, pt, xy);
+  }
+  // AngleAxisToQuaternion (rotation.h:246-270)
+  static void AngleAxisToQuaternion(const double* aa, double* q) {
+    const double theta2 = aa[0] * aa[0] + aa[1] * aa[1] + aa[2] * aa[2];
+    if (theta2 > 0.0) {
+      const double theta = std::sqrt(theta2), k = std::sin(theta * 0.5) / theta;
+      q[0] = std::cos(theta * 0.5); q[1] = aa[0] * k; q[2] = aa[1] * k; q[3] = aa[2] * k;
+    } else {
+      q[0] = 1.0; q[1] = aa[0] * 0.5; q[2] = aa[1] * 0.5; q[3] = aa[2] * 0.5;
+    }
+  }
+
+  // losses: one object per residual block when `loss_factory` is set (as bundle_adjuster does), else `loss` for all
+  BalProgram(int num_cameras, int num_points, double visibility, unsigned seed, const LossFunction* loss = nullptr, bool quaternion = false,
+             std::function<const LossFunction*(size_t)> loss_factory = nullptr)
+      : C(num_cameras), P(num_points), camera_size(quaternion ? 10 : 9) {
     std::mt19937 prng(seed);
     std::normal_distribution<double> normal(0.0, 1.0);
     std::uniform_real_distribution<double> uni(0.0, 1.0);
@@ -345,19 +384,38 @@ struct BalProgram {
     for (size_t k = 0; k < truth.size(); ++k) user_state[k] = truth[k];
     for (int i = 0; i < C; ++i) { for (int k = 0; k < 3; ++k) user_state[size_t(9 * i + k)] += 0.01 * normal(prng); for (int k = 3; k < 6; ++k) user_state[size_t(9 * i + k)] += 0.05 * normal(prng); }
     for (int j = 0; j < 3 * P; ++j) user_state[size_t(9 * C + j)] += 0.05 * normal(prng);
+    if (quaternion) {  // BALProblem(filename, use_quaternions): the angle-axis of every camera becomes a quaternion (bal_problem.cc:110-128)
+      std::vector<double> q_state(size_t(10 * C + 3 * P));
+      for (int i = 0; i < C; ++i) {
+        AngleAxisToQuaternion(&user_state[size_t(9 * i)], &q_state[size_t(10 * i)]);
+        for (int k = 3; k < 9; ++k) q_state[size_t(10 * i + k + 1)] = user_state[size_t(9 * i + k)];
+      }
+      std::copy(user_state.begin() + 9 * C, user_state.end(), q_state.begin() + 10 * C);
+      user_state.swap(q_state);
+      camera_manifold.reset(new ProductManifold<QuaternionManifold, EuclideanManifold<6>>());
+    }
 
     // Problem -> Program: parameter blocks in the order ApplyOrdering gives for ordering {points: 0, cameras: 1}
-    for (int j = 0; j < P; ++j) parameter_blocks.emplace_back(new ParameterBlock(&user_state[size_t(9 * C + 3 * j)], 3, j));
-    for (int i = 0; i < C; ++i) parameter_blocks.emplace_back(new ParameterBlock(&user_state[size_t(9 * i)], 9, P + i));
+    for (int j = 0; j < P; ++j) parameter_blocks.emplace_back(new ParameterBlock(&user_state[size_t(camera_size * C + 3 * j)], 3, j));
+    for (int i = 0; i < C; ++i) {
+      parameter_blocks.emplace_back(new ParameterBlock(&user_state[size_t(camera_size * i)], camera_size, P + i));
+      if (quaternion) parameter_blocks.back()->SetManifold(camera_manifold.get());
+    }
     for (auto& pb : parameter_blocks) program.mutable_parameter_blocks()->push_back(pb.get());
     program.SetParameterOffsetsAndIndex();
     // residual blocks in input order, then LexicographicallyOrderResidualBlocks (reorder_program.cc:256-338)
     const size_t O = camera_index.size();
     std::vector<ResidualBlock*> input(O);
     for (size_t k = 0; k < O; ++k) {
-      cost_functions.emplace_back(new Snavely(new examples::SnavelyReprojectionError(observations[2 * k], observations[2 * k + 1])));
+      if (quaternion) cost_functions.emplace_back(new SnavelyQuaternion(new examples::SnavelyReprojectionErrorWithQuaternions(observations[2 * k], observations[2 * k + 1])));
+      else cost_functions.emplace_back(new Snavely(new examples::SnavelyReprojectionError(observations[2 * k], observations[2 * k + 1])));
       std::vector<ParameterBlock*> blocks = {parameter_blocks[size_t(P + camera_index[k])].get(), parameter_blocks[size_t(point_index[k])].get()};
-      residual_blocks.emplace_back(new ResidualBlock(cost_functions.back().get(), loss, blocks, int(k)));
+      if (loss_factory) {
+        owned_losses.emplace_back(loss_factory(k));
+        residual_blocks.emplace_back(new ResidualBlock(cost_functions.back().get(), owned_losses.back().get(), blocks, int(k)));
+      } else {
+        residual_blocks.emplace_back(new ResidualBlock(cost_functions.back().get(), loss, blocks, int(k)));
+      }
       input[k] = residual_blocks.back().get();
     }
     std::vector<int> offsets(size_t(P) + 1, 0);
@@ -521,11 +579,21 @@ static void TestEvaluatorToSolverThroughTheInterfaces() {
     o = evaluator_options;
     o.num_eliminate_blocks = kPoints - 1;
     EXPECT(CxBalEvaluator::TryCreate(o, &bal.program, &why) == nullptr, "wrong elimination group must be declined (%s)", why.c_str());
-    SoftLOneStandIn loss;
-    BalProgram robust(4, 40, 0.6, 3u, &loss);
+    // a loss the device does not evaluate (ScaledLoss around a built-in one) is declined; so are blocks whose losses differ
+    ScaledLoss scaled(new HuberLoss(1.0), 2.0);
+    BalProgram robust(4, 40, 0.6, 3u, &scaled);
     o = evaluator_options;
     o.num_eliminate_blocks = 40;
-    EXPECT(CxBalEvaluator::TryCreate(o, &robust.program, &why) == nullptr && why == "loss function present", "loss: %s", why.c_str());
+    EXPECT(CxBalEvaluator::TryCreate(o, &robust.program, &why) == nullptr && why.find("built-in") != std::string::npos, "ScaledLoss: %s", why.c_str());
+    BalProgram mixed(4, 40, 0.6, 3u, nullptr, false, [](size_t k) -> const LossFunction* { return new HuberLoss(k % 2 ? 1.0 : 2.0); });
+    EXPECT(CxBalEvaluator::TryCreate(o, &mixed.program, &why) == nullptr && why.find("different loss") != std::string::npos, "mixed losses: %s", why.c_str());
+    BalProgram partly(4, 40, 0.6, 3u, nullptr, false, [](size_t k) -> const LossFunction* { return k % 2 ? new HuberLoss(1.0) : nullptr; });
+    EXPECT(CxBalEvaluator::TryCreate(o, &partly.program, &why) == nullptr, "loss on some blocks only: %s", why.c_str());
+    // a loss that is the identity (TrivialLoss, or a user's class behaving like it) is no loss
+    SoftLOneStandIn identity;
+    BalProgram trivial(4, 40, 0.6, 3u, &identity);
+    std::unique_ptr<Evaluator> te = CxBalEvaluator::TryCreate(o, &trivial.program, &why);
+    EXPECT(te != nullptr && static_cast<CxBalEvaluator*>(te.get())->loss_type() == CX_LOSS_NONE, "identity loss: %s", why.c_str());
   }
 
   // residual r of the program's block k must be the reprojection error of ITS observation: checks the row order
@@ -729,10 +797,102 @@ static void TestShardsBehindTheInterfaces() {
   CxSetDevices({0});
 }
 
+// the programs bundle_adjuster builds with --robustify and with --use_quaternions --use_manifolds
+// (examples/bundle_adjuster.cc:316-346) go through TryCreate: the loss is recovered from the LossFunction objects
+// (one HuberLoss(1.0) per residual block, as the example news them), the camera manifold is recognised by type.
+// The trust-region loop through the interfaces must take the steps of cx_minimize with the same settings, and the
+// cost at the start must equal the host sum 1/2 sum rho(|r|^2) over the program's residual blocks.
+static void TestRobustAndQuaternionPrograms() {
+  const int kCameras = 16, kPoints = 900, kIterations = 5;
+  const double kEta = 1e-2;
+  for (int variant = 0; variant < 3; ++variant) {
+    const bool robust = variant != 1, quaternion = variant != 0;
+    const char* name = variant == 0 ? "--robustify" : (variant == 1 ? "--use_quaternions --use_manifolds" : "--robustify --use_quaternions --use_manifolds");
+    std::function<const LossFunction*(size_t)> factory;
+    if (robust) factory = [](size_t) -> const LossFunction* { return new HuberLoss(1.0); };
+    BalProgram bal(kCameras, kPoints, 0.4, 23u, nullptr, quaternion, factory);
+    Evaluator::Options evaluator_options;
+    evaluator_options.linear_solver_type = ITERATIVE_SCHUR;
+    evaluator_options.num_eliminate_blocks = kPoints;
+    std::string why;
+    std::unique_ptr<Evaluator> evaluator = CxBalEvaluator::TryCreate(evaluator_options, &bal.program, &why);
+    EXPECT(evaluator != nullptr, "%s: TryCreate declined: %s", name, why.c_str());
+    if (!evaluator) continue;
+    auto* cxe = static_cast<CxBalEvaluator*>(evaluator.get());
+    EXPECT(cxe->loss_type() == (robust ? CX_LOSS_HUBER : CX_LOSS_NONE) && (!robust || cxe->loss_a() == 1.0), "%s: loss %d (%.17g)", name,
+           cxe->loss_type(), cxe->loss_a());
+    EXPECT(cxe->camera_model() == (quaternion ? CX_CAMERA_QUATERNION_MANIFOLD : CX_CAMERA_ANGLE_AXIS), "%s: camera model", name);
+    EXPECT(evaluator->NumParameters() == 3 * kPoints + bal.camera_size * kCameras && evaluator->NumEffectiveParameters() == 3 * kPoints + 9 * kCameras,
+           "%s: ambient %d / tangent %d", name, evaluator->NumParameters(), evaluator->NumEffectiveParameters());
+    const std::vector<double> x0 = bal.StateVector();
+    // cost at the start against the host sum over the program's residual blocks (with and without the loss)
+    for (bool apply_loss : {true, false}) {
+      Evaluator::EvaluateOptions eo;
+      eo.apply_loss_function = apply_loss;
+      double cost = 0.0, want = 0.0;
+      EXPECT(evaluator->Evaluate(eo, x0.data(), &cost, nullptr, nullptr, nullptr), "%s: cost evaluation", name);
+      for (const ResidualBlock* rb : bal.program.residual_blocks()) {
+        double xy[2], ox, oy;
+        bal.ProjectModel(x0.data() + rb->parameter_blocks()[0]->state_offset(), x0.data() + rb->parameter_blocks()[1]->state_offset(), xy);
+        if (quaternion) { const auto& f = static_cast<const BalProgram::SnavelyQuaternion*>(rb->cost_function())->functor(); ox = f.observed_x; oy = f.observed_y; }
+        else { const auto& f = static_cast<const BalProgram::Snavely*>(rb->cost_function())->functor(); ox = f.observed_x; oy = f.observed_y; }
+        const double sq = (xy[0] - ox) * (xy[0] - ox) + (xy[1] - oy) * (xy[1] - oy);
+        double rho[3] = {sq, 1.0, 0.0};
+        if (apply_loss && rb->loss_function() != nullptr) rb->loss_function()->Evaluate(sq, rho);
+        want += 0.5 * rho[0];
+      }
+      EXPECT(std::abs(cost - want) <= 1e-10 * want, "%s (apply_loss_function %d): cost %.12e vs %.12e", name, int(apply_loss), cost, want);
+    }
+    LinearSolver::Options solver_options;
+    solver_options.type = ITERATIVE_SCHUR;
+    solver_options.preconditioner_type = JACOBI;
+    solver_options.elimination_groups = {kPoints, kCameras};
+    solver_options.max_num_iterations = 500;
+    std::unique_ptr<SparseMatrix> jacobian = evaluator->CreateJacobian();
+    CxLinearSolver solver(solver_options);
+    LmTrace t = RunTrustRegionLoop(evaluator.get(), jacobian.get(), &solver, x0, kIterations, kEta);
+    EXPECT(t.ok && t.num_successful >= 3 && t.costs.back() < 0.2 * t.costs.front(), "%s: %d successful steps, cost %.4e -> %.4e", name,
+           t.num_successful, t.costs.front(), t.costs.back());
+    // cx_minimize with the same settings stated directly
+    cx_context* ctx = CxSharedContext();
+    cx_evaluator* e = nullptr;
+    cx_solver* s = nullptr;
+    EXPECT(cx_evaluator_create_bal(ctx, kCameras, kPoints, int64_t(bal.camera_index.size()), bal.camera_index.data(), bal.point_index.data(),
+                                   bal.observations.data(), &e) == CX_OK, "%s", cx_last_error());
+    if (quaternion) EXPECT(cx_evaluator_set_camera_model(e, CX_CAMERA_QUATERNION_MANIFOLD) == CX_OK, "%s", cx_last_error());
+    if (robust) EXPECT(cx_evaluator_set_loss(e, CX_LOSS_HUBER, 1.0, 0.0) == CX_OK, "%s", cx_last_error());
+    cx_solver_options so;
+    cx_solver_default_options(&so);
+    so.type = CX_ITERATIVE_SCHUR;
+    so.preconditioner_type = CX_JACOBI;
+    so.num_eliminate_blocks = kPoints;
+    EXPECT(cx_solver_create(ctx, &so, &s) == CX_OK, "%s", cx_last_error());
+    cx_minimizer_options mo;
+    cx_minimizer_default_options(&mo);
+    mo.max_num_iterations = kIterations;
+    mo.eta = kEta;
+    mo.function_tolerance = mo.gradient_tolerance = mo.parameter_tolerance = 0.0;
+    std::vector<double> state = x0;
+    cx_minimizer_summary ms;
+    std::vector<cx_iteration_summary> its(static_cast<size_t>(kIterations + 2));
+    EXPECT(cx_minimize(e, s, &mo, state.data(), CX_HOST, &ms, its.data(), int32_t(its.size())) == CX_OK, "%s", cx_last_error());
+    std::vector<double> costs;
+    for (int k = 0; k < ms.num_iterations && k < int(its.size()); ++k)
+      if (k == 0 || its[size_t(k)].step_is_successful) costs.push_back(its[size_t(k)].cost);
+    EXPECT(costs.size() == t.costs.size(), "%s: cx_minimize %zu accepted costs vs %zu", name, costs.size(), t.costs.size());
+    for (size_t k = 0; k < std::min(costs.size(), t.costs.size()); ++k)
+      EXPECT(std::abs(costs[k] - t.costs[k]) <= 1e-7 * t.costs[k], "%s: cost %zu: %.12e vs %.12e", name, k, costs[k], t.costs[k]);
+    cx_solver_destroy(s);
+    cx_evaluator_destroy(e);
+    std::printf("%-50s cost %.6e -> %.6e in %d steps\n", name, t.costs.front(), t.costs.back(), t.num_successful);
+  }
+}
+
 int main() {
   TestSolversOnHostJacobian();
   TestEvaluatorToSolverThroughTheInterfaces();
   TestShardsBehindTheInterfaces();
+  TestRobustAndQuaternionPrograms();
   std::printf("%s\n", failures ? "FAILED" : "ALL OK");
   return failures ? 1 : 0;
 }

@@ -184,3 +184,14 @@ def test_sparse_cholesky_plan_host_dissects_a_long_scene(oracle):
     T = plan["num_tile_rows"]
     assert T >= 3000 * 9 // 64
     assert plan["num_levels"] < T // 2, (plan["num_levels"], T)
+
+
+def test_loss_function_recovery_on_the_host():
+    """host/cx_loss_probe.h: the constructor arguments of every built-in LossFunction (private in the reference,
+    loss_function.h:174-292) are recovered through LossFunction::Evaluate, so that CxBalEvaluator::TryCreate can accept
+    bundle_adjuster --robustify programs; ScaledLoss and other non-built-in losses are declined.  Pure host code."""
+    import subprocess
+    host = os.path.join(ROOT, "ceres-solver-ceres-solver_amd", "host")
+    subprocess.check_call(["make", "-s", "-C", host, "test_loss_probe"])
+    out = subprocess.run([os.path.join(host, "test_loss_probe")], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0 and "ALL OK" in out.stdout, out.stdout + out.stderr
