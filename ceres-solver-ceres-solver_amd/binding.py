@@ -25,7 +25,7 @@ SUCCESS, NO_CONVERGENCE, FAILURE, FATAL_ERROR = 0, 1, 2, 3
 
 # every symbol include/cxschur.h declares (tests check that the library exports them all)
 EXPORTED_SYMBOLS = [
-    "cx_context_create", "cx_context_destroy", "cx_comm_unique_id", "cx_context_set_comm", "cx_context_set_comm_callback", "cx_context_rank",
+    "cx_context_create", "cx_context_create_multi", "cx_context_num_shards", "cx_matrix_shard_layout", "cx_context_destroy", "cx_comm_unique_id", "cx_context_set_comm", "cx_context_set_comm_callback", "cx_context_rank",
     "cx_context_num_ranks", "cx_allreduce_sum", "cx_malloc", "cx_free", "cx_memcpy_h2d", "cx_memcpy_d2h",
     "cx_memset_zero", "cx_synchronize", "cx_context_stream", "cx_last_error", "cx_device_name",
     "cx_matrix_create", "cx_matrix_destroy", "cx_matrix_num_rows", "cx_matrix_num_cols",
