@@ -25,7 +25,7 @@ SUCCESS, NO_CONVERGENCE, FAILURE, FATAL_ERROR = 0, 1, 2, 3
 
 # every symbol include/cxschur.h declares (tests check that the library exports them all)
 EXPORTED_SYMBOLS = [
-    "cx_context_create", "cx_context_create_multi", "cx_context_num_shards", "cx_matrix_shard_layout", "cx_context_destroy", "cx_comm_unique_id", "cx_context_set_comm", "cx_context_set_comm_callback", "cx_context_rank",
+    "cx_context_create", "cx_schur_pair_lists_host", "cx_context_create_multi", "cx_context_num_shards", "cx_matrix_shard_layout", "cx_context_destroy", "cx_comm_unique_id", "cx_context_set_comm", "cx_context_set_comm_callback", "cx_context_rank",
     "cx_context_num_ranks", "cx_allreduce_sum", "cx_malloc", "cx_free", "cx_memcpy_h2d", "cx_memcpy_d2h",
     "cx_memset_zero", "cx_synchronize", "cx_context_stream", "cx_last_error", "cx_device_name",
     "cx_matrix_create", "cx_matrix_destroy", "cx_matrix_num_rows", "cx_matrix_num_cols",
@@ -671,6 +671,22 @@ def visibility_clusters_host(bs, num_eliminate_blocks, preconditioner_type, clus
     _check(lib.cx_visibility_clusters_host(bs.c, int(num_eliminate_blocks), int(preconditioner_type), int(clustering_type),
                                            _ptr(membership), ctypes.byref(nc), ctypes.byref(ncp), _ptr(cp1), _ptr(cp2), ncp.value))
     return membership, nc.value, np.stack([cp1, cp2], 1)
+
+
+def schur_pair_lists_host(bs, num_eliminate_blocks, want_pairs=False):
+    """Host half of the explicit-S gather assembly (no device): (cell_row, cell_col, num_pairs, num_items[, pair_rows])."""
+    lib = load_library()
+    nc, npairs, ni = ctypes.c_int64(), ctypes.c_int64(), ctypes.c_int64()
+    _check(lib.cx_schur_pair_lists_host(bs.c, int(num_eliminate_blocks), ctypes.byref(nc), ctypes.byref(npairs), ctypes.byref(ni),
+                                        None, None, ctypes.c_int64(0), None, ctypes.c_int64(0)))
+    if nc.value < 0:
+        return None, None, npairs.value, -1
+    r, c = np.zeros(nc.value, dtype=np.int32), np.zeros(nc.value, dtype=np.int32)
+    pr = np.zeros(2 * npairs.value if want_pairs else 0, dtype=np.int32)
+    _check(lib.cx_schur_pair_lists_host(bs.c, int(num_eliminate_blocks), ctypes.byref(nc), ctypes.byref(npairs), ctypes.byref(ni),
+                                        _ptr(r), _ptr(c), ctypes.c_int64(r.size), _ptr(pr) if want_pairs else None,
+                                        ctypes.c_int64(pr.size)))
+    return (r, c, npairs.value, ni.value, pr) if want_pairs else (r, c, npairs.value, ni.value)
 
 
 def detect_structure(bs, num_eliminate_blocks):

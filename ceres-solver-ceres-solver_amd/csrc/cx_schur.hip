@@ -837,8 +837,18 @@ constexpr int64_t kMaxPairs = int64_t(1) << 28;
 constexpr int kPairGroups = 28;             // 28 groups of 9 threads, each thread a 3x3 piece of the 9x9 product
 constexpr int kPairItem = kPairGroups * 8;  // pairs per work item
 
-int cxs_build_pair_lists(cx_matrix* A) {
-  if (A->pairs_state != 0) return CX_OK;
+// Host half of the gather assembly's structure: everything cxs_build_pair_lists derives from the block structure alone.
+// No device is touched (the sanitizer builds of tools/sanitize run it on the CPU), threads: up to 16.
+struct PairListsHost {
+  int64_t total = 0;            // pairs
+  bool too_many = false;        // more than kMaxPairs (or CX_ELIM_ATOMICS=1): the atomics path is used instead
+  std::unique_ptr<int32_t[]> pairs;  // [2 * total] (row of camera c1, row of camera c2) per pair, cells in order, chunk order inside
+  std::vector<int32_t> cell_c1, cell_c2, cell_item_start, row_cells, col_count, col_cells;
+  std::vector<int64_t> item_begin;
+  int64_t num_items = 0, num_cells = 0;
+};
+
+static int BuildPairListsHost(const cx_cell* cells, int32_t P, int32_t C, int64_t O, PairListsHost* out) {
   const bool verbose = std::getenv("CX_SPARSE_CHOLESKY_VERBOSE") != nullptr;
   auto t_last = std::chrono::steady_clock::now();
   auto lap = [&](const char* what) {
@@ -846,40 +856,39 @@ int cxs_build_pair_lists(cx_matrix* A) {
     if (verbose) std::fprintf(stderr, "[cxschur] pair lists: %s %.3f s\n", what, std::chrono::duration<double>(now - t_last).count());
     t_last = now;
   };
-  const int C = A->C;
-  const int64_t O = A->O;
   int64_t total = 0;
-  std::vector<int32_t> start(size_t(A->P) + 1, 0);
+  std::vector<int32_t> start(size_t(P) + 1, 0);
   {
     // rows are sorted by point: chunk of point p = rows with cells[2r].block_id == p
     int64_t r = 0;
-    for (int p = 0; p < A->P; ++p) {
+    for (int p = 0; p < P; ++p) {
       start[p] = int32_t(r);
-      while (r < O && A->cells[2 * r].block_id == p) ++r;
+      while (r < O && cells[2 * r].block_id == p) ++r;
       const int64_t k = r - start[p];
       total += k * (k + 1) / 2;
     }
-    start[A->P] = int32_t(r);
+    start[P] = int32_t(r);
   }
+  out->total = total;
   // CX_ELIM_ATOMICS=1 selects the scatter (fp64 atomics) path, otherwise only used when the list would be huge
   const char* force = std::getenv("CX_ELIM_ATOMICS");
   if (total > kMaxPairs || (force && force[0] == '1')) {
-    A->pairs_state = 2;
+    out->too_many = true;
     return CX_OK;
   }
-  auto cam_of = [&](int64_t r) { return A->cells[2 * r + 1].block_id - A->P; };
+  auto cam_of = [&](int64_t r) { return cells[2 * r + 1].block_id - P; };
   // 1. bucket the pairs by their smaller camera c1 (stable: chunk order inside a bucket).  Worker threads take
   //    contiguous ranges of points balanced by pair count; thread t's pairs of a bucket go behind those of threads
   //    < t, which is the chunk order (one thread walking 164 M pairs of the Final shape twice took 1.1 s of the
   //    1.9 s one-time set-up of SPARSE_SCHUR).
   struct Pair { int32_t c2, ri, rj; };
   const unsigned hw = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
-  std::vector<int> range(size_t(hw) + 1, A->P);
+  std::vector<int> range(size_t(hw) + 1, P);
   {
     range[0] = 0;
     int64_t acc = 0;
     unsigned t = 1;
-    for (int p = 0; p < A->P && t < hw; ++p) {
+    for (int p = 0; p < P && t < hw; ++p) {
       const int64_t k = start[p + 1] - start[p];
       acc += k * (k + 1) / 2;
       if (acc * int64_t(hw) >= total * int64_t(t)) range[t++] = p + 1;
@@ -930,7 +939,8 @@ int cxs_build_pair_lists(cx_matrix* A) {
   // 2. inside every bucket a stable counting sort by c2 gives the cells of block row c1 in order, each with
   //    its pairs in chunk order; the diagonal cell (c1, c1) exists even without pairs.  Buckets are
   //    independent: worker threads take them round-robin.
-  std::vector<int32_t> row_cells(size_t(C) + 1, 0);  // cells per block row, then prefix sums
+  std::vector<int32_t>& row_cells = out->row_cells;  // cells per block row, then prefix sums
+  row_cells.assign(size_t(C) + 1, 0);
   std::unique_ptr<int32_t[]> pairs(new int32_t[static_cast<size_t>(std::max<int64_t>(2 * total, 1))]);
   std::vector<std::vector<int32_t>> row_c2(static_cast<size_t>(C));     // c2 of the row's cells
   std::vector<std::vector<int64_t>> row_begin(static_cast<size_t>(C));  // first pair of each of them
@@ -969,18 +979,21 @@ int cxs_build_pair_lists(cx_matrix* A) {
   lap("sort by second camera");
   for (int c = 0; c < C; ++c) row_cells[size_t(c) + 1] = row_cells[size_t(c)] + int32_t(row_c2[size_t(c)].size());
   const int64_t ncell = row_cells[size_t(C)];
-  A->h_cell_c1.resize(size_t(ncell));
-  A->h_cell_c2.resize(size_t(ncell));
-  std::vector<int64_t> item_begin;
-  std::vector<int32_t> cell_item_start(size_t(ncell) + 1, 0);
-  std::vector<int32_t> col_count(size_t(C) + 1, 0);
+  out->cell_c1.resize(size_t(ncell));
+  out->cell_c2.resize(size_t(ncell));
+  std::vector<int64_t>& item_begin = out->item_begin;
+  item_begin.clear();
+  std::vector<int32_t>& cell_item_start = out->cell_item_start;
+  cell_item_start.assign(size_t(ncell) + 1, 0);
+  std::vector<int32_t>& col_count = out->col_count;
+  col_count.assign(size_t(C) + 1, 0);
   for (int c1 = 0; c1 < C; ++c1) {
     const auto& c2s = row_c2[size_t(c1)];
     const auto& begins = row_begin[size_t(c1)];
     for (size_t k = 0; k < c2s.size(); ++k) {
       const int64_t cell = row_cells[size_t(c1)] + int64_t(k);
-      A->h_cell_c1[size_t(cell)] = c1;
-      A->h_cell_c2[size_t(cell)] = c2s[k];
+      out->cell_c1[size_t(cell)] = c1;
+      out->cell_c2[size_t(cell)] = c2s[k];
       if (c2s[k] != c1) col_count[size_t(c2s[k]) + 1]++;
       // work items: the cell's pair run cut into pieces of at most kPairItem pairs
       const int64_t b0 = begins[k];
@@ -990,32 +1003,79 @@ int cxs_build_pair_lists(cx_matrix* A) {
     }
   }
   cell_item_start[size_t(ncell)] = int32_t(item_begin.size());
-  A->num_items = int64_t(item_begin.size());
+  out->num_items = int64_t(item_begin.size());
   item_begin.push_back(total);  // consecutive items meet at a cell boundary, so item i ends where item i + 1 begins
   // transposed index: the off-diagonal cells of block column c2, by ascending c1
   for (int c = 0; c < C; ++c) col_count[size_t(c) + 1] += col_count[size_t(c)];
-  std::vector<int32_t> col_cells(static_cast<size_t>(col_count[size_t(C)]), 0);
+  std::vector<int32_t>& col_cells = out->col_cells;
+  col_cells.assign(static_cast<size_t>(col_count[size_t(C)]), 0);
   {
     std::vector<int32_t> fill(col_count.begin(), col_count.end() - 1);
     for (int64_t cell = 0; cell < ncell; ++cell)
-      if (A->h_cell_c1[size_t(cell)] != A->h_cell_c2[size_t(cell)]) col_cells[size_t(fill[size_t(A->h_cell_c2[size_t(cell)])]++)] = int32_t(cell);
+      if (out->cell_c1[size_t(cell)] != out->cell_c2[size_t(cell)]) col_cells[size_t(fill[size_t(out->cell_c2[size_t(cell)])]++)] = int32_t(cell);
   }
   lap("cell and item index");
+  out->pairs = std::move(pairs);
+  out->num_cells = ncell;
+  return CX_OK;
+}
+
+int cxs_build_pair_lists(cx_matrix* A) {
+  if (A->pairs_state != 0) return CX_OK;
+  PairListsHost h;
+  CX_TRY(BuildPairListsHost(A->cells.data(), A->P, A->C, A->O, &h));
+  if (h.too_many) {
+    A->pairs_state = 2;
+    return CX_OK;
+  }
+  const int64_t total = h.total;
+  A->h_cell_c1 = h.cell_c1;
+  A->h_cell_c2 = h.cell_c2;
+  A->num_items = h.num_items;
   hipStream_t st = A->ctx->stream;
-  CX_TRY(A->d_pair_rows.upload(pairs.get(), static_cast<size_t>(2 * total), st));
-  CX_TRY(A->d_item_begin.upload(item_begin, st));
-  CX_TRY(A->d_cell_item_start.upload(cell_item_start, st));
-  A->h_cell_item_start = cell_item_start;
+  CX_TRY(A->d_pair_rows.upload(h.pairs.get(), static_cast<size_t>(2 * total), st));
+  CX_TRY(A->d_item_begin.upload(h.item_begin, st));
+  CX_TRY(A->d_cell_item_start.upload(h.cell_item_start, st));
+  A->h_cell_item_start = h.cell_item_start;
   CX_TRY(A->d_cell_c1.upload(A->h_cell_c1, st));
   CX_TRY(A->d_cell_c2.upload(A->h_cell_c2, st));
-  CX_TRY(A->d_cell_row_start.upload(row_cells, st));
-  CX_TRY(A->d_col_cell_start.upload(col_count, st));
-  CX_TRY(A->d_col_cells.upload(col_cells, st));
+  CX_TRY(A->d_cell_row_start.upload(h.row_cells, st));
+  CX_TRY(A->d_col_cell_start.upload(h.col_count, st));
+  CX_TRY(A->d_col_cells.upload(h.col_cells, st));
   CX_TRY(A->d_item_partial.alloc(size_t(std::max<int64_t>(A->num_items, 1)) * 81));
   A->num_pairs = total;
-  A->num_cells = ncell;
+  A->num_cells = h.num_cells;
   A->pairs_state = 1;
-  lap("uploads");
+  return CX_OK;
+}
+
+// The same structure from the flat block structure alone, for callers without a device (cxschur.h)
+extern "C" int cx_schur_pair_lists_host(const cx_block_structure* bs, int32_t num_eliminate_blocks, int64_t* num_cells,
+                                        int64_t* num_pairs, int64_t* num_items, int32_t* cell_row, int32_t* cell_col,
+                                        int64_t cell_capacity, int32_t* pair_rows, int64_t pair_capacity) {
+  CX_CHECK_ARG(bs != nullptr && num_cells != nullptr && num_pairs != nullptr && num_items != nullptr);
+  const int32_t P = num_eliminate_blocks, C = bs->num_col_blocks - P;
+  const int64_t O = bs->num_row_blocks;
+  CX_CHECK_ARG(P > 0 && C > 0 && cell_capacity >= 0 && pair_capacity >= 0);
+  for (int64_t r = 0; r < O; ++r) {  // the static layout: two cells per row, e-block first, rows sorted by e-block
+    const bool ok = bs->row_cell_begin[r] == 2 * r && bs->row_cell_begin[r + 1] == 2 * r + 2 && bs->cells[2 * r].block_id < P &&
+                    bs->cells[2 * r + 1].block_id >= P && (r == 0 || bs->cells[2 * r].block_id >= bs->cells[2 * r - 2].block_id);
+    if (!ok) {
+      cx_set_error("row block %lld does not have the static two-cell layout", (long long)r);
+      return CX_ERR_UNSUPPORTED;
+    }
+  }
+  PairListsHost h;
+  CX_TRY(BuildPairListsHost(bs->cells, P, C, O, &h));
+  *num_pairs = h.total;
+  *num_cells = h.too_many ? -1 : h.num_cells;
+  *num_items = h.too_many ? -1 : h.num_items;
+  if (h.too_many) return CX_OK;
+  if (cell_row && cell_col && cell_capacity >= h.num_cells) {
+    std::copy(h.cell_c1.begin(), h.cell_c1.end(), cell_row);
+    std::copy(h.cell_c2.begin(), h.cell_c2.end(), cell_col);
+  }
+  if (pair_rows && pair_capacity >= 2 * h.total) std::copy(h.pairs.get(), h.pairs.get() + 2 * h.total, pair_rows);
   return CX_OK;
 }
 

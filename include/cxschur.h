@@ -495,6 +495,16 @@ int cx_sparse_cholesky_plan_host(int32_t num_cameras, const int32_t* cell_row, c
                                  int32_t* camera_first_row, int32_t* num_tile_rows, int32_t* num_levels, int64_t* num_tiles,
                                  int64_t* num_tile_pair_updates, int32_t* tile_row_level, int32_t* tile_row_start,
                                  int32_t capacity_rows, int32_t* tile_cols, int64_t capacity_tiles);
+/* Host half of the gather assembly of the explicit S (SchurEliminator::Eliminate into the InitStorage cell set,
+ * schur_eliminator_impl.h:512-561, schur_complement_solver.cc:224-290) -- no device needed: the cells of the upper block
+ * triangle of S in InitStorage order and, per cell, the row pairs (row of the cell's first camera, row of its second) that
+ * update it, in chunk order.  Static <2,3,9> layout (two cells per row block, e-block first, rows sorted by e-block).
+ * Counts are always set (-1 cells / items when the pair list would exceed 2^28 pairs and the scatter path is used
+ * instead); the arrays (may be NULL) are filled when their capacity suffices: cell_row / cell_col [num_cells],
+ * pair_rows [2 * num_pairs]. */
+int cx_schur_pair_lists_host(const cx_block_structure* bs, int32_t num_eliminate_blocks, int64_t* num_cells,
+                             int64_t* num_pairs, int64_t* num_items, int32_t* cell_row, int32_t* cell_col,
+                             int64_t cell_capacity, int32_t* pair_rows, int64_t pair_capacity);
 /* Partition the first num_eliminate_blocks column blocks (points) into nranks
  * contiguous ranges holding about equal numbers of non-zeros -- the balancing
  * PartitionRangeForParallelFor does on cumulative_nnz

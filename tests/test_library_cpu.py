@@ -195,3 +195,38 @@ def test_loss_function_recovery_on_the_host():
     subprocess.check_call(["make", "-s", "-C", host, "test_loss_probe"])
     out = subprocess.run([os.path.join(host, "test_loss_probe")], capture_output=True, text=True, timeout=120)
     assert out.returncode == 0 and "ALL OK" in out.stdout, out.stdout + out.stderr
+
+
+@pytest.mark.parametrize("C,P,O,seed", [(6, 40, 150, 1), (14, 900, 4200, 6), (60, 1500, 7000, 12), (3, 4, 9, 1)])
+def test_pair_lists_host_match_the_oracle_cell_set(oracle, C, P, O, seed):
+    """cx_schur_pair_lists_host (the structure half of the gather assembly of S, no device): the cell list is
+    SparseSchurComplementSolver::InitStorage's (schur_complement_solver.cc:224-290) -- bit-exact against the oracle -- and
+    the pairs of a cell are exactly the row pairs (row of c1, row of c2) of every chunk that sees both cameras, chunks in
+    order: integers, compared exactly with a brute-force numpy enumeration."""
+    prob = cx.bal.make_bal_like(C, P, O, seed=seed)
+    bs, _ = cx.bal.build_structure(prob)
+    r, c, num_pairs, num_items, pairs = cx.binding.schur_pair_lists_host(bs, P, want_pairs=True)
+    r_ref, c_ref = oracle.schur_sparse_structure(bs, P)
+    assert np.array_equal(r, r_ref) and np.array_equal(c, c_ref)
+    row_pt = bs.cells["block_id"][0::2].astype(np.int64)
+    row_cam = bs.cells["block_id"][1::2].astype(np.int64) - P
+    want = {}
+    start = np.searchsorted(row_pt, np.arange(P + 1))
+    for p in range(P):
+        rows = range(start[p], start[p + 1])
+        for i in rows:
+            for j in rows:
+                if j < i:
+                    continue
+                ci, cj = row_cam[i], row_cam[j]
+                key = (min(ci, cj), max(ci, cj))
+                want.setdefault(key, []).append((i, j) if ci <= cj else (j, i))
+    assert num_pairs == sum(len(v) for v in want.values())
+    pairs = pairs.reshape(-1, 2)
+    pos = 0
+    for c1, c2 in zip(r, c):
+        lst = want.get((c1, c2), [])
+        got = [tuple(q) for q in pairs[pos:pos + len(lst)]]
+        assert got == lst, (c1, c2)
+        pos += len(lst)
+    assert pos == num_pairs and num_items >= len(r)
