@@ -21,7 +21,13 @@ PRESETS = {
     "dubrovnik356": (356, 226730, 1255268, 356),
     "final13682": (13682, 4456117, 28987644, 13682),
     "synthetic10M": (5000, 1500000, 10000000, 10),
+    # the Final-13682 sizes on a second kind of scene: the trajectory passes every place twice (5 % of the points are also
+    # seen from the cameras half a ring away), so the camera graph is a ring with chords -- loop closures -- instead of a band
+    "final13682_revisit": (13682, 4456117, 28987644, 13682),
+    "dubrovnik356_revisit": (356, 226730, 1255268, 356),
 }
+# generator options of a preset beyond (cameras, points, observations, seed)
+PRESET_OPTIONS = {"final13682_revisit": {"revisit_fraction": 0.05}, "dubrovnik356_revisit": {"revisit_fraction": 0.05}}
 
 
 @dataclass
@@ -90,10 +96,14 @@ def _track_lengths(rng, C, P, O):
     return k + 2
 
 
-def make_bal_like(C, P, O, seed, noise_px=0.5, perturb=True):
+def make_bal_like(C, P, O, seed, noise_px=0.5, perturb=True, revisit_fraction=0.0):
     """Cameras on a noisy ring looking at a point cloud; each point is seen from a
     window of neighbouring cameras, so the reduced camera matrix is banded like
-    real SfM data.  Deterministic in (C, P, O, seed)."""
+    real SfM data.  Deterministic in (C, P, O, seed).
+    revisit_fraction > 0: that share of the points (those with at least four observations) has its last two
+    observations taken by the cameras half a ring away instead -- loop closures: the co-visibility graph of the
+    cameras becomes a ring with chords, the structure nested dissection and the visibility clusterings of real
+    reconstructions have to cope with.  The observation count stays O."""
     rng = np.random.default_rng(seed)
     # ---- scene
     ang = 2.0 * np.pi * np.arange(C) / C
@@ -125,6 +135,11 @@ def make_bal_like(C, P, O, seed, noise_px=0.5, perturb=True):
     first = np.concatenate([[0], np.cumsum(k)[:-1]])
     within = np.arange(O, dtype=np.int64) - np.repeat(first, k)
     camera_index = (np.repeat(home, k) + within * np.repeat(stride, k)) % C
+    if revisit_fraction > 0.0:
+        # a generator of its own: the presets without revisits keep their random stream (and their published numbers)
+        revisit = (np.random.default_rng(seed + 7919).random(P) < revisit_fraction) & (k >= 4) & (3 * k < C // 2)
+        far = np.repeat(revisit, k) & (within >= np.repeat(k, k) - 2)
+        camera_index = np.where(far, (camera_index + C // 2) % C, camera_index)
     # BAL lists observations point-major with ascending camera index
     key = point_index * C + camera_index
     order = np.argsort(key, kind="stable")
@@ -148,7 +163,7 @@ def make_bal_like(C, P, O, seed, noise_px=0.5, perturb=True):
 
 def make_preset(name, **kw):
     C, P, O, seed = PRESETS[name]
-    return make_bal_like(C, P, O, seed, **kw)
+    return make_bal_like(C, P, O, seed, **{**PRESET_OPTIONS.get(name, {}), **kw})
 
 
 def residual_order(point_index, num_points):

@@ -750,14 +750,25 @@ int cx_evaluator_evaluate(cx_evaluator* e, const double* state, double* cost, do
   // borrows it as scratch for the residuals of ITS state, after which the copy no longer matches the caller's host array
   if (residuals != nullptr || res_dev == e->d_res.p) e->res_valid = res_to_host;
   const int grid = int((e->O + kBlock - 1) / kBlock);
-  double* E = A->d_values.p;
-  double* F = A->d_values.p + 6 * e->O;
+  // A gradient without a Jacobian (evaluate_jacobian == 0, gradient != NULL) still needs J for g = J'r, but must leave
+  // the evaluator's matrix alone: that storage is what CreateJacobian handed to the caller, possibly column-scaled
+  // since (ProgramEvaluator uses per-thread scratch for this case, program_evaluator.h:186-206).  The values of such a
+  // call go to scratch arrays of the same layout, which stand in for the matrix' arrays during the product below.
+  const bool scratch_j = with_j && evaluate_jacobian == 0;
+  if (scratch_j) {
+    CX_TRY(e->d_scratch_values.alloc(size_t(24 * e->O)));
+    CX_TRY(e->d_scratch_Ft.alloc(size_t(18 * e->O)));
+  }
+  double* E = scratch_j ? e->d_scratch_values.p : A->d_values.p;
+  double* F = E + 6 * e->O;
   const LossParams loss{e->loss_type, e->loss_a, e->loss_b};
   // the camera-major copy of F is written by the same kernel unless the caller said that a ScaleColumns follows
   // (which rewrites it anyway) -- cx_evaluator_set_emit_camera_major
   static const bool emit_allowed = std::getenv("CX_NO_FT_EMIT") == nullptr;  // A/B switch
   double* ft_out = nullptr;
-  if (with_j && e->emit_ft && emit_allowed) {
+  if (scratch_j) {
+    ft_out = e->d_scratch_Ft.p;
+  } else if (with_j && e->emit_ft && emit_allowed) {
     CX_TRY(A->d_Ft.alloc(size_t(A->O) * 18));
     ft_out = A->d_Ft.p;
   }
@@ -801,11 +812,25 @@ int cx_evaluator_evaluate(cx_evaluator* e, const double* state, double* cost, do
   }
   CX_HIP(hipGetLastError());
   CX_HIP(hipEventRecord(ctx->ev[7], st));
-  if (with_j) { A->ft_valid = ft_out != nullptr; A->f32_valid = false; }
+  if (with_j && !scratch_j) { A->ft_valid = ft_out != nullptr; A->f32_valid = false; }
   if (gradient) {
     // g = J' r (program_evaluator.h:242-258)
     CX_HIP(hipMemsetAsync(hg.dptr, 0, size_t(ncols) * sizeof(double), st));
-    CX_TRY(cxk_left_multiply(A, res_dev, hg.dptr));
+    if (scratch_j) {  // the product reads the scratch copies (pointers are taken at launch), the matrix keeps its own
+      const bool ft_valid = A->ft_valid, use_f32 = A->use_f32;
+      std::swap(A->d_values.p, e->d_scratch_values.p);
+      std::swap(A->d_Ft.p, e->d_scratch_Ft.p);
+      A->ft_valid = true;
+      A->use_f32 = false;
+      const int rc = cxk_left_multiply(A, res_dev, hg.dptr);
+      std::swap(A->d_values.p, e->d_scratch_values.p);
+      std::swap(A->d_Ft.p, e->d_scratch_Ft.p);
+      A->ft_valid = ft_valid;
+      A->use_f32 = use_f32;
+      CX_TRY(rc);
+    } else {
+      CX_TRY(cxk_left_multiply(A, res_dev, hg.dptr));
+    }
     if (ctx->nranks > 1) CX_TRY(cx_allreduce_device(ctx, hg.dptr + 3 * int64_t(e->P), 9 * int64_t(e->C)));
   }
   if (cost) {

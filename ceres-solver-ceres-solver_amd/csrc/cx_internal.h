@@ -263,6 +263,7 @@ struct cx_evaluator {
   std::vector<int64_t> row_of_obs;   // input observation -> row block
   DevBuf<double> d_obs;              // [2O] in row order
   DevBuf<double> d_partial, d_state, d_res;
+  DevBuf<double> d_scratch_values, d_scratch_Ft;  // J of a gradient-only evaluation (the matrix keeps its values)
   bool emit_ft = true;               // Jacobian evaluations also write the camera-major copy of F (cx_matrix::d_Ft)
   bool res_valid = false;            // d_res holds the residuals last handed out in host memory
   float last_ms = 0.f;

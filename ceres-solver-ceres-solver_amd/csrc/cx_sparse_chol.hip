@@ -997,6 +997,9 @@ void BuildHostPlan(int C, const int32_t* cell_c1, const int32_t* cell_c2, int64_
           srcs.push_back(Src{l, int32_t(it - row_tiles.begin()), I, qa, qb});
         }
       }
+      // the plan's source and target indices are int32 (and the list itself 20 bytes per update on the host): a structure
+      // with more than 2^30 tile-pair updates is refused like one whose pool does not fit
+      if (srcs.size() > (size_t(1) << 30)) { H->fits = false; return; }
     }
   }
   lpb[size_t(L)] = int32_t(panel_row.size());
@@ -1289,14 +1292,32 @@ int cxsp_build_plan_sharded(cx_matrix* A) {
   cx_context* ctx = A->ctx;
   hipStream_t st = ctx->stream;
   const int C = A->C;
-  CX_TRY(cxs_build_pair_lists(A));
-  // (every rank takes part in the exchange below, whatever its own structure allowed)
-  if (int64_t(C) > 16384) {
+  if (int64_t(C) > 16384) {  // (the same on every rank: all of them return here)
     cx_set_error("SPARSE_SCHUR on a sharded matrix is limited to 16384 cameras (dense exchange of the cell structure)");
     return CX_ERR_UNSUPPORTED;
   }
-  DevBuf<double> present;
-  CX_TRY(present.alloc(size_t(C) * C + 1));
+  // Everything that can fail on ONE rank only (its pair lists, its 8 C^2 bytes of exchange buffer) happens before a
+  // one-number agreement: a rank that failed says so, and then NO rank enters the large exchange -- instead of the
+  // failed rank returning while the others wait in the all-reduce for good.
+  DevBuf<double> present, agree;
+  int local_rc = cxs_build_pair_lists(A);
+  if (local_rc == CX_OK) local_rc = present.alloc(size_t(C) * C + 1);
+  const std::string local_error = local_rc == CX_OK ? std::string() : std::string(cx_last_error());
+  CX_TRY(agree.alloc(1));
+  const double failed_here = local_rc == CX_OK ? 0.0 : 1.0;
+  CX_HIP(hipMemcpyAsync(agree.p, &failed_here, sizeof(double), hipMemcpyHostToDevice, st));
+  CX_TRY(cx_allreduce_device(ctx, agree.p, 1));
+  double failed_anywhere = 0.0;
+  CX_HIP(hipMemcpyAsync(&failed_anywhere, agree.p, sizeof(double), hipMemcpyDeviceToHost, st));
+  CX_HIP(hipStreamSynchronize(st));
+  if (local_rc != CX_OK) {
+    cx_set_error("%s", local_error.c_str());
+    return local_rc;
+  }
+  if (failed_anywhere > 0.0) {
+    cx_set_error("another rank could not build its part of the S structure");
+    return CX_ERR_COMM;
+  }
   CX_HIP(hipMemsetAsync(present.p, 0, (size_t(C) * C + 1) * sizeof(double), st));
   if (A->pairs_state == 1 && A->num_cells > 0)
     hipLaunchKernelGGL(k_sp_mark_cells, dim3(unsigned((A->num_cells + 255) / 256)), dim3(256), 0, st, (const int32_t*)A->d_cell_c1.p,

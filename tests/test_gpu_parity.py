@@ -260,6 +260,18 @@ def test_evaluator(ctx, oracle, C, P, O, seed):
     # residual-only evaluation takes the plain-double path
     cost2, res2, _ = ev.evaluate(state, want_gradient=False, want_jacobian=False)
     assert relerr(res2, res_r) < 1e-11 and abs(cost2 - cost_r) <= 1e-11 * cost_r
+    # a gradient WITHOUT a Jacobian (Evaluate(..., gradient, jacobian = nullptr)) at another state: g = J'r of that state,
+    # while the matrix the caller holds -- column-scaled in the meantime -- keeps its values to the bit
+    # (ProgramEvaluator computes such a gradient from scratch blocks, program_evaluator.h:186-258)
+    Jm.scale_columns(1.0 / (1.0 + np.sqrt(Jm.squared_column_norm())))
+    kept = Jm.get_values()
+    state2 = state + 1e-3 * np.random.default_rng(seed).standard_normal(state.size)
+    cost4, res4, grad4 = ev.evaluate(state2, want_jacobian=False)
+    cost_r2, res_r2, grad_r2, _ = oracle.bal_evaluate(bs, C, P, prob.camera_index, prob.point_index, prob.observations, order, state2)
+    assert relerr(grad4, grad_r2) < 1e-10 and relerr(res4, res_r2) < 1e-11 and abs(cost4 - cost_r2) <= 1e-11 * cost_r2
+    assert np.array_equal(Jm.get_values(), kept)
+    y = np.random.default_rng(1).standard_normal(Jm.num_rows)
+    assert relerr(Jm.left_multiply(y), oracle.left_multiply(bs, kept, y)) < 1e-12      # the camera-major copy is the scaled one still
     ev.close()
 
 
