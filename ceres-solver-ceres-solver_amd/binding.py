@@ -25,7 +25,7 @@ SUCCESS, NO_CONVERGENCE, FAILURE, FATAL_ERROR = 0, 1, 2, 3
 
 # every symbol include/cxschur.h declares (tests check that the library exports them all)
 EXPORTED_SYMBOLS = [
-    "cx_context_create", "cx_schur_pair_lists_host", "cx_context_create_multi", "cx_context_num_shards", "cx_matrix_shard_layout", "cx_context_destroy", "cx_comm_unique_id", "cx_context_set_comm", "cx_context_set_comm_callback", "cx_context_rank",
+    "cx_context_create", "cx_evaluator_set_column_scale", "cx_schur_pair_lists_host", "cx_context_create_multi", "cx_context_num_shards", "cx_matrix_shard_layout", "cx_context_destroy", "cx_comm_unique_id", "cx_context_set_comm", "cx_context_set_comm_callback", "cx_context_rank",
     "cx_context_num_ranks", "cx_allreduce_sum", "cx_malloc", "cx_free", "cx_memcpy_h2d", "cx_memcpy_d2h",
     "cx_memset_zero", "cx_synchronize", "cx_context_stream", "cx_last_error", "cx_device_name",
     "cx_matrix_create", "cx_matrix_destroy", "cx_matrix_num_rows", "cx_matrix_num_cols",
@@ -547,6 +547,11 @@ class Evaluator:
     def set_emit_camera_major(self, on):
         """Whether Jacobian evaluations also write the camera-major copy of F (off when ScaleColumns always follows)."""
         _check(self.lib.cx_evaluator_set_emit_camera_major(self._h, int(bool(on))))
+
+    def set_column_scale(self, scale):
+        """Jacobian evaluations write J diag(scale) (and the camera-major copy) in one pass; None clears it."""
+        scale = _f64(scale)
+        _check(self.lib.cx_evaluator_set_column_scale(self._h, _ptr(scale), _space(scale)))
 
     def set_camera_model(self, model):
         """CAMERA_ANGLE_AXIS (9 parameters) or CAMERA_QUATERNION_MANIFOLD (10 parameters, 9 tangent)."""

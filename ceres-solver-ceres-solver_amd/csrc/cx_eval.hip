@@ -414,7 +414,13 @@ __device__ __forceinline__ int eval_tile(int k, int num_tiles) {
 // 1.9 -> 1.55 ms with the Jacobian, 0.53 -> 0.46 ms for values and residuals.
 // VARIANT (A/B, CX_EVAL_VARIANT): bit 0 dual numbers (Jet<12>) instead of the closed-form Jacobian, bit 2 plain instead of
 // cooperative camera gather, bit 1 probe: every load and store, no arithmetic.
-template <bool WITH_J, int MODEL, int VARIANT = 0>
+// SCALED (round 3): the Jacobi scaling of TrustRegionMinimizer (trust_region_minimizer.cc:263-279) folded in.  The
+// scaling vector is computed once, at iteration 0, and ScaleColumns re-applies it after EVERY evaluation -- a second pass
+// over all of J per LM iteration (416 B per residual block, 3.3 ms on the Final shape).  With col_scale set the kernel
+// multiplies the blocks by the column scales in registers, after the Corrector and before they are stored: the values are
+// bit for bit those of evaluate -> ScaleColumns (one rounding per product either way), and the camera-major copy is
+// written in the same pass.
+template <bool WITH_J, int MODEL, int VARIANT = 0, bool SCALED = false>
 __global__ __launch_bounds__(kBlock, !WITH_J ? 4 : ((MODEL == CX_CAMERA_ANGLE_AXIS && !(VARIANT & 1)) ? 3 : 2)) void k_bal_evaluate(const double* __restrict__ state,
                                                          const double* __restrict__ obs,
                                                          const int32_t* __restrict__ row_pt,
@@ -423,7 +429,8 @@ __global__ __launch_bounds__(kBlock, !WITH_J ? 4 : ((MODEL == CX_CAMERA_ANGLE_AX
                                                          double* __restrict__ E, double* __restrict__ F,
                                                          double* __restrict__ cost_partial, LossParams loss_in,
                                                          double* __restrict__ Ft, const int32_t* __restrict__ cam_pos,
-                                                         int num_tiles) {
+                                                         int num_tiles, const double* __restrict__ col_scale) {
+  static_assert(!SCALED || WITH_J, "column scales apply to the Jacobian");
   constexpr bool kClosed = (VARIANT & 1) == 0;
   constexpr bool kCoop = (VARIANT & 4) == 0 && MODEL == CX_CAMERA_ANGLE_AXIS;  // (64 x 9 doubles per wavefront = the LDS buffer)
   constexpr int kCam = (MODEL == CX_CAMERA_ANGLE_AXIS) ? 9 : 10;
@@ -445,6 +452,7 @@ __global__ __launch_bounds__(kBlock, !WITH_J ? 4 : ((MODEL == CX_CAMERA_ANGLE_AX
     }
   }
   double cam_n[kCam], pt_n[3];
+  int32_t ci_cur = ci, pi_cur = pi;  // SCALED: block ids of the tile being processed (its scales are requested at the loop's top)
   double2 o_n = make_double2(0.0, 0.0);
   {
     gather_by_row<kCam, kCoop>(state + cam_off, ci, tid0 & 63, cam_n);  // (rows past O read block 0: valid memory, never used)
@@ -468,6 +476,7 @@ __global__ __launch_bounds__(kBlock, !WITH_J ? 4 : ((MODEL == CX_CAMERA_ANGLE_AX
 #pragma unroll
   for (int i = 0; i < 3; ++i) asm volatile("" : "+v"(pt_n[i]));
   asm volatile("" : "+v"(o_n.x), "+v"(o_n.y), "+v"(ci), "+v"(pi), "+v"(cp_n));
+  if constexpr (SCALED) asm volatile("" : "+v"(ci_cur), "+v"(pi_cur));
   for (int k = 0; tile >= 0; ++k) {
     // the thread index and the loss parameters pass through an opaque statement per tile.  Left visible as loop
     // invariants, everything derived from them (LDS and global addresses, the index arithmetic of the stores; every
@@ -486,6 +495,21 @@ __global__ __launch_bounds__(kBlock, !WITH_J ? 4 : ((MODEL == CX_CAMERA_ANGLE_AX
     for (int i = 0; i < 3; ++i) pt[i] = pt_n[i];
     const double2 o = o_n;
     const int32_t cp = cp_n;
+    // SCALED: the column scales of THIS tile, requested first of the iteration's loads (they are the oldest when the
+    // multiplications at the end of the arithmetic wait for them, so the younger requests of the next tiles stay in
+    // flight) and not a tile ahead: prefetching them like the parameters costs 24 more live registers and spills.
+    // Lane-per-row loads: a cooperative gather would need the LDS slice that holds the transposed parameters.
+    double sc[SCALED ? 9 : 1], sp[SCALED ? 3 : 1];
+    if constexpr (SCALED) {
+      const double* scp = col_scale + cam_off + 9 * int64_t(ci_cur);  // tangent columns: points first, 9 per camera
+#pragma unroll
+      for (int i = 0; i < 9; ++i) sc[i] = scp[i];
+      const double* spp = col_scale + 3 * int64_t(pi_cur);
+#pragma unroll
+      for (int i = 0; i < 3; ++i) sp[i] = spp[i];
+      ci_cur = ci;  // (ci, pi still name the next tile's blocks here)
+      pi_cur = pi;
+    }
     if constexpr (kCoop) {
       transpose_gathered<kCam>(lds + (tid >> 6) * 64 * kCam, tid & 63, cam);
       __syncthreads();  // the slices are the staging buffer of the stores below
@@ -550,6 +574,12 @@ __global__ __launch_bounds__(kBlock, !WITH_J ? 4 : ((MODEL == CX_CAMERA_ANGLE_AX
         res0 *= residual_scaling;
         res1 *= residual_scaling;
       }
+      if constexpr (SCALED) {  // ScaleColumns (block_sparse_matrix.cc:403-450): every value times the scale of its column
+#pragma unroll
+        for (int i = 0; i < 9; ++i) { jc[i] *= sc[i]; jc[9 + i] *= sc[i]; }
+#pragma unroll
+        for (int i = 0; i < 3; ++i) { jp[i] *= sp[i]; jp[3 + i] *= sp[i]; }
+      }
     }
     // The requests of the next tiles are waited for HERE, before this tile's stores are issued: vmcnt counts loads and
     // stores in one in-order counter, and the number of stores below depends on nvalid, so a wait placed after them
@@ -603,6 +633,11 @@ __global__ __launch_bounds__(256) void k_sum_partials(const double* __restrict__
     *out = v[0];
     __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
+}
+
+__global__ __launch_bounds__(256) void k_divide_by(double* __restrict__ v, const double* __restrict__ d, int64_t n) {
+  const int64_t i = int64_t(blockIdx.x) * 256 + threadIdx.x;
+  if (i < n) v[i] = v[i] / d[i];
 }
 
 // Evaluator::Plus (program_evaluator.h:306-320): out = x + sign * delta on Euclidean blocks ...
@@ -765,6 +800,11 @@ int cx_evaluator_evaluate(cx_evaluator* e, const double* state, double* cost, do
   // the camera-major copy of F is written by the same kernel unless the caller said that a ScaleColumns follows
   // (which rewrites it anyway) -- cx_evaluator_set_emit_camera_major
   static const bool emit_allowed = std::getenv("CX_NO_FT_EMIT") == nullptr;  // A/B switch
+  // a column scale registered with the evaluator (cx_evaluator_set_column_scale) is applied by the kernel itself: no
+  // ScaleColumns follows such an evaluation.  Whether the kernel also writes the camera-major copy stays the caller's
+  // choice (emit_ft): measured on the Final shape, scattering the 144-byte cells from this kernel costs 2.5 ms, while
+  // the gather pass that rebuilds the copy at its first use (k_permute_ft: scattered READS, streamed writes) costs 1.75.
+  const bool scaled_j = with_j && !scratch_j && e->has_col_scale;
   double* ft_out = nullptr;
   if (scratch_j) {
     ft_out = e->d_scratch_Ft.p;
@@ -777,21 +817,25 @@ int cx_evaluator_evaluate(cx_evaluator* e, const double* state, double* cost, do
   static const bool persistent = !(std::getenv("CX_EVAL_PERSISTENT") && std::atoi(std::getenv("CX_EVAL_PERSISTENT")) == 0);
   static const int variant = std::getenv("CX_EVAL_VARIANT") ? std::atoi(std::getenv("CX_EVAL_VARIANT")) : 0;  // A/B switch
   CX_HIP(hipEventRecord(ctx->ev[6], st));
-#define CX_LAUNCH_EVAL_V(WJ, MODEL, V)                                                                                 \
+#define CX_LAUNCH_EVAL_VS(WJ, MODEL, V, S)                                                                             \
   do {                                                                                                                 \
     static int occ = 0;                                                                                                \
     if (occ == 0) {                                                                                                    \
-      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_bal_evaluate<WJ, MODEL, V>, kBlock, 0) != hipSuccess || occ < 1) occ = 1; \
+      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_bal_evaluate<WJ, MODEL, V, S>, kBlock, 0) != hipSuccess || occ < 1) occ = 1; \
     }                                                                                                                  \
     const int resident = std::max(8, (ctx->num_cus * occ) / 8 * 8);                                                    \
     const int launch_grid = persistent ? std::min(xcd_grid(grid), resident) : xcd_grid(grid);                          \
-    hipLaunchKernelGGL((k_bal_evaluate<WJ, MODEL, V>), dim3(launch_grid), dim3(kBlock), 0, st, (const double*)hs.dptr,  \
+    hipLaunchKernelGGL((k_bal_evaluate<WJ, MODEL, V, S>), dim3(launch_grid), dim3(kBlock), 0, st, (const double*)hs.dptr, \
                        (const double*)e->d_obs.p, (const int32_t*)A->d_row_pt.p, (const int32_t*)A->d_row_cam.p, e->O,  \
                        3 * int64_t(e->P), res_dev, E, F, cost ? e->d_partial.p : nullptr, loss, ft_out,                \
-                       (const int32_t*)A->d_cam_pos.p, grid);                                                          \
+                       (const int32_t*)A->d_cam_pos.p, grid, (const double*)(S ? e->d_col_scale.p : nullptr));         \
   } while (0)
+#define CX_LAUNCH_EVAL_V(WJ, MODEL, V) CX_LAUNCH_EVAL_VS(WJ, MODEL, V, false)
 #define CX_LAUNCH_EVAL(WJ, MODEL) CX_LAUNCH_EVAL_V(WJ, MODEL, 0)
-  if (e->camera_model == CX_CAMERA_ANGLE_AXIS) {
+  if (scaled_j) {
+    if (e->camera_model == CX_CAMERA_ANGLE_AXIS) CX_LAUNCH_EVAL_VS(true, CX_CAMERA_ANGLE_AXIS, 0, true);
+    else CX_LAUNCH_EVAL_VS(true, CX_CAMERA_QUATERNION_MANIFOLD, 0, true);
+  } else if (e->camera_model == CX_CAMERA_ANGLE_AXIS) {
     if (with_j && variant == 1) CX_LAUNCH_EVAL_V(true, CX_CAMERA_ANGLE_AXIS, 1);
     else if (with_j && variant == 2) CX_LAUNCH_EVAL_V(true, CX_CAMERA_ANGLE_AXIS, 2);
     else if (with_j && variant == 4) CX_LAUNCH_EVAL_V(true, CX_CAMERA_ANGLE_AXIS, 4);
@@ -804,6 +848,7 @@ int cx_evaluator_evaluate(cx_evaluator* e, const double* state, double* cost, do
   }
 #undef CX_LAUNCH_EVAL
 #undef CX_LAUNCH_EVAL_V
+#undef CX_LAUNCH_EVAL_VS
   if (cost) {
     // layout of d_partial: [grid] per-workgroup costs | total | [256] slice sums | ticket (kept zero between launches)
     const int slices = std::min(256, grid);
@@ -811,8 +856,11 @@ int cx_evaluator_evaluate(cx_evaluator* e, const double* state, double* cost, do
                        e->d_partial.p + grid + 1, reinterpret_cast<unsigned*>(e->d_partial.p + grid + 1 + 256), e->d_partial.p + grid);
   }
   CX_HIP(hipGetLastError());
-  CX_HIP(hipEventRecord(ctx->ev[7], st));
   if (with_j && !scratch_j) { A->ft_valid = ft_out != nullptr; A->f32_valid = false; }
+  // an evaluation that applied the column scale is not followed by a ScaleColumns that would rebuild the camera-major
+  // copy: it is rebuilt here, by the gather pass, inside the evaluation's own time
+  if (scaled_j && !A->ft_valid) CX_TRY(cx_matrix_ensure_ft(A));
+  CX_HIP(hipEventRecord(ctx->ev[7], st));
   if (gradient) {
     // g = J' r (program_evaluator.h:242-258)
     CX_HIP(hipMemsetAsync(hg.dptr, 0, size_t(ncols) * sizeof(double), st));
@@ -832,6 +880,10 @@ int cx_evaluator_evaluate(cx_evaluator* e, const double* state, double* cost, do
       CX_TRY(cxk_left_multiply(A, res_dev, hg.dptr));
     }
     if (ctx->nranks > 1) CX_TRY(cx_allreduce_device(ctx, hg.dptr + 3 * int64_t(e->P), 9 * int64_t(e->C)));
+    // the stored J carries the column scales: (J S)'r = S J'r, and the gradient of the caller's (unscaled) problem is
+    // that divided by the scales (trust_region_minimizer.cc:263-279 evaluates the gradient before it scales J)
+    if (scaled_j)
+      hipLaunchKernelGGL(k_divide_by, dim3(unsigned((ncols + 255) / 256)), dim3(256), 0, st, hg.dptr, (const double*)e->d_col_scale.p, ncols);
   }
   if (cost) {
     if (ctx->nranks > 1) CX_TRY(cx_allreduce_device(ctx, e->d_partial.p + grid, 1));  // shards sum their costs
@@ -854,6 +906,24 @@ int cx_evaluator_set_emit_camera_major(cx_evaluator* e, int32_t on) {
   CX_CHECK_ARG(e != nullptr);
   e->emit_ft = on != 0;
   return e->parts.empty() ? CX_OK : cxm_evaluator_forward_settings(e);
+}
+
+int cx_evaluator_set_column_scale(cx_evaluator* e, const double* scale, int32_t memspace) {
+  CX_CHECK_ARG(e != nullptr);
+  if (!e->parts.empty()) return cxm_evaluator_set_column_scale(e, scale, memspace);
+  if (scale == nullptr) {
+    e->has_col_scale = false;
+    return CX_OK;
+  }
+  cx_context* ctx = e->ctx;
+  CX_HIP(hipSetDevice(ctx->device));
+  const size_t n = size_t(3 * int64_t(e->P) + 9 * int64_t(e->C));
+  CX_TRY(e->d_col_scale.alloc(n));
+  CX_HIP(hipMemcpyAsync(e->d_col_scale.p, scale, n * sizeof(double), memspace == CX_HOST ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice,
+                        ctx->stream));
+  CX_HIP(hipStreamSynchronize(ctx->stream));
+  e->has_col_scale = true;
+  return CX_OK;
 }
 
 int cx_evaluator_set_camera_model(cx_evaluator* e, int32_t camera_model) {

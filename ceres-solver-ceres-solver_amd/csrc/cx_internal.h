@@ -264,6 +264,8 @@ struct cx_evaluator {
   DevBuf<double> d_obs;              // [2O] in row order
   DevBuf<double> d_partial, d_state, d_res;
   DevBuf<double> d_scratch_values, d_scratch_Ft;  // J of a gradient-only evaluation (the matrix keeps its values)
+  DevBuf<double> d_col_scale;        // [3P + 9C] column scales applied by Jacobian evaluations (cx_evaluator_set_column_scale)
+  bool has_col_scale = false;
   bool emit_ft = true;               // Jacobian evaluations also write the camera-major copy of F (cx_matrix::d_Ft)
   bool res_valid = false;            // d_res holds the residuals last handed out in host memory
   float last_ms = 0.f;
@@ -297,6 +299,7 @@ void cxm_evaluator_destroy(cx_evaluator* e);
 int cxm_evaluator_evaluate(cx_evaluator* e, const double* state, double* cost, double* residuals, double* gradient,
                            int32_t evaluate_jacobian, int32_t memspace);
 int cxm_evaluator_plus(cx_evaluator* e, const double* x, const double* delta, double* x_plus_delta, int32_t memspace);
+int cxm_evaluator_set_column_scale(cx_evaluator* e, const double* scale, int32_t memspace);
 int cxm_evaluator_forward_settings(cx_evaluator* e);  // loss, camera model, emit_ft of the front -> its parts
 const double* cxm_evaluator_device_residuals(const cx_evaluator* e);
 double cxm_evaluator_last_kernel_ms(const cx_evaluator* e);

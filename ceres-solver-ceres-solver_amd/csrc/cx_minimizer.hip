@@ -273,7 +273,11 @@ struct Minimizer {
     *ok = false;
     // with Jacobi scaling the ScaleColumns below rewrites F and its camera-major copy: no point in the
     // evaluation kernel writing that copy as well
+    static const bool fuse_scaling = std::getenv("CX_NO_FUSED_SCALING") == nullptr;  // A/B switch
     const bool emit_saved = e->emit_ft;
+    // with Jacobi scaling either a ScaleColumns follows (iteration 0: it writes the camera-major copy) or the evaluator
+    // applies the scale itself and the copy is rebuilt by the gather pass at its first use, which is cheaper than
+    // scattering it from the evaluation kernel (cx_eval.hip)
     if (o.jacobi_scaling) e->emit_ft = false;
     const int eval_rc = cx_evaluator_evaluate(e, x.p, &x_cost, residuals.p, gradient.p, 1, CX_DEVICE);
     e->emit_ft = emit_saved;
@@ -285,11 +289,15 @@ struct Minimizer {
       return CX_OK;
     }
     it.cost = x_cost;
-    if (o.jacobi_scaling) {
-      if (it.iteration == 0) {
-        CX_TRY(SquaredColumnNorm(scaling.p));
-        hipLaunchKernelGGL(k_jacobi_scaling, dim3(grid_for(n)), dim3(kBlock), 0, st, scaling.p, n);
-      }
+    if (o.jacobi_scaling && it.iteration == 0) {
+      // jacobian_scaling_ is computed once (trust_region_minimizer.cc:263-279).  This first evaluation is scaled by a
+      // pass of its own; from then on the evaluator applies the same vector while it writes J (cx_evaluator_set_column_scale),
+      // which is what ScaleColumns after every later evaluation amounts to, without the second pass over J.
+      CX_TRY(SquaredColumnNorm(scaling.p));
+      hipLaunchKernelGGL(k_jacobi_scaling, dim3(grid_for(n)), dim3(kBlock), 0, st, scaling.p, n);
+      CX_TRY(cx_matrix_scale_columns(J, scaling.p, CX_DEVICE));
+      if (fuse_scaling) CX_TRY(cx_evaluator_set_column_scale(e, scaling.p, CX_DEVICE));
+    } else if (o.jacobi_scaling && !fuse_scaling) {
       CX_TRY(cx_matrix_scale_columns(J, scaling.p, CX_DEVICE));
     }
     // |x - Plus(x, -gradient)| in the ambient space; candidate_x is free at this point and serves as scratch
@@ -572,7 +580,11 @@ int cx_minimize(cx_evaluator* e, cx_solver* s, const cx_minimizer_options* optio
   mz.out = summary;
   mz.iterations = iterations;
   mz.capacity = capacity;
-  return mz.Run(state, memspace);
+  (void)cx_evaluator_set_column_scale(e, nullptr, CX_HOST);
+  const int rc = mz.Run(state, memspace);
+  // the Jacobi scaling the loop registered with the evaluator ends with the minimisation
+  (void)cx_evaluator_set_column_scale(e, nullptr, CX_HOST);
+  return rc;
 }
 
 }  // extern "C"

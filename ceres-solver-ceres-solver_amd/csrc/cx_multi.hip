@@ -725,6 +725,20 @@ int cxm_evaluator_forward_settings(cx_evaluator* e) {
   return CX_OK;
 }
 
+int cxm_evaluator_set_column_scale(cx_evaluator* e, const double* scale, int32_t memspace) {
+  if (scale == nullptr) {
+    for (cx_evaluator* p : e->parts) CX_TRY(cx_evaluator_set_column_scale(p, nullptr, CX_HOST));
+    return CX_OK;
+  }
+  CX_TRY(RequireHost(memspace, "cx_evaluator_set_column_scale"));
+  cx_matrix* A = e->J;
+  std::vector<std::vector<double>> parts(e->parts.size());
+  return e->ctx->group->run([&](int i) -> int {
+    GatherCols(A, i, scale, A->num_cols_e, A->num_cols_f, &parts[size_t(i)]);
+    return cx_evaluator_set_column_scale(e->parts[size_t(i)], parts[size_t(i)].data(), CX_HOST);
+  });
+}
+
 static int64_t CameraStateSize(const cx_evaluator* e) { return e->camera_model == CX_CAMERA_ANGLE_AXIS ? 9 : 10; }
 
 int cxm_evaluator_evaluate(cx_evaluator* e, const double* state, double* cost, double* residuals, double* gradient,

@@ -209,6 +209,26 @@ class CxBalEvaluator final : public Evaluator {
     return std::unique_ptr<Evaluator>(e.release());
   }
 
+  // Jacobi scaling inside the evaluation.  TrustRegionMinimizer computes jacobian_scaling_ once and calls
+  // jacobian->ScaleColumns(jacobian_scaling_.data()) after EVERY Evaluate (trust_region_minimizer.cc:263-279): a second
+  // pass over all of J per iteration.  With this switch on, the vector of the first ScaleColumns on this evaluator's
+  // Jacobian is registered with the device evaluator (cx_evaluator_set_column_scale), later evaluations write
+  // J diag(scale) themselves -- bit for bit what Evaluate + ScaleColumns leaves -- and the ScaleColumns that follows is a
+  // no-op.  Opt-in, like residual aliasing: SparseMatrix::ScaleColumns promises nothing about its argument staying the
+  // same array with the same contents, so the caller vouches that it does (TrustRegionMinimizer: it does) and that
+  // exactly one ScaleColumns follows every Jacobian evaluation.  The gradient Evaluate returns stays unscaled.
+  void set_fuse_jacobi_scaling(bool on) {
+    handle_->fuse_scaling = on;
+    if (!on) {
+      cx_evaluator_set_column_scale(handle_->evaluator, nullptr, CX_HOST);
+      handle_->registered_scale_host = nullptr;
+      handle_->values_carry_registered_scale = false;
+    }
+    // a ScaleColumns (iteration 0) or the evaluator's own gather pass produces the camera-major copy: the evaluation
+    // kernel need not scatter it
+    cx_evaluator_set_emit_camera_major(handle_->evaluator, on ? 0 : 1);
+  }
+
   // Robust loss by (type, arguments): what TryCreate recovers from the program's LossFunction objects, or what a caller
   // of Create states directly.
   bool SetLoss(int32_t loss_type, double a, double b) {
@@ -260,7 +280,10 @@ class CxBalEvaluator final : public Evaluator {
     const int rc = cx_evaluator_evaluate(e, state, cost, residuals, gradient, jacobian != nullptr ? 1 : 0, CX_HOST);
     if (suspend_loss) cx_evaluator_set_loss(e, loss_type_, loss_a_, loss_b_);
     if (rc != CX_OK) return false;
-    if (device_jacobian != nullptr) device_jacobian->DeviceValuesChanged();
+    if (device_jacobian != nullptr) {
+      device_jacobian->DeviceValuesChanged();
+      handle_->values_carry_registered_scale = handle_->fuse_scaling && handle_->registered_scale_host != nullptr;
+    }
     if (residuals != nullptr) handle_->last_residuals_host = residuals;
     return true;
   }

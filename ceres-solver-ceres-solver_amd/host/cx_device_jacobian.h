@@ -47,6 +47,12 @@ struct CxEvaluatorHandle {
   cx_evaluator* evaluator = nullptr;
   // the host array the evaluator last wrote residuals to; their device copy is cx_evaluator_device_residuals()
   const double* last_residuals_host = nullptr;
+  // Jacobi scaling folded into the evaluation (CxBalEvaluator::set_fuse_jacobi_scaling): the vector of the first
+  // ScaleColumns is registered with the device evaluator, which from then on writes J diag(scale) itself; the
+  // ScaleColumns call that follows such an evaluation finds its work done
+  bool fuse_scaling = false;
+  const double* registered_scale_host = nullptr;
+  bool values_carry_registered_scale = false;
   ~CxEvaluatorHandle() {
     if (evaluator) cx_evaluator_destroy(evaluator);
   }
@@ -90,6 +96,19 @@ class CxDeviceJacobian final : public SparseMatrix {
   }
   void ScaleColumns(const double* scale) final {
     Flush();
+    if (handle_->fuse_scaling && handle_->evaluator != nullptr) {
+      if (handle_->registered_scale_host == scale && handle_->values_carry_registered_scale) {
+        handle_->values_carry_registered_scale = false;  // the evaluation already wrote J diag(scale): this call's work is done
+        return;
+      }
+      if (handle_->registered_scale_host == nullptr) {  // the first call (iteration 0): scale now, and tell the evaluator
+        host_valid_ = false;
+        CX_ADAPTER_CHECK(cx_matrix_scale_columns(matrix_, scale, CX_HOST));
+        CX_ADAPTER_CHECK(cx_evaluator_set_column_scale(handle_->evaluator, scale, CX_HOST));
+        handle_->registered_scale_host = scale;
+        return;
+      }
+    }
     host_valid_ = false;
     CX_ADAPTER_CHECK(cx_matrix_scale_columns(matrix_, scale, CX_HOST));
   }

@@ -651,6 +651,19 @@ static void TestEvaluatorToSolverThroughTheInterfaces() {
     EXPECT(t.costs == device_trace.costs && t.linear_iterations == device_trace.linear_iterations, "aliased residuals change nothing");
   }
 
+  // (ii b) Jacobi scaling folded into the evaluation (set_fuse_jacobi_scaling): J carries the same bits as after
+  // Evaluate + ScaleColumns, so the loop walks the same costs to the last bit -- with one pass over J less per iteration
+  {
+    std::unique_ptr<Evaluator> evaluator3 = CxBalEvaluator::TryCreate(evaluator_options, &bal.program, &why);
+    static_cast<CxBalEvaluator*>(evaluator3.get())->set_fuse_jacobi_scaling(true);
+    std::unique_ptr<SparseMatrix> jacobian3 = evaluator3->CreateJacobian();
+    CxLinearSolver solver3(solver_options);
+    LmTrace t = RunTrustRegionLoop(evaluator3.get(), jacobian3.get(), &solver3, x0, kIterations, kEta);
+    EXPECT(t.ok && t.costs == device_trace.costs && t.linear_iterations == device_trace.linear_iterations,
+           "fused Jacobi scaling must not change a bit of the loop (%zu vs %zu accepted)", t.costs.size(), device_trace.costs.size());
+    EXPECT(static_cast<CxDeviceJacobian*>(jacobian3.get())->num_downloads() == 0, "fused scaling keeps J in HBM");
+  }
+
   // (iii) the reference-style path: host BlockSparseMatrix, host products, values uploaded on every Solve
   HostJacobianEvaluator host_evaluator(evaluator.get());
   std::unique_ptr<SparseMatrix> host_jacobian = host_evaluator.CreateJacobian();

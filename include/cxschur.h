@@ -393,6 +393,14 @@ double cx_evaluator_last_kernel_ms(const cx_evaluator* e);
  * with jacobi_scaling, trust_region_minimizer.cc:263-279 -- turns that off (on = 0) because cx_matrix_scale_columns
  * rewrites the copy anyway.  Either way the copy is rebuilt lazily if it is ever found stale. */
 int cx_evaluator_set_emit_camera_major(cx_evaluator* e, int32_t on);
+/* Column scaling inside the evaluation (round 3).  TrustRegionMinimizer computes its Jacobi scaling once, at iteration 0,
+ * and calls jacobian->ScaleColumns(jacobian_scaling_) after EVERY evaluation (trust_region_minimizer.cc:263-279): a second
+ * pass over all of J per iteration.  With a scale vector registered here ([num_effective_parameters], copied; NULL clears
+ * it) every Jacobian evaluation writes J diag(scale) directly -- the same bits as Evaluate followed by ScaleColumns; the
+ * gradient it returns is still J'r of the UNscaled problem, as the reference evaluates it before scaling.  A gradient-only
+ * evaluation (no Jacobian) ignores the scale.  (Whether the kernel also writes the camera-major copy is
+ * cx_evaluator_set_emit_camera_major's business; without it the copy is rebuilt by a gather pass at its first use.) */
+int cx_evaluator_set_column_scale(cx_evaluator* e, const double* scale, int32_t memspace);
 /* Device copy of the residuals the last cx_evaluator_evaluate wrote to HOST memory (NULL when it wrote none, or
  * wrote them to a caller's device buffer): the same vector can go into cx_solver_solve as b with
  * cx_per_solve_options.b_on_device = 1, without a second trip across PCIe.  Valid until the next evaluate that

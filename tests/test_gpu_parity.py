@@ -275,6 +275,45 @@ def test_evaluator(ctx, oracle, C, P, O, seed):
     ev.close()
 
 
+@pytest.mark.parametrize("loss", [None, (cx.binding.LOSS_HUBER, 1.0, 0.0)])
+@pytest.mark.parametrize("quaternion", [False, True])
+def test_evaluator_applies_a_registered_column_scale(ctx, oracle, loss, quaternion):
+    """cx_evaluator_set_column_scale: TrustRegionMinimizer re-applies ONE scaling vector after every
+    evaluation (trust_region_minimizer.cc:263-279); the evaluator that knows it writes J diag(s) in the evaluation kernel.
+    Bit-identical to evaluate -> ScaleColumns (values and the camera-major copy behind the products), residuals and cost
+    untouched, gradient still J'r of the unscaled problem; a gradient-only evaluation ignores the scale; clearing restores
+    the plain evaluation.  More tiles than resident workgroups, so the persistent loop takes several rounds."""
+    C, P, O = 40, 70000, 300000
+    prob = cx.bal.make_bal_like(C, P, O, 21)
+    ev = cx.Evaluator(ctx, prob)
+    state = prob.state()
+    if quaternion:
+        ev.set_camera_model(cx.binding.CAMERA_QUATERNION_MANIFOLD)
+        state = cx.bal.state_quaternion(prob)
+    if loss:
+        ev.set_loss(*loss)
+    cost0, res0, grad0 = ev.evaluate(state)
+    J = ev.jacobian()
+    scale = 1.0 / (1.0 + np.sqrt(J.squared_column_norm()))
+    J.scale_columns(scale)
+    want = J.get_values()
+    y = np.random.default_rng(2).standard_normal(J.num_rows)
+    want_jty, want_sq = J.left_multiply(y), J.squared_column_norm()
+    ev.set_column_scale(scale)
+    cost1, res1, grad1 = ev.evaluate(state)
+    assert np.array_equal(J.get_values(), want)
+    assert np.array_equal(J.left_multiply(y), want_jty) and np.array_equal(J.squared_column_norm(), want_sq)
+    assert cost1 == cost0 and np.array_equal(res1, res0)
+    assert relerr(grad1, grad0) < 1e-14
+    _, _, grad2 = ev.evaluate(state, want_jacobian=False)          # gradient-only: scratch J, unscaled
+    assert relerr(grad2, grad0) < 1e-14 and np.array_equal(J.get_values(), want)
+    ev.set_column_scale(None)
+    ev.evaluate(state)
+    J.scale_columns(scale)
+    assert np.array_equal(J.get_values(), want)
+    ev.close()
+
+
 @pytest.mark.parametrize("env", [{}, {"CX_EVAL_VARIANT": "1"}, {"CX_EVAL_VARIANT": "4"}, {"CX_EVAL_PERSISTENT": "0"}],
                          ids=["default", "dual-numbers", "plain-gather", "one-tile-per-workgroup"])
 def test_evaluator_variants(env):
