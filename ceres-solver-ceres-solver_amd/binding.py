@@ -25,7 +25,7 @@ SUCCESS, NO_CONVERGENCE, FAILURE, FATAL_ERROR = 0, 1, 2, 3
 
 # every symbol include/cxschur.h declares (tests check that the library exports them all)
 EXPORTED_SYMBOLS = [
-    "cx_context_create", "cx_evaluator_set_column_scale", "cx_schur_pair_lists_host", "cx_context_create_multi", "cx_context_num_shards", "cx_matrix_shard_layout", "cx_context_destroy", "cx_comm_unique_id", "cx_context_set_comm", "cx_context_set_comm_callback", "cx_context_rank",
+    "cx_context_create", "cx_matrix_static_path", "cx_evaluator_set_column_scale", "cx_schur_pair_lists_host", "cx_context_create_multi", "cx_context_num_shards", "cx_matrix_shard_layout", "cx_context_destroy", "cx_comm_unique_id", "cx_context_set_comm", "cx_context_set_comm_callback", "cx_context_rank",
     "cx_context_num_ranks", "cx_allreduce_sum", "cx_malloc", "cx_free", "cx_memcpy_h2d", "cx_memcpy_d2h",
     "cx_memset_zero", "cx_synchronize", "cx_context_stream", "cx_last_error", "cx_device_name",
     "cx_matrix_create", "cx_matrix_destroy", "cx_matrix_num_rows", "cx_matrix_num_cols",
@@ -166,7 +166,7 @@ def load_library():
     lib.cx_evaluator_jacobian.restype = ctypes.c_void_p
     lib.cx_context_stream.restype = ctypes.c_void_p
     for name in ("cx_matrix_destroy", "cx_solver_destroy", "cx_evaluator_destroy", "cx_context_destroy",
-                 "cx_matrix_num_rows", "cx_matrix_num_cols", "cx_matrix_num_nonzeros", "cx_matrix_is_static_239",
+                 "cx_matrix_num_rows", "cx_matrix_num_cols", "cx_matrix_num_nonzeros", "cx_matrix_is_static_239", "cx_matrix_static_path",
                  "cx_matrix_device_values", "cx_matrix_last_kernel_ms", "cx_evaluator_jacobian",
                  "cx_evaluator_last_kernel_ms", "cx_evaluator_device_residuals", "cx_context_stream", "cx_context_rank",
                  "cx_context_num_ranks", "cx_context_num_shards"):
@@ -354,6 +354,7 @@ class Matrix:
     num_cols = property(lambda s: s.lib.cx_matrix_num_cols(s._h))
     num_nonzeros = property(lambda s: s.lib.cx_matrix_num_nonzeros(s._h))
     is_static_239 = property(lambda s: bool(s.lib.cx_matrix_is_static_239(s._h)))
+    static_path = property(lambda s: int(s.lib.cx_matrix_static_path(s._h)))   # 0 dynamic-size, 1 native <2,3,9>, 2 embedded
     last_kernel_ms = property(lambda s: s.lib.cx_matrix_last_kernel_ms(s._h))
 
     def shard_layout(self):

@@ -8,6 +8,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
+#include <functional>
 #include <string>
 #include <memory>
 #include <vector>
@@ -119,6 +120,23 @@ struct cx_sp_plan {
   DevBuf<double> d_union_values;
 };
 
+// -------------------------------------------------- embedding into the static layout (cx_embed.hip)
+// A matrix whose structure is <2, e <= 3, f <= 9> (+ trailing rows with one f cell) keeps, beside its own values, an
+// inner matrix in the <2,3,9> layout that the static kernels run on.
+struct cx_matrix;
+struct cx_embed {
+  cx_matrix* inner = nullptr;
+  int e = 3, f = 9;
+  int32_t P = 0, C = 0;   // e-blocks and f-blocks of the caller's matrix
+  int32_t P_in = 0;       // points of the inner matrix: P + one dummy point per two-row slice of a trailing row
+  int64_t O_main = 0;     // e-rows
+  int64_t O_in = 0;       // row blocks of the inner matrix
+  bool dirty = true;      // the caller's values changed since the inner values were written
+  DevBuf<int32_t> d_epos, d_fpos, d_valid;  // [O_in] where the inner row's E and F cell come from (E: -1 = zero), rows it has
+  DevBuf<int32_t> d_tail_src;               // [2 (O_in - O_main)] caller's scalar row of every trailing inner row, -1 = padding
+  DevBuf<double> d_cols, d_rows, d_b, d_D, d_x;  // vectors in the inner spaces
+};
+
 // ----------------------------------------------------------------- matrix
 // Tile of the point-major ("chunk") kernels: whole chunks, at most kTileRows rows,
 // unless a single chunk is larger than that (then the tile is that one chunk).
@@ -204,6 +222,11 @@ struct cx_matrix {
   float last_ms = 0.f;
   // when set, the product kernels return at once if *stop != 0 (CG termination flag)
   const int* stop = nullptr;
+  // the visibility based preconditioners count points and rows up to these (-1: all): an inner matrix of an embedding
+  // carries dummy points for its trailing rows, which see no point in the reference (visibility.cc:50-85)
+  int32_t P_vis = -1;
+  int64_t O_vis = -1;
+  cx_embed* embed = nullptr;  // dynamic-size matrix with a static <2,3,9> image (cx_embed.hip)
 
   // ---- front of a matrix on a multi-shard context (cx_multi.hip): the e-blocks (points) are cut into contiguous ranges,
   // parts[i] lives on shard i and holds the rows of its range with columns [its e-blocks | all f-blocks]; the front keeps
@@ -277,6 +300,14 @@ struct cx_evaluator {
 // out = Plus(x, sign * delta) on device pointers (Evaluator::Plus), enqueued on the context stream
 int cxe_plus(cx_evaluator* e, const double* x, const double* delta, double sign, double* out);
 
+
+// ------------------------------------------- embedding (cx_embed.hip)
+int cxe_try_embed(cx_matrix* A);
+void cxe_destroy(cx_matrix* A);
+int cxe_sync(cx_matrix* A);
+int cxe_matrix_op(cx_matrix* A, int op, const double* x, double* y);  // 0: y += A x, 1: y += A'x, 2: y = diag(A'A)
+int cxe_solve(cx_matrix* A, const double* b, const double* D, double* x,
+              const std::function<int(cx_matrix*, const double*, const double*, double*)>& solve);
 
 // ------------------------------------------- multi-shard fronts (cx_multi.hip)
 // The public entry points hand a front object (ctx->shards / A->parts / S->parts / e->parts non-empty) to these.

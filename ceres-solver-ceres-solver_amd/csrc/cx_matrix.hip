@@ -771,8 +771,10 @@ int cx_matrix_create(cx_context* ctx, const cx_block_structure* bs, int32_t neli
     if (rc == CX_OK) rc = A->d_cols.upload(A->cols, st);
     if (rc == CX_OK) rc = A->d_rcb.upload(A->rcb, st);
     if (rc == CX_OK) rc = A->d_cells.upload(A->cells, st);
+    if (rc == CX_OK) rc = cxe_try_embed(A);  // <2, e <= 3, f <= 9> structures get a static image (cx_embed.hip)
   }
   if (rc != CX_OK) {
+    cxe_destroy(A);
     delete A;
     return rc;
   }
@@ -785,6 +787,7 @@ void cx_matrix_destroy(cx_matrix* A) {
   if (!A->parts.empty() || cxm_is_front(A->ctx)) return cxm_matrix_destroy(A);
   (void)hipSetDevice(A->ctx->device);
   (void)hipStreamSynchronize(A->ctx->stream);
+  cxe_destroy(A);
   delete A;
 }
 
@@ -792,6 +795,7 @@ int64_t cx_matrix_num_rows(const cx_matrix* A) { return A ? A->num_rows : 0; }
 int64_t cx_matrix_num_cols(const cx_matrix* A) { return A ? A->num_cols : 0; }
 int64_t cx_matrix_num_nonzeros(const cx_matrix* A) { return A ? A->nnz : 0; }
 int cx_matrix_is_static_239(const cx_matrix* A) { return A && A->is239 ? 1 : 0; }
+int cx_matrix_static_path(const cx_matrix* A) { return !A ? 0 : (A->is239 ? 1 : (A->embed ? 2 : 0)); }
 double* cx_matrix_device_values(cx_matrix* A) { return A ? A->d_values.p : nullptr; }  // NULL for a multi-shard front
 
 int cx_matrix_values_changed(cx_matrix* A) {
@@ -799,6 +803,7 @@ int cx_matrix_values_changed(cx_matrix* A) {
   if (!A->parts.empty()) return cxm_matrix_values_changed(A);
   A->ft_valid = false;
   A->f32_valid = false;
+  if (A->embed) A->embed->dirty = true;
   return CX_OK;
 }
 
@@ -811,6 +816,7 @@ int cx_matrix_set_values(cx_matrix* A, const double* src, int32_t memspace) {
   CX_HIP(hipStreamSynchronize(A->ctx->stream));
   A->ft_valid = false;
   A->f32_valid = false;
+  if (A->embed) A->embed->dirty = true;
   return CX_OK;
 }
 
@@ -828,6 +834,7 @@ int cx_matrix_set_zero(cx_matrix* A) {
   if (A->nnz) CX_HIP(hipMemsetAsync(A->d_values.p, 0, size_t(A->nnz) * sizeof(double), A->ctx->stream));
   A->ft_valid = false;
   A->f32_valid = false;
+  if (A->embed) A->embed->dirty = true;
   return CX_OK;
 }
 
@@ -837,7 +844,7 @@ int cx_matrix_right_multiply(cx_matrix* A, const double* x, double* y, int32_t m
   HostOrDevice hx(A->ctx), hy(A->ctx);
   CX_TRY(hx.in(x, size_t(A->num_cols), memspace));
   CX_TRY(hy.inout(y, size_t(A->num_rows), memspace, true));
-  CX_TRY(Timed(A, [&] { return cxk_right_multiply(A, hx.dptr, hy.dptr); }));
+  CX_TRY(Timed(A, [&] { return A->embed ? cxe_matrix_op(A, 0, hx.dptr, hy.dptr) : cxk_right_multiply(A, hx.dptr, hy.dptr); }));
   return hy.out();
 }
 
@@ -848,7 +855,7 @@ int cx_matrix_left_multiply(cx_matrix* A, const double* x, double* y, int32_t me
   CX_TRY(hx.in(x, size_t(A->num_rows), memspace));
   CX_TRY(hy.inout(y, size_t(A->num_cols), memspace, true));
   CX_TRY(cx_matrix_ensure_ft(A));  // the camera-major copy is part of the matrix, not of the product
-  CX_TRY(Timed(A, [&] { return cxk_left_multiply(A, hx.dptr, hy.dptr); }));
+  CX_TRY(Timed(A, [&] { return A->embed ? cxe_matrix_op(A, 1, hx.dptr, hy.dptr) : cxk_left_multiply(A, hx.dptr, hy.dptr); }));
   return hy.out();
 }
 
@@ -858,7 +865,7 @@ int cx_matrix_squared_column_norm(cx_matrix* A, double* x, int32_t memspace) {
   HostOrDevice hx(A->ctx);
   CX_TRY(hx.inout(x, size_t(A->num_cols), memspace, false));
   CX_TRY(cx_matrix_ensure_ft(A));
-  CX_TRY(Timed(A, [&] { return cxk_squared_column_norm(A, hx.dptr); }));
+  CX_TRY(Timed(A, [&] { return A->embed ? cxe_matrix_op(A, 2, nullptr, hx.dptr) : cxk_squared_column_norm(A, hx.dptr); }));
   return hx.out();
 }
 
@@ -867,7 +874,8 @@ int cx_matrix_scale_columns(cx_matrix* A, const double* scale, int32_t memspace)
   if (!A->parts.empty()) return cxm_matrix_op(A, 3, scale, nullptr, memspace);
   HostOrDevice hs(A->ctx);
   CX_TRY(hs.in(scale, size_t(A->num_cols), memspace));
-  CX_TRY(Timed(A, [&] { return cxk_scale_columns(A, hs.dptr); }));
+  CX_TRY(Timed(A, [&] { return cxk_scale_columns(A, hs.dptr); }));  // (an embedded matrix scales the caller's values: dynamic-size kernel)
+  if (A->embed) A->embed->dirty = true;
   return CX_OK;
 }
 

@@ -1450,16 +1450,20 @@ int cx_solver_solve(cx_solver* S, cx_matrix* A, const double* b, const cx_per_so
   // unwritten is zero, in the caller's host buffer as well (the staging copy is not initialised otherwise)
   CX_HIP(hipMemsetAsync(hx.dptr, 0, size_t(A->num_cols) * sizeof(double), ctx->stream));
   int rc;
-  if (A->is239) {
+  // the static solvers, on a <2,3,9> matrix: the caller's, or the inner matrix of an embedding (cx_embed.hip)
+  auto solve_static = [&](cx_matrix* M, const double* bd, const double* Dd, double* xd) -> int {
     switch (o.type) {
       case CX_ITERATIVE_SCHUR:
-        rc = o.use_explicit_schur_complement
-                 ? SolveExplicitSchur239(S, A, hb.dptr, hD.dptr, ps->r_tolerance, ps->q_tolerance, hx.dptr, summary)
-                 : SolveIterativeSchur239(S, A, hb.dptr, hD.dptr, ps->r_tolerance, ps->q_tolerance, hx.dptr, summary);
-        break;
-      case CX_CGNR: rc = SolveCgnr239(S, A, hb.dptr, hD.dptr, ps->r_tolerance, ps->q_tolerance, hx.dptr, summary); break;
-      default: rc = SolveDenseSchur239(S, A, hb.dptr, hD.dptr, hx.dptr, summary); break;
+        return o.use_explicit_schur_complement ? SolveExplicitSchur239(S, M, bd, Dd, ps->r_tolerance, ps->q_tolerance, xd, summary)
+                                               : SolveIterativeSchur239(S, M, bd, Dd, ps->r_tolerance, ps->q_tolerance, xd, summary);
+      case CX_CGNR: return SolveCgnr239(S, M, bd, Dd, ps->r_tolerance, ps->q_tolerance, xd, summary);
+      default: return SolveDenseSchur239(S, M, bd, Dd, xd, summary);
     }
+  };
+  if (A->is239) {
+    rc = solve_static(A, hb.dptr, hD.dptr, hx.dptr);
+  } else if (A->embed && ctx->nranks == 1) {
+    rc = cxe_solve(A, hb.dptr, hD.dptr, hx.dptr, solve_static);
   } else if (o.type == CX_ITERATIVE_SCHUR && o.use_explicit_schur_complement) {
     cx_set_error("use_explicit_schur_complement needs the static <2,3,9> layout");
     rc = CX_ERR_UNSUPPORTED;
@@ -1490,6 +1494,7 @@ int cx_solver_solve(cx_solver* S, cx_matrix* A, const double* b, const cx_per_so
 // ---- Schur pieces on their own (parity tests)
 int cx_schur_sparse_structure(cx_matrix* A, int64_t* num_cells, int32_t* cell_row, int32_t* cell_col, int64_t capacity) {
   CX_CHECK_ARG(A && num_cells && capacity >= 0);
+  if (A->embed) A = A->embed->inner;  // the f-blocks of an embedding keep their numbers
   if (!A->is239) {
     cx_set_error("cx_schur_sparse_structure needs the static <2,3,9> layout");
     return CX_ERR_UNSUPPORTED;

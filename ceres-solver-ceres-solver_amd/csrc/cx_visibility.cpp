@@ -48,7 +48,9 @@ struct Graph {
 
 // ComputeVisibility: points of every camera and cameras of every point, both ascending and distinct
 // (cells: two per row block, point cell then camera cell, rows sorted by point -- the static <2,3,9> layout)
-void Visibility(const cx_cell* cells, int C, int P, int64_t O, Csr* cam_pts, Csr* pt_cams) {
+void Visibility(const cx_cell* cells, int C, int P, int64_t O, Csr* cam_pts, Csr* pt_cams, int first_camera_block = -1) {
+  // (first_camera_block: column block of camera 0 when it is not P -- an embedding's dummy points sit between)
+  if (first_camera_block < 0) first_camera_block = P;
   pt_cams->start.assign(size_t(P) + 1, 0);
   pt_cams->idx.clear();
   pt_cams->idx.reserve(size_t(O));
@@ -57,7 +59,7 @@ void Visibility(const cx_cell* cells, int C, int P, int64_t O, Csr* cam_pts, Csr
   for (int p = 0; p < P; ++p) {
     tmp.clear();
     while (r < O && cells[size_t(2 * r)].block_id == p) {
-      tmp.push_back(cells[size_t(2 * r + 1)].block_id - P);
+      tmp.push_back(cells[size_t(2 * r + 1)].block_id - first_camera_block);
       ++r;
     }
     std::sort(tmp.begin(), tmp.end());
@@ -322,12 +324,12 @@ int ClusterForest(cx_context* ctx, int K, const std::vector<int32_t>& membership
 // Clusters and cluster pairs (everything VisibilityBasedPreconditioner derives from the structure alone).  ctx is the
 // context of a sharded matrix (the counts are then summed over its ranks) or null: no device is touched without it.
 int ComputeClusters(const cx_cell* cells, int C, int P, int64_t O, cx_context* ctx, int preconditioner_type, int clustering_type,
-                    cx_vis_plan* plan, std::vector<std::array<int32_t, 2>>* partner_out) {
+                    cx_vis_plan* plan, std::vector<std::array<int32_t, 2>>* partner_out, int first_camera_block = -1) {
   plan->preconditioner_type = preconditioner_type;
   plan->clustering_type = clustering_type;
   const bool sharded = ctx != nullptr && ctx->nranks > 1;
   Csr cam_pts, pt_cams;
-  Visibility(cells, C, P, O, &cam_pts, &pt_cams);
+  Visibility(cells, C, P, O, &cam_pts, &pt_cams, first_camera_block);
   PairCounts upper = SharedPointCounts(C, cam_pts, pt_cams);
   std::vector<size_t> sizes(static_cast<size_t>(C));
   for (int c = 0; c < C; ++c) sizes[size_t(c)] = size_t(cam_pts.start[size_t(c) + 1] - cam_pts.start[size_t(c)]);
@@ -391,7 +393,9 @@ int ComputeClusters(const cx_cell* cells, int C, int P, int64_t O, cx_context* c
 int BuildPlan(cx_matrix* A, int preconditioner_type, int clustering_type, cx_vis_plan* plan) {
   const int C = A->C;
   std::vector<std::array<int32_t, 2>> partner;
-  CX_TRY(ComputeClusters(A->cells.data(), C, A->P, A->O, A->ctx, preconditioner_type, clustering_type, plan, &partner));
+  // (an embedding's inner matrix: real points and e-rows only, cx_matrix::P_vis)
+  CX_TRY(ComputeClusters(A->cells.data(), C, A->P_vis >= 0 ? A->P_vis : A->P, A->O_vis >= 0 ? A->O_vis : A->O, A->ctx, preconditioner_type,
+                         clustering_type, plan, &partner, A->P));
   const int K = plan->num_clusters;
   // block pairs: the S cells (all diagonal cells + co-visible pairs, lexicographic: cxs_build_pair_lists) whose
   // cluster pair is in the preconditioner
@@ -533,6 +537,7 @@ int BuildPlan(cx_matrix* A, int preconditioner_type, int clustering_type, cx_vis
 }  // namespace
 
 int cxv_get_plan(cx_matrix* A, int preconditioner_type, int clustering_type, cx_vis_plan** out) {
+  if (A->embed) A = A->embed->inner;
   if (!A->is239) {
     cx_set_error("CLUSTER_JACOBI / CLUSTER_TRIDIAGONAL are available for the static <2,3,9> layout only");
     return CX_ERR_UNSUPPORTED;

@@ -258,6 +258,12 @@ int64_t cx_matrix_num_cols(const cx_matrix* A);
 int64_t cx_matrix_num_nonzeros(const cx_matrix* A);
 /* 1 when the <2,3,9> bundle-adjustment kernels are in use (detect_structure.cc:39-120) */
 int cx_matrix_is_static_239(const cx_matrix* A);
+/* Which kernels serve this matrix: 0 the dynamic-size path (Eigen::Dynamic instantiations of the reference,
+ * schur_eliminator.cc:140-142), 1 the static <2,3,9> path on the caller's own layout, 2 the static path through an
+ * embedded <2,3,9> image -- structures with 2-row e-rows, e-blocks of one size e <= 3 and f-blocks of one size f <= 9
+ * (<2,3,6>, <2,3,3>, <2,3,4>, <2,2,2>, <2,2,3>, <2,2,4>, or <2,3,9> in another cell layout), optionally followed by rows
+ * that hold a single f cell (NoEBlockRowsUpdate, schur_eliminator_impl.h:567-659). */
+int cx_matrix_static_path(const cx_matrix* A);
 /* BlockSparseMatrix::mutable_values(): device pointer to num_nonzeros doubles */
 double* cx_matrix_device_values(cx_matrix* A);
 /* copy values in (memspace says where src lives) */
