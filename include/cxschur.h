@@ -123,7 +123,9 @@ typedef struct {
   int32_t residual_reset_period;      /* default 10  */
   int32_t num_eliminate_blocks;       /* == elimination_groups[0]; 0 for CGNR */
   int32_t use_mixed_precision_solves; /* CGNR / ITERATIVE_SCHUR: CG operator streams fp32 copies of the J values (fp64
-                                       * accumulation and vectors); DENSE_SCHUR / SPARSE_SCHUR: see DESIGN.md */
+                                       * accumulation and vectors).  DENSE_SCHUR / SPARSE_SCHUR: accepted; the device
+                                       * factorisation stays in fp64 (at least the accuracy of the reference's fp32 factor +
+                                       * refinement, dense_cholesky.cc:582-645), and the summary message says so */
   int32_t max_num_refinement_iterations;
   int32_t max_num_spse_iterations;    /* default 5 */
   int32_t use_spse_initialization;    /* default 0 */
