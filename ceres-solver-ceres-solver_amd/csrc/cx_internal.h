@@ -204,6 +204,7 @@ struct cx_matrix {
   DevBuf<int32_t> d_pair_rows;           // [2 * num_pairs] (row of camera c1, row of camera c2)
   DevBuf<int64_t> d_item_begin;          // [num_items + 1] work items: runs of <= kPairItem pairs of one cell
   DevBuf<int32_t> d_cell_item_start;     // [num_cells + 1] items of each cell
+  DevBuf<int32_t> d_item_order;          // [num_items] launch order of the items (a permutation, cx_schur.hip)
   DevBuf<double> d_item_partial;         // [num_items][81]
   DevBuf<double> d_S;                    // [num_cells][81] sparse S values (without D_f^2), ExplicitSchur
   int64_t num_items = 0;

@@ -843,7 +843,7 @@ struct PairListsHost {
   int64_t total = 0;            // pairs
   bool too_many = false;        // more than kMaxPairs (or CX_ELIM_ATOMICS=1): the atomics path is used instead
   std::unique_ptr<int32_t[]> pairs;  // [2 * total] (row of camera c1, row of camera c2) per pair, cells in order, chunk order inside
-  std::vector<int32_t> cell_c1, cell_c2, cell_item_start, row_cells, col_count, col_cells;
+  std::vector<int32_t> cell_c1, cell_c2, cell_item_start, row_cells, col_count, col_cells, item_order;
   std::vector<int64_t> item_begin;
   int64_t num_items = 0, num_cells = 0;
 };
@@ -1017,6 +1017,24 @@ static int BuildPairListsHost(const cx_cell* cells, int32_t P, int32_t C, int64_
   lap("cell and item index");
   out->pairs = std::move(pairs);
   out->num_cells = ncell;
+  // Launch order of the items (a permutation; sums do not depend on it): kItemRowGroup consecutive block rows of S at a
+  // time, inside a group by block column -- the cells (c1 .. c1 + g - 1, c2) follow each other, so the right operands (rows
+  // of camera c2, largely the same points for neighbouring c1) are fetched once per group instead of once per block row,
+  // while the left operands of the group's cameras still fit an XCD's L2.  CX_PAIR_ROW_GROUP=1 restores cell order.
+  {
+    static const int group = std::max(1, std::getenv("CX_PAIR_ROW_GROUP") ? std::atoi(std::getenv("CX_PAIR_ROW_GROUP")) : 4);
+    struct Key { int32_t g, c2, c1, item; };
+    std::vector<Key> keys(static_cast<size_t>(out->num_items));
+    for (int64_t cell = 0; cell < ncell; ++cell)
+      for (int32_t it = out->cell_item_start[size_t(cell)]; it < out->cell_item_start[size_t(cell) + 1]; ++it)
+        keys[size_t(it)] = Key{out->cell_c1[size_t(cell)] / group, out->cell_c2[size_t(cell)], out->cell_c1[size_t(cell)], it};
+    if (group > 1)
+      std::sort(keys.begin(), keys.end(), [](const Key& a, const Key& b) {
+        return a.g != b.g ? a.g < b.g : (a.c2 != b.c2 ? a.c2 < b.c2 : (a.c1 != b.c1 ? a.c1 < b.c1 : a.item < b.item));
+      });
+    out->item_order.resize(keys.size());
+    for (size_t i = 0; i < keys.size(); ++i) out->item_order[i] = keys[i].item;
+  }
   return CX_OK;
 }
 
@@ -1043,6 +1061,7 @@ int cxs_build_pair_lists(cx_matrix* A) {
   CX_TRY(A->d_col_cell_start.upload(h.col_count, st));
   CX_TRY(A->d_col_cells.upload(h.col_cells, st));
   CX_TRY(A->d_item_partial.alloc(size_t(std::max<int64_t>(A->num_items, 1)) * 81));
+  CX_TRY(A->d_item_order.upload(h.item_order, st));
   A->num_pairs = total;
   A->num_cells = h.num_cells;
   A->pairs_state = 1;
@@ -1295,6 +1314,163 @@ __global__ __launch_bounds__(kBlock) void k_pair_items_staged(const int32_t* __r
 #undef CX_PAIR_FETCH
 }
 
+// ---- Round 3: ONE operand table instead of two.  B_i'(E'E + D^2)^-1 B_j = (K'B_i)'(K'B_j) with the Cholesky factor K of the
+// 3 x 3 inverse ((E'E + D^2)^-1 = K K'), so every row r carries ONE 3 x 9 block H_r = K'B_r that serves as the left and
+// as the right operand of its pairs.  Two [O][16] arrays (H0 = the first 16 entries of H, H1 = the other 11): a row's
+// halves are one aligned 128-byte line each -- an operand is exactly two lines instead of 216 bytes at an arbitrary
+// 8-byte boundary (2.7 lines on average) -- and the table is 7.4 GB instead of 12.5 GB on the Final shape, read in both
+// roles, which is what the caches see.  The sums differ from the B'G form in rounding only (and make S symmetric by
+// construction).  Measured on the Final shape (tools/pmc_sparse.sh, same box): FETCH_SIZE of the item kernel 58.3 -> 32.9 GB
+// (4.4 -> 2.5 x the algorithmic 13.1 GB), 13.6 -> 11.5 ms; the row kernel 3.5 -> 2.5 ms; Eliminate 18.8 -> 16.2 ms.
+// CX_PAIR_BG=1 keeps the B'G form for A/B runs.  Two or three steps of operands in flight instead of one made it SLOWER
+// again (16.2 -> 17.3 / 22.4 ms Eliminate): the wider window of concurrent items lowers the L2 hit rate of the shared
+// left operands -- the kernel is bound by the rate of its random 128-byte line fetches from HBM (2.9 TB/s), not by
+// their latency.
+__global__ __launch_bounds__(kBlock) void k_row_h(const double* __restrict__ E, const double* __restrict__ F,
+                                                  const int32_t* __restrict__ row_pt, const double* __restrict__ ete_inv,
+                                                  int64_t O, double* __restrict__ h0, double* __restrict__ h1) {
+  __shared__ double lds[kBlock * 18];
+  const int64_t r0 = int64_t(blockIdx.x) * kBlock;
+  const int nvalid = int(min(int64_t(kBlock), O - r0));
+  const int tid = threadIdx.x;
+  double f[18], e[6];
+  stage_cells<18>(F + 18 * r0, nvalid, lds, f);
+  stage_cells<6>(E + 6 * r0, nvalid, lds, e);
+  double o0[16], o1[16];
+#pragma unroll
+  for (int k = 0; k < 16; ++k) { o0[k] = 0.0; o1[k] = 0.0; }
+  if (tid < nvalid) {
+    const double* m = ete_inv + 9 * int64_t(row_pt[r0 + tid]);
+    // lower Cholesky factor of the symmetric positive definite 3 x 3 inverse: M^-1 = K K'
+    const double k00 = sqrt(m[0]);
+    const double k10 = m[3] / k00, k20 = m[6] / k00;
+    const double k11 = sqrt(m[4] - k10 * k10);
+    const double k21 = (m[7] - k20 * k10) / k11;
+    const double k22 = sqrt(m[8] - k20 * k20 - k21 * k21);
+    double H[27];
+#pragma unroll
+    for (int a = 0; a < 9; ++a) {
+      const double b0 = e[0] * f[a] + e[3] * f[9 + a];  // B = E'F, rows q = 0, 1, 2
+      const double b1 = e[1] * f[a] + e[4] * f[9 + a];
+      const double b2 = e[2] * f[a] + e[5] * f[9 + a];
+      H[a] = k00 * b0 + k10 * b1 + k20 * b2;            // H = K'B
+      H[9 + a] = k11 * b1 + k21 * b2;
+      H[18 + a] = k22 * b2;
+    }
+#pragma unroll
+    for (int k = 0; k < 16; ++k) o0[k] = H[k];
+#pragma unroll
+    for (int k = 16; k < 27; ++k) o1[k - 16] = H[k];
+  }
+  unstage_cells<16>(h0 + 16 * r0, nvalid, lds, o0);
+  unstage_cells<16>(h1 + 16 * r0, nvalid, lds, o1);
+}
+
+// k_pair_items_staged on the one-table operands: per pair 14 + 14 sixteen-byte pieces (8 of the row's H0 line, 6 of its H1
+// line, for the left row and for the right row), staged one step ahead; sum of H_ri' H_rj over the item's pairs.
+__global__ __launch_bounds__(kBlock) void k_pair_items_h(const int32_t* __restrict__ pair_rows, const int64_t* __restrict__ item_begin,
+                                                         const int32_t* __restrict__ item_ids, const double* __restrict__ h0,
+                                                         const double* __restrict__ h1, double* __restrict__ item_partial,
+                                                         int num_launch_items) {
+  constexpr int kStage = kPairGroups * 2 * kPairOperand;  // doubles per buffer
+  __shared__ double lds[(2 * kStage > kPairGroups * 81) ? 2 * kStage : kPairGroups * 81];
+  const int tid = threadIdx.x;
+  const int slot = num_launch_items > 0 ? xcd_segment(num_launch_items) : int(blockIdx.x);
+  if (slot < 0) return;
+  const int64_t item = item_ids ? int64_t(item_ids[slot]) : int64_t(slot);
+  const int64_t p0 = item_begin[item], p1 = item_begin[item + 1];
+  const int steps = int((p1 - p0 + kPairGroups - 1) / kPairGroups);
+  int pg[4], dst[4], off[4], sel[4];  // sel: bit 0 = H1 (else H0), bit 1 = right operand (else left)
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int q = tid + i * kBlock;
+    const int g = q / 28, w = q - g * 28;
+    const int operand = w / 14, pc = w - operand * 14;
+    pg[i] = q < kPairPieces ? g : -1;
+    sel[i] = 2 * operand + (pc < 8 ? 0 : 1);
+    off[i] = pc < 8 ? 2 * pc : 2 * (pc - 8);
+    dst[i] = (g * 2 + operand) * kPairOperand + 2 * pc;
+  }
+#define CX_PAIR_ROW(i, step, out)                                                                     \
+  do {                                                                                                \
+    const int64_t k_ = p0 + int64_t(step) * kPairGroups + pg[i];                                      \
+    out = (pg[i] >= 0 && k_ < p1) ? pair_rows[2 * k_ + (sel[i] >> 1)] : -1;                           \
+  } while (0)
+#define CX_PAIR_FETCH(i, row, out)                                                                    \
+  do {                                                                                                \
+    const double* base_ = (sel[i] & 1) ? h1 : h0;                                                     \
+    out = (row) < 0 ? make_double2(0.0, 0.0)                                                          \
+                    : *reinterpret_cast<const double2*>(base_ + 16 * int64_t(row) + off[i]);         \
+  } while (0)
+  int32_t rows_next[4];
+  double2 v[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) CX_PAIR_ROW(i, 0, rows_next[i]);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) CX_PAIR_FETCH(i, rows_next[i], v[i]);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    if (steps > 1) CX_PAIR_ROW(i, 1, rows_next[i]);
+    else rows_next[i] = -1;
+  }
+  const int g = tid / 9, sub = tid - g * 9;
+  const int a0 = 3 * (sub / 3), c0 = 3 * (sub - 3 * (sub / 3));
+  double acc[9];
+#pragma unroll
+  for (int k = 0; k < 9; ++k) acc[k] = 0.0;
+  for (int s = 0; s < steps; ++s) {
+    double* buf = lds + (s & 1) * kStage;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      if (pg[i] >= 0) *reinterpret_cast<double2*>(buf + dst[i]) = v[i];
+    __syncthreads();
+    if (s + 1 < steps) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) CX_PAIR_FETCH(i, rows_next[i], v[i]);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        if (s + 2 < steps) CX_PAIR_ROW(i, s + 2, rows_next[i]);
+        else rows_next[i] = -1;
+      }
+    }
+    if (g < kPairGroups && p0 + int64_t(s) * kPairGroups + g < p1) {
+      const double* Hl = buf + (g * 2) * kPairOperand;
+      const double* Hr = Hl + kPairOperand;
+      double B[9], G[9];
+#pragma unroll
+      for (int i = 0; i < 3; ++i) {
+        B[i] = Hl[a0 + i];
+        B[3 + i] = Hl[9 + a0 + i];
+        B[6 + i] = Hl[18 + a0 + i];
+        G[i] = Hr[c0 + i];
+        G[3 + i] = Hr[9 + c0 + i];
+        G[6 + i] = Hr[18 + c0 + i];
+      }
+#pragma unroll
+      for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) acc[i * 3 + j] += (B[i] * G[j] + B[3 + i] * G[3 + j]) + B[6 + i] * G[6 + j];
+    }
+  }
+  __syncthreads();  // the staging buffers become the groups' partial sums
+  double* part = lds;
+  if (g < kPairGroups) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+      for (int j = 0; j < 3; ++j) part[g * 81 + (a0 + i) * 9 + c0 + j] = acc[i * 3 + j];
+  }
+  __syncthreads();
+  if (tid < 81) {
+    double v81 = 0.0;
+#pragma unroll 4
+    for (int q = 0; q < kPairGroups; ++q) v81 += part[q * 81 + tid];
+    item_partial[item * 81 + tid] = v81;
+  }
+#undef CX_PAIR_ROW
+#undef CX_PAIR_FETCH
+}
+
 // Stage 2, 81 threads per non-zero cell (c1 <= c2): [c1 == c2] F'F - sum of the cell's items, written either
 // into the dense row-major lhs (pre-zeroed; D_f^2 added on the diagonal -- the reference's dense S) or
 // into the cell-major sparse value array (81 contiguous doubles per cell, D_f^2 NOT added: the sparse
@@ -1466,6 +1642,28 @@ int cxs_assemble_pair_items(cx_matrix* A, const double* D, const int32_t* item_i
   // the cofactor inverse reports nothing, exactly as InvertPSDMatrix<3> (invert_psd_matrix.h:60-63): a singular
   // E'E + D^2 shows as Inf/NaN in S and ends the solve in the Cholesky factorisation, as in the reference
   CX_TRY(cxs_compute_ete_inverse(A, D, nullptr, A->d_elim_ete.p, nullptr, false, nullptr));
+  static const bool one_table = std::getenv("CX_PAIR_BG") == nullptr && std::getenv("CX_PAIR_ITEMS_DIRECT") == nullptr;  // A/B switch
+  if (one_table) {  // round 3: H = K'B, one operand table (k_row_h / k_pair_items_h)
+    const size_t rows16 = size_t(std::max<int64_t>(16 * A->O, 1));
+    CX_TRY(A->d_elim_bg0.alloc(rows16));
+    CX_TRY(A->d_elim_bg1.alloc(rows16));
+    if (A->O > 0)
+      hipLaunchKernelGGL(k_row_h, dim3(grid_for(A->O, kBlock)), dim3(kBlock), 0, st, (const double*)A->d_values.p,
+                         (const double*)(A->d_values.p + 6 * A->O), (const int32_t*)A->d_row_pt.p, (const double*)A->d_elim_ete.p,
+                         A->O, A->d_elim_bg0.p, A->d_elim_bg1.p);
+    CX_TRY(cxs_camera_block_diagonal(A, A->d_elim_diag.p));
+    // all items: in the launch order of the pair-list builder (groups of block rows interleaved by block column, so that the
+    // right operands of neighbouring block rows meet in one XCD's L2)
+    const int32_t* ids = item_ids ? item_ids : (A->d_item_order.n > 0 && A->d_item_order.p ? (const int32_t*)A->d_item_order.p : nullptr);
+    const int64_t n_items = item_ids ? num_selected : A->num_items;
+    static const bool xcd = std::getenv("CX_NO_XCD_ITEMS") == nullptr;
+    if (n_items > 0)
+      hipLaunchKernelGGL(k_pair_items_h, dim3(unsigned(xcd ? xcd_grid(int(n_items)) : n_items)), dim3(kBlock), 0, st,
+                         (const int32_t*)A->d_pair_rows.p, (const int64_t*)A->d_item_begin.p, ids, (const double*)A->d_elim_bg0.p,
+                         (const double*)A->d_elim_bg1.p, A->d_item_partial.p, xcd ? int(n_items) : 0);
+    CX_HIP(hipGetLastError());
+    return CX_OK;
+  }
   const size_t rows18 = size_t(std::max<int64_t>(18 * A->O, 1));
   CX_TRY(A->d_elim_bg0.alloc(rows18));
   CX_TRY(A->d_elim_bg1.alloc(rows18));
