@@ -435,6 +435,7 @@ __global__ __launch_bounds__(kBlock, !WITH_J ? 4 : ((MODEL == CX_CAMERA_ANGLE_AX
   constexpr bool kCoop = (VARIANT & 4) == 0 && MODEL == CX_CAMERA_ANGLE_AXIS;  // (64 x 9 doubles per wavefront = the LDS buffer)
   constexpr int kCam = (MODEL == CX_CAMERA_ANGLE_AXIS) ? 9 : 10;
   __shared__ double lds[kBlock * 9];
+  __shared__ double lds_scale[SCALED ? kBlock * 9 : 1];  // SCALED: the wavefronts' slices for the gathered column scales
   __shared__ double red[4];
   __shared__ int cpos[kBlock];
   const int tid0 = threadIdx.x;
@@ -498,12 +499,11 @@ __global__ __launch_bounds__(kBlock, !WITH_J ? 4 : ((MODEL == CX_CAMERA_ANGLE_AX
     // SCALED: the column scales of THIS tile, requested first of the iteration's loads (they are the oldest when the
     // multiplications at the end of the arithmetic wait for them, so the younger requests of the next tiles stay in
     // flight) and not a tile ahead: prefetching them like the parameters costs 24 more live registers and spills.
-    // Lane-per-row loads: a cooperative gather would need the LDS slice that holds the transposed parameters.
+    // The 9 scales of a camera come by the cooperative gather (consecutive lanes read consecutive words) and reach their
+    // rows through a slice of LDS of their own just before they are used.
     double sc[SCALED ? 9 : 1], sp[SCALED ? 3 : 1];
     if constexpr (SCALED) {
-      const double* scp = col_scale + cam_off + 9 * int64_t(ci_cur);  // tangent columns: points first, 9 per camera
-#pragma unroll
-      for (int i = 0; i < 9; ++i) sc[i] = scp[i];
+      gather_by_row<9, true>(col_scale + cam_off, ci_cur, tid & 63, sc);  // tangent columns: points first, 9 per camera
       const double* spp = col_scale + 3 * int64_t(pi_cur);
 #pragma unroll
       for (int i = 0; i < 3; ++i) sp[i] = spp[i];
@@ -574,7 +574,12 @@ __global__ __launch_bounds__(kBlock, !WITH_J ? 4 : ((MODEL == CX_CAMERA_ANGLE_AX
         res0 *= residual_scaling;
         res1 *= residual_scaling;
       }
-      if constexpr (SCALED) {  // ScaleColumns (block_sparse_matrix.cc:403-450): every value times the scale of its column
+    }
+    if constexpr (SCALED) {  // ScaleColumns (block_sparse_matrix.cc:403-450): every value times the scale of its column
+      // every lane of the wavefront hands on the words it gathered (also the lanes past the last row of the last tile), so
+      // the exchange sits outside the `tid < nvalid` block; the slice is the wavefront's own: no barrier
+      transpose_gathered<9>(lds_scale + (tid >> 6) * 64 * 9, tid & 63, sc);
+      if (tid < nvalid) {
 #pragma unroll
         for (int i = 0; i < 9; ++i) { jc[i] *= sc[i]; jc[9 + i] *= sc[i]; }
 #pragma unroll

@@ -1322,10 +1322,11 @@ __global__ __launch_bounds__(kBlock) void k_pair_items_staged(const int32_t* __r
 // roles, which is what the caches see.  The sums differ from the B'G form in rounding only (and make S symmetric by
 // construction).  Measured on the Final shape (tools/pmc_sparse.sh, same box): FETCH_SIZE of the item kernel 58.3 -> 32.9 GB
 // (4.4 -> 2.5 x the algorithmic 13.1 GB), 13.6 -> 11.5 ms; the row kernel 3.5 -> 2.5 ms; Eliminate 18.8 -> 16.2 ms.
-// CX_PAIR_BG=1 keeps the B'G form for A/B runs.  Two or three steps of operands in flight instead of one made it SLOWER
-// again (16.2 -> 17.3 / 22.4 ms Eliminate): the wider window of concurrent items lowers the L2 hit rate of the shared
-// left operands -- the kernel is bound by the rate of its random 128-byte line fetches from HBM (2.9 TB/s), not by
-// their latency.
+// CX_PAIR_BG=1 keeps the B'G form for A/B runs.  Tried on top, same box: two / three steps of operands in flight instead of
+// one -- SLOWER again (Eliminate + 1.1 / + 6.1 ms), so it is not the latency of the fetches; launching the items in groups
+// of 2 / 4 / 8 block rows interleaved by block column (CX_PAIR_ROW_GROUP; right operands shared inside a group) -- 16.4 ->
+// 16.3 / 16.2 / 16.2 ms, so it is not the reuse of the right operands either.  What is left is 32.9 GB of random 128-byte
+// line fetches at 2.9 TB/s.
 __global__ __launch_bounds__(kBlock) void k_row_h(const double* __restrict__ E, const double* __restrict__ F,
                                                   const int32_t* __restrict__ row_pt, const double* __restrict__ ete_inv,
                                                   int64_t O, double* __restrict__ h0, double* __restrict__ h1) {
