@@ -25,7 +25,7 @@ SUCCESS, NO_CONVERGENCE, FAILURE, FATAL_ERROR = 0, 1, 2, 3
 
 # every symbol include/cxschur.h declares (tests check that the library exports them all)
 EXPORTED_SYMBOLS = [
-    "cx_context_create", "cx_matrix_static_path", "cx_evaluator_set_column_scale", "cx_schur_pair_lists_host", "cx_context_create_multi", "cx_context_num_shards", "cx_matrix_shard_layout", "cx_context_destroy", "cx_comm_unique_id", "cx_context_set_comm", "cx_context_set_comm_callback", "cx_context_rank",
+    "cx_context_create", "cx_sparse_cholesky_distribution_host", "cx_matrix_static_path", "cx_evaluator_set_column_scale", "cx_schur_pair_lists_host", "cx_context_create_multi", "cx_context_num_shards", "cx_matrix_shard_layout", "cx_context_destroy", "cx_comm_unique_id", "cx_context_set_comm", "cx_context_set_comm_callback", "cx_context_rank",
     "cx_context_num_ranks", "cx_allreduce_sum", "cx_malloc", "cx_free", "cx_memcpy_h2d", "cx_memcpy_d2h",
     "cx_memset_zero", "cx_synchronize", "cx_context_stream", "cx_last_error", "cx_device_name",
     "cx_matrix_create", "cx_matrix_destroy", "cx_matrix_num_rows", "cx_matrix_num_cols",
@@ -635,6 +635,24 @@ def sparse_cholesky_plan_host(num_cameras, cell_row, cell_col):
                                             _ptr(cols), ctypes.c_int64(nt.value)))
     return dict(camera_first_row=first, num_tile_rows=T.value, num_levels=L.value, num_tiles=nt.value,
                 num_tile_pair_updates=npairs.value, tile_row_level=level, tile_row_start=start, tile_cols=cols)
+
+
+def sparse_cholesky_distribution_host(num_cameras, cell_row, cell_col, nranks):
+    """How the distributed factorisation divides the tile rows over nranks ranks (no device): dict with updates_per_rank,
+    updates_replicated, tiles_replicated, owner (rank of every tile row, -1 = replicated top)."""
+    lib = load_library()
+    r = np.ascontiguousarray(cell_row, dtype=np.int32)
+    c = np.ascontiguousarray(cell_col, dtype=np.int32)
+    per = np.zeros(nranks, dtype=np.int64)
+    rep, tiles = ctypes.c_int64(), ctypes.c_int64()
+    T = lib.cx_sparse_cholesky_distribution_host(int(num_cameras), _ptr(r), _ptr(c), ctypes.c_int64(r.size), int(nranks), _ptr(per),
+                                                 ctypes.byref(rep), ctypes.byref(tiles), None, 0)
+    if T < 0:
+        _check(T)
+    owner = np.zeros(T, dtype=np.int32)
+    _check(min(0, lib.cx_sparse_cholesky_distribution_host(int(num_cameras), _ptr(r), _ptr(c), ctypes.c_int64(r.size), int(nranks), _ptr(per),
+                                                           ctypes.byref(rep), ctypes.byref(tiles), _ptr(owner), T)))
+    return dict(updates_per_rank=per, updates_replicated=rep.value, tiles_replicated=tiles.value, owner=owner)
 
 
 def schur_sparse_structure(A):

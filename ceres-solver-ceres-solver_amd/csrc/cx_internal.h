@@ -118,6 +118,15 @@ struct cx_sp_plan {
   int64_t num_union_cells = 0;
   DevBuf<int32_t> d_union_c1, d_union_c2, d_local_to_union;
   DevBuf<double> d_union_values;
+  // distributed factorisation (sharded SPARSE_SCHUR, cx_sparse_chol.hip): levels [0, level_split) hold this rank's own tile
+  // rows, levels [level_split, num_levels) the rows every rank factors; -1: not distributed
+  int level_split = -1;
+  int64_t num_shared_tiles = 0;
+  DevBuf<int32_t> d_shared_tiles;    // pool slots of the replicated rows' tiles (summed over the ranks at the split)
+  DevBuf<int32_t> d_row_keep;        // [T] 1: this rank contributes the row's part of the solution to the final sum
+  DevBuf<double> d_exchange;         // packed shared tiles + one slot for the not-positive-definite flag
+  std::vector<int64_t> h_work_per_rank;
+  int64_t h_work_shared = 0;
 };
 
 // -------------------------------------------------- embedding into the static layout (cx_embed.hip)

@@ -40,7 +40,10 @@ int cxsp_factor_and_solve_sharded(cx_matrix* A, const double* Df, const double* 
 // preconditioners): plan from the cells (c1 <= c2, every diagonal cell present), assembly of the selected cells
 // (sel_cells = ids into A's cell list or NULL for all; sel_offdiag / offdiag_scale as k_band_assemble), numeric
 // factorisation in place, and M^-1 r by a forward and a backward sweep over the levels (r, z in camera order).
-int cxsp_plan_from_cells(cx_context* ctx, int C, const int32_t* cell_c1, const int32_t* cell_c2, int64_t num_cells, cx_sp_plan* plan);
+// distribute: on a sharded context, give every rank the factorisation of its own subtrees of the elimination tree (only
+// the solve-at-once path, cxsp_factor_and_solve_sharded, knows how to use such a plan)
+int cxsp_plan_from_cells(cx_context* ctx, int C, const int32_t* cell_c1, const int32_t* cell_c2, int64_t num_cells, cx_sp_plan* plan,
+                         bool distribute = false);
 int cxsp_assemble(cx_matrix* A, cx_sp_plan* plan, const double* Df, const int32_t* sel_cells, const int32_t* sel_offdiag,
                   int64_t num_sel, double offdiag_scale);
 int cxsp_factor(cx_context* ctx, cx_sp_plan* plan, int* d_flag);

@@ -910,9 +910,85 @@ struct HostPlan {
   int T = 0, L = 0;
   int64_t num_tiles = 0;
   bool fits = true;
+  // Distributed factorisation (nranks > 1): owner[I] = the rank that factors tile row I alone, -1 = a row every rank
+  // factors (the top of the elimination tree).  The schedule then holds this rank's rows in levels [0, L_split) and the
+  // replicated rows in levels [L_split, L): everything a rank's own subtrees need lies below the split, everything the
+  // top needs from the subtrees arrives with ONE exchange at the split.
+  std::vector<int32_t> owner;
+  int L_split = -1;
+  std::vector<int64_t> work_per_rank;  // tile-pair updates of every rank's own rows
+  int64_t work_shared = 0;
 };
 
-void BuildHostPlan(int C, const int32_t* cell_c1, const int32_t* cell_c2, int64_t num_cells, HostPlan* H) {
+// Which rank factors which tile row.  Proportional mapping by splitting: the candidate subtrees start as the roots of
+// the elimination forest; the heaviest candidate is replaced by its children (and becomes a row of the replicated top)
+// until no candidate carries more than 1 / (4 nranks) of the work that is still distributable; the candidates then go to
+// the ranks largest first, each to the least loaded rank.  Deterministic, the same on every rank.
+void AssignOwners(const std::vector<int32_t>& row_start, const std::vector<int32_t>& row_tiles, int T, int nranks, HostPlan* H) {
+  std::vector<int32_t> parent(static_cast<size_t>(T), -1);
+  std::vector<std::vector<int32_t>> children(static_cast<size_t>(T));
+  std::vector<int64_t> work(static_cast<size_t>(T), 0), subtree(static_cast<size_t>(T), 0);
+  for (int I = 0; I < T; ++I) {
+    const int64_t m = row_start[size_t(I) + 1] - row_start[size_t(I)] - 1;  // tiles right of the diagonal incl. the right-hand side
+    work[size_t(I)] = m * (m - 1) / 2 + m;                                  // its tile-pair updates, about
+    const int32_t p = row_tiles[size_t(row_start[size_t(I)]) + 1];
+    if (p < T) { parent[size_t(I)] = p; children[size_t(p)].push_back(I); }
+  }
+  for (int I = 0; I < T; ++I) {  // children have smaller indices
+    subtree[size_t(I)] += work[size_t(I)];
+    if (parent[size_t(I)] >= 0) subtree[size_t(parent[size_t(I)])] += subtree[size_t(I)];
+  }
+  H->owner.assign(size_t(T), -1);
+  std::vector<int32_t> cand, root_shared;
+  int64_t distributable = 0;
+  for (int I = 0; I < T; ++I)
+    if (parent[size_t(I)] < 0) { cand.push_back(I); distributable += subtree[size_t(I)]; }
+  auto heavier = [&](int32_t a, int32_t b) { return subtree[size_t(a)] != subtree[size_t(b)] ? subtree[size_t(a)] < subtree[size_t(b)] : a > b; };
+  std::make_heap(cand.begin(), cand.end(), heavier);
+  H->work_shared = 0;
+  const int64_t total = distributable;
+  std::vector<int32_t> atomic;  // candidates that cannot be split: chains of tile rows (the band pieces of the dissection)
+  while (!cand.empty()) {
+    const int32_t top = cand.front();
+    // small enough: so is everything else.  (And the replicated top may not grow beyond a quarter of all the work.)
+    if (subtree[size_t(top)] * 4 * nranks <= total || H->work_shared * 4 > total) break;
+    std::pop_heap(cand.begin(), cand.end(), heavier);
+    cand.pop_back();
+    // a split only helps where the tree branches: walk down the chain below `top` to the first row with several children
+    int32_t branch = top;
+    int64_t chain_work = 0;
+    while (children[size_t(branch)].size() == 1) { chain_work += work[size_t(branch)]; branch = children[size_t(branch)][0]; }
+    if (children[size_t(branch)].empty() || (H->work_shared + chain_work + work[size_t(branch)]) * 4 > total) {
+      atomic.push_back(top);
+      continue;
+    }
+    for (int32_t I = top;; I = children[size_t(I)][0]) {  // the chain and the branching row join the replicated top
+      H->work_shared += work[size_t(I)];
+      distributable -= work[size_t(I)];
+      root_shared.push_back(I);
+      if (I == branch) break;
+    }
+    for (int32_t c : children[size_t(branch)]) { cand.push_back(c); std::push_heap(cand.begin(), cand.end(), heavier); }
+  }
+  cand.insert(cand.end(), atomic.begin(), atomic.end());
+  std::sort(cand.begin(), cand.end(), [&](int32_t a, int32_t b) { return heavier(b, a); });  // largest first
+  H->work_per_rank.assign(size_t(nranks), 0);
+  std::vector<int32_t> root_owner(static_cast<size_t>(T), -1);
+  for (int32_t c : cand) {
+    int best = 0;
+    for (int r = 1; r < nranks; ++r)
+      if (H->work_per_rank[size_t(r)] < H->work_per_rank[size_t(best)]) best = r;
+    H->work_per_rank[size_t(best)] += subtree[size_t(c)];
+    root_owner[size_t(c)] = best;
+  }
+  for (int I = T - 1; I >= 0; --I) {  // parents have larger indices: owners flow down the subtrees
+    if (root_owner[size_t(I)] >= 0) H->owner[size_t(I)] = root_owner[size_t(I)];
+    else if (parent[size_t(I)] >= 0 && H->owner[size_t(parent[size_t(I)])] >= 0) H->owner[size_t(I)] = H->owner[size_t(parent[size_t(I)])];
+  }
+}
+
+// rank < 0: the whole factorisation on one device; otherwise the schedule of `rank` of `nranks` (see HostPlan::owner)
+void BuildHostPlan(int C, const int32_t* cell_c1, const int32_t* cell_c2, int64_t num_cells, HostPlan* H, int rank = -1, int nranks = 1) {
   std::vector<std::vector<int32_t>> adj(static_cast<size_t>(C));
   for (int64_t k = 0; k < num_cells; ++k) {
     const int c1 = cell_c1[k], c2 = cell_c2[k];
@@ -965,19 +1041,34 @@ void BuildHostPlan(int C, const int32_t* cell_c1, const int32_t* cell_c2, int64_
     if (parent < T) height[size_t(parent)] = std::max(height[size_t(parent)], height[size_t(I)] + 1);
     max_h = std::max(max_h, height[size_t(I)]);
   }
-  const int L = T > 0 ? max_h + 1 : 0;
+  const int tree_levels = T > 0 ? max_h + 1 : 0;
+  // the level of a row in the schedule: its height -- for a distributed plan the replicated rows come after ALL levels of
+  // the rank's own rows (their heights shifted by the number of levels), rows of other ranks are left out (-1)
+  const bool distributed = rank >= 0 && nranks > 1 && T > 0;
+  std::vector<int32_t> vlevel(height);
+  if (distributed) {
+    AssignOwners(row_start, row_tiles, T, nranks, H);
+    for (int I = 0; I < T; ++I) {
+      const int32_t o = H->owner[size_t(I)];
+      vlevel[size_t(I)] = o < 0 ? tree_levels + height[size_t(I)] : (o == rank ? height[size_t(I)] : -1);
+    }
+    H->L_split = tree_levels;
+  }
+  const int L = distributed ? 2 * tree_levels : tree_levels;
   H->L = L;
   std::vector<int32_t>&lrb = H->lrb, &lpb = H->lpb, &ltb = H->ltb;
   lrb.assign(size_t(L) + 1, 0);
   lpb.assign(size_t(L) + 1, 0);
   ltb.assign(size_t(L) + 1, 0);
-  for (int I = 0; I < T; ++I) lrb[size_t(height[size_t(I)]) + 1]++;
+  for (int I = 0; I < T; ++I)
+    if (vlevel[size_t(I)] >= 0) lrb[size_t(vlevel[size_t(I)]) + 1]++;
   for (int l = 0; l < L; ++l) lrb[size_t(l) + 1] += lrb[size_t(l)];
   std::vector<int32_t>& level_rows = H->level_rows;
-  level_rows.assign(static_cast<size_t>(T), 0);
+  level_rows.assign(static_cast<size_t>(lrb[size_t(L)]), 0);
   {
     std::vector<int32_t> cur(lrb.begin(), lrb.end() - 1);
-    for (int I = 0; I < T; ++I) level_rows[size_t(cur[size_t(height[size_t(I)])]++)] = I;
+    for (int I = 0; I < T; ++I)
+      if (vlevel[size_t(I)] >= 0) level_rows[size_t(cur[size_t(vlevel[size_t(I)])]++)] = I;
   }
   std::vector<int32_t>&panel_row = H->panel_row, &panel_pool = H->panel_pool;
   struct Src { int32_t level, tgt, row, qa, qb; };
@@ -1043,12 +1134,15 @@ void BuildHostPlan(int C, const int32_t* cell_c1, const int32_t* cell_c2, int64_
 }
 }  // namespace
 
-int cxsp_plan_from_cells(cx_context* ctx, int C, const int32_t* cell_c1, const int32_t* cell_c2, int64_t num_cells, cx_sp_plan* P) {
+int cxsp_plan_from_cells(cx_context* ctx, int C, const int32_t* cell_c1, const int32_t* cell_c2, int64_t num_cells, cx_sp_plan* P,
+                         bool distribute) {
   if (P->state != 0) return CX_OK;
   P->C = C;
   const int n = 9 * C;
   HostPlan H;
-  BuildHostPlan(C, cell_c1, cell_c2, num_cells, &H);
+  static const bool distribution_off = std::getenv("CX_SPARSE_DISTRIBUTE") && std::atoi(std::getenv("CX_SPARSE_DISTRIBUTE")) == 0;  // A/B switch
+  const bool dist = distribute && ctx->nranks > 1 && !distribution_off;
+  BuildHostPlan(C, cell_c1, cell_c2, num_cells, &H, dist ? ctx->rank : -1, dist ? ctx->nranks : 1);
   if (!H.fits) { P->state = 2; return CX_OK; }
   hipStream_t st = ctx->stream;
   const int T = H.T, L = H.L;
@@ -1077,6 +1171,28 @@ int cxsp_plan_from_cells(cx_context* ctx, int C, const int32_t* cell_c1, const i
   P->num_levels = L;
   P->num_tiles = num_tiles;
   P->T = T;
+  P->level_split = H.L_split;
+  if (H.L_split >= 0) {
+    std::vector<int32_t> shared_tiles, keep(static_cast<size_t>(T), 0);
+    for (int I = 0; I < T; ++I) {
+      const int32_t o = H.owner[size_t(I)];
+      keep[size_t(I)] = (o == ctx->rank || (o < 0 && ctx->rank == 0)) ? 1 : 0;
+      if (o < 0)
+        for (int32_t q = row_start[size_t(I)]; q < row_start[size_t(I) + 1]; ++q) shared_tiles.push_back(q);
+    }
+    P->num_shared_tiles = int64_t(shared_tiles.size());
+    CX_TRY(P->d_shared_tiles.upload(shared_tiles, st));
+    CX_TRY(P->d_row_keep.upload(keep, st));
+    P->h_work_per_rank = H.work_per_rank;
+    P->h_work_shared = H.work_shared;
+    if (std::getenv("CX_SPARSE_CHOLESKY_VERBOSE")) {
+      std::fprintf(stderr, "[cxschur] distributed factorisation, rank %d of %d: %lld tiles of replicated rows (%.2f GB exchanged per solve), "
+                   "tile-pair updates replicated %lld, per rank", ctx->rank, ctx->nranks, (long long)P->num_shared_tiles,
+                   double(P->num_shared_tiles) * kTileDoubles * 8e-9, (long long)H.work_shared);
+      for (int64_t w : H.work_per_rank) std::fprintf(stderr, " %lld", (long long)w);
+      std::fprintf(stderr, "\n");
+    }
+  }
   P->state = 1;
   if (std::getenv("CX_SPARSE_CHOLESKY_VERBOSE"))
     std::fprintf(stderr, "[cxschur] tile-sparse Cholesky plan: %d cameras, %d tile rows (%d rows of padding) in %d levels, %lld tiles (%.2f GB, "
@@ -1130,6 +1246,50 @@ int cxsp_assemble(cx_matrix* A, cx_sp_plan* P, const double* Df, const int32_t* 
   return CX_OK;
 }
 
+namespace {
+// ---- distributed factorisation: the exchange at the split and its helpers
+__global__ void k_sp_zero_tiles(double* __restrict__ W, const int32_t* __restrict__ tiles, int64_t n) {
+  const int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i >= n * kTileDoubles) return;
+  W[int64_t(tiles[i / kTileDoubles]) * kTileDoubles + (i % kTileDoubles)] = 0.0;
+}
+// dir 0: pool -> packed (and the flag into the last slot), 1: packed -> pool (and the summed flag back)
+__global__ void k_sp_pack_tiles(double* __restrict__ W, const int32_t* __restrict__ tiles, int64_t n, double* __restrict__ packed,
+                                int* __restrict__ flag, int dir) {
+  const int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i == n * kTileDoubles) {
+    if (dir == 0) packed[i] = double(*flag != 0);
+    else if (packed[i] > 0.0) *flag = 1;
+    return;
+  }
+  if (i > n * kTileDoubles) return;
+  const int64_t w = int64_t(tiles[i / kTileDoubles]) * kTileDoubles + (i % kTileDoubles);
+  if (dir == 0) packed[i] = W[w];
+  else W[w] = packed[i];
+}
+__global__ void k_sp_mask_rows(double* __restrict__ xp, const int32_t* __restrict__ keep, int64_t n) {
+  const int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i < n && !keep[i / kTile]) xp[i] = 0.0;
+}
+// The tiles of the replicated rows hold, on every rank, what the rank's own subtrees subtracted from them (rank 0: on top of
+// the assembled values, the others: on top of zeros, cxsp_prepare_distributed): their sum is the matrix the top of the tree
+// is factored from.  A rank whose subtree met a non-positive pivot says so in the same message, so that every rank ends the
+// solve the same way.
+int ExchangeSharedTiles(cx_context* ctx, cx_sp_plan* P, int* d_flag) {
+  hipStream_t st = ctx->stream;
+  const int64_t n = P->num_shared_tiles, count = n * kTileDoubles + 1;
+  CX_TRY(P->d_exchange.alloc(size_t(count)));
+  hipLaunchKernelGGL(k_sp_pack_tiles, dim3(unsigned((count + 255) / 256)), dim3(256), 0, st, P->d_W.p, (const int32_t*)P->d_shared_tiles.p, n,
+                     P->d_exchange.p, d_flag, 0);
+  CX_HIP(hipGetLastError());
+  CX_TRY(cx_allreduce_device(ctx, P->d_exchange.p, count));
+  hipLaunchKernelGGL(k_sp_pack_tiles, dim3(unsigned((count + 255) / 256)), dim3(256), 0, st, P->d_W.p, (const int32_t*)P->d_shared_tiles.p, n,
+                     P->d_exchange.p, d_flag, 1);
+  CX_HIP(hipGetLastError());
+  return CX_OK;
+}
+}  // namespace
+
 // numeric factorisation of the assembled pool, in place, level by level; a right-hand side placed in the rows' last
 // tiles (k_sp_rhs) is forward-substituted along
 int cxsp_factor(cx_context* ctx, cx_sp_plan* P, int* d_flag) {
@@ -1140,6 +1300,7 @@ int cxsp_factor(cx_context* ctx, cx_sp_plan* P, int* d_flag) {
   const int32_t* valid = P->d_valid.p;
   const int32_t* rows = P->d_level_rows.p;
   for (int l = 0; l < P->num_levels; ++l) {
+    if (l == P->level_split) CX_TRY(ExchangeSharedTiles(ctx, P, d_flag));  // the ranks' own subtrees are done: sum what they sent up
     const int r0 = P->h_level_row_begin[size_t(l)], nr = P->h_level_row_begin[size_t(l) + 1] - r0;
     const int p0 = P->h_level_panel_begin[size_t(l)], np = P->h_level_panel_begin[size_t(l) + 1] - p0;
     const int t0 = P->h_level_tgt_begin[size_t(l)], nt = P->h_level_tgt_begin[size_t(l) + 1] - t0;
@@ -1352,7 +1513,7 @@ int cxsp_build_plan_sharded(cx_matrix* A) {
   CX_TRY(P->d_union_c1.upload(u1, st));
   CX_TRY(P->d_union_c2.upload(u2, st));
   CX_TRY(P->d_local_to_union.upload(local_to_union, st));
-  return cxsp_plan_from_cells(ctx, C, u1.data(), u2.data(), P->num_union_cells, P);
+  return cxsp_plan_from_cells(ctx, C, u1.data(), u2.data(), P->num_union_cells, P, /*distribute=*/true);
 }
 
 int cxsp_factor_and_solve_sharded(cx_matrix* A, const double* Df, const double* rhs, double* z, int* d_flag) {
@@ -1378,10 +1539,25 @@ int cxsp_factor_and_solve_sharded(cx_matrix* A, const double* Df, const double* 
                      P->num_union_cells);
   hipLaunchKernelGGL(k_sp_rhs, dim3((n + 255) / 256), dim3(256), 0, st, rhs, (const int32_t*)P->d_cam_pos.p,
                      (const int32_t*)P->d_row_start.p, P->d_W.p, C);
+  const bool distributed = P->level_split >= 0;
+  if (distributed && ctx->rank != 0 && P->num_shared_tiles > 0) {
+    // every rank assembled the whole matrix; in the sum over the ranks at the split the assembled values (and right-hand
+    // side) of the replicated rows must count once: rank 0 keeps them, the others start those tiles from zero
+    const int64_t cnt = P->num_shared_tiles * kTileDoubles;
+    hipLaunchKernelGGL(k_sp_zero_tiles, dim3(unsigned((cnt + 255) / 256)), dim3(256), 0, st, P->d_W.p, (const int32_t*)P->d_shared_tiles.p,
+                       P->num_shared_tiles);
+  }
   CX_TRY(cxsp_factor(ctx, P, d_flag));
   Scratch sc;
   CX_TRY(GetScratch(P, &sc));
+  if (distributed) CX_HIP(hipMemsetAsync(sc.xp, 0, size_t(P->T) * kTile * sizeof(double), st));  // (rows of other ranks stay zero)
   CX_TRY(BackwardSweep(ctx, P, sc, 0));
+  if (distributed) {
+    // every rank holds the solution of its own rows (and of the replicated ones): the whole vector is their sum
+    const int64_t npad = int64_t(P->T) * kTile;
+    hipLaunchKernelGGL(k_sp_mask_rows, dim3(unsigned((npad + 255) / 256)), dim3(256), 0, st, sc.xp, (const int32_t*)P->d_row_keep.p, npad);
+    CX_TRY(cx_allreduce_device(ctx, sc.xp, npad));
+  }
   hipLaunchKernelGGL(k_sp_unpermute, dim3((n + 255) / 256), dim3(256), 0, st, (const double*)sc.xp, (const int32_t*)P->d_cam_pos.p, z, C);
   CX_HIP(hipGetLastError());
   return CX_OK;
@@ -1414,3 +1590,36 @@ extern "C" int cx_sparse_cholesky_plan_host(int32_t num_cameras, const int32_t* 
   if (tile_cols && capacity_tiles >= H.num_tiles) std::copy(H.row_tiles.begin(), H.row_tiles.end(), tile_cols);
   return CX_OK;
 }
+
+// How the distributed factorisation of a sharded SPARSE_SCHUR divides the tile rows of this structure over nranks ranks
+// (no device): see cxschur.h
+extern "C" int cx_sparse_cholesky_distribution_host(int32_t num_cameras, const int32_t* cell_row, const int32_t* cell_col, int64_t num_cells,
+                                                    int32_t nranks, int64_t* updates_per_rank, int64_t* updates_replicated,
+                                                    int64_t* tiles_replicated, int32_t* tile_row_owner, int32_t capacity_rows) {
+  CX_CHECK_ARG(num_cameras > 0 && cell_row && cell_col && num_cells >= num_cameras && nranks >= 1 && nranks <= 64 && updates_per_rank &&
+               updates_replicated && tiles_replicated);
+  for (int64_t k = 0; k < num_cells; ++k)
+    CX_CHECK_ARG(cell_row[k] >= 0 && cell_row[k] <= cell_col[k] && cell_col[k] < num_cameras);
+  HostPlan H;
+  BuildHostPlan(num_cameras, cell_row, cell_col, num_cells, &H, 0, nranks);
+  if (!H.fits) {
+    cx_set_error("the tile-sparse Cholesky of this structure would need more than 160 GB");
+    return CX_ERR_UNSUPPORTED;
+  }
+  if (nranks == 1) {  // nothing is distributed: everything is rank 0's
+    updates_per_rank[0] = int64_t(H.src_a.size());
+    *updates_replicated = 0;
+    *tiles_replicated = 0;
+    if (tile_row_owner && capacity_rows >= H.T) std::fill(tile_row_owner, tile_row_owner + H.T, 0);
+    return H.T;
+  }
+  std::copy(H.work_per_rank.begin(), H.work_per_rank.end(), updates_per_rank);
+  *updates_replicated = H.work_shared;
+  int64_t tiles = 0;
+  for (int I = 0; I < H.T; ++I)
+    if (H.owner[size_t(I)] < 0) tiles += H.row_start[size_t(I) + 1] - H.row_start[size_t(I)];
+  *tiles_replicated = tiles;
+  if (tile_row_owner && capacity_rows >= H.T) std::copy(H.owner.begin(), H.owner.end(), tile_row_owner);
+  return H.T;
+}
+

@@ -521,6 +521,14 @@ int cx_sparse_cholesky_plan_host(int32_t num_cameras, const int32_t* cell_row, c
 int cx_schur_pair_lists_host(const cx_block_structure* bs, int32_t num_eliminate_blocks, int64_t* num_cells,
                              int64_t* num_pairs, int64_t* num_items, int32_t* cell_row, int32_t* cell_col,
                              int64_t cell_capacity, int32_t* pair_rows, int64_t pair_capacity);
+/* How the DISTRIBUTED factorisation of a sharded SPARSE_SCHUR (several ranks) divides this structure:
+ * every rank factors the subtrees of the tile elimination tree it owns, the rows above them (the top separators of the
+ * dissection) are factored by every rank after ONE exchange of their tiles.  Same input as cx_sparse_cholesky_plan_host.
+ * Returns the number of tile rows (negative: error); updates_per_rank[nranks] = tile-pair updates of each rank's own rows,
+ * *updates_replicated / *tiles_replicated = the replicated top, tile_row_owner[rows] (may be NULL) = owning rank or -1. */
+int cx_sparse_cholesky_distribution_host(int32_t num_cameras, const int32_t* cell_row, const int32_t* cell_col, int64_t num_cells,
+                                         int32_t nranks, int64_t* updates_per_rank, int64_t* updates_replicated,
+                                         int64_t* tiles_replicated, int32_t* tile_row_owner, int32_t capacity_rows);
 /* Partition the first num_eliminate_blocks column blocks (points) into nranks
  * contiguous ranges holding about equal numbers of non-zeros -- the balancing
  * PartitionRangeForParallelFor does on cumulative_nnz

@@ -22,6 +22,10 @@ RUNS = [
     "--workload dubrovnik356 --solver sparse_schur --steps 10 --warmup 3 --force-tile-sparse",
     "--workload synthetic10M --solver cgnr --steps 10 --warmup 3",
     "--workload synthetic10M --solver cgnr --mixed --steps 10 --warmup 3",
+    # the second scene (round 3): the Final sizes with loop closures (5 % of the points also seen half a ring away)
+    "--workload final13682_revisit --solver iterative_schur --steps 5 --warmup 2",
+    "--workload final13682_revisit --solver sparse_schur --steps 3 --warmup 1",
+    "--workload final13682_revisit --solver iterative_schur --preconditioner cluster_tridiagonal --steps 3 --warmup 1",
 ]
 
 
@@ -30,7 +34,7 @@ def bench(args, eta):
     if "--force-tile-sparse" in args:      # SPARSE_SCHUR stays dense below 512 cameras unless told otherwise
         env["CX_SPARSE_CHOLESKY"] = "1"
         args = args.replace(" --force-tile-sparse", "")
-    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--no-cpu-baseline", "--eta", str(eta)] + args.split()
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--no-cpu-baseline", "--no-sparse-schur", "--eta", str(eta)] + args.split()
     out = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True, check=True, env=env).stdout
     return json.loads([l for l in out.splitlines() if l.startswith("{")][-1])
 
@@ -47,6 +51,7 @@ def main():
                    "phases_ms": {k: round(v, 3) for k, v in a["phases_ms_per_solve"].items() if k != "setup_ms" and not k.startswith("allreduce")},
                    "values_update_ms": {k: round(v, 3) for k, v in (a.get("values_update_per_lm_iteration") or {}).items() if k.endswith("_ms")},
                    "kernels_avg_ms": {k: round(v["avg_ms"], 4) for k, v in (a.get("kernels") or {}).items()},
+                   "lm_iteration_ms": round(a["lm_iteration_ms"], 3) if a.get("lm_iteration_ms") else None,
                    "spmv_frac_of_8TBps": [round(a["spmv"]["right_frac_of_8TBps"], 3), round(a["spmv"]["left_frac_of_8TBps"], 3)]}
             if "sparse_schur" not in args and "dense_schur" not in args:
                 b = bench(args, 0.01)

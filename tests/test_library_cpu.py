@@ -230,3 +230,39 @@ def test_pair_lists_host_match_the_oracle_cell_set(oracle, C, P, O, seed):
         assert got == lst, (c1, c2)
         pos += len(lst)
     assert pos == num_pairs and num_items >= len(r)
+
+
+@pytest.mark.parametrize("C,P,O,seed", [(700, 5000, 26000, 8), (2000, 20000, 110000, 3)])
+def test_distribution_of_the_tile_sparse_factorisation(C, P, O, seed):
+    """cx_sparse_cholesky_distribution_host (the host half of the distributed SPARSE_SCHUR factorisation): every tile row is
+    either owned by exactly one rank or part of the replicated top; an owned row's whole subtree of the elimination tree
+    belongs to the same rank (so a rank's phase needs nothing from the others), the parent chain of a replicated row is
+    replicated (so the top needs nothing after the one exchange), and the ranks' shares of the tile-pair updates are
+    balanced.  Integers, checked exactly."""
+    prob = cx.bal.make_bal_like(C, P, O, seed=seed)
+    bs, _ = cx.bal.build_structure(prob)
+    r, c, _, _ = cx.binding.schur_pair_lists_host(bs, P)
+    plan = cx.binding.sparse_cholesky_plan_host(C, r, c)
+    T, start, cols = plan["num_tile_rows"], plan["tile_row_start"], plan["tile_cols"]
+    parent = np.array([cols[start[i] + 1] if cols[start[i] + 1] < T else -1 for i in range(T)])
+    one = cx.binding.sparse_cholesky_distribution_host(C, r, c, 1)
+    assert one["updates_per_rank"][0] == plan["num_tile_pair_updates"] and one["tiles_replicated"] == 0
+    for nranks in (2, 4, 8):
+        d = cx.binding.sparse_cholesky_distribution_host(C, r, c, nranks)
+        owner = d["owner"]
+        assert owner.size == T and owner.min() >= -1 and owner.max() < nranks
+        for i in range(T):
+            p = parent[i]
+            if p < 0:
+                continue
+            if owner[i] < 0:
+                assert owner[p] < 0                          # above a replicated row everything is replicated
+            else:
+                assert owner[p] in (-1, owner[i])            # a subtree does not change hands
+        per = d["updates_per_rank"]
+        assert per.sum() > 0 and d["updates_replicated"] >= 0
+        if T >= 16 * nranks:
+            assert per.max() <= 1.5 * per.mean() + 1, (nranks, per)      # largest-first onto the least loaded rank
+        replicated_rows = int((owner < 0).sum())
+        assert d["tiles_replicated"] == sum(start[i + 1] - start[i] for i in range(T) if owner[i] < 0)
+        assert replicated_rows < T

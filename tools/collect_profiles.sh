@@ -10,7 +10,7 @@ mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 run() {  # name, bench args...
   local name=$1; shift
-  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/$name -- python3 $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline "$@" > $OUT/$name.json 2> $OUT/$name.err
+  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/$name -- python3 $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --no-sparse-schur "$@" > $OUT/$name.json 2> $OUT/$name.err
   cp $(ls $OUT/$name/*/*kernel_stats.csv | head -1) $OUT/${name}_kernel_stats.csv
   echo "$name done" 
 }
@@ -19,7 +19,7 @@ run final13682_sparse_schur --solver sparse_schur --steps 2 --warmup 1
 run final13682_cluster_tridiagonal --eta 1e-2 --preconditioner cluster_tridiagonal --steps 2 --warmup 1
 run dubrovnik356_dense_schur --workload dubrovnik356 --solver dense_schur --steps 5 --warmup 2
 for c in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --pmc $c --kernel-trace --output-format csv -d $OUT/pmc_$c -- python3 $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --steps 2 --warmup 1 > /dev/null 2> $OUT/pmc_$c.err
+  rocprofv3 --pmc $c --kernel-trace --output-format csv -d $OUT/pmc_$c -- python3 $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --no-sparse-schur --steps 2 --warmup 1 > /dev/null 2> $OUT/pmc_$c.err
   cp $(ls $OUT/pmc_$c/*/*counter_collection.csv | head -1) $OUT/pmc_$c.csv
   echo "pmc $c done"
 done
