@@ -43,3 +43,49 @@ base = out[0]
 for r in out:
     r["compute_speedup_vs_1"] = base["solve_ms"] / r["solve_ms"]
 print(json.dumps({"summary": [{k: (round(v, 3) if isinstance(v, float) else v) for k, v in r.items()} for r in out]}))
+
+# ---- SPARSE_SCHUR with the distributed tile-sparse factorisation (round 3): rank 0 of N = 1, 2, 4, 8 alone on the GPU.
+# The exchange step is replaced by a callback that leaves the buffers as they are, EXCEPT the one-time presence exchange of
+# the structure, which gets the true union of all ranks' S cells (computed here from the whole problem) -- so rank 0 holds the
+# real plan of an N-rank run (its own subtrees + the replicated top) and does a rank's real work: eliminating its points,
+# assembling, factoring its subtrees, factoring the top, the triangular solves.  The numbers it computes are NOT the solution
+# (the other ranks' contributions are missing); the times are a rank's compute times, without the collectives.
+import ctypes
+if "--sparse-schur" in sys.argv:
+    C, P = full.num_cameras, full.num_points
+    bs_full, _ = cx.bal.build_structure(full)
+    cr, cc, _, _ = cx.binding.schur_pair_lists_host(bs_full, P)
+    presence = np.zeros(C * C + 1)
+    presence[cr.astype(np.int64) * C + cc] = 1.0
+    lib = cx.load_library()
+    sparse_out = []
+    for n in (1, 2, 4, 8):
+        c2 = cx.Context(0)
+        if n > 1:
+            def raw_cb(dptr, count, _user, _c=c2):
+                if count == C * C + 1:
+                    lib.cx_memcpy_h2d(_c._h, ctypes.c_void_p(dptr), presence.ctypes.data_as(ctypes.c_void_p), ctypes.c_size_t(8 * (C * C + 1)))
+                return 0
+            c2._raw_cb = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p)(raw_cb)
+            assert lib.cx_context_set_comm_callback(c2._h, 0, n, c2._raw_cb, None) == 0
+        bounds = cx.bal.partition_points(full, n)
+        prob = full if n == 1 else cx.bal.shard(full, int(bounds[0]), int(bounds[1]))
+        ev, A, b, D, cost, eval_ms, upd = bench.lm_prepare_device(cx, c2, prob)
+        S = cx.Solver(c2, type=cx.SPARSE_SCHUR, num_eliminate_blocks=prob.num_points)
+        x = c2.empty(A.num_cols)
+        S.solve(A, b, D, x=x)
+        reps = []
+        for _ in range(3):
+            S.solve(A, b, D, x=x)
+            reps.append(S.timing())
+        tm = {k: float(np.median([r[k] for r in reps])) for k in reps[0]}
+        dist = cx.binding.sparse_cholesky_distribution_host(C, cr, cc, n)
+        rec = {"solver": "sparse_schur", "ranks": n, "residual_blocks_of_rank_0": int(prob.num_observations),
+               "eliminate_ms": tm["eliminate_ms"], "reduced_solve_ms": tm["reduced_solve_ms"], "back_substitute_ms": tm["back_substitute_ms"],
+               "device_total_ms": tm["total_ms"], "collectives_per_solve": tm["allreduce_calls"], "collective_bytes_per_solve": tm["allreduce_bytes"],
+               "tile_pair_updates_own_rank_0": int(dist["updates_per_rank"][0]), "tile_pair_updates_replicated": int(dist["updates_replicated"]),
+               "tiles_replicated": int(dist["tiles_replicated"])}
+        sparse_out.append(rec)
+        print(json.dumps(rec), flush=True)
+        S.close(); ev.close(); c2.close()
+    print(json.dumps({"sparse_schur_summary": [{k: (round(v, 3) if isinstance(v, float) else v) for k, v in r.items()} for r in sparse_out]}))
