@@ -403,6 +403,11 @@ int cxm_matrix_create(cx_context* ctx, const cx_block_structure* bs, int32_t nel
   A->nnz = std::accumulate(part_nnz.begin(), part_nnz.end(), int64_t(0));
   A->is239 = true;
   for (cx_matrix* p : A->parts) A->is239 = A->is239 && p->is239;
+  if (!A->is239) {  // the sharded solvers exist for the native static layout only: say so now, not at the first solve
+    cxm_matrix_destroy(A);
+    cx_set_error("a multi-shard context takes matrices in the static <2,3,9> layout (BuildJacobianLayout) only");
+    return CX_ERR_UNSUPPORTED;
+  }
   cx_detect_structure(bs, nelim, &A->row_size, &A->e_size, &A->f_size);
   if (A->is239) {
     A->O = R;

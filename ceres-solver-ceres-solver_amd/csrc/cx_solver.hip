@@ -1475,7 +1475,12 @@ int cx_solver_solve(cx_solver* S, cx_matrix* A, const double* b, const cx_per_so
   };
   if (A->is239) {
     rc = solve_static(A, hb.dptr, hD.dptr, hx.dptr);
-  } else if (A->embed && ctx->nranks == 1) {
+  } else if (ctx->nranks > 1) {
+    // the sharded solvers (points over ranks, camera-space sums exchanged) exist for the native <2,3,9> layout only
+    cx_set_error("a sharded context solves matrices in the static <2,3,9> layout only (this one takes the %s path)",
+                 A->embed ? "embedded" : "dynamic-size");
+    rc = CX_ERR_UNSUPPORTED;
+  } else if (A->embed) {
     rc = cxe_solve(A, hb.dptr, hD.dptr, hx.dptr, solve_static);
   } else if (o.type == CX_ITERATIVE_SCHUR && o.use_explicit_schur_complement) {
     cx_set_error("use_explicit_schur_complement needs the static <2,3,9> layout");
