@@ -266,3 +266,45 @@ def test_distribution_of_the_tile_sparse_factorisation(C, P, O, seed):
         replicated_rows = int((owner < 0).sum())
         assert d["tiles_replicated"] == sum(start[i + 1] - start[i] for i in range(T) if owner[i] < 0)
         assert replicated_rows < T
+
+
+def test_ticket_reductions_keep_their_instruction_order():
+    """The fused reductions (cx_solver.hip: dot2_finish, cx_eval.hip: k_sum_partials) finish in the workgroup that draws the
+    last ticket.  Their ordering rests on instructions, not on a fence: the partial sums are stored with
+    agent-scope (sc1) stores that are COMPLETE (s_waitcnt vmcnt(0)) before the ticket atomic is issued, and the last workgroup
+    reads them with agent-scope (sc1) loads issued only after its own ticket atomic has returned (s_waitcnt vmcnt(0) behind
+    the returning atomic).  A compiler that reorders or weakens any of it would break the reductions silently on some
+    launches, so the gfx950 code objects of the build are disassembled and checked here, kernel by kernel.  No GPU."""
+    import subprocess
+    objdump = "/opt/rocm/lib/llvm/bin/llvm-objdump"
+    if not os.path.exists(objdump):
+        pytest.skip("llvm-objdump of the ROCm toolchain not found")
+    csrc = os.path.join(ROOT, "ceres-solver-ceres-solver_amd", "csrc")
+    checked = 0
+    for unit in ("cx_solver.o", "cx_eval.o"):
+        obj = os.path.join(csrc, unit)
+        assert os.path.exists(obj), "build first (__graft_entry__.build())"
+        subprocess.run([objdump, "--offloading", obj], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, check=False)
+        code = [f for f in os.listdir(csrc) if f.startswith(unit + ".") and "gfx950" in f]
+        try:
+            assert code, "no gfx950 code object in " + unit
+            asm = subprocess.run([objdump, "-d", os.path.join(csrc, code[0])], capture_output=True, text=True, check=True).stdout
+        finally:
+            for f in os.listdir(csrc):
+                if f.startswith(unit + "."):
+                    os.remove(os.path.join(csrc, f))
+        for fn in re.split(r"\n(?=[0-9a-f]{16} <)", asm):
+            name = fn.split(">:")[0]
+            ins = [l.split("//")[0].strip() for l in fn.splitlines()[1:] if l.strip()]
+            tickets = [i for i, l in enumerate(ins) if re.match(r"global_atomic_add(_u32)? v\d+,", l)]   # the returning ticket atomic
+            for t in tickets:
+                stores = [i for i in range(max(0, t - 60), t) if ins[i].startswith("global_store_dwordx2")]
+                if not stores:
+                    continue            # (an atomic add that is not a reduction's ticket)
+                assert all("sc1" in ins[i] for i in stores[-2:]), (name, [ins[i] for i in stores[-2:]])
+                assert any(ins[i].startswith("s_waitcnt vmcnt(0)") for i in range(stores[-1], t)), (name, "stores not complete before the ticket")
+                loads = [i for i in range(t + 1, min(len(ins), t + 120)) if ins[i].startswith("global_load_dwordx2") and "sc1" in ins[i]]
+                assert loads, (name, "the partial sums are not read with agent-scope loads")
+                assert any(ins[i].startswith("s_waitcnt vmcnt(0)") for i in range(t, loads[0])), (name, "loads issued before the ticket returned")
+                checked += 1
+    assert checked >= 5, checked     # k_dot2_fused, k_blockdiag9_dot, k_cam_reduce9_dot, k_update_xr_dot, k_sum_partials, ...
