@@ -59,6 +59,9 @@ def main(argv=None):
     ap.add_argument("--no_normalize", action="store_true", help="skip BALProblem::Normalize")
     ap.add_argument("--final_bal", help="write the optimised problem to this BAL file")
     ap.add_argument("--device", type=int, default=0)
+    ap.add_argument("--devices", help="comma separated device list: several shards behind one set of handles in this process "
+                                      "(cx_context_create_multi) -- distinct devices exchange through RCCL, a repeated id means "
+                                      "logical shards on that GPU, e.g. 0,0,0,0")
     args = ap.parse_args(argv)
     if bool(args.input) == bool(args.preset):
         ap.error("exactly one of --input / --preset")
@@ -71,14 +74,14 @@ def main(argv=None):
         if not args.no_normalize:
             prob = bal.normalize(prob)  # bundle_adjuster.cc:371
     else:
-        prob = bal.make_bal_like(*bal.PRESETS[args.preset])
+        prob = bal.make_preset(args.preset)
     if args.rotation_sigma or args.translation_sigma or args.point_sigma:
         prob = bal.perturb(prob, args.rotation_sigma, args.translation_sigma, args.point_sigma, args.random_seed)
     print("problem: %d cameras, %d points, %d observations (loaded in %.2f s)" %
           (prob.num_cameras, prob.num_points, prob.num_observations, time.time() - t0))
 
-    ctx = cx.Context(args.device)
-    print("device:", ctx.name)
+    ctx = cx.Context(devices=[int(d) for d in args.devices.split(",")]) if args.devices else cx.Context(args.device)
+    print("device:", ctx.name, "(%d shards)" % ctx.num_shards if args.devices else "")
     t0 = time.time()
     ev = cx.Evaluator(ctx, prob)
     if args.robustify:
