@@ -512,7 +512,13 @@ static void DestroySolverParts(cx_solver* S) {
 void cxm_solver_destroy(cx_solver* S) { DestroySolverParts(S); }
 
 static int EnsureSolverParts(cx_solver* S, const cx_matrix* A) {
-  if (!S->parts.empty() && S->parts_for == A) return CX_OK;
+  if (!S->parts.empty() && S->parts_for == A) {
+    // (the same address may belong to a NEW matrix with another cut: the shards' solvers are only good for the e-blocks
+    // they were created with)
+    bool same_cut = S->parts.size() == A->parts.size();
+    for (size_t i = 0; same_cut && i < S->parts.size(); ++i) same_cut = S->parts[i]->opt.num_eliminate_blocks == A->parts[i]->nelim;
+    if (same_cut) return CX_OK;
+  }
   DestroySolverParts(S);
   const int n = int(A->parts.size());
   S->parts.assign(size_t(n), nullptr);
