@@ -356,6 +356,8 @@ struct Generic {
   int mult(int sel, bool transpose, const double* x, double* y) {
     const int off = (sel == SEL_F) ? int(ne) : 0;
     if (g.R == 0) return CX_OK;
+    static const bool atomics = std::getenv("CX_GENERIC_ATOMICS") != nullptr;  // A/B switch: the scatter form with fp64 atomics
+    if (transpose && !atomics) return cxk_generic_left_multiply(A, sel, off, x, y);  // gather over the transposed index, fixed order
     if (transpose) hipLaunchKernelGGL(kg_mult_t, dim3(grid_for(g.R, 128)), dim3(128), 0, st, g, (const double*)A->d_values.p, x, y, sel, off);
     else hipLaunchKernelGGL(kg_mult, dim3(grid_for(g.R, 128)), dim3(128), 0, st, g, (const double*)A->d_values.p, x, y, sel, off);
     CX_HIP(hipGetLastError());

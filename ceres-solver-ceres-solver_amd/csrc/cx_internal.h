@@ -175,6 +175,17 @@ struct cx_matrix {
   std::vector<int64_t> blk_off;   // packed size^2 offsets of the column blocks, [Cb+1]
   DevBuf<int64_t> d_blk_off;
   bool generic_ready = false;
+  // transposed index of the dynamic-size structure (the reference's transpose block structure, block_sparse_matrix.cc:784-808):
+  // the cells of every column block in ascending row order -- what lets A'x be a gather with a fixed summation order instead
+  // of atomics (cx_matrix.hip: cxk_build_transpose)
+  // per entry: position of the cell's values, first scalar row of its row block, row block size | (1 << 8 for the e cell of
+  // an e-row); the column's entries are cut into segments of at most kTransposeSegment, one wavefront each
+  DevBuf<int32_t> d_t_pos, d_t_rp, d_t_meta;     // [cells]
+  DevBuf<int32_t> d_t_seg_begin, d_t_seg_col;    // [segments + 1], [segments]
+  DevBuf<int32_t> d_t_col_seg;                   // [Cb + 1] segments of every column block
+  DevBuf<double> d_t_partial;                    // [segments][16] partial sums of the columns that have several segments
+  int32_t num_t_segments = 0;
+  bool transpose_ready = false;
 
   // values
   DevBuf<double> d_values;
@@ -268,6 +279,10 @@ struct HostOrDevice {
 
 // ------------------------------------------------ kernels (cx_matrix.hip etc.)
 int cx_matrix_ensure_ft(cx_matrix* A);
+int cxk_build_transpose(cx_matrix* A);  // dynamic-size matrices: the transposed index above
+// y += A_sel' x over the transposed index (sel 0 all cells, 1 the e cell of every e-row, 2 the other cells; col_off is
+// subtracted from column positions): one wavefront per column block, fixed summation order, no atomics
+int cxk_generic_left_multiply(cx_matrix* A, int sel, int col_off, const double* x, double* y);
 int cx_matrix_ensure_f32(cx_matrix* A);
 
 // all of these enqueue on ctx->stream and work on device pointers

@@ -359,6 +359,60 @@ __global__ void kg_left(const cx_block* __restrict__ rows, const cx_block* __res
   }
 }
 
+// y += A_sel' x as a GATHER over the transposed index (round 3; the atomics form kg_left took 10 x the time of y += A x).
+// The entries of a column block (its cells in ascending row order) are cut into segments of at most kTransposeSegment; one
+// wavefront per segment: the 64 lanes form 64 / cs_pad groups of cs_pad lanes (cs_pad = the block's size rounded up to a
+// power of two), lane j of group g sums column j over the entries g, g + groups, ... of the segment, the group sums are
+// added by a fixed butterfly.  A column with one segment is finished there; the others leave a partial sum per segment and
+// kg_left_finish adds them in segment order.  No atomics, the same bits every time.
+constexpr int kTransposeSegment = 128;
+__global__ __launch_bounds__(256) void kg_left_gather(const cx_block* __restrict__ cols, const int32_t* __restrict__ seg_begin,
+                                                      const int32_t* __restrict__ seg_col, const int32_t* __restrict__ col_seg,
+                                                      const int32_t* __restrict__ t_pos, const int32_t* __restrict__ t_rp,
+                                                      const int32_t* __restrict__ t_meta, const double* __restrict__ values,
+                                                      const double* __restrict__ x, double* __restrict__ y, double* __restrict__ partial,
+                                                      int num_segments, int first_col, int end_col, int sel, int col_off) {
+  const int s = int(blockIdx.x) * 4 + int(threadIdx.x >> 6);
+  if (s >= num_segments) return;
+  const int cb = seg_col[s];
+  if (cb < first_col || cb >= end_col) return;
+  const int lane = threadIdx.x & 63;
+  const int cs = cols[cb].size;
+  int cs_pad = 1;
+  while (cs_pad < cs) cs_pad <<= 1;
+  const int groups = 64 / cs_pad, g = lane / cs_pad, j = lane - g * cs_pad;
+  double acc = 0.0;
+  if (j < cs) {
+    for (int k = seg_begin[s] + g; k < seg_begin[s + 1]; k += groups) {
+      const int meta = t_meta[k];
+      const bool is_e_cell = (meta >> 8) != 0;
+      if ((sel == 1 && !is_e_cell) || (sel == 2 && is_e_cell)) continue;
+      const int rs = meta & 0xff;
+      const double* m = values + t_pos[k] + j;
+      const double* xr = x + t_rp[k];
+      double sum = 0.0;
+      for (int i = 0; i < rs; ++i) sum += m[i * cs] * xr[i];
+      acc += sum;
+    }
+  }
+  for (int off = cs_pad; off < 64; off <<= 1) acc += __shfl_xor(acc, off, 64);
+  if (g == 0 && j < cs) {
+    if (col_seg[cb + 1] - col_seg[cb] == 1) y[cols[cb].position - col_off + j] += acc;
+    else partial[int64_t(s) * 16 + j] = acc;
+  }
+}
+__global__ void kg_left_finish(const cx_block* __restrict__ cols, const int32_t* __restrict__ col_seg, const double* __restrict__ partial,
+                               double* __restrict__ y, int first_col, int end_col, int col_off) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  const int cb = first_col + t / 16, j = t & 15;
+  if (cb >= end_col || j >= cols[cb].size) return;
+  const int s0 = col_seg[cb], s1 = col_seg[cb + 1];
+  if (s1 - s0 <= 1) return;
+  double v = 0.0;
+  for (int s = s0; s < s1; ++s) v += partial[int64_t(s) * 16 + j];
+  y[cols[cb].position - col_off + j] += v;
+}
+
 __global__ void kg_sqnorm(const cx_block* __restrict__ rows, const cx_block* __restrict__ cols,
                           const int32_t* __restrict__ rcb, const cx_cell* __restrict__ cells,
                           const double* __restrict__ values, double* __restrict__ x, int R) {
@@ -615,8 +669,12 @@ int cxk_left_multiply(cx_matrix* A, const double* x, double* y) {
                          A->d_tile_row.p, A->d_tile_pt.p, A->d_pt_start.p, x, y, 1, A->stop);
     CX_TRY(cxk_ft_multiply(A, x, y + 3 * int64_t(A->P), true));
   } else if (A->R > 0) {
-    hipLaunchKernelGGL(kg_left, dim3(grid_for(A->R, 128)), dim3(128), 0, st, A->d_rows.p, A->d_cols.p,
-                       A->d_rcb.p, A->d_cells.p, A->d_values.p, x, y, A->R, A->num_row_blocks_e, 0, 0);
+    static const bool atomics = std::getenv("CX_GENERIC_ATOMICS") != nullptr;  // A/B switch: round 1's scatter form
+    if (atomics)
+      hipLaunchKernelGGL(kg_left, dim3(grid_for(A->R, 128)), dim3(128), 0, st, A->d_rows.p, A->d_cols.p,
+                         A->d_rcb.p, A->d_cells.p, A->d_values.p, x, y, A->R, A->num_row_blocks_e, 0, 0);
+    else
+      CX_TRY(cxk_generic_left_multiply(A, 0, 0, x, y));
   }
   CX_HIP(hipGetLastError());
   return CX_OK;
@@ -662,6 +720,63 @@ int cxk_scale_columns(cx_matrix* A, const double* scale) {
     A->ft_valid = false;
   }
   A->f32_valid = false;
+  CX_HIP(hipGetLastError());
+  return CX_OK;
+}
+
+int cxk_build_transpose(cx_matrix* A) {
+  if (A->transpose_ready) return CX_OK;
+  const size_t ncells = A->cells.size();
+  std::vector<int32_t> start(size_t(A->Cb) + 1, 0), pos(ncells), rp(ncells), meta(ncells);
+  for (const cx_cell& c : A->cells) start[size_t(c.block_id) + 1]++;
+  for (int c = 0; c < A->Cb; ++c) start[size_t(c) + 1] += start[size_t(c)];
+  std::vector<int32_t> fill(start.begin(), start.end() - 1);
+  for (int r = 0; r < A->R; ++r)  // ascending rows: every column's cells come out in row order
+    for (int c = A->rcb[size_t(r)]; c < A->rcb[size_t(r) + 1]; ++c) {
+      const int32_t slot = fill[size_t(A->cells[size_t(c)].block_id)]++;
+      pos[size_t(slot)] = A->cells[size_t(c)].position;
+      rp[size_t(slot)] = A->rows[size_t(r)].position;
+      const bool is_e_cell = r < A->num_row_blocks_e && c == A->rcb[size_t(r)];
+      meta[size_t(slot)] = A->rows[size_t(r)].size | (is_e_cell ? 1 << 8 : 0);
+    }
+  std::vector<int32_t> seg_begin, seg_col, col_seg(size_t(A->Cb) + 1, 0);
+  for (int c = 0; c < A->Cb; ++c) {
+    col_seg[size_t(c)] = int32_t(seg_col.size());
+    for (int32_t k = start[size_t(c)]; k < start[size_t(c) + 1]; k += kTransposeSegment) {
+      seg_begin.push_back(k);
+      seg_col.push_back(c);
+    }
+  }
+  col_seg[size_t(A->Cb)] = int32_t(seg_col.size());
+  seg_begin.push_back(int32_t(ncells));
+  hipStream_t st = A->ctx->stream;
+  CX_TRY(A->d_t_pos.upload(pos, st));
+  CX_TRY(A->d_t_rp.upload(rp, st));
+  CX_TRY(A->d_t_meta.upload(meta, st));
+  CX_TRY(A->d_t_seg_begin.upload(seg_begin, st));
+  CX_TRY(A->d_t_seg_col.upload(seg_col, st));
+  CX_TRY(A->d_t_col_seg.upload(col_seg, st));
+  A->num_t_segments = int32_t(seg_col.size());
+  CX_TRY(A->d_t_partial.alloc(size_t(std::max(A->num_t_segments, 1)) * 16));
+  A->transpose_ready = true;
+  return CX_OK;
+}
+
+int cxk_generic_left_multiply(cx_matrix* A, int sel, int col_off, const double* x, double* y) {
+  if (A->R == 0 || A->Cb == 0) return CX_OK;
+  CX_TRY(cxk_build_transpose(A));
+  // sel 1: only the e-blocks' columns can receive anything, sel 2: only the f-blocks' (and every column of a matrix
+  // without e-blocks)
+  const int first = sel == 2 ? A->nelim : 0;
+  const int end = sel == 1 ? A->nelim : A->Cb;
+  if (end <= first || A->num_t_segments == 0) return CX_OK;
+  hipStream_t st = A->ctx->stream;
+  hipLaunchKernelGGL(kg_left_gather, dim3(unsigned((A->num_t_segments + 3) / 4)), dim3(256), 0, st, (const cx_block*)A->d_cols.p,
+                     (const int32_t*)A->d_t_seg_begin.p, (const int32_t*)A->d_t_seg_col.p, (const int32_t*)A->d_t_col_seg.p,
+                     (const int32_t*)A->d_t_pos.p, (const int32_t*)A->d_t_rp.p, (const int32_t*)A->d_t_meta.p, (const double*)A->d_values.p,
+                     x, y, A->d_t_partial.p, A->num_t_segments, first, end, sel, col_off);
+  hipLaunchKernelGGL(kg_left_finish, dim3(unsigned((int64_t(end - first) * 16 + 255) / 256)), dim3(256), 0, st, (const cx_block*)A->d_cols.p,
+                     (const int32_t*)A->d_t_col_seg.p, (const double*)A->d_t_partial.p, y, first, end, col_off);
   CX_HIP(hipGetLastError());
   return CX_OK;
 }
@@ -912,8 +1027,7 @@ static int PartitionedMultiply(cx_matrix* A, int part, bool transpose, const dou
         hipLaunchKernelGGL(kg_right, dim3(grid_for(A->R, 128)), dim3(128), 0, st, A->d_rows.p, A->d_cols.p, A->d_rcb.p,
                            A->d_cells.p, A->d_values.p, (const double*)hx.dptr, hy.dptr, A->R, A->num_row_blocks_e, part, off);
       else
-        hipLaunchKernelGGL(kg_left, dim3(grid_for(A->R, 128)), dim3(128), 0, st, A->d_rows.p, A->d_cols.p, A->d_rcb.p,
-                           A->d_cells.p, A->d_values.p, (const double*)hx.dptr, hy.dptr, A->R, A->num_row_blocks_e, part, off);
+        CX_TRY(cxk_generic_left_multiply(A, part, off, hx.dptr, hy.dptr));
     }
     CX_HIP(hipGetLastError());
     return CX_OK;
