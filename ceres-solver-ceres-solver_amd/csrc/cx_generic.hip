@@ -367,7 +367,9 @@ struct Generic {
   int block_diag_inverse(int sel, int first, int count, const double* D, double* blocks, bool allreduce) {
     const int64_t off0 = A->blk_off[first], total = A->blk_off[first + count] - off0;
     CX_TRY(zero(blocks, total));
-    if (g.R) hipLaunchKernelGGL(kg_block_diag, dim3(grid_for(g.R, 128)), dim3(128), 0, st, g, (const double*)A->d_values.p,
+    static const bool atomics = std::getenv("CX_GENERIC_ATOMICS") != nullptr;  // A/B switch
+    if (g.R && !atomics) CX_TRY(cxk_generic_block_diagonal(A, sel, first, count, off0, blocks));  // gather over the transposed index
+    else if (g.R) hipLaunchKernelGGL(kg_block_diag, dim3(grid_for(g.R, 128)), dim3(128), 0, st, g, (const double*)A->d_values.p,
                                 (const int64_t*)A->d_blk_off.p, off0, blocks, sel);
     if (allreduce && ctx->nranks > 1) CX_TRY(cx_allreduce_device(ctx, blocks, total));
     if (count) hipLaunchKernelGGL(kg_blockdiag_invert, dim3(grid_for(count, 64)), dim3(64), 0, st, (const cx_block*)A->d_cols.p,

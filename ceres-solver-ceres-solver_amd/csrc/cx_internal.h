@@ -184,6 +184,7 @@ struct cx_matrix {
   DevBuf<int32_t> d_t_seg_begin, d_t_seg_col;    // [segments + 1], [segments]
   DevBuf<int32_t> d_t_col_seg;                   // [Cb + 1] segments of every column block
   DevBuf<double> d_t_partial;                    // [segments][16] partial sums of the columns that have several segments
+  DevBuf<double> d_t_partial_blocks;             // [segments][256] the same for the block diagonal
   int32_t num_t_segments = 0;
   bool transpose_ready = false;
 
@@ -283,6 +284,9 @@ int cxk_build_transpose(cx_matrix* A);  // dynamic-size matrices: the transposed
 // y += A_sel' x over the transposed index (sel 0 all cells, 1 the e cell of every e-row, 2 the other cells; col_off is
 // subtracted from column positions): one wavefront per column block, fixed summation order, no atomics
 int cxk_generic_left_multiply(cx_matrix* A, int sel, int col_off, const double* x, double* y);
+// blocks[blk_off[c] - off0 ..] = sum over the selected cells of column block c of cell' cell, for c in [first, first + count):
+// the block diagonal of A_sel' A_sel over the same transposed index (overwrites; fixed order, no atomics)
+int cxk_generic_block_diagonal(cx_matrix* A, int sel, int first, int count, int64_t off0, double* blocks);
 int cx_matrix_ensure_f32(cx_matrix* A);
 
 // all of these enqueue on ctx->stream and work on device pointers

@@ -724,6 +724,61 @@ int cxk_scale_columns(cx_matrix* A, const double* scale) {
   return CX_OK;
 }
 
+// The block diagonal of A_sel' A_sel over the transposed index: one wavefront per segment, lane l owns the entries l, l + 64,
+// ... of the cs x cs block and walks the segment's cells in row order; single-segment columns are written directly, the
+// others through per-segment partial blocks summed in segment order (kg_blockdiag_finish).
+__global__ __launch_bounds__(256) void kg_blockdiag_gather(const cx_block* __restrict__ cols, const int32_t* __restrict__ seg_begin,
+                                                           const int32_t* __restrict__ seg_col, const int32_t* __restrict__ col_seg,
+                                                           const int32_t* __restrict__ t_pos, const int32_t* __restrict__ t_meta,
+                                                           const double* __restrict__ values, const int64_t* __restrict__ blk_off,
+                                                           int64_t off0, double* __restrict__ blocks, double* __restrict__ partial,
+                                                           int num_segments, int first_col, int end_col, int sel) {
+  const int s = int(blockIdx.x) * 4 + int(threadIdx.x >> 6);
+  if (s >= num_segments) return;
+  const int cb = seg_col[s];
+  if (cb < first_col || cb >= end_col) return;
+  const int lane = threadIdx.x & 63;
+  const int cs = cols[cb].size, n = cs * cs;
+  double acc[4] = {0.0, 0.0, 0.0, 0.0};  // cs <= 16: at most four entries per lane
+  for (int k = seg_begin[s]; k < seg_begin[s + 1]; ++k) {
+    const int meta = t_meta[k];
+    const bool is_e_cell = (meta >> 8) != 0;
+    if ((sel == 1 && !is_e_cell) || (sel == 2 && is_e_cell)) continue;
+    const int rs = meta & 0xff;
+    const double* m = values + t_pos[k];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int e = lane + 64 * q;
+      if (e < n) {
+        const int a = e / cs, b = e - a * cs;
+        double sum = 0.0;
+        for (int i = 0; i < rs; ++i) sum += m[i * cs + a] * m[i * cs + b];
+        acc[q] += sum;
+      }
+    }
+  }
+  const bool single = col_seg[cb + 1] - col_seg[cb] == 1;
+  double* out = single ? blocks + (blk_off[cb] - off0) : partial + int64_t(s) * 256;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int e = lane + 64 * q;
+    if (e < n) out[e] = acc[q];
+  }
+}
+__global__ void kg_blockdiag_finish(const cx_block* __restrict__ cols, const int32_t* __restrict__ col_seg, const double* __restrict__ partial,
+                                    const int64_t* __restrict__ blk_off, int64_t off0, double* __restrict__ blocks, int first_col, int end_col) {
+  const int cb = first_col + int(blockIdx.x);
+  if (cb >= end_col) return;
+  const int s0 = col_seg[cb], s1 = col_seg[cb + 1];
+  const int cs = cols[cb].size, n = cs * cs;
+  if (s1 - s0 == 1) return;
+  for (int e = threadIdx.x; e < n; e += blockDim.x) {
+    double v = 0.0;
+    for (int s = s0; s < s1; ++s) v += partial[int64_t(s) * 256 + e];
+    blocks[blk_off[cb] - off0 + e] = v;  // (a column without cells: zero)
+  }
+}
+
 int cxk_build_transpose(cx_matrix* A) {
   if (A->transpose_ready) return CX_OK;
   const size_t ncells = A->cells.size();
@@ -777,6 +832,23 @@ int cxk_generic_left_multiply(cx_matrix* A, int sel, int col_off, const double* 
                      x, y, A->d_t_partial.p, A->num_t_segments, first, end, sel, col_off);
   hipLaunchKernelGGL(kg_left_finish, dim3(unsigned((int64_t(end - first) * 16 + 255) / 256)), dim3(256), 0, st, (const cx_block*)A->d_cols.p,
                      (const int32_t*)A->d_t_col_seg.p, (const double*)A->d_t_partial.p, y, first, end, col_off);
+  CX_HIP(hipGetLastError());
+  return CX_OK;
+}
+
+int cxk_generic_block_diagonal(cx_matrix* A, int sel, int first, int count, int64_t off0, double* blocks) {
+  if (count <= 0) return CX_OK;
+  CX_TRY(cxk_build_transpose(A));
+  CX_TRY(A->d_t_partial_blocks.alloc(size_t(std::max(A->num_t_segments, 1)) * 256));
+  hipStream_t st = A->ctx->stream;
+  if (A->num_t_segments > 0)
+    hipLaunchKernelGGL(kg_blockdiag_gather, dim3(unsigned((A->num_t_segments + 3) / 4)), dim3(256), 0, st, (const cx_block*)A->d_cols.p,
+                       (const int32_t*)A->d_t_seg_begin.p, (const int32_t*)A->d_t_seg_col.p, (const int32_t*)A->d_t_col_seg.p,
+                       (const int32_t*)A->d_t_pos.p, (const int32_t*)A->d_t_meta.p, (const double*)A->d_values.p,
+                       (const int64_t*)A->d_blk_off.p, off0, blocks, A->d_t_partial_blocks.p, A->num_t_segments, first, first + count, sel);
+  hipLaunchKernelGGL(kg_blockdiag_finish, dim3(unsigned(count)), dim3(64), 0, st, (const cx_block*)A->d_cols.p,
+                     (const int32_t*)A->d_t_col_seg.p, (const double*)A->d_t_partial_blocks.p, (const int64_t*)A->d_blk_off.p, off0, blocks,
+                     first, first + count);
   CX_HIP(hipGetLastError());
   return CX_OK;
 }

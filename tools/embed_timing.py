@@ -1,4 +1,7 @@
-import sys; sys.path.insert(0,'tests')
+"""Products and a 20-iteration ITERATIVE_SCHUR solve of a <2,3,6> problem (400 cameras, 500 k observations) through the embedded static
+image, beside the native <2,3,9> problem on the same visibility; CX_NO_EMBEDDING=1: the dynamic-size path."""
+import os, sys
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', 'tests'))
 import conftest, numpy as np
 cx=conftest.cx
 ctx=cx.Context(0)
@@ -8,7 +11,6 @@ O, P, C = prob.num_observations, prob.num_points, prob.num_cameras
 rows = [(2, [(int(bs9.cells["block_id"][2 * r]), 6 * r), (int(bs9.cells["block_id"][2 * r + 1]), 6 * O + 12 * r)]) for r in range(O)]
 bs6 = cx.BlockStructure.from_rows([3] * P + [6] * C, rows)
 rng = np.random.default_rng(1)
-import os
 for name, bs, nnz in (("239", bs9, 24 * O), ("236", bs6, 18 * O)):
     A = cx.Matrix(ctx, bs, P); A.set_values(rng.standard_normal(nnz))
     x = rng.standard_normal(bs.num_cols); y = rng.standard_normal(bs.num_rows)
