@@ -1369,7 +1369,10 @@ __global__ __launch_bounds__(kBlock) void k_row_h(const double* __restrict__ E, 
 
 // k_pair_items_staged on the one-table operands: per pair 14 + 14 sixteen-byte pieces (8 of the row's H0 line, 6 of its H1
 // line, for the left row and for the right row), staged one step ahead; sum of H_ri' H_rj over the item's pairs.
-__global__ __launch_bounds__(kBlock) void k_pair_items_h(const int32_t* __restrict__ pair_rows, const int64_t* __restrict__ item_begin,
+#ifndef CX_PAIR_H_OCCUPANCY
+#define CX_PAIR_H_OCCUPANCY 5
+#endif
+__global__ __launch_bounds__(kBlock, CX_PAIR_H_OCCUPANCY) void k_pair_items_h(const int32_t* __restrict__ pair_rows, const int64_t* __restrict__ item_begin,
                                                          const int32_t* __restrict__ item_ids, const double* __restrict__ h0,
                                                          const double* __restrict__ h1, double* __restrict__ item_partial,
                                                          int num_launch_items) {
@@ -1381,27 +1384,29 @@ __global__ __launch_bounds__(kBlock) void k_pair_items_h(const int32_t* __restri
   const int64_t item = item_ids ? int64_t(item_ids[slot]) : int64_t(slot);
   const int64_t p0 = item_begin[item], p1 = item_begin[item + 1];
   const int steps = int((p1 - p0 + kPairGroups - 1) / kPairGroups);
-  int pg[4], dst[4], off[4], sel[4];  // sel: bit 0 = H1 (else H0), bit 1 = right operand (else left)
+  // the (up to four) pieces this thread moves per step, packed: pair slot g (bits 0-4, 31 = none), offset in the source line
+  // in doubles (5-8), source array H1 (9), right operand (10), place in the staging buffer in doubles (11-22)
+  int piece[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int q = tid + i * kBlock;
     const int g = q / 28, w = q - g * 28;
     const int operand = w / 14, pc = w - operand * 14;
-    pg[i] = q < kPairPieces ? g : -1;
-    sel[i] = 2 * operand + (pc < 8 ? 0 : 1);
-    off[i] = pc < 8 ? 2 * pc : 2 * (pc - 8);
-    dst[i] = (g * 2 + operand) * kPairOperand + 2 * pc;
+    const int off = pc < 8 ? 2 * pc : 2 * (pc - 8);
+    const int dst = (g * 2 + operand) * kPairOperand + 2 * pc;
+    piece[i] = (q < kPairPieces ? g : 31) | (off << 5) | ((pc < 8 ? 0 : 1) << 9) | (operand << 10) | (dst << 11);
   }
 #define CX_PAIR_ROW(i, step, out)                                                                     \
   do {                                                                                                \
-    const int64_t k_ = p0 + int64_t(step) * kPairGroups + pg[i];                                      \
-    out = (pg[i] >= 0 && k_ < p1) ? pair_rows[2 * k_ + (sel[i] >> 1)] : -1;                           \
+    const int g_ = piece[i] & 31;                                                                     \
+    const int64_t k_ = p0 + int64_t(step) * kPairGroups + g_;                                         \
+    out = (g_ != 31 && k_ < p1) ? pair_rows[2 * k_ + ((piece[i] >> 10) & 1)] : -1;                    \
   } while (0)
 #define CX_PAIR_FETCH(i, row, out)                                                                    \
   do {                                                                                                \
-    const double* base_ = (sel[i] & 1) ? h1 : h0;                                                     \
+    const double* base_ = ((piece[i] >> 9) & 1) ? h1 : h0;                                            \
     out = (row) < 0 ? make_double2(0.0, 0.0)                                                          \
-                    : *reinterpret_cast<const double2*>(base_ + 16 * int64_t(row) + off[i]);         \
+                    : *reinterpret_cast<const double2*>(base_ + 16 * int64_t(row) + ((piece[i] >> 5) & 15)); \
   } while (0)
   int32_t rows_next[4];
   double2 v[4];
@@ -1423,7 +1428,7 @@ __global__ __launch_bounds__(kBlock) void k_pair_items_h(const int32_t* __restri
     double* buf = lds + (s & 1) * kStage;
 #pragma unroll
     for (int i = 0; i < 4; ++i)
-      if (pg[i] >= 0) *reinterpret_cast<double2*>(buf + dst[i]) = v[i];
+      if ((piece[i] & 31) != 31) *reinterpret_cast<double2*>(buf + (piece[i] >> 11)) = v[i];
     __syncthreads();
     if (s + 1 < steps) {
 #pragma unroll
@@ -1437,20 +1442,16 @@ __global__ __launch_bounds__(kBlock) void k_pair_items_h(const int32_t* __restri
     if (g < kPairGroups && p0 + int64_t(s) * kPairGroups + g < p1) {
       const double* Hl = buf + (g * 2) * kPairOperand;
       const double* Hr = Hl + kPairOperand;
-      double B[9], G[9];
+      // one row of the two 3 x 9 operands at a time (six values live instead of eighteen: the kernel's occupancy is set by
+      // its registers, and it lives on the number of scattered line fetches it keeps in flight)
 #pragma unroll
-      for (int i = 0; i < 3; ++i) {
-        B[i] = Hl[a0 + i];
-        B[3 + i] = Hl[9 + a0 + i];
-        B[6 + i] = Hl[18 + a0 + i];
-        G[i] = Hr[c0 + i];
-        G[3 + i] = Hr[9 + c0 + i];
-        G[6 + i] = Hr[18 + c0 + i];
+      for (int q = 0; q < 3; ++q) {
+        const double b0 = Hl[9 * q + a0], b1 = Hl[9 * q + a0 + 1], b2 = Hl[9 * q + a0 + 2];
+        const double g0 = Hr[9 * q + c0], g1 = Hr[9 * q + c0 + 1], g2 = Hr[9 * q + c0 + 2];
+        acc[0] += b0 * g0; acc[1] += b0 * g1; acc[2] += b0 * g2;
+        acc[3] += b1 * g0; acc[4] += b1 * g1; acc[5] += b1 * g2;
+        acc[6] += b2 * g0; acc[7] += b2 * g1; acc[8] += b2 * g2;
       }
-#pragma unroll
-      for (int i = 0; i < 3; ++i)
-#pragma unroll
-        for (int j = 0; j < 3; ++j) acc[i * 3 + j] += (B[i] * G[j] + B[3 + i] * G[3 + j]) + B[6 + i] * G[6 + j];
     }
   }
   __syncthreads();  // the staging buffers become the groups' partial sums
