@@ -451,6 +451,14 @@ __global__ __launch_bounds__(256, kWgPerCu) void k_sp_update_slices(double* __re
   subtract_block(acc, dst, 32, 32, (flags & 1) && qi == qj);
 }
 
+// (Round 3 A/B, not kept: ONE WAVEFRONT per target tile -- the whole 64 x 64 in 128 accumulator registers, each source tile
+// loaded once per product (64 instead of 128 KB), four targets of one tile row per workgroup, two wavefronts per SIMD.  Per
+// level, tools/sparse_levels.sh: 24 ns per product on the wide levels against 18.5 (reduced solve 46.3 against 38.2 ms at
+// window 1, 35.3 against 32.2 at window 4) and 25 instead of 11 us for a lone target: with 32 MFMAs behind one slice of
+// loads and two wavefronts on a SIMD the loads are not hidden.  And the wide levels are no longer where the time is: with
+// chains (CX_SPARSE_WINDOW) they run at 12-15 ns per product, and what the chip SUSTAINS in fp64 MFMAs is 10.9 ns
+// (48 TFLOP/s, tools/mfma_peak.hip).)
+
 // Backward substitution of a level (top down), part 1: workgroup = one tile F(I, J) right of the diagonal of a row of
 // the level: partial[tile][r] = sum_c F(I, J)[r][c] x_J[c].
 __global__ __launch_bounds__(256) void k_sp_bwd_partial(const double* __restrict__ W, const int32_t* __restrict__ row_tiles,
@@ -1094,6 +1102,42 @@ void BuildHostPlan(int C, const int32_t* cell_c1, const int32_t* cell_c2, int64_
     }
   }
   lpb[size_t(L)] = int32_t(panel_row.size());
+  // WHEN a product runs.  The contribution of row I to the tile (Ja, Jb) may be subtracted after any level from I's own up
+  // to the one before Ja's.  Right after I's level (a right-looking schedule) nearly every target of a launch has ONE source
+  // (1.06 on the Final shape), and such a workgroup is a dispatch, an index chain, the target's read-modify-write and a
+  // drain around 1.7 us of products (see k_sp_update).  So a target's contributions are collected over a window of
+  // `window` levels and subtracted by one workgroup as one chain of sources (the operands of the next source are requested
+  // behind the current products, the target is read and written once per chain): the window opens at the target's first
+  // pending source level l0 and closes at min(l0 + window - 1, level(Ja) - 1) -- per target, so the closing levels are spread
+  // evenly instead of spiking every `window` levels.  window = 1 is the right-looking schedule, a large window the
+  // left-looking one (everything just in time, which leaves the narrow top levels with long serial chains).  A distributed
+  // plan closes every window of own levels before the exchange of the replicated tiles.
+  // Measured (tools/sparse_window_ab.sh, reduced solve, Final shape / second scene): window 1: 38.5 / 111.2 ms, 4: 32.2 / 81.8,
+  // 8: 34.4 / 82.7, 16: 39.9 / 92.0, 64: 73.3 / 157.2.  Per level (tools/sparse_levels.sh): the wide levels go from 18.5 to
+  // 12-15 ns per product (the sustained fp64 MFMA rate is 10.9), the target's 64 KB of read-modify-write being shared by a
+  // chain; longer windows leave the same rate on the wide levels and serial chains of 16-32 sources on the narrow ones.
+  {
+    int window = 4;
+    if (const char* e = std::getenv("CX_SPARSE_WINDOW")) window = std::max(1, std::atoi(e));
+    if (window > 1) {
+      std::vector<int32_t> row_of_slot(static_cast<size_t>(num_tiles));
+      for (int J = 0; J < T; ++J)
+        for (int32_t q = row_start[size_t(J)]; q < row_start[size_t(J) + 1]; ++q) row_of_slot[size_t(q)] = J;
+      std::sort(srcs.begin(), srcs.end(), [](const Src& x, const Src& y) {
+        return x.tgt != y.tgt ? x.tgt < y.tgt : (x.level != y.level ? x.level < y.level : x.row < y.row);
+      });
+      const int32_t split = distributed ? tree_levels : 0;
+      size_t i = 0;
+      while (i < srcs.size()) {
+        const int32_t tq = srcs[i].tgt, l0 = srcs[i].level;
+        int32_t close = std::min<int32_t>(l0 + window - 1, vlevel[size_t(row_of_slot[size_t(tq)])] - 1);
+        if (l0 < split) close = std::min<int32_t>(close, split - 1);
+        size_t j = i;
+        while (j < srcs.size() && srcs[j].tgt == tq && srcs[j].level <= close) srcs[j++].level = close;
+        i = j;
+      }
+    }
+  }
   std::sort(srcs.begin(), srcs.end(), [](const Src& x, const Src& y) {
     return x.level != y.level ? x.level < y.level : (x.tgt != y.tgt ? x.tgt < y.tgt : x.row < y.row);
   });
@@ -1118,6 +1162,15 @@ void BuildHostPlan(int C, const int32_t* cell_c1, const int32_t* cell_c2, int64_
     }
     while (level < L) ltb[size_t(++level)] = int32_t(tgt_pool.size());
     src_begin.push_back(int32_t(srcs.size()));
+  }
+  if (std::getenv("CX_SPARSE_PLAN_STATS") != nullptr) {  // per level: rows, panel tiles, update targets, products, longest chain
+    for (int l = 0; l < L; ++l) {
+      int32_t longest = 0;
+      for (int32_t t = ltb[size_t(l)]; t < ltb[size_t(l) + 1]; ++t) longest = std::max(longest, src_begin[size_t(t) + 1] - src_begin[size_t(t)]);
+      const int32_t t0 = ltb[size_t(l)], t1 = ltb[size_t(l) + 1];
+      std::fprintf(stderr, "cxsp level %d rows %d panels %d targets %d products %d longest %d\n", l, lrb[size_t(l) + 1] - lrb[size_t(l)],
+                   lpb[size_t(l) + 1] - lpb[size_t(l)], t1 - t0, t1 > t0 ? src_begin[size_t(t1)] - src_begin[size_t(t0)] : 0, longest);
+    }
   }
   // transposed index for forward solves with the stored factor: the tiles (K < I, I) of tile column I, ascending K
   std::vector<int32_t>&col_start = H->col_start, &col_pool = H->col_pool;
