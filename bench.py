@@ -186,6 +186,9 @@ def main():
                     choices=["jacobi", "schur_jacobi", "identity", "cluster_jacobi", "cluster_tridiagonal"])
     ap.add_argument("--mixed", action="store_true", help="CG products on fp32 copies of the J values: CGNR (BASELINE config 5) or ITERATIVE_SCHUR; "
                                                      "fp64 accumulation, vectors, set-up and back substitution")
+    ap.add_argument("--refinements", type=int, default=0,
+                    help="max_num_refinement_iterations (solver.h:587-590): with --solver dense_schur / sparse_schur, fp64 refinement steps "
+                         "after the reduced solve; with --mixed there the factorisation is single precision (fp32 tile pool)")
     ap.add_argument("--explicit-schur", action="store_true",
                     help="ITERATIVE_SCHUR on the explicitly computed block-sparse S (Solver::Options::"
                          "use_explicit_schur_complement, solver.h:518-540); needs --preconditioner schur_jacobi")
@@ -264,7 +267,7 @@ def main():
              "cluster_tridiagonal": cx.CLUSTER_TRIDIAGONAL}[args.preconditioner]
     solver_kw = dict(type=stype, preconditioner_type=ptype, num_eliminate_blocks=prob.num_points,
                      max_num_iterations=500, min_num_iterations=0, residual_reset_period=10,
-                     use_mixed_precision_solves=1 if args.mixed else 0,
+                     use_mixed_precision_solves=1 if args.mixed else 0, max_num_refinement_iterations=args.refinements,
                      use_explicit_schur_complement=1 if args.explicit_schur else 0)
     S = cx.Solver(ctx, **solver_kw)
     x = ctx.empty(A.num_cols)
@@ -416,7 +419,7 @@ def main():
         out = {
             "metric": "linear_solve_ms_per_iter", "value": ms_per_step, "unit": "ms",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
-            "higher_is_better": False, "scaling": "strong", "vs_baseline": None, "dtype": "f64 (J values stored fp32)" if args.mixed else "f64", "data": "synthetic",
+            "higher_is_better": False, "scaling": "strong", "vs_baseline": None, "dtype": ("f64" if not args.mixed else "f64 (S factored in fp32, %d fp64 refinement steps)" % args.refinements if args.solver in ("dense_schur", "sparse_schur") else "f64 (J values stored fp32)"), "data": "synthetic",
             "config": {"workload": "%s: %s%s + %s, q_tol=%g, synthetic BAL-shaped J "
                                    "(%d cameras, %d points, %d residual blocks)" % (args.workload, args.solver.upper(),
                                                                                    " (explicit S)" if args.explicit_schur else "",

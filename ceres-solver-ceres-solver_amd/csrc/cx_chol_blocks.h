@@ -25,7 +25,9 @@ __device__ __forceinline__ double readlane_f64(double v, int l) {
 // Second half of the diagonal-block routines below: U (upper, row-major, zeros below the diagonal) and 1 / diag(U) are in
 // LDS (lds[r * NB + c], lds[NB * NB + j]); store U into the factor and form U^-1 (see potrf_inverse_block).
 // uinv_lds (optional, NB * NB doubles of LDS outside `lds`): a second copy of the inverse for a caller that goes on to use it.
-__device__ __forceinline__ void potrf_tail(double* __restrict__ Fblk, int ldf, int kb, double* __restrict__ uinv, double* __restrict__ lds,
+// TF: the scalar type the factor is stored in (double; float for the fp32 tile pool of use_mixed_precision_solves)
+template <typename TF>
+__device__ __forceinline__ void potrf_tail(TF* __restrict__ Fblk, int ldf, int kb, double* __restrict__ uinv, double* __restrict__ lds,
                                            double* __restrict__ uinv_lds = nullptr) {
   const int lane = threadIdx.x & 63;
   // (single wavefront: its LDS writes are ordered before its LDS reads, no barrier needed)
@@ -34,7 +36,7 @@ __device__ __forceinline__ void potrf_tail(double* __restrict__ Fblk, int ldf, i
   for (int it = 0; it < NB / 2; ++it) {
     const int r = 2 * it + (lane >> 5), c = lane & 31;
     const double v = lds[r * NB + c];
-    if (r < kb && c < kb && c >= r) Fblk[size_t(r) * ldf + c] = v;
+    if (r < kb && c < kb && c >= r) Fblk[size_t(r) * ldf + c] = TF(v);
   }
   // V = U^-1 by blocks of 16: U = [U11 U12; 0 U22]  =>  V = [V11  -V11 U12 V22; 0  V22].
   //  * V11 and V22 side by side: lanes 0-15 own the columns of V11, lanes 16-31 those of V22 (16 registers each),
@@ -273,7 +275,8 @@ __device__ __forceinline__ void potrf_core_mfma(double4_t (&T)[2][2], int* __res
 // The block is handed over IN REGISTERS (C layout, tile (1, 0) ignored; entries outside the kb x kb block and below the
 // diagonal must hold the padding: unit diagonal, zeros) -- for a caller that has just computed it (the look-ahead of a
 // step kernel: no store, fence and reload between the trailing update and the next factorisation).
-__device__ __forceinline__ void potrf_inverse_regs(double4_t (&T)[2][2], double* __restrict__ Fblk, int ldf, int kb,
+template <typename TF>
+__device__ __forceinline__ void potrf_inverse_regs(double4_t (&T)[2][2], TF* __restrict__ Fblk, int ldf, int kb,
                                                    double* __restrict__ uinv, int* __restrict__ not_pd, double* __restrict__ lds,
                                                    double* __restrict__ uinv_lds = nullptr) {
   potrf_core_mfma(T, not_pd, lds);

@@ -113,6 +113,11 @@ struct cx_sp_plan {
   DevBuf<int32_t> d_tgt_pool, d_tgt_flags, d_src_begin, d_src_a, d_src_b;
   DevBuf<int32_t> d_col_start, d_col_pool;  // transposed index: the tiles (K < I, I) of tile column I, ascending K (forward solves)
   DevBuf<double> d_W, d_x;                  // tile pool (factored in place); vectors, block inverses, partial products
+  // use_mixed_precision_solves: the pool is kept (and factored) in single precision, d_W32 instead of d_W; the caller sets f32
+  // before cxsp_assemble / cxsp_factor_and_solve*, vectors and the 32 x 32 block inverses stay double
+  bool f32 = false;
+  bool replicate = false;  // sharded: keep the whole factor on every rank (refinement solves need cxsp_solve), see cxsp_build_plan_sharded
+  DevBuf<float> d_W32;
   // sharded matrix (points over ranks): the plan is built from the UNION of the ranks' S cells; a rank scatters its own
   // cell values into the common cell-major array, which is summed over the ranks and assembled into the pool
   int64_t num_union_cells = 0;

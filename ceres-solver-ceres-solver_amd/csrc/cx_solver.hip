@@ -746,6 +746,15 @@ struct ExplicitSchurOp : LinOp {
   }
 };
 
+// residual = rhs - (S z), the D_f^2 z term of S added here (iterative_refiner.cc:60-63)
+__global__ void k_refine_residual(const double* __restrict__ rhs, const double* __restrict__ sz, const double* __restrict__ Df,
+                                  const double* __restrict__ z, double* __restrict__ out, int64_t n) {
+  const int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const double d = Df ? Df[i] : 0.0;
+  out[i] = rhs[i] - (sz[i] + d * d * z[i]);
+}
+
 __global__ void k_axpy1(double* __restrict__ y, const double* __restrict__ x, int64_t n) {
   const int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
   if (i < n) y[i] += x[i];
@@ -1243,6 +1252,11 @@ int SolveSparseSchur239(cx_solver* S, cx_matrix* A, const double* b, const doubl
   summary->num_iterations = 1;
   summary->termination_type = CX_SUCCESS;
   std::snprintf(summary->message, sizeof(summary->message), "Success.");
+  // use_mixed_precision_solves: S is assembled from fp64 values into a SINGLE PRECISION tile pool and factored there
+  // (FloatSuiteSparseCholesky / CudaSparseCholesky<float>, sparse_cholesky.cc:53-100; cx_sparse_chol.hip, k_sp_update_f32)
+  const bool mixed = S->opt.use_mixed_precision_solves != 0;
+  const int refinements = std::max(0, S->opt.max_num_refinement_iterations);
+  A->sp.f32 = mixed;
   if (sharded) CX_TRY(cxsp_factor_and_solve_sharded(A, D ? D + ne : nullptr, S->v_rhs.p, z, S->flag.p));
   else CX_TRY(cxsp_factor_and_solve(A, D ? D + ne : nullptr, S->v_rhs.p, z, S->flag.p));
   bool failed = false;
@@ -1250,7 +1264,30 @@ int SolveSparseSchur239(cx_solver* S, cx_matrix* A, const double* b, const doubl
   if (failed) {
     summary->num_iterations = 1;
     CX_HIP(hipMemsetAsync(z, 0, size_t(nf) * sizeof(double), st));  // not the NaNs of the failed factorisation
+  } else if (refinements > 0 && nf > 0) {
+    // RefinedSparseCholesky::Solve -> SparseIterativeRefiner::Refine (sparse_cholesky.cc:148-160, iterative_refiner.cc:53-72),
+    // with either factor, as the reference wraps either: residual = rhs - S z in fp64, z += factor^-1 residual, a fixed
+    // number of times.  S z is the implicit product of ITERATIVE_SCHUR (chunk pass + camera-major pass on the fp64 J and the
+    // (E'E + D_e^2)^-1 the elimination left behind): S itself is not kept beside its factor.
+    CX_TRY(S->v_rows.alloc(size_t(A->num_rows)));
+    CX_TRY(S->v_p.alloc(nf));
+    CX_TRY(S->v_tmp.alloc(nf));
+    const double* Df = D ? D + ne : nullptr;
+    for (int it = 0; it < refinements; ++it) {
+      CX_TRY(cxs_chunk_pass(A, 0, A->d_elim_ete.p, z, nullptr, S->v_rows.p));
+      CX_TRY(cxk_ft_multiply(A, S->v_rows.p, S->v_tmp.p, false));
+      if (sharded) CX_TRY(cx_allreduce_device(ctx, S->v_tmp.p, nf));
+      hipLaunchKernelGGL(k_refine_residual, dim3(grid_for(nf, 256)), dim3(256), 0, st, (const double*)S->v_rhs.p, (const double*)S->v_tmp.p, Df,
+                         (const double*)z, S->v_p.p, nf);
+      CX_HIP(hipGetLastError());
+      CX_TRY(cxsp_solve(ctx, &A->sp, S->v_p.p, S->v_tmp.p));
+      hipLaunchKernelGGL(k_axpy1, dim3(grid_for(nf, 256)), dim3(256), 0, st, z, (const double*)S->v_tmp.p, nf);
+    }
+    CX_HIP(hipGetLastError());
   }
+  if (!failed && (mixed || refinements > 0))
+    std::snprintf(summary->message, sizeof(summary->message), "Success. (%s factorisation, %d refinement step%s)",
+                  mixed ? "single precision" : "double precision", refinements, refinements == 1 ? "" : "s");
   CX_TRY(sw.stop(&S->timing.reduced_solve_ms));
   CX_TRY(sw.start());
   if (summary->termination_type == CX_SUCCESS) CX_TRY(cxs_chunk_pass(A, 2, A->d_elim_ete.p, z, b, x));
@@ -1262,23 +1299,23 @@ int SolveDenseSchur239(cx_solver* S, cx_matrix* A, const double* b, const double
   cx_context* ctx = S->ctx;
   hipStream_t st = ctx->stream;
   const int64_t nf = 9 * int64_t(A->C), ne = 3 * int64_t(A->P);
-  if (S->opt.type == CX_SPARSE_SCHUR) {
+  // use_mixed_precision_solves / max_num_refinement_iterations (solver.h:572-590; DenseCholesky::Create, dense_cholesky.cc:84-136,
+  // SparseCholesky::Create, sparse_cholesky.cc:45-118): the single precision factorisation and the solves with a stored factor
+  // that refinement needs live in the tile code (cx_sparse_chol.hip), so either option sends DENSE_SCHUR and SPARSE_SCHUR of any
+  // size there -- for a dense S the plan simply holds every tile.
+  const bool wants_tiles = S->opt.use_mixed_precision_solves != 0 || S->opt.max_num_refinement_iterations > 0;
+  if (S->opt.type == CX_SPARSE_SCHUR || wants_tiles) {
     // tile-sparse factorisation when it stores less than half of the dense upper triangle, or when the dense
     // matrix (and its working copy) would not be reasonable any more; small problems stay dense (fewer steps).
     // On a sharded matrix the plan comes from the union of the ranks' cells, so every rank decides the same.
-    const bool forced = std::getenv("CX_SPARSE_CHOLESKY") != nullptr;
+    const bool forced = std::getenv("CX_SPARSE_CHOLESKY") != nullptr || wants_tiles;
     if (forced || A->C >= kSparseCholeskyMinCameras) {
+      A->sp.replicate = S->opt.max_num_refinement_iterations > 0;
       if (ctx->nranks > 1) CX_TRY(cxsp_build_plan_sharded(A));
       else CX_TRY(cxsp_build_plan(A));
       if (A->sp.state == 1) {
         const int64_t T = A->sp.T, dense_tiles = T * (T + 1) / 2 + T;
-        if (forced || 2 * A->sp.num_tiles <= dense_tiles || A->C >= kDenseSchurMaxCameras) {
-          CX_TRY(SolveSparseSchur239(S, A, b, D, x, summary));
-          if (S->opt.use_mixed_precision_solves && summary->termination_type == CX_SUCCESS)  // (see the end of this function)
-            std::snprintf(summary->message, sizeof(summary->message),
-                          "Success. (use_mixed_precision_solves: the device factorisation runs in fp64; no refinement needed)");
-          return CX_OK;
-        }
+        if (forced || 2 * A->sp.num_tiles <= dense_tiles || A->C >= kDenseSchurMaxCameras) return SolveSparseSchur239(S, A, b, D, x, summary);
       }
     }
   }
@@ -1328,14 +1365,10 @@ int SolveDenseSchur239(cx_solver* S, cx_matrix* A, const double* b, const double
     CX_TRY(cxs_chunk_pass(A, 2, S->ete_inv.p, z, b, x));
   }
   CX_TRY(sw.stop(&S->timing.back_substitute_ms));
-  // use_mixed_precision_solves asks the reference for an fp32 factorisation + max_num_refinement_iterations steps of fp64
-  // refinement (dense_cholesky.cc:582-645, sparse_cholesky.cc:135-165, iterative_refiner.cc).  The factorisations here stay
-  // in fp64 -- at least the accuracy that mode delivers, with nothing to refine: they are bound by the chain of 32 x 32
-  // diagonal blocks (dense) and by level launches (tile-sparse), not by the flops an fp32 factor would halve (DESIGN.md
-  // section 8).  The option is honoured in that sense, and the summary says so instead of leaving the caller guessing.
-  if (S->opt.use_mixed_precision_solves && summary->termination_type == CX_SUCCESS)
+  // (reached with use_mixed_precision_solves / refinement only when no tile plan could be built for this structure)
+  if (wants_tiles && summary->termination_type == CX_SUCCESS)
     std::snprintf(summary->message, sizeof(summary->message),
-                  "Success. (use_mixed_precision_solves: the device factorisation runs in fp64; no refinement needed)");
+                  "Success. (no tile plan for this structure: double precision dense factorisation, no refinement)");
   return CX_OK;
 }
 

@@ -32,6 +32,7 @@
 #include <cstdlib>
 #include <queue>
 #include <string>
+#include <type_traits>
 
 #include "cx_chol_blocks.h"
 #include "cx_internal.h"
@@ -55,13 +56,16 @@ __device__ __forceinline__ int tile_find(const int32_t* __restrict__ row_tiles, 
   return lo;
 }
 
+// The kernels below are templates on TW, the scalar type of the tile pool: double, or float for the single precision
+// factorisation of use_mixed_precision_solves (see k_sp_update_f32).
 // S cells (gather assembly of cx_schur.hip) -> tile pool at the permuted positions; 81 threads per cell
+template <typename TW>
 __global__ __launch_bounds__(3 * 81) void k_sp_assemble(const int32_t* __restrict__ cell_c1, const int32_t* __restrict__ cell_c2,
                                                         const int32_t* __restrict__ cell_item_start,
                                                         const double* __restrict__ item_partial, const double* __restrict__ diag,
                                                         const double* __restrict__ Df, const int32_t* __restrict__ cam_pos,
                                                         const int32_t* __restrict__ row_start, const int32_t* __restrict__ row_tiles,
-                                                        double* __restrict__ W, int64_t num_cells,
+                                                        TW* __restrict__ W, int64_t num_cells,
                                                         const int32_t* __restrict__ sel_cells, const int32_t* __restrict__ sel_offdiag,
                                                         double offdiag_scale) {
   // sel_cells != NULL: only these cells of the list (a visibility based preconditioner keeps a subset of S), the ones
@@ -87,24 +91,26 @@ __global__ __launch_bounds__(3 * 81) void k_sp_assemble(const int32_t* __restric
   if (row > col) return;                                                 // lower half of a diagonal cell
   const int I = row >> 6, J = col >> 6;
   const int idx = tile_find(row_tiles, row_start[I], row_start[I + 1], J);
-  W[size_t(idx) * kTileDoubles + (row & 63) * kTile + (col & 63)] = v;
+  W[size_t(idx) * kTileDoubles + (row & 63) * kTile + (col & 63)] = TW(v);
 }
 
 // right-hand side (camera order) -> column 0 of every tile row's last tile
+template <typename TW>
 __global__ void k_sp_rhs(const double* __restrict__ rhs, const int32_t* __restrict__ cam_pos, const int32_t* __restrict__ row_start,
-                         double* __restrict__ W, int C) {
+                         TW* __restrict__ W, int C) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= 9 * C) return;
   const int c = i / 9, a = i - 9 * c;
   const int row = cam_pos[c] + a;
   const int I = row >> 6;
-  W[size_t(row_start[I + 1] - 1) * kTileDoubles + (row & 63) * kTile] = rhs[i];
+  W[size_t(row_start[I + 1] - 1) * kTileDoubles + (row & 63) * kTile] = TW(rhs[i]);
 }
 
 // out[m] = sum_c M[m][c] v[c] for a 32 x 32 block, 8 threads per row.  In two halves, so that a kernel can request the
 // matrix entries of all its products up front (they do not depend on the vectors) and only the LDS-resident vectors are
 // left on its chain of dependent steps.
-__device__ __forceinline__ void sp_gemv32_load(const double* __restrict__ M, int ldm, int rows_valid, int cols_valid, double (&a)[4]) {
+template <typename TM>
+__device__ __forceinline__ void sp_gemv32_load(const TM* __restrict__ M, int ldm, int rows_valid, int cols_valid, double (&a)[4]) {
   const int t = threadIdx.x, m = t >> 3, part = t & 7;
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
@@ -135,7 +141,8 @@ __device__ __forceinline__ void sp_gemv32(const double* __restrict__ M, int ldm,
 // forward-substituted right-hand side in column 0).
 
 // X (see cxchol::panel_x) -> rows of a tile: X[m][c], m < kb, c < ncols
-__device__ __forceinline__ void store_rows(const double4_t (&X)[2][2], double* __restrict__ dst, int kb, int ncols) {
+template <typename TW>
+__device__ __forceinline__ void store_rows(const double4_t (&X)[2][2], TW* __restrict__ dst, int kb, int ncols) {
   const int lane = threadIdx.x & 63, li = lane & 15, lk = lane >> 4;
 #pragma unroll
   for (int mt = 0; mt < 2; ++mt)
@@ -144,13 +151,14 @@ __device__ __forceinline__ void store_rows(const double4_t (&X)[2][2], double* _
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         const int m = 16 * mt + lk + 4 * g, c = 16 * nt + li;
-        if (m < kb && c < ncols) dst[size_t(m) * kTile + c] = X[mt][nt][g];
+        if (m < kb && c < ncols) dst[size_t(m) * kTile + c] = TW(X[mt][nt][g]);
       }
 }
 
 // a 32 x 32 block of a tile in the operand layout of the trailing update (register g of tile (mt, nt) of lane l is
 // element [16 mt + (l >> 4) + 4 g][16 nt + (l & 15)]); rows >= kb and columns >= ncols read as zero
-__device__ __forceinline__ void load_operand(const double* __restrict__ src, int kb, int ncols, double4_t (&X)[2][2]) {
+template <typename TW>
+__device__ __forceinline__ void load_operand(const TW* __restrict__ src, int kb, int ncols, double4_t (&X)[2][2]) {
   const int lane = threadIdx.x & 63, li = lane & 15, lk = lane >> 4;
 #pragma unroll
   for (int mt = 0; mt < 2; ++mt)
@@ -197,7 +205,8 @@ __device__ __forceinline__ void load_aop(const double* __restrict__ uinv, double
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt) aop[s][mt] = uinv[(4 * s + lk) * NB + 16 * mt + li];
 }
-__device__ __forceinline__ void load_bop(const double* __restrict__ Wrow, int kb, int ncols, double (&bop)[8][2]) {
+template <typename TW>
+__device__ __forceinline__ void load_bop(const TW* __restrict__ Wrow, int kb, int ncols, double (&bop)[8][2]) {
   const int lane = threadIdx.x & 63, li = lane & 15, lk = lane >> 4;
 #pragma unroll
   for (int s = 0; s < 8; ++s)
@@ -224,13 +233,14 @@ __device__ __forceinline__ void solve_x(const double (&aop)[8][2], const double 
 // U12 = U11^-T A12; A22 -= U12' U12; U22 = chol(A22) and its inverse.  The whole tile is requested up front and the chain
 // runs in registers (the 32 x 32 routine takes and leaves its block in the MFMA C layout, U11^-1 stays in LDS for the
 // panel product): one memory round trip instead of the four of a store / wait / reload between the stages (27 -> ... us).
-__global__ __launch_bounds__(64) void k_sp_diag(double* __restrict__ W, const int32_t* __restrict__ row_start,
+template <typename TW>
+__global__ __launch_bounds__(64) void k_sp_diag(TW* __restrict__ W, const int32_t* __restrict__ row_start,
                                                 const int32_t* __restrict__ level_rows, const int32_t* __restrict__ valid,
                                                 double* __restrict__ uinv, int* __restrict__ not_pd) {
   __shared__ double lds[cxchol::kPotrfLds];
   __shared__ double inv1[NB * NB];
   const int I = level_rows[blockIdx.x];
-  double* D = W + size_t(row_start[I]) * kTileDoubles;
+  TW* D = W + size_t(row_start[I]) * kTileDoubles;
   const int kb1 = min(NB, valid[I]), kb2 = max(0, min(NB, valid[I] - NB));
   double* ui1 = uinv + size_t(2 * I) * NB * NB;
   const int lane = threadIdx.x & 63, li = lane & 15, lk = lane >> 4;
@@ -276,7 +286,7 @@ __global__ __launch_bounds__(64) void k_sp_diag(double* __restrict__ W, const in
         const int r = 16 * a + 4 * g + lk, c = 16 * b + li;
         if (r < kb2 && c < kb2 && c >= r) T2[a][b][g] -= acc[a][b][g];
       }
-  double* D22 = D + size_t(NB) * kTile + NB;
+  TW* D22 = D + size_t(NB) * kTile + NB;
   cxchol::potrf_inverse_regs(T2, D22, kTile, kb2, ui1 + NB * NB, not_pd, lds);
 }
 
@@ -285,7 +295,8 @@ __global__ __launch_bounds__(64) void k_sp_diag(double* __restrict__ W, const in
 // Everything the chain needs is requested up front (both inverses, U12, both halves of the tile): the result registers
 // of U12' X1 have the layout of the next product's B operand, so W2 - U12' X1 never leaves the registers -- one
 // memory round trip per tile.
-__global__ __launch_bounds__(128) void k_sp_panel(double* __restrict__ W, const int32_t* __restrict__ row_start,
+template <typename TW>
+__global__ __launch_bounds__(128) void k_sp_panel(TW* __restrict__ W, const int32_t* __restrict__ row_start,
                                                   const int32_t* __restrict__ row_tiles, const int32_t* __restrict__ panel_row,
                                                   const int32_t* __restrict__ panel_pool, const int32_t* __restrict__ valid, int T,
                                                   const double* __restrict__ uinv) {
@@ -294,8 +305,8 @@ __global__ __launch_bounds__(128) void k_sp_panel(double* __restrict__ W, const 
   const int wave = threadIdx.x >> 6;
   const int ncols = (J < T) ? max(0, min(32, valid[J] - 32 * wave)) : (wave == 0 ? 1 : 0);
   if (ncols <= 0) return;
-  double* Wt = W + size_t(q) * kTileDoubles + 32 * wave;
-  const double* D = W + size_t(row_start[I]) * kTileDoubles;
+  TW* Wt = W + size_t(q) * kTileDoubles + 32 * wave;
+  const TW* D = W + size_t(row_start[I]) * kTileDoubles;
   const int kb1 = min(NB, valid[I]), kb2 = max(0, min(NB, valid[I] - NB));
   const double* ui1 = uinv + size_t(2 * I) * NB * NB;
   double a1[8][2], a2[8][2], w1[8][2], w2[8][2];
@@ -451,6 +462,80 @@ __global__ __launch_bounds__(256, kWgPerCu) void k_sp_update_slices(double* __re
   subtract_block(acc, dst, 32, 32, (flags & 1) && qi == qj);
 }
 
+// The update on a SINGLE PRECISION pool (use_mixed_precision_solves: "the Gauss-Newton matrix is computed in double precision,
+// but its factorization is computed in single precision", solver.h:572-585; FloatSuiteSparseCholesky / CudaSparseCholesky<float>,
+// sparse_cholesky.cc:53-100): v_mfma_f32_16x16x4_f32 on float operands, float accumulators, the target read and written as
+// floats.  Half the bytes of every operand and target, and the instruction occupies its SIMD for 32 cycles instead of the 64
+// nominal / 105 sustained of the fp64 one.  Same workgroup shape as k_sp_update_slices (wavefront = 32 x 32 quadrant, slices
+// of the 64-row K dimension requested one ahead).  A lane loads two ADJACENT columns of a source row as one 8-byte load
+// (16 lanes = one 128-byte line), so MFMA tile `a` of the quadrant holds the columns 2 i + a, not 16 a + i: the result
+// register g of tile (a, b) of lane (li, lk) is the target element [2 (4 lk + g) + a][2 li + b] of the quadrant, and the two
+// column tiles of a row go out as one 8-byte store.  The diagonal and panel kernels keep their fp64 register chains on the
+// float pool (they are latency chains of 32 x 32 blocks, not flops; their results are rounded once, on the store).
+typedef float float4_t __attribute__((ext_vector_type(4)));
+typedef float float2_t __attribute__((ext_vector_type(2)));
+template <int kSteps, int kWgPerCu>
+__global__ __launch_bounds__(256, kWgPerCu) void k_sp_update_f32(float* __restrict__ W, const int32_t* __restrict__ tgt_pool,
+                                                                 const int32_t* __restrict__ tgt_flags, const int32_t* __restrict__ src_begin,
+                                                                 const int32_t* __restrict__ src_a, const int32_t* __restrict__ src_b) {
+  constexpr int kSlices = 16 / kSteps;  // per source: 64 rows of K
+  const int t = blockIdx.x;
+  const int wave = threadIdx.x >> 6;
+  const int qi = wave >> 1, qj = wave & 1;
+  const int flags = tgt_flags[t];
+  if ((flags & 1) && qi == 1 && qj == 0) return;
+  if ((flags & 2) && qj == 1) return;
+  const int lane = threadIdx.x & 63, li = lane & 15, lk = lane >> 4;
+  float4_t acc[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b) acc[a][b] = float4_t{0.f, 0.f, 0.f, 0.f};
+  const int s0 = src_begin[t], s1 = src_begin[t + 1];
+  const int nq = kSlices * (s1 - s0);
+  float2_t A[kSteps], B[kSteps], An[kSteps], Bn[kSteps];
+#define CX_SP_REQUEST(q, a, b)                                                                                         \
+  do {                                                                                                                 \
+    const int s_ = s0 + (q) / kSlices;                                                                                 \
+    const size_t row_ = size_t(4 * kSteps * ((q) % kSlices) + lk) * kTile + 2 * li;                                   \
+    const float* pb_ = W + size_t(src_b[s_]) * kTileDoubles + 32 * qj + row_;                                         \
+    const float* pa_ = W + size_t(src_a[s_]) * kTileDoubles + 32 * qi + row_;                                         \
+    _Pragma("unroll") for (int g = 0; g < kSteps; ++g) b[g] = *reinterpret_cast<const float2_t*>(pb_ + size_t(4 * g) * kTile); \
+    _Pragma("unroll") for (int g = 0; g < kSteps; ++g) a[g] = *reinterpret_cast<const float2_t*>(pa_ + size_t(4 * g) * kTile); \
+  } while (0)
+  if (nq > 0) CX_SP_REQUEST(0, A, B);
+  for (int q = 0; q < nq; ++q) {
+    if (q + 1 < nq) CX_SP_REQUEST(q + 1, An, Bn);
+#pragma unroll
+    for (int g = 0; g < kSteps; ++g) {
+      acc[0][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(A[g].x, B[g].x, acc[0][0], 0, 0, 0);
+      acc[0][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(A[g].x, B[g].y, acc[0][1], 0, 0, 0);
+      acc[1][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(A[g].y, B[g].x, acc[1][0], 0, 0, 0);
+      acc[1][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(A[g].y, B[g].y, acc[1][1], 0, 0, 0);
+    }
+#pragma unroll
+    for (int g = 0; g < kSteps; ++g) { A[g] = An[g]; B[g] = Bn[g]; }
+  }
+#undef CX_SP_REQUEST
+  float* dst = W + size_t(tgt_pool[t]) * kTileDoubles + size_t(32 * qi) * kTile + 32 * qj;
+  const bool upper_only = (flags & 1) && qi == qj;
+  float2_t cur[2][4];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) cur[a][g] = *reinterpret_cast<const float2_t*>(dst + size_t(8 * lk + 2 * g + a) * kTile + 2 * li);
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int i = 8 * lk + 2 * g + a, j = 2 * li;
+      float2_t v = cur[a][g];
+      if (!upper_only || j >= i) v.x -= acc[a][0][g];
+      if (!upper_only || j + 1 >= i) v.y -= acc[a][1][g];
+      *reinterpret_cast<float2_t*>(dst + size_t(i) * kTile + j) = v;
+    }
+}
+
 // (Round 3 A/B, not kept: ONE WAVEFRONT per target tile -- the whole 64 x 64 in 128 accumulator registers, each source tile
 // loaded once per product (64 instead of 128 KB), four targets of one tile row per workgroup, two wavefronts per SIMD.  Per
 // level, tools/sparse_levels.sh: 24 ns per product on the wide levels against 18.5 (reduced solve 46.3 against 38.2 ms at
@@ -461,14 +546,15 @@ __global__ __launch_bounds__(256, kWgPerCu) void k_sp_update_slices(double* __re
 
 // Backward substitution of a level (top down), part 1: workgroup = one tile F(I, J) right of the diagonal of a row of
 // the level: partial[tile][r] = sum_c F(I, J)[r][c] x_J[c].
-__global__ __launch_bounds__(256) void k_sp_bwd_partial(const double* __restrict__ W, const int32_t* __restrict__ row_tiles,
+template <typename TW>
+__global__ __launch_bounds__(256) void k_sp_bwd_partial(const TW* __restrict__ W, const int32_t* __restrict__ row_tiles,
                                                         const int32_t* __restrict__ panel_pool, const int32_t* __restrict__ valid, int T,
                                                         const double* __restrict__ x, double* __restrict__ partial) {
   const int q = panel_pool[blockIdx.x];
   const int J = row_tiles[q];
   if (J >= T) return;  // the right-hand-side tile
   const int t = threadIdx.x, r = t >> 2, part = t & 3;
-  const double* __restrict__ row = W + size_t(q) * kTileDoubles + size_t(r) * kTile + 16 * part;
+  const TW* __restrict__ row = W + size_t(q) * kTileDoubles + size_t(r) * kTile + 16 * part;
   const double* __restrict__ xj = x + size_t(kTile) * J + 16 * part;
   const int nvalid = valid[J] - 16 * part;
   double s = 0.0;
@@ -481,7 +567,8 @@ __global__ __launch_bounds__(256) void k_sp_bwd_partial(const double* __restrict
 
 // ... part 2: workgroup = tile row I: y_I (column 0 of the row's last tile) minus the partial sums of its tiles in
 // ascending order, then the 64 x 64 triangular solve with the kept inverses (x2 = U22^-1 y2, x1 = U11^-1 (y1 - U12 x2)).
-__global__ __launch_bounds__(256) void k_sp_bwd_level(const double* __restrict__ W, const int32_t* __restrict__ row_start,
+template <typename TW>
+__global__ __launch_bounds__(256) void k_sp_bwd_level(const TW* __restrict__ W, const int32_t* __restrict__ row_start,
                                                       const int32_t* __restrict__ level_rows, const int32_t* __restrict__ valid,
                                                       const double* __restrict__ uinv, const double* __restrict__ partial,
                                                       double* __restrict__ x, int y_in_x) {
@@ -493,7 +580,7 @@ __global__ __launch_bounds__(256) void k_sp_bwd_level(const double* __restrict__
   const int k0 = kTile * I;
   const int kb1 = min(NB, valid[I]), kb2 = max(0, min(NB, valid[I] - NB));
   const int q0 = row_start[I], q1 = row_start[I + 1] - 1;  // [q0] diagonal tile, [q1] right-hand-side tile
-  const double* __restrict__ D = W + size_t(q0) * kTileDoubles;
+  const TW* __restrict__ D = W + size_t(q0) * kTileDoubles;
   const double* __restrict__ ui1 = uinv + size_t(2 * I) * NB * NB;
   // the entries of the three 32 x 32 products are requested before the row's partial sums are gathered: five dependent
   // steps of global-memory latency per level become two
@@ -530,7 +617,8 @@ __global__ __launch_bounds__(256) void k_sp_bwd_level(const double* __restrict__
 
 // out[m] = sum_c M[c][m] v[c] (the transposed 32 x 32 block), 8 threads per output: the load half (the apply half is
 // sp_gemv32_apply)
-__device__ __forceinline__ void sp_gemv32_t_load(const double* __restrict__ M, int ldm, int rows_valid, int cols_valid, double (&a)[4]) {
+template <typename TM>
+__device__ __forceinline__ void sp_gemv32_t_load(const TM* __restrict__ M, int ldm, int rows_valid, int cols_valid, double (&a)[4]) {
   const int t = threadIdx.x, m = t >> 3, part = t & 7;
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
@@ -542,7 +630,8 @@ __device__ __forceinline__ void sp_gemv32_t_load(const double* __restrict__ M, i
 // Forward substitution U' y = r with a stored factor, by levels bottom up.  Part 1, workgroup = tile row I of the level:
 // r_I minus the partial products of the tiles of COLUMN I (rows K < I, all of lower levels, ascending K), then
 // y1 = U11^-T v1, y2 = U22^-T (v2 - U12' y1) with the kept inverses.  y holds r on entry and y on exit.
-__global__ __launch_bounds__(256) void k_sp_fwd_level(const double* __restrict__ W, const int32_t* __restrict__ row_start,
+template <typename TW>
+__global__ __launch_bounds__(256) void k_sp_fwd_level(const TW* __restrict__ W, const int32_t* __restrict__ row_start,
                                                       const int32_t* __restrict__ level_rows, const int32_t* __restrict__ valid,
                                                       const double* __restrict__ uinv, const int32_t* __restrict__ col_start,
                                                       const int32_t* __restrict__ col_pool, const double* __restrict__ partial,
@@ -552,7 +641,7 @@ __global__ __launch_bounds__(256) void k_sp_fwd_level(const double* __restrict__
   const int t = threadIdx.x;
   const int k0 = kTile * I;
   const int kb1 = min(NB, valid[I]), kb2 = max(0, min(NB, valid[I] - NB));
-  const double* __restrict__ D = W + size_t(row_start[I]) * kTileDoubles;
+  const TW* __restrict__ D = W + size_t(row_start[I]) * kTileDoubles;
   const double* __restrict__ ui1 = uinv + size_t(2 * I) * NB * NB;
   double a11[4], a12[4], a22[4];  // (requested before the partial sums are gathered, see k_sp_bwd_level)
   sp_gemv32_t_load(ui1, NB, NB, NB, a11);
@@ -588,7 +677,8 @@ __global__ __launch_bounds__(256) void k_sp_fwd_level(const double* __restrict__
 
 // ... part 2, workgroup = one tile F(K, J) right of the diagonal of a row K of the level: partial[tile][c] =
 // sum_r F(K, J)[r][c] y_K[r], gathered later by tile row J.
-__global__ __launch_bounds__(256) void k_sp_fwd_partial(const double* __restrict__ W, const int32_t* __restrict__ row_tiles,
+template <typename TW>
+__global__ __launch_bounds__(256) void k_sp_fwd_partial(const TW* __restrict__ W, const int32_t* __restrict__ row_tiles,
                                                         const int32_t* __restrict__ panel_row, const int32_t* __restrict__ panel_pool,
                                                         int T, const double* __restrict__ y, double* __restrict__ partial) {
   __shared__ double red[4][kTile];
@@ -596,7 +686,7 @@ __global__ __launch_bounds__(256) void k_sp_fwd_partial(const double* __restrict
   if (row_tiles[q] >= T) return;  // the right-hand-side tile
   const int K = panel_row[blockIdx.x];
   const int t = threadIdx.x, c = t & 63, part = t >> 6;
-  const double* __restrict__ F = W + size_t(q) * kTileDoubles + size_t(16 * part) * kTile + c;
+  const TW* __restrict__ F = W + size_t(q) * kTileDoubles + size_t(16 * part) * kTile + c;
   const double* __restrict__ yk = y + size_t(kTile) * K + 16 * part;
   double s = 0.0;
 #pragma unroll
@@ -1271,6 +1361,22 @@ namespace {
 // layout of plan->d_x: [T * 64] vector in the padded elimination order | two inverted 32 x 32 diagonal blocks per tile row |
 // [tiles][64] partial products of the sweeps
 struct Scratch { double *xp, *uinv, *partial; };
+// f(pool pointer) with the pool in its scalar type (see cx_sp_plan::f32)
+template <typename F>
+int WithPool(cx_sp_plan* P, F&& f) {
+  return P->f32 ? f(P->d_W32.p) : f(P->d_W.p);
+}
+int AllocPool(cx_sp_plan* P, hipStream_t st) {
+  const size_t pool = size_t(P->num_tiles) * kTileDoubles;
+  if (P->f32) {
+    CX_TRY(P->d_W32.alloc(pool));
+    CX_HIP(hipMemsetAsync(P->d_W32.p, 0, pool * sizeof(float), st));
+  } else {
+    CX_TRY(P->d_W.alloc(pool));
+    CX_HIP(hipMemsetAsync(P->d_W.p, 0, pool * sizeof(double), st));
+  }
+  return CX_OK;
+}
 int GetScratch(cx_sp_plan* P, Scratch* s) {
   const size_t npad = size_t(P->T) * kTile;
   CX_TRY(P->d_x.alloc(npad + 2 * size_t(P->T) * NB * NB + size_t(P->num_tiles) * kTile));
@@ -1286,28 +1392,32 @@ int GetScratch(cx_sp_plan* P, Scratch* s) {
 int cxsp_assemble(cx_matrix* A, cx_sp_plan* P, const double* Df, const int32_t* sel_cells, const int32_t* sel_offdiag, int64_t num_sel,
                   double offdiag_scale) {
   hipStream_t st = A->ctx->stream;
-  const size_t pool = size_t(P->num_tiles) * kTileDoubles;
-  CX_TRY(P->d_W.alloc(pool));
-  CX_HIP(hipMemsetAsync(P->d_W.p, 0, pool * sizeof(double), st));
+  CX_TRY(AllocPool(P, st));
   const int64_t count = sel_cells ? num_sel : A->num_cells;
   if (count > 0)
-    hipLaunchKernelGGL(k_sp_assemble, dim3(unsigned((count + 2) / 3)), dim3(3 * 81), 0, st, (const int32_t*)A->d_cell_c1.p,
-                       (const int32_t*)A->d_cell_c2.p, (const int32_t*)A->d_cell_item_start.p, (const double*)A->d_item_partial.p,
-                       (const double*)A->d_elim_diag.p, Df, (const int32_t*)P->d_cam_pos.p, (const int32_t*)P->d_row_start.p,
-                       (const int32_t*)P->d_row_tiles.p, P->d_W.p, count, sel_cells, sel_offdiag, offdiag_scale);
+    CX_TRY(WithPool(P, [&](auto* W) -> int {
+      using TW = std::remove_pointer_t<decltype(W)>;
+      hipLaunchKernelGGL(k_sp_assemble<TW>, dim3(unsigned((count + 2) / 3)), dim3(3 * 81), 0, st, (const int32_t*)A->d_cell_c1.p,
+                         (const int32_t*)A->d_cell_c2.p, (const int32_t*)A->d_cell_item_start.p, (const double*)A->d_item_partial.p,
+                         (const double*)A->d_elim_diag.p, Df, (const int32_t*)P->d_cam_pos.p, (const int32_t*)P->d_row_start.p,
+                         (const int32_t*)P->d_row_tiles.p, W, count, sel_cells, sel_offdiag, offdiag_scale);
+      return CX_OK;
+    }));
   CX_HIP(hipGetLastError());
   return CX_OK;
 }
 
 namespace {
 // ---- distributed factorisation: the exchange at the split and its helpers
-__global__ void k_sp_zero_tiles(double* __restrict__ W, const int32_t* __restrict__ tiles, int64_t n) {
+template <typename TW>
+__global__ void k_sp_zero_tiles(TW* __restrict__ W, const int32_t* __restrict__ tiles, int64_t n) {
   const int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
   if (i >= n * kTileDoubles) return;
-  W[int64_t(tiles[i / kTileDoubles]) * kTileDoubles + (i % kTileDoubles)] = 0.0;
+  W[int64_t(tiles[i / kTileDoubles]) * kTileDoubles + (i % kTileDoubles)] = TW(0);
 }
 // dir 0: pool -> packed (and the flag into the last slot), 1: packed -> pool (and the summed flag back)
-__global__ void k_sp_pack_tiles(double* __restrict__ W, const int32_t* __restrict__ tiles, int64_t n, double* __restrict__ packed,
+template <typename TW>
+__global__ void k_sp_pack_tiles(TW* __restrict__ W, const int32_t* __restrict__ tiles, int64_t n, double* __restrict__ packed,
                                 int* __restrict__ flag, int dir) {
   const int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
   if (i == n * kTileDoubles) {
@@ -1317,8 +1427,8 @@ __global__ void k_sp_pack_tiles(double* __restrict__ W, const int32_t* __restric
   }
   if (i > n * kTileDoubles) return;
   const int64_t w = int64_t(tiles[i / kTileDoubles]) * kTileDoubles + (i % kTileDoubles);
-  if (dir == 0) packed[i] = W[w];
-  else W[w] = packed[i];
+  if (dir == 0) packed[i] = double(W[w]);
+  else W[w] = TW(packed[i]);
 }
 __global__ void k_sp_mask_rows(double* __restrict__ xp, const int32_t* __restrict__ keep, int64_t n) {
   const int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
@@ -1332,24 +1442,30 @@ int ExchangeSharedTiles(cx_context* ctx, cx_sp_plan* P, int* d_flag) {
   hipStream_t st = ctx->stream;
   const int64_t n = P->num_shared_tiles, count = n * kTileDoubles + 1;
   CX_TRY(P->d_exchange.alloc(size_t(count)));
-  hipLaunchKernelGGL(k_sp_pack_tiles, dim3(unsigned((count + 255) / 256)), dim3(256), 0, st, P->d_W.p, (const int32_t*)P->d_shared_tiles.p, n,
-                     P->d_exchange.p, d_flag, 0);
-  CX_HIP(hipGetLastError());
-  CX_TRY(cx_allreduce_device(ctx, P->d_exchange.p, count));
-  hipLaunchKernelGGL(k_sp_pack_tiles, dim3(unsigned((count + 255) / 256)), dim3(256), 0, st, P->d_W.p, (const int32_t*)P->d_shared_tiles.p, n,
-                     P->d_exchange.p, d_flag, 1);
-  CX_HIP(hipGetLastError());
+  auto pack = [&](int dir) {
+    return WithPool(P, [&](auto* W) -> int {
+      using TW = std::remove_pointer_t<decltype(W)>;
+      hipLaunchKernelGGL(k_sp_pack_tiles<TW>, dim3(unsigned((count + 255) / 256)), dim3(256), 0, st, W, (const int32_t*)P->d_shared_tiles.p, n,
+                         P->d_exchange.p, d_flag, dir);
+      CX_HIP(hipGetLastError());
+      return CX_OK;
+    });
+  };
+  CX_TRY(pack(0));
+  CX_TRY(cx_allreduce_device(ctx, P->d_exchange.p, count));  // (in double for either pool: the ranks' sums round once)
+  CX_TRY(pack(1));
   return CX_OK;
 }
 }  // namespace
 
 // numeric factorisation of the assembled pool, in place, level by level; a right-hand side placed in the rows' last
 // tiles (k_sp_rhs) is forward-substituted along
-int cxsp_factor(cx_context* ctx, cx_sp_plan* P, int* d_flag) {
+namespace {
+template <typename TW>
+int FactorLevels(cx_context* ctx, cx_sp_plan* P, TW* W, int* d_flag) {
   hipStream_t st = ctx->stream;
   Scratch sc;
   CX_TRY(GetScratch(P, &sc));
-  double* W = P->d_W.p;
   const int32_t* valid = P->d_valid.p;
   const int32_t* rows = P->d_level_rows.p;
   for (int l = 0; l < P->num_levels; ++l) {
@@ -1358,12 +1474,17 @@ int cxsp_factor(cx_context* ctx, cx_sp_plan* P, int* d_flag) {
     const int p0 = P->h_level_panel_begin[size_t(l)], np = P->h_level_panel_begin[size_t(l) + 1] - p0;
     const int t0 = P->h_level_tgt_begin[size_t(l)], nt = P->h_level_tgt_begin[size_t(l) + 1] - t0;
     if (nr > 0)
-      hipLaunchKernelGGL(k_sp_diag, dim3(unsigned(nr)), dim3(64), 0, st, W, (const int32_t*)P->d_row_start.p, rows + r0, valid, sc.uinv, d_flag);
+      hipLaunchKernelGGL(k_sp_diag<TW>, dim3(unsigned(nr)), dim3(64), 0, st, W, (const int32_t*)P->d_row_start.p, rows + r0, valid, sc.uinv, d_flag);
     if (np > 0)
-      hipLaunchKernelGGL(k_sp_panel, dim3(unsigned(np)), dim3(128), 0, st, W, (const int32_t*)P->d_row_start.p,
+      hipLaunchKernelGGL(k_sp_panel<TW>, dim3(unsigned(np)), dim3(128), 0, st, W, (const int32_t*)P->d_row_start.p,
                          (const int32_t*)P->d_row_tiles.p, (const int32_t*)P->d_panel_row.p + p0,
                          (const int32_t*)P->d_panel_pool.p + p0, valid, P->T, (const double*)sc.uinv);
     if (nt > 0) {
+      if constexpr (std::is_same_v<TW, float>) {
+        hipLaunchKernelGGL((k_sp_update_f32<4, 8>), dim3(unsigned(nt)), dim3(256), 0, st, W, (const int32_t*)P->d_tgt_pool.p + t0,
+                           (const int32_t*)P->d_tgt_flags.p + t0, (const int32_t*)P->d_src_begin.p + t0, (const int32_t*)P->d_src_a.p,
+                           (const int32_t*)P->d_src_b.p);
+      } else {
       static const int occ = [] { const char* v = std::getenv("CX_SPARSE_UPDATE_OCCUPANCY"); return v ? atoi(v) : 3; }();
 #define CX_SP_UPDATE(K)                                                                                                          \
   hipLaunchKernelGGL(k_sp_update<K>, dim3(unsigned(nt)), dim3(256), 0, st, W, (const int32_t*)P->d_tgt_pool.p + t0,              \
@@ -1382,10 +1503,15 @@ int cxsp_factor(cx_context* ctx, cx_sp_plan* P, int* d_flag) {
       else CX_SP_UPDATE(2);
 #undef CX_SP_UPDATE
 #undef CX_SP_SLICES
+      }
     }
   }
   CX_HIP(hipGetLastError());
   return CX_OK;
+}
+}  // namespace
+int cxsp_factor(cx_context* ctx, cx_sp_plan* P, int* d_flag) {
+  return WithPool(P, [&](auto* W) -> int { return FactorLevels(ctx, P, W, d_flag); });
 }
 
 namespace {
@@ -1399,12 +1525,17 @@ int BackwardSweep(cx_context* ctx, cx_sp_plan* P, const Scratch& sc, int y_in_x)
     // (A/B, round 2: both parts of a level in one launch -- the workgroup that finishes a row's last tile, told by an arrival
     // counter, going on with the row's part 2 -- took the same time: 3.474 against 3.472 ms per CG iteration with
     // CLUSTER_TRIDIAGONAL on the Final shape; the ticket costs what the kernel boundary cost.  Not kept.)
-    if (np > 0)
-      hipLaunchKernelGGL(k_sp_bwd_partial, dim3(unsigned(np)), dim3(256), 0, st, (const double*)P->d_W.p, (const int32_t*)P->d_row_tiles.p,
-                         (const int32_t*)P->d_panel_pool.p + p0, (const int32_t*)P->d_valid.p, P->T, (const double*)sc.xp, sc.partial);
-    if (nr > 0)
-      hipLaunchKernelGGL(k_sp_bwd_level, dim3(unsigned(nr)), dim3(256), 0, st, (const double*)P->d_W.p, (const int32_t*)P->d_row_start.p,
-                         rows + r0, (const int32_t*)P->d_valid.p, (const double*)sc.uinv, (const double*)sc.partial, sc.xp, y_in_x);
+    CX_TRY(WithPool(P, [&](auto* Wp) -> int {
+      using TW = std::remove_pointer_t<decltype(Wp)>;
+      const TW* W = Wp;
+      if (np > 0)
+        hipLaunchKernelGGL(k_sp_bwd_partial<TW>, dim3(unsigned(np)), dim3(256), 0, st, W, (const int32_t*)P->d_row_tiles.p,
+                           (const int32_t*)P->d_panel_pool.p + p0, (const int32_t*)P->d_valid.p, P->T, (const double*)sc.xp, sc.partial);
+      if (nr > 0)
+        hipLaunchKernelGGL(k_sp_bwd_level<TW>, dim3(unsigned(nr)), dim3(256), 0, st, W, (const int32_t*)P->d_row_start.p,
+                           rows + r0, (const int32_t*)P->d_valid.p, (const double*)sc.uinv, (const double*)sc.partial, sc.xp, y_in_x);
+      return CX_OK;
+    }));
   }
   CX_HIP(hipGetLastError());
   return CX_OK;
@@ -1424,13 +1555,18 @@ int cxsp_solve(cx_context* ctx, cx_sp_plan* P, const double* r, double* z) {
   for (int l = 0; l < P->num_levels; ++l) {
     const int r0 = P->h_level_row_begin[size_t(l)], nr = P->h_level_row_begin[size_t(l) + 1] - r0;
     const int p0 = P->h_level_panel_begin[size_t(l)], np = P->h_level_panel_begin[size_t(l) + 1] - p0;
-    if (nr > 0)
-      hipLaunchKernelGGL(k_sp_fwd_level, dim3(unsigned(nr)), dim3(256), 0, st, (const double*)P->d_W.p, (const int32_t*)P->d_row_start.p,
-                         rows + r0, (const int32_t*)P->d_valid.p, (const double*)sc.uinv, (const int32_t*)P->d_col_start.p,
-                         (const int32_t*)P->d_col_pool.p, (const double*)sc.partial, sc.xp);
-    if (np > 0)
-      hipLaunchKernelGGL(k_sp_fwd_partial, dim3(unsigned(np)), dim3(256), 0, st, (const double*)P->d_W.p, (const int32_t*)P->d_row_tiles.p,
-                         (const int32_t*)P->d_panel_row.p + p0, (const int32_t*)P->d_panel_pool.p + p0, P->T, (const double*)sc.xp, sc.partial);
+    CX_TRY(WithPool(P, [&](auto* Wp) -> int {
+      using TW = std::remove_pointer_t<decltype(Wp)>;
+      const TW* W = Wp;
+      if (nr > 0)
+        hipLaunchKernelGGL(k_sp_fwd_level<TW>, dim3(unsigned(nr)), dim3(256), 0, st, W, (const int32_t*)P->d_row_start.p,
+                           rows + r0, (const int32_t*)P->d_valid.p, (const double*)sc.uinv, (const int32_t*)P->d_col_start.p,
+                           (const int32_t*)P->d_col_pool.p, (const double*)sc.partial, sc.xp);
+      if (np > 0)
+        hipLaunchKernelGGL(k_sp_fwd_partial<TW>, dim3(unsigned(np)), dim3(256), 0, st, W, (const int32_t*)P->d_row_tiles.p,
+                           (const int32_t*)P->d_panel_row.p + p0, (const int32_t*)P->d_panel_pool.p + p0, P->T, (const double*)sc.xp, sc.partial);
+      return CX_OK;
+    }));
   }
   CX_TRY(BackwardSweep(ctx, P, sc, 1));
   hipLaunchKernelGGL(k_sp_unpermute, dim3((n + 255) / 256), dim3(256), 0, st, (const double*)sc.xp, (const int32_t*)P->d_cam_pos.p, z, C);
@@ -1447,8 +1583,12 @@ int cxsp_factor_and_solve(cx_matrix* A, const double* Df, const double* rhs, dou
   const int C = A->C, n = 9 * C;
   if (n == 0) return CX_OK;
   CX_TRY(cxsp_assemble(A, P, Df, nullptr, nullptr, 0, 1.0));
-  hipLaunchKernelGGL(k_sp_rhs, dim3((n + 255) / 256), dim3(256), 0, st, rhs, (const int32_t*)P->d_cam_pos.p,
-                     (const int32_t*)P->d_row_start.p, P->d_W.p, C);
+  CX_TRY(WithPool(P, [&](auto* W) -> int {
+    using TW = std::remove_pointer_t<decltype(W)>;
+    hipLaunchKernelGGL(k_sp_rhs<TW>, dim3((n + 255) / 256), dim3(256), 0, st, rhs, (const int32_t*)P->d_cam_pos.p,
+                       (const int32_t*)P->d_row_start.p, W, C);
+    return CX_OK;
+  }));
   CX_TRY(cxsp_factor(ctx, P, d_flag));
   Scratch sc;
   CX_TRY(GetScratch(P, &sc));
@@ -1476,10 +1616,11 @@ __global__ void k_sp_scatter_cells(const double* __restrict__ local, const int32
   values[int64_t(local_to_union[cell]) * 81 + (i - cell * 81)] = local[i];
 }
 // k_sp_assemble for cell values that are already summed (over items and over ranks): D_f^2 is added here, once
+template <typename TW>
 __global__ __launch_bounds__(3 * 81) void k_sp_assemble_values(const int32_t* __restrict__ cell_c1, const int32_t* __restrict__ cell_c2,
                                                                const double* __restrict__ values, const double* __restrict__ Df,
                                                                const int32_t* __restrict__ cam_pos, const int32_t* __restrict__ row_start,
-                                                               const int32_t* __restrict__ row_tiles, double* __restrict__ W,
+                                                               const int32_t* __restrict__ row_tiles, TW* __restrict__ W,
                                                                int64_t num_cells) {
   const int64_t cell = int64_t(blockIdx.x) * 3 + threadIdx.x / 81;
   if (cell >= num_cells) return;
@@ -1496,12 +1637,15 @@ __global__ __launch_bounds__(3 * 81) void k_sp_assemble_values(const int32_t* __
   if (row > col) return;
   const int I = row >> 6, J = col >> 6;
   const int idx = tile_find(row_tiles, row_start[I], row_start[I + 1], J);
-  W[size_t(idx) * kTileDoubles + (row & 63) * kTile + (col & 63)] = v;
+  W[size_t(idx) * kTileDoubles + (row & 63) * kTile + (col & 63)] = TW(v);
 }
 }  // namespace
 
 int cxsp_build_plan_sharded(cx_matrix* A) {
   cx_sp_plan* P = &A->sp;
+  // (the solves with a stored factor that iterative refinement needs, cxsp_solve, exist for a whole factor only: a plan that
+  // was distributed is rebuilt when the caller now wants the factor replicated -- the same decision on every rank)
+  if (P->state == 1 && P->replicate && P->level_split >= 0) P->state = 0;
   if (P->state != 0) return CX_OK;
   cx_context* ctx = A->ctx;
   hipStream_t st = ctx->stream;
@@ -1566,7 +1710,7 @@ int cxsp_build_plan_sharded(cx_matrix* A) {
   CX_TRY(P->d_union_c1.upload(u1, st));
   CX_TRY(P->d_union_c2.upload(u2, st));
   CX_TRY(P->d_local_to_union.upload(local_to_union, st));
-  return cxsp_plan_from_cells(ctx, C, u1.data(), u2.data(), P->num_union_cells, P, /*distribute=*/true);
+  return cxsp_plan_from_cells(ctx, C, u1.data(), u2.data(), P->num_union_cells, P, /*distribute=*/!P->replicate);
 }
 
 int cxsp_factor_and_solve_sharded(cx_matrix* A, const double* Df, const double* rhs, double* z, int* d_flag) {
@@ -1583,23 +1727,25 @@ int cxsp_factor_and_solve_sharded(cx_matrix* A, const double* Df, const double* 
                        (const int32_t*)P->d_local_to_union.p, A->num_cells, P->d_union_values.p);
   CX_HIP(hipGetLastError());
   CX_TRY(cx_allreduce_device(ctx, P->d_union_values.p, int64_t(count)));
-  const size_t pool = size_t(P->num_tiles) * kTileDoubles;
-  CX_TRY(P->d_W.alloc(pool));
-  CX_HIP(hipMemsetAsync(P->d_W.p, 0, pool * sizeof(double), st));
-  hipLaunchKernelGGL(k_sp_assemble_values, dim3(unsigned((P->num_union_cells + 2) / 3)), dim3(3 * 81), 0, st,
-                     (const int32_t*)P->d_union_c1.p, (const int32_t*)P->d_union_c2.p, (const double*)P->d_union_values.p, Df,
-                     (const int32_t*)P->d_cam_pos.p, (const int32_t*)P->d_row_start.p, (const int32_t*)P->d_row_tiles.p, P->d_W.p,
-                     P->num_union_cells);
-  hipLaunchKernelGGL(k_sp_rhs, dim3((n + 255) / 256), dim3(256), 0, st, rhs, (const int32_t*)P->d_cam_pos.p,
-                     (const int32_t*)P->d_row_start.p, P->d_W.p, C);
+  CX_TRY(AllocPool(P, st));
   const bool distributed = P->level_split >= 0;
-  if (distributed && ctx->rank != 0 && P->num_shared_tiles > 0) {
-    // every rank assembled the whole matrix; in the sum over the ranks at the split the assembled values (and right-hand
-    // side) of the replicated rows must count once: rank 0 keeps them, the others start those tiles from zero
-    const int64_t cnt = P->num_shared_tiles * kTileDoubles;
-    hipLaunchKernelGGL(k_sp_zero_tiles, dim3(unsigned((cnt + 255) / 256)), dim3(256), 0, st, P->d_W.p, (const int32_t*)P->d_shared_tiles.p,
-                       P->num_shared_tiles);
-  }
+  CX_TRY(WithPool(P, [&](auto* W) -> int {
+    using TW = std::remove_pointer_t<decltype(W)>;
+    hipLaunchKernelGGL(k_sp_assemble_values<TW>, dim3(unsigned((P->num_union_cells + 2) / 3)), dim3(3 * 81), 0, st,
+                       (const int32_t*)P->d_union_c1.p, (const int32_t*)P->d_union_c2.p, (const double*)P->d_union_values.p, Df,
+                       (const int32_t*)P->d_cam_pos.p, (const int32_t*)P->d_row_start.p, (const int32_t*)P->d_row_tiles.p, W,
+                       P->num_union_cells);
+    hipLaunchKernelGGL(k_sp_rhs<TW>, dim3((n + 255) / 256), dim3(256), 0, st, rhs, (const int32_t*)P->d_cam_pos.p,
+                       (const int32_t*)P->d_row_start.p, W, C);
+    if (distributed && ctx->rank != 0 && P->num_shared_tiles > 0) {
+      // every rank assembled the whole matrix; in the sum over the ranks at the split the assembled values (and right-hand
+      // side) of the replicated rows must count once: rank 0 keeps them, the others start those tiles from zero
+      const int64_t cnt = P->num_shared_tiles * kTileDoubles;
+      hipLaunchKernelGGL(k_sp_zero_tiles<TW>, dim3(unsigned((cnt + 255) / 256)), dim3(256), 0, st, W, (const int32_t*)P->d_shared_tiles.p,
+                         P->num_shared_tiles);
+    }
+    return CX_OK;
+  }));
   CX_TRY(cxsp_factor(ctx, P, d_flag));
   Scratch sc;
   CX_TRY(GetScratch(P, &sc));

@@ -240,7 +240,8 @@ def visibility_structure(bs, num_eliminate_blocks, preconditioner_type, clusteri
 def make_options(type=ITERATIVE_SCHUR, preconditioner_type=JACOBI, num_eliminate_blocks=0,
                  min_num_iterations=0, max_num_iterations=500, residual_reset_period=10,
                  max_num_spse_iterations=5, use_spse_initialization=0, spse_tolerance=0.1,
-                 use_explicit_schur_complement=0, visibility_clustering_type=0):
+                 use_explicit_schur_complement=0, visibility_clustering_type=0, use_mixed_precision_solves=0,
+                 max_num_refinement_iterations=0):
     o = cx_solver_options()
     o.type = type
     o.preconditioner_type = preconditioner_type
@@ -253,6 +254,8 @@ def make_options(type=ITERATIVE_SCHUR, preconditioner_type=JACOBI, num_eliminate
     o.spse_tolerance = spse_tolerance
     o.use_explicit_schur_complement = use_explicit_schur_complement
     o.visibility_clustering_type = visibility_clustering_type
+    o.use_mixed_precision_solves = use_mixed_precision_solves       # DENSE_SCHUR / SPARSE_SCHUR: float factor (orc_schur.cpp)
+    o.max_num_refinement_iterations = max_num_refinement_iterations
     return o
 
 
@@ -331,6 +334,15 @@ def dense_cholesky_solve(lhs, rhs):
     n = a.shape[0]
     x = np.zeros(n)
     t = lib().orc_dense_cholesky_solve(n, _p(a), _p(_f64(rhs)), _p(x))
+    return x, t
+
+
+def dense_cholesky_solve_refined(lhs, rhs, use_float, refinements):
+    """FloatEigenDenseCholesky / RefinedDenseCholesky (dense_cholesky.cc:180-204, 322-347; iterative_refiner.cc:83-99)."""
+    a = _f64(lhs)
+    n = a.shape[0]
+    x = np.zeros(n)
+    t = lib().orc_dense_cholesky_solve_refined(n, _p(a), _p(_f64(rhs)), _p(x), int(bool(use_float)), int(refinements))
     return x, t
 
 

@@ -40,6 +40,10 @@ int orc_schur_back_substitute(const cx_block_structure* bs, const double* values
 /* DenseCholesky::FactorAndSolve on the upper triangle of row-major lhs (lhs is
  * overwritten by the factor).  Returns cx_termination. */
 int orc_dense_cholesky_solve(int n, double* lhs, const double* rhs, double* x);
+/* ... with a single precision factor (use_float) and / or `refinements` steps of iterative refinement in double
+   (FloatEigenDenseCholesky, RefinedDenseCholesky, DenseIterativeRefiner: dense_cholesky.cc:180-204, 322-347, iterative_refiner.cc:83-99);
+   lhs (upper triangle, row-major) is left intact */
+int orc_dense_cholesky_solve_refined(int n, const double* lhs, const double* rhs, double* x, int use_float, int refinements);
 
 /* ImplicitSchurComplement (implicit_schur_complement.cc): y = S x; rhs optional */
 int orc_implicit_schur_multiply(const cx_block_structure* bs, const double* values, const double* D,

@@ -314,17 +314,18 @@ struct Eliminator {
 // Blocked right-looking Cholesky A = U'U on the upper triangle of row-major A
 // (== Eigen::LLT<Lower> on the column-major view the reference factors,
 // dense_cholesky.cc:153-178).  Returns false when not positive definite.
-inline bool CholeskyUpper(double* A, int n, int threads) {
+template <typename T>
+inline bool CholeskyUpperT(T* A, int n, int threads) {
   const int NB = 64;
   for (int k0 = 0; k0 < n; k0 += NB) {
     const int kb = std::min(NB, n - k0);
     // factor diagonal block
     for (int j = k0; j < k0 + kb; ++j) {
       for (int i = k0; i <= j; ++i) {
-        double s = A[size_t(i) * n + j];
+        T s = A[size_t(i) * n + j];
         for (int k = k0; k < i; ++k) s -= A[size_t(k) * n + i] * A[size_t(k) * n + j];
         if (i == j) {
-          if (!(s > 0.0)) return false;
+          if (!(s > T(0))) return false;
           A[size_t(i) * n + i] = std::sqrt(s);
         } else {
           A[size_t(i) * n + j] = s / A[size_t(i) * n + i];
@@ -336,7 +337,7 @@ inline bool CholeskyUpper(double* A, int n, int threads) {
 #pragma omp parallel for schedule(static) num_threads(threads)
     for (int j = rest; j < n; ++j) {
       for (int i = k0; i < k0 + kb; ++i) {
-        double s = A[size_t(i) * n + j];
+        T s = A[size_t(i) * n + j];
         for (int k = k0; k < i; ++k) s -= A[size_t(k) * n + i] * A[size_t(k) * n + j];
         A[size_t(i) * n + j] = s / A[size_t(i) * n + i];
       }
@@ -344,16 +345,18 @@ inline bool CholeskyUpper(double* A, int n, int threads) {
     // trailing update: A(i,j) -= sum_k U(k,i) U(k,j), i<=j in rest..n
 #pragma omp parallel for schedule(dynamic, 8) num_threads(threads)
     for (int i = rest; i < n; ++i) {
-      double* Ai = A + size_t(i) * n;
+      T* Ai = A + size_t(i) * n;
       for (int k = k0; k < k0 + kb; ++k) {
-        const double uki = A[size_t(k) * n + i];
-        const double* Uk = A + size_t(k) * n;
+        const T uki = A[size_t(k) * n + i];
+        const T* Uk = A + size_t(k) * n;
         for (int j = i; j < n; ++j) Ai[j] -= uki * Uk[j];
       }
     }
   }
   return true;
 }
+
+inline bool CholeskyUpper(double* A, int n, int threads) { return CholeskyUpperT<double>(A, n, threads); }
 
 }  // namespace orc
 #endif

@@ -680,7 +680,11 @@ static cx_summary SolveDenseSchur(const cx_block_structure* s, const double* val
   if (n == 0) {
     summary.termination_type = CX_SUCCESS;
   } else {
-    summary.termination_type = orc_dense_cholesky_solve(n, lhs.data(), rhs.data(), reduced);
+    if (o.use_mixed_precision_solves || o.max_num_refinement_iterations > 0)  // DenseCholesky::Create, dense_cholesky.cc:84-136
+      summary.termination_type = orc_dense_cholesky_solve_refined(n, lhs.data(), rhs.data(), reduced, o.use_mixed_precision_solves != 0,
+                                                                  std::max(0, o.max_num_refinement_iterations));
+    else
+      summary.termination_type = orc_dense_cholesky_solve(n, lhs.data(), rhs.data(), reduced);
     summary.num_iterations = 1;
     if (summary.termination_type != CX_SUCCESS) SetMessage(&summary, "Eigen failure. Unable to perform dense Cholesky factorization.");
     else SetMessage(&summary, "Success.");
@@ -783,6 +787,10 @@ static double g_sparse_chol_stats[8] = {0};
 static cx_summary SolveSparseSchur(const cx_block_structure* s, const double* values, const double* b,
                                    const double* D, const cx_solver_options& o, double* x,
                                    const Comm& comm, int threads) {
+  // use_mixed_precision_solves / max_num_refinement_iterations (SparseCholesky::Create, sparse_cholesky.cc:45-118: a float
+  // factorisation and / or RefinedSparseCholesky): the float factor and the refinement loop are restated once, on the dense
+  // reduced matrix (orc_dense_cholesky_solve_refined) -- the same mathematics as a float sparse factor of the same S
+  if (o.use_mixed_precision_solves || o.max_num_refinement_iterations > 0) return SolveDenseSchur(s, values, b, D, o, x, comm, threads);
   const int nelim = o.num_eliminate_blocks;
   Eliminator el(s, values, nelim);
   auto sizes = el.FBlockSizes();

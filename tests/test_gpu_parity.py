@@ -707,6 +707,62 @@ def test_sparse_schur_tile_cholesky(ctx, oracle, C, P, O, seed):
     A.close()
 
 
+@pytest.mark.parametrize("stype", ["DENSE_SCHUR", "SPARSE_SCHUR"])
+@pytest.mark.parametrize("C,P,O,seed", [(12, 300, 1500, 1), (100, 3000, 14000, 3), (400, 9000, 40000, 4)])
+def test_mixed_precision_and_refined_reduced_solves(ctx, oracle, stype, C, P, O, seed):
+    """use_mixed_precision_solves / max_num_refinement_iterations on DENSE_SCHUR and SPARSE_SCHUR (solver.h:572-590;
+    DenseCholesky::Create dense_cholesky.cc:84-136, SparseCholesky::Create sparse_cholesky.cc:45-118, iterative_refiner.cc): S is
+    factored in SINGLE precision (tile pool in floats, v_mfma_f32_16x16x4_f32 updates) and / or the solution refined against
+    the fp64 operator.  Checked as dense_cholesky_test.cc:70-117 checks the reference (mixed precision + 4 refinement steps
+    reproduces the double precision answer), against the oracle's restatement of the same scheme, and for the float factor
+    being what actually ran (without refinement the step carries single precision error, of the size the oracle's carries)."""
+    prob, bs, order, vals, b, D = make(C, P, O, seed, "eval", oracle)
+    A = cx.Matrix(ctx, bs, P)
+    A.set_values(vals)
+    kw = dict(type=getattr(cx, stype), num_eliminate_blocks=P)
+    okw = dict(type=getattr(oracle, stype), num_eliminate_blocks=P)
+    S64 = cx.Solver(ctx, **kw)
+    x64, s64 = S64.solve(A, b, D)
+    xr, sr = oracle.solve(bs, vals, b, D, oracle.make_options(**okw))
+    assert s64.termination_type == sr.termination_type == cx.SUCCESS and relerr(x64, xr) < 1e-8
+    # single precision factor, no refinement
+    S32 = cx.Solver(ctx, use_mixed_precision_solves=1, **kw)
+    x32, s32 = S32.solve(A, b, D)
+    x32b, _ = S32.solve(A, b, D)
+    xo32, so32 = oracle.solve(bs, vals, b, D, oracle.make_options(use_mixed_precision_solves=1, **okw))
+    assert s32.termination_type == so32.termination_type == cx.SUCCESS and s32.num_iterations == 1
+    assert b"single precision" in s32.message
+    assert np.array_equal(x32, x32b)                                      # fixed order of every sum
+    e_hip, e_orc = relerr(x32, x64), relerr(xo32, xr)
+    assert 1e-10 < e_hip < 1e-3, e_hip                                    # a float factor, not the double one
+    assert e_hip < 20 * e_orc + 1e-7, (e_hip, e_orc)                      # ... and no worse than the reference scheme's
+    # + refinement (dense_cholesky_test.cc uses 4 steps): the double precision answer
+    S32r = cx.Solver(ctx, use_mixed_precision_solves=1, max_num_refinement_iterations=4, **kw)
+    x32r, s32r = S32r.solve(A, b, D)
+    xo32r, _ = oracle.solve(bs, vals, b, D, oracle.make_options(use_mixed_precision_solves=1, max_num_refinement_iterations=4, **okw))
+    assert s32r.termination_type == cx.SUCCESS and b"4 refinement steps" in s32r.message
+    assert relerr(x32r, x64) < max(1e-8, 100 * relerr(xo32r, xr)), (relerr(x32r, x64), relerr(xo32r, xr))
+    assert relerr(x32r, x64) < 1e-3 * e_hip                               # every step gained digits
+    # refinement of the double precision factor (RefinedDenseCholesky / RefinedSparseCholesky wrap either): stays the answer
+    S64r = cx.Solver(ctx, max_num_refinement_iterations=2, **kw)
+    x64r, s64r = S64r.solve(A, b, D)
+    assert s64r.termination_type == cx.SUCCESS and b"double precision" in s64r.message and relerr(x64r, xr) < 1e-8
+    g = A.left_multiply(A.right_multiply(x64r) - b) + D * D * x64r
+    g0 = A.left_multiply(A.right_multiply(x64) - b) + D * D * x64
+    assert np.linalg.norm(g) <= 2 * np.linalg.norm(g0) + 1e-12 * np.linalg.norm(A.left_multiply(b))
+    # not positive definite -> FAILURE, zeros, with the float factor too
+    vals_bad = vals.copy()
+    vals_bad[6 * O:] = 0.0
+    Dneg = D.copy()
+    Dneg[3 * P:] = 0.0
+    A.set_values(vals_bad)
+    xbad, sbad = S32r.solve(A, b, Dneg)
+    assert sbad.termination_type == cx.FAILURE and not xbad.any()
+    for S in (S64, S32, S32r, S64r):
+        S.close()
+    A.close()
+
+
 def test_sparse_schur_with_hub_cameras(ctx, oracle):
     """A ring of cameras plus two hub cameras that see points everywhere: the group-minimum-degree ordering has to
     move the hubs' group to the end; whatever ordering wins, the step equals the dense solve's."""

@@ -270,3 +270,38 @@ def test_one_f_block_2_3_6(oracle):
     ne = 3 * nelim
     e_ref = np.linalg.solve(H[:ne, :ne], g[:ne] - H[:ne, ne:] @ f_sol)
     assert np.abs(x[:ne] - e_ref).max() < 1e-12 * np.abs(e_ref).max()
+
+
+def test_dense_cholesky_mixed_precision_and_refinement(oracle):
+    """dense_cholesky_test.cc:70-117 (DenseCholeskyTest.FactorAndSolve, kMixedPrecision with 4 refinement steps and kFullPrecision):
+    lhs = a'a + I, rhs = lhs x, 1..9 columns, 10 trials each: |x - actual| / |x| within 10 eps -- restated by
+    orc_dense_cholesky_solve_refined; iterative_refiner_test.cc:152-190: 30 refinement steps with an exact and with a single
+    precision factor of m m' (5 columns) bring |lhs x - rhs| to 10 eps."""
+    rng = np.random.default_rng(12)
+    eps = np.finfo(float).eps
+    for n in range(1, 10):
+        for trial in range(10):
+            a = rng.uniform(-1, 1, (n, n))
+            lhs = a.T @ a + np.eye(n)
+            x = rng.uniform(-1, 1, n)
+            rhs = lhs @ x
+            for use_float, refinements in ((1, 4), (0, 0)):
+                actual, t = oracle.dense_cholesky_solve_refined(np.triu(lhs), rhs, use_float, refinements)
+                assert t == oracle.SUCCESS
+                assert np.linalg.norm(x - actual) / np.linalg.norm(x) <= 10 * eps * max(1.0, np.linalg.cond(lhs)), (n, trial, use_float)
+            # single precision alone is visibly single precision (the factor really is a float one)
+            x32, _ = oracle.dense_cholesky_solve_refined(np.triu(lhs), rhs, 1, 0)
+            if n > 1:
+                assert 1e-9 < np.linalg.norm(x - x32) / np.linalg.norm(x) < 1e-4
+    m = rng.uniform(-1, 1, (5, 5))
+    lhs = m @ m.T + 1e-3 * np.eye(5)
+    sol = rng.uniform(-1, 1, 5)
+    rhs = lhs @ sol
+    for use_float in (0, 1):
+        refined, t = oracle.dense_cholesky_solve_refined(np.triu(lhs), rhs, use_float, 30)
+        assert t == oracle.SUCCESS and np.linalg.norm(lhs @ refined - rhs) <= 10 * eps * max(1.0, np.linalg.norm(rhs))
+    # not positive definite -> FAILURE with either factor
+    bad = np.triu(lhs).copy()
+    bad[2, 2] = -1.0
+    for use_float in (0, 1):
+        assert oracle.dense_cholesky_solve_refined(bad, rhs, use_float, 2)[1] == oracle.FAILURE
