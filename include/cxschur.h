@@ -122,11 +122,13 @@ typedef struct {
   int32_t max_num_iterations;         /* default 500 (solver.h max_linear_solver_iterations) */
   int32_t residual_reset_period;      /* default 10  */
   int32_t num_eliminate_blocks;       /* == elimination_groups[0]; 0 for CGNR */
-  int32_t use_mixed_precision_solves; /* CGNR / ITERATIVE_SCHUR: CG operator streams fp32 copies of the J values (fp64
-                                       * accumulation and vectors).  DENSE_SCHUR / SPARSE_SCHUR: accepted; the device
-                                       * factorisation stays in fp64 (at least the accuracy of the reference's fp32 factor +
-                                       * refinement, dense_cholesky.cc:582-645), and the summary message says so */
-  int32_t max_num_refinement_iterations;
+  int32_t use_mixed_precision_solves; /* DENSE_SCHUR / SPARSE_SCHUR (solver.h:572-585; dense_cholesky.cc:84-136, sparse_cholesky.cc:
+                                       * 45-118): S, computed in double, is factored in SINGLE precision (float tile pool, fp32
+                                       * matrix instructions).  CGNR / ITERATIVE_SCHUR (not in the reference): the CG operator
+                                       * streams fp32 copies of the J values (fp64 accumulation and vectors) */
+  int32_t max_num_refinement_iterations; /* solver.h:587-590; DENSE_SCHUR / SPARSE_SCHUR: that many steps of residual = rhs - S z in
+                                       * double, z += factor^-1 residual, after the solve -- with either factor, as
+                                       * RefinedDenseCholesky / RefinedSparseCholesky wrap either (iterative_refiner.cc) */
   int32_t max_num_spse_iterations;    /* default 5 */
   int32_t use_spse_initialization;    /* default 0 */
   double spse_tolerance;              /* default 0.1 */
