@@ -51,6 +51,8 @@ def main(argv=None):
     ap.add_argument("--use_quaternions", action="store_true",
                     help="quaternion cameras on ProductManifold<QuaternionManifold, EuclideanManifold<6>> "
                          "(the reference's --use_quaternions --use_manifolds)")
+    ap.add_argument("--mixed_precision_solves", action="store_true", help="bundle_adjuster.cc:141, 170-171")
+    ap.add_argument("--max_num_refinement_iterations", type=int, default=0, help="bundle_adjuster.cc:142, 172-173")
     ap.add_argument("--nonmonotonic_steps", action="store_true")
     ap.add_argument("--rotation_sigma", type=float, default=0.0)
     ap.add_argument("--translation_sigma", type=float, default=0.0)
@@ -93,6 +95,8 @@ def main(argv=None):
                        num_eliminate_blocks=0 if stype == cx.binding.CGNR else prob.num_points,
                        max_num_iterations=args.max_linear_solver_iterations,
                        use_explicit_schur_complement=int(args.explicit_schur_complement),
+                       use_mixed_precision_solves=int(args.mixed_precision_solves),
+                       max_num_refinement_iterations=args.max_num_refinement_iterations,
                        visibility_clustering_type=getattr(cx.binding, args.visibility_clustering.upper()))
     preprocess_s = time.time() - t0
     opts = cx.binding.minimizer_options(max_num_iterations=args.num_iterations, eta=args.eta,

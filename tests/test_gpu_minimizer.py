@@ -73,6 +73,39 @@ def test_minimize_matches_oracle(ctx, oracle, stype, ptype, loss):
     ev.close()
 
 
+@pytest.mark.parametrize("stype", ["DENSE_SCHUR", "SPARSE_SCHUR"])
+def test_minimize_with_mixed_precision_solves(ctx, oracle, stype):
+    """bundle_adjuster --mixed_precision_solves [--max_num_refinement_iterations N] (bundle_adjuster.cc:141-142, 170-173): the LM
+    loop on single precision reduced solves.  An LM step only has to be a descent step of the right size: with the float factor
+    the iterations accept / reject as the oracle's mixed run does and land on the same cost (to single precision of the step);
+    with refinement steps the trajectory is the double precision one."""
+    C, P, O = 12, 300, 2400
+    prob = cx.bal.make_bal_like(C, P, O, 3)
+    mo = cx.binding.minimizer_options(max_num_iterations=8)
+    omo = oracle.minimizer_options(max_num_iterations=8)
+    ev = cx.Evaluator(ctx, prob)
+    kw = dict(type=getattr(cx.binding, stype), num_eliminate_blocks=P)
+    okw = dict(type=getattr(oracle, stype), num_eliminate_blocks=P)
+    run = lambda **extra: cx.binding.minimize(ev, cx.Solver(ctx, **kw, **extra), prob.state(), mo)
+    orun = lambda **extra: oracle.minimize_bal(C, P, prob.camera_index, prob.point_index, prob.observations, prob.state(),
+                                               oracle.make_options(**okw, **extra), omo)
+    x64, s64, it64 = run()
+    x32, s32, it32 = run(use_mixed_precision_solves=1)
+    x32r, s32r, it32r = run(use_mixed_precision_solves=1, max_num_refinement_iterations=3)
+    xo32, so32, ito32 = orun(use_mixed_precision_solves=1)
+    assert s32["termination_type"] == so32["termination_type"] and len(it32) == len(ito32)
+    assert s32["num_successful_steps"] == so32["num_successful_steps"]
+    for a, b in zip(it32, ito32):
+        assert a["step_is_successful"] == b["step_is_successful"] and abs(a["cost"] - b["cost"]) <= 1e-4 * abs(b["cost"])
+    assert abs(s32["final_cost"] - s64["final_cost"]) <= 1e-4 * s64["final_cost"]
+    assert x32.tobytes() != x64.tobytes()                                  # the float factor really ran
+    assert len(it32r) == len(it64)
+    for a, b in zip(it32r, it64):
+        assert abs(a["cost"] - b["cost"]) <= 1e-9 * abs(b["cost"])
+    assert relerr(x32r, x64) < 1e-7
+    ev.close()
+
+
 def test_minimize_rejected_steps_and_nonmonotonic_option(ctx, oracle):
     """Bundle adjustment from a perturbed start is so close to Gauss-Newton-ideal that no step is ever rejected
     (and starts that do get rejections are singular: costs ~1e30).  Rejections are therefore forced through
