@@ -145,6 +145,20 @@ def test_sparse_schur_700_cameras_through_the_front(oracle):
     x, s = S.solve(ev.jacobian(bs), res, D)
     assert s.termination_type == s_r.termination_type
     assert np.abs(x - x_r).max() <= 1e-8 * np.abs(x_r).max()
+    # use_mixed_precision_solves on shards: the float tile pool under the distributed factorisation (the exchange of the
+    # replicated tiles converts to double and back); with refinement steps the factor is kept whole on every shard (the plan is
+    # rebuilt: stored-factor sweeps need it) and the step comes back to double precision
+    S32 = cx.Solver(ctx, type=cx.SPARSE_SCHUR, num_eliminate_blocks=P, use_mixed_precision_solves=1)
+    x32, s32 = S32.solve(ev.jacobian(bs), res, D)
+    e32 = np.abs(x32 - x_r).max() / np.abs(x_r).max()
+    assert s32.termination_type == cx.SUCCESS and 1e-10 < e32 < 1e-3, e32
+    S32r = cx.Solver(ctx, type=cx.SPARSE_SCHUR, num_eliminate_blocks=P, use_mixed_precision_solves=1, max_num_refinement_iterations=3)
+    x32r, s32r = S32r.solve(ev.jacobian(bs), res, D)
+    assert s32r.termination_type == cx.SUCCESS and np.abs(x32r - x_r).max() <= max(1e-8, 1e-3 * e32) * np.abs(x_r).max()
+    x2, s2 = S.solve(ev.jacobian(bs), res, D)          # (and the double precision solver on the rebuilt, replicated plan)
+    assert np.abs(x2 - x_r).max() <= 1e-8 * np.abs(x_r).max()
+    S32.close()
+    S32r.close()
     S.close()
     ev.close()
     ctx.close()
