@@ -38,7 +38,7 @@ EXPORTED_SYMBOLS = [
     "cx_implicit_schur_multiply", "cx_dense_cholesky_solve", "cx_evaluator_create_bal", "cx_evaluator_destroy",
     "cx_evaluator_jacobian", "cx_evaluator_row_of_observation", "cx_evaluator_evaluate", "cx_evaluator_set_loss", "cx_minimizer_default_options", "cx_minimize", "cx_schur_sparse_structure", "cx_visibility_structure", "cx_visibility_clusters_host",
     "cx_evaluator_set_camera_model", "cx_evaluator_num_parameters", "cx_evaluator_num_effective_parameters", "cx_evaluator_plus",
-    "cx_evaluator_last_kernel_ms", "cx_evaluator_device_residuals", "cx_evaluator_set_emit_camera_major", "cx_sparse_cholesky_plan_host", "cx_detect_structure", "cx_partition_points", "cx_stable_schur_ordering",
+    "cx_evaluator_last_kernel_ms", "cx_evaluator_device_residuals", "cx_evaluator_set_emit_camera_major", "cx_sparse_cholesky_plan_host", "cx_sparse_cholesky_schedule_host", "cx_detect_structure", "cx_partition_points", "cx_stable_schur_ordering",
 ]
 
 
@@ -635,6 +635,20 @@ def sparse_cholesky_plan_host(num_cameras, cell_row, cell_col):
                                             _ptr(cols), ctypes.c_int64(nt.value)))
     return dict(camera_first_row=first, num_tile_rows=T.value, num_levels=L.value, num_tiles=nt.value,
                 num_tile_pair_updates=npairs.value, tile_row_level=level, tile_row_start=start, tile_cols=cols)
+
+
+def sparse_cholesky_schedule_host(num_cameras, cell_row, cell_col, window, nranks=1, rank=0):
+    """The update schedule of the tile-sparse factorisation under a window, checked from its definition (no device): dict with
+    num_tile_rows, num_products, num_chains, longest_chain, violations (must be 0)."""
+    lib = load_library()
+    r = np.ascontiguousarray(cell_row, dtype=np.int32)
+    c = np.ascontiguousarray(cell_col, dtype=np.int32)
+    prod, chains, bad, longest = ctypes.c_int64(), ctypes.c_int64(), ctypes.c_int64(), ctypes.c_int32()
+    T = lib.cx_sparse_cholesky_schedule_host(int(num_cameras), _ptr(r), _ptr(c), ctypes.c_int64(r.size), int(nranks), int(rank), int(window),
+                                             ctypes.byref(prod), ctypes.byref(chains), ctypes.byref(longest), ctypes.byref(bad))
+    if T < 0:
+        _check(T)
+    return dict(num_tile_rows=T, num_products=prod.value, num_chains=chains.value, longest_chain=longest.value, violations=bad.value)
 
 
 def sparse_cholesky_distribution_host(num_cameras, cell_row, cell_col, nranks):

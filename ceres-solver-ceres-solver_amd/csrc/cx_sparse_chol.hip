@@ -1016,6 +1016,11 @@ struct HostPlan {
   int L_split = -1;
   std::vector<int64_t> work_per_rank;  // tile-pair updates of every rank's own rows
   int64_t work_shared = 0;
+  // the schedule of the updates: window <= 0 = the default (CX_SPARSE_WINDOW, 4); keep_schedule: per product (in the order of
+  // src_a / src_b) its source row, and per tile row the level of the schedule it is factored in (-1: another rank's)
+  int window = 0;
+  bool keep_schedule = false;
+  std::vector<int32_t> src_row, row_level;
 };
 
 // Which rank factors which tile row.  Proportional mapping by splitting: the candidate subtrees start as the roots of
@@ -1209,6 +1214,7 @@ void BuildHostPlan(int C, const int32_t* cell_c1, const int32_t* cell_c2, int64_
   {
     int window = 4;
     if (const char* e = std::getenv("CX_SPARSE_WINDOW")) window = std::max(1, std::atoi(e));
+    if (H->window > 0) window = H->window;
     if (window > 1) {
       std::vector<int32_t> row_of_slot(static_cast<size_t>(num_tiles));
       for (int J = 0; J < T; ++J)
@@ -1249,6 +1255,11 @@ void BuildHostPlan(int C, const int32_t* cell_c1, const int32_t* cell_c2, int64_
       }
       src_a[i] = srcs[i].qa;
       src_b[i] = srcs[i].qb;
+    }
+    if (H->keep_schedule) {
+      H->src_row.resize(srcs.size());
+      for (size_t i = 0; i < srcs.size(); ++i) H->src_row[i] = srcs[i].row;
+      H->row_level = vlevel;
     }
     while (level < L) ltb[size_t(++level)] = int32_t(tgt_pool.size());
     src_begin.push_back(int32_t(srcs.size()));
@@ -1822,3 +1833,62 @@ extern "C" int cx_sparse_cholesky_distribution_host(int32_t num_cameras, const i
   return H.T;
 }
 
+
+// The schedule of the tile-pair updates under a window (see BuildHostPlan), checked from its definition -- no device: every
+// product F(I, Ja)' F(I, Jb) of the symbolic factor appears exactly once, runs after its source row I is factored and before
+// its target's row Ja is, and (distributed plan of `rank` of `nranks`) products of the rank's own rows all run before the
+// exchange of the replicated tiles.  Returns the number of tile rows, or a negative error.
+extern "C" int cx_sparse_cholesky_schedule_host(int32_t num_cameras, const int32_t* cell_row, const int32_t* cell_col, int64_t num_cells,
+                                                int32_t nranks, int32_t rank, int32_t window, int64_t* num_products, int64_t* num_chains,
+                                                int32_t* longest_chain, int64_t* violations) {
+  CX_CHECK_ARG(num_cameras > 0 && cell_row && cell_col && num_cells >= num_cameras && nranks >= 1 && nranks <= 64 && rank >= 0 &&
+               rank < nranks && window >= 1 && num_products && num_chains && longest_chain && violations);
+  for (int64_t k = 0; k < num_cells; ++k)
+    CX_CHECK_ARG(cell_row[k] >= 0 && cell_row[k] <= cell_col[k] && cell_col[k] < num_cameras);
+  HostPlan H;
+  H.window = window;
+  H.keep_schedule = true;
+  BuildHostPlan(num_cameras, cell_row, cell_col, num_cells, &H, nranks > 1 ? rank : -1, nranks);
+  if (!H.fits) {
+    cx_set_error("the tile-sparse Cholesky of this structure would need more than 160 GB");
+    return CX_ERR_UNSUPPORTED;
+  }
+  const int T = H.T;
+  int64_t bad = 0, expected = 0;
+  for (int I = 0; I < T; ++I)
+    if (H.row_level[size_t(I)] >= 0) {
+      const int64_t m = H.row_start[size_t(I) + 1] - H.row_start[size_t(I)] - 1;  // tiles right of the diagonal, right-hand side included
+      expected += m * (m + 1) / 2 - 1 + (m == 0 ? 1 : 0);                           // pairs (Ja <= Jb), Ja a real tile row: all but (rhs, rhs)
+    }
+  std::vector<int32_t> row_of_slot(static_cast<size_t>(H.num_tiles));
+  for (int J = 0; J < T; ++J)
+    for (int32_t q = H.row_start[size_t(J)]; q < H.row_start[size_t(J) + 1]; ++q) row_of_slot[size_t(q)] = J;
+  std::vector<std::pair<int32_t, int32_t>> seen;  // (qa, qb) of every product: each once
+  seen.reserve(H.src_a.size());
+  int32_t longest = 0;
+  for (int l = 0; l < H.L; ++l)
+    for (int32_t t = H.ltb[size_t(l)]; t < H.ltb[size_t(l) + 1]; ++t) {
+      const int32_t tq = H.tgt_pool[size_t(t)], Ja = row_of_slot[size_t(tq)], Jb = H.row_tiles[size_t(tq)];
+      longest = std::max(longest, H.src_begin[size_t(t) + 1] - H.src_begin[size_t(t)]);
+      for (int32_t i = H.src_begin[size_t(t)]; i < H.src_begin[size_t(t) + 1]; ++i) {
+        const int32_t I = H.src_row[size_t(i)], qa = H.src_a[size_t(i)], qb = H.src_b[size_t(i)];
+        const int32_t lI = H.row_level[size_t(I)], lJ = H.row_level[size_t(Ja)];
+        bool ok = lI >= 0 && lJ >= 0 && lI <= l && l < lJ;                                      // after I is factored, before Ja is
+        ok = ok && row_of_slot[size_t(qa)] == I && row_of_slot[size_t(qb)] == I;                // both operands are tiles of row I
+        ok = ok && H.row_tiles[size_t(qa)] == Ja && H.row_tiles[size_t(qb)] == Jb && qa <= qb;   // ... the ones this target needs
+        ok = ok && (H.L_split < 0 || lI >= H.L_split || l < H.L_split);                          // own rows: before the exchange
+        ok = ok && (i == H.src_begin[size_t(t)] || H.src_row[size_t(i) - 1] < I);               // ascending source rows in a chain
+        if (!ok) ++bad;
+        seen.emplace_back(qa, qb);
+      }
+    }
+  std::sort(seen.begin(), seen.end());
+  for (size_t i = 1; i < seen.size(); ++i)
+    if (seen[i] == seen[i - 1]) ++bad;
+  if (int64_t(seen.size()) != expected) ++bad;
+  *num_products = int64_t(seen.size());
+  *num_chains = int64_t(H.tgt_pool.size());
+  *longest_chain = longest;
+  *violations = bad;
+  return T;
+}

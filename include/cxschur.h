@@ -523,6 +523,15 @@ int cx_sparse_cholesky_plan_host(int32_t num_cameras, const int32_t* cell_row, c
 int cx_schur_pair_lists_host(const cx_block_structure* bs, int32_t num_eliminate_blocks, int64_t* num_cells,
                              int64_t* num_pairs, int64_t* num_items, int32_t* cell_row, int32_t* cell_col,
                              int64_t cell_capacity, int32_t* pair_rows, int64_t pair_capacity);
+/* The schedule of the tile-pair updates of that factorisation under an update window (a target tile's
+ * contributions of `window` consecutive levels are subtracted as one chain), checked from its definition -- no device: every
+ * product of the symbolic factor is scheduled exactly once, after its source row is factored and before its target's row is
+ * (for rank `rank` of a plan distributed over `nranks`: own rows' products before the exchange of the replicated tiles), source
+ * rows ascending inside a chain.  Same input as cx_sparse_cholesky_plan_host.  Returns the number of tile rows (< 0: error);
+ * *violations must come back 0. */
+int cx_sparse_cholesky_schedule_host(int32_t num_cameras, const int32_t* cell_row, const int32_t* cell_col, int64_t num_cells,
+                                     int32_t nranks, int32_t rank, int32_t window, int64_t* num_products, int64_t* num_chains,
+                                     int32_t* longest_chain, int64_t* violations);
 /* How the DISTRIBUTED factorisation of a sharded SPARSE_SCHUR (several ranks) divides this structure:
  * every rank factors the subtrees of the tile elimination tree it owns, the rows above them (the top separators of the
  * dissection) are factored by every rank after ONE exchange of their tiles.  Same input as cx_sparse_cholesky_plan_host.

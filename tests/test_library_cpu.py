@@ -269,6 +269,38 @@ def test_distribution_of_the_tile_sparse_factorisation(C, P, O, seed):
         assert replicated_rows < T
 
 
+@pytest.mark.parametrize("C,P,O,seed", [(700, 5000, 26000, 8), (2000, 20000, 110000, 3)])
+def test_update_windows_of_the_tile_sparse_factorisation(C, P, O, seed):
+    """cx_sparse_cholesky_schedule_host: the schedule of the tile-pair updates under an update window (a target's contributions of
+    `window` levels subtracted as one chain), checked from its definition on the host: every product of the symbolic factor is
+    scheduled exactly once, after its source row is factored and before its target's row is, ascending source rows inside a chain;
+    on a distributed plan a rank's own products all run before the exchange.  Integers, checked exactly."""
+    prob = cx.bal.make_bal_like(C, P, O, seed=seed)
+    bs, _ = cx.bal.build_structure(prob)
+    r, c, _, _ = cx.binding.schur_pair_lists_host(bs, P)
+    plan = cx.binding.sparse_cholesky_plan_host(C, r, c)
+    one = cx.binding.sparse_cholesky_schedule_host(C, r, c, window=1)
+    assert one["violations"] == 0 and one["num_tile_rows"] == plan["num_tile_rows"]
+    assert one["num_products"] == plan["num_tile_pair_updates"]
+    chains = [one["num_chains"]]
+    for window in (2, 4, 16, 1000):
+        w = cx.binding.sparse_cholesky_schedule_host(C, r, c, window=window)
+        assert w["violations"] == 0 and w["num_products"] == one["num_products"]
+        assert w["num_chains"] <= chains[-1] and w["longest_chain"] >= one["longest_chain"]   # same work in fewer, longer chains
+        chains.append(w["num_chains"])
+    assert chains[-1] < chains[0]
+    for nranks in (2, 4):
+        total = 0
+        for rank in range(nranks):
+            w = cx.binding.sparse_cholesky_schedule_host(C, r, c, window=4, nranks=nranks, rank=rank)
+            assert w["violations"] == 0
+            total += w["num_products"]
+        d = cx.binding.sparse_cholesky_distribution_host(C, r, c, nranks)
+        m = np.diff(plan["tile_row_start"]) - 1                         # tiles right of the diagonal, right-hand side included
+        replicated = int((m * (m + 1) // 2 - 1)[d["owner"] < 0].sum())
+        assert total == one["num_products"] + (nranks - 1) * replicated  # the top is factored by every rank
+
+
 def test_ticket_reductions_keep_their_instruction_order():
     """The fused reductions (cx_solver.hip: dot2_finish, cx_eval.hip: k_sum_partials) finish in the workgroup that draws the
     last ticket.  Their ordering rests on instructions, not on a fence: the partial sums are stored with
