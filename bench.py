@@ -404,6 +404,18 @@ def main():
         sparse = {"ms": float(np.median(reps)), "termination": int(summ_s.termination_type),
                   "phases_ms": {k: tm[k] for k in ("eliminate_ms", "reduced_solve_ms", "back_substitute_ms", "total_ms")}}
         SS.close()
+        # ... and with use_mixed_precision_solves (solver.h:572-585): S factored in single precision, no refinement
+        SM = cx.Solver(ctx, type=cx.SPARSE_SCHUR, num_eliminate_blocks=prob.num_points, use_mixed_precision_solves=1)
+        SM.solve(A, b, D, x=x)
+        reps = []
+        for _ in range(3):
+            barrier()
+            t1 = time.perf_counter()
+            SM.solve(A, b, D, x=x)
+            barrier()
+            reps.append((time.perf_counter() - t1) * 1e3)
+        sparse["single_precision_factor_ms"] = float(np.median(reps))
+        SM.close()
 
     out = None
     if rank == 0:

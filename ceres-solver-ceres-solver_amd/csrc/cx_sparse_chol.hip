@@ -1472,6 +1472,15 @@ int ExchangeSharedTiles(cx_context* ctx, cx_sp_plan* P, int* d_flag) {
 // numeric factorisation of the assembled pool, in place, level by level; a right-hand side placed in the rows' last
 // tiles (k_sp_rhs) is forward-substituted along
 namespace {
+// (Round 3 A/B, not kept: TWO STREAMS.  Only the chains whose targets lie in rows of the next level have to precede the next
+// diagonal kernel; the others -- window closings, with the rule that no window closes at the level before its target's last --
+// were launched on a second stream beside the diagonal and panel kernels of the next two levels, with one event each way per
+// level.  Reduced solve 32.1 -> 31.1 ms (Final), 81.8 -> 78.6 (second scene), against the ~5 ms the 190 x 45 us of diagonal +
+// panel kernels suggested.  The kernel trace says why: (1) the two streams' kernels are dispatched one grid at a time -- a
+// 27-wavefront diagonal kernel issued beside a 15 k-workgroup update STARTS at once but ends 116-250 us later, about when the
+// update's last workgroup has been placed, at equal and at highest-against-lowest stream priority alike; (2) every cross-stream
+// event costs ~11 us between the panel kernel's end and the next launch's start, 2 ms per factorisation; (3) the just-in-time part
+// is 40-50 % of a wide level's products.  What it hid did not pay for a second stream, five events and a schedule rule.)
 template <typename TW>
 int FactorLevels(cx_context* ctx, cx_sp_plan* P, TW* W, int* d_flag) {
   hipStream_t st = ctx->stream;
