@@ -536,6 +536,92 @@ __global__ __launch_bounds__(256, kWgPerCu) void k_sp_update_f32(float* __restri
     }
 }
 
+// k_sp_update_f32 with both source tiles staged ONCE per workgroup through LDS.  On the float pool the update is no longer
+// bound by the matrix cores (64 v_mfma_f32_16x16x4_f32 per wavefront and source = 2 048 cycles) but by the bytes its four
+// wavefronts pull through the caches: each loads a 32-column half of both tiles, 64 KB per product, 9-10 ns per product on the
+// wide levels = ~7 TB/s on the CU side.  Here the workgroup's 256 threads fetch the two 16 KB tiles once (32 KB per product,
+// 16-byte loads, a wavefront = 1 KB contiguous), the next source's pieces are requested into registers before the current
+// products and written to LDS behind them (one 32 KB buffer, four workgroups per CU).  LDS image: row-major 64 x 64 floats with
+// the two 32-column halves swapped on odd rows, so the four rows a k-step reads (one per 16-lane group) fall on both halves
+// of the 64 banks: a ds_read_b64 of 64 lanes takes its minimum of two passes.  Same products in the same order as
+// k_sp_update_f32: bitwise the same result.
+template <int kWgPerCu>
+__global__ __launch_bounds__(256, kWgPerCu) void k_sp_update_f32_lds(float* __restrict__ W, const int32_t* __restrict__ tgt_pool,
+                                                                     const int32_t* __restrict__ tgt_flags, const int32_t* __restrict__ src_begin,
+                                                                     const int32_t* __restrict__ src_a, const int32_t* __restrict__ src_b) {
+  __shared__ float lds[2 * kTileDoubles];  // A image | B image
+  typedef float float4v __attribute__((ext_vector_type(4)));
+  const int t = blockIdx.x;
+  const int tid = threadIdx.x, wave = tid >> 6;
+  const int qi = wave >> 1, qj = wave & 1;
+  const int flags = tgt_flags[t];
+  const bool computes = !((flags & 1) && qi == 1 && qj == 0) && !((flags & 2) && qj == 1);  // (every wavefront loads)
+  const int lane = tid & 63, li = lane & 15, lk = lane >> 4;
+  float4_t acc[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b) acc[a][b] = float4_t{0.f, 0.f, 0.f, 0.f};
+  const int s0 = src_begin[t], s1 = src_begin[t + 1];
+  // piece j of this thread: float4 number tid + 256 j of a tile = row (tid + 256 j) / 16, columns 4 ((tid + 256 j) % 16) ...
+  float4v ra[4], rb[4];
+  auto request = [&](int s) {
+    const float* pa = W + size_t(src_a[s]) * kTileDoubles + 4 * tid;
+    const float* pb = W + size_t(src_b[s]) * kTileDoubles + 4 * tid;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) ra[j] = *reinterpret_cast<const float4v*>(pa + 1024 * j);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) rb[j] = *reinterpret_cast<const float4v*>(pb + 1024 * j);
+  };
+  auto deposit = [&]() {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int idx = tid + 256 * j, k = idx >> 4, c = (idx & 15) << 2;
+      const int at = k * kTile + (c ^ ((k & 1) << 5));
+      *reinterpret_cast<float4v*>(lds + at) = ra[j];
+      *reinterpret_cast<float4v*>(lds + kTileDoubles + at) = rb[j];
+    }
+  };
+  if (s1 > s0) request(s0);
+  for (int s = s0; s < s1; ++s) {
+    deposit();
+    __syncthreads();
+    if (s + 1 < s1) request(s + 1);
+    if (computes) {
+#pragma unroll
+      for (int g = 0; g < 16; ++g) {
+        const int k = 4 * g + lk;
+        const int sw = (lk & 1) << 5;  // (k & 1) == (lk & 1)
+        const float2_t av = *reinterpret_cast<const float2_t*>(lds + k * kTile + ((32 * qi + 2 * li) ^ sw));
+        const float2_t bv = *reinterpret_cast<const float2_t*>(lds + kTileDoubles + k * kTile + ((32 * qj + 2 * li) ^ sw));
+        acc[0][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.x, bv.x, acc[0][0], 0, 0, 0);
+        acc[0][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.x, bv.y, acc[0][1], 0, 0, 0);
+        acc[1][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.y, bv.x, acc[1][0], 0, 0, 0);
+        acc[1][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.y, bv.y, acc[1][1], 0, 0, 0);
+      }
+    }
+    __syncthreads();  // the images are free for the next source
+  }
+  if (!computes) return;
+  float* dst = W + size_t(tgt_pool[t]) * kTileDoubles + size_t(32 * qi) * kTile + 32 * qj;
+  const bool upper_only = (flags & 1) && qi == qj;
+  float2_t cur[2][4];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) cur[a][g] = *reinterpret_cast<const float2_t*>(dst + size_t(8 * lk + 2 * g + a) * kTile + 2 * li);
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int i = 8 * lk + 2 * g + a, j = 2 * li;
+      float2_t v = cur[a][g];
+      if (!upper_only || j >= i) v.x -= acc[a][0][g];
+      if (!upper_only || j + 1 >= i) v.y -= acc[a][1][g];
+      *reinterpret_cast<float2_t*>(dst + size_t(i) * kTile + j) = v;
+    }
+}
+
 // (Round 3 A/B, not kept: ONE WAVEFRONT per target tile -- the whole 64 x 64 in 128 accumulator registers, each source tile
 // loaded once per product (64 instead of 128 KB), four targets of one tile row per workgroup, two wavefronts per SIMD.  Per
 // level, tools/sparse_levels.sh: 24 ns per product on the wide levels against 18.5 (reduced solve 46.3 against 38.2 ms at
@@ -1501,9 +1587,15 @@ int FactorLevels(cx_context* ctx, cx_sp_plan* P, TW* W, int* d_flag) {
                          (const int32_t*)P->d_panel_pool.p + p0, valid, P->T, (const double*)sc.uinv);
     if (nt > 0) {
       if constexpr (std::is_same_v<TW, float>) {
-        hipLaunchKernelGGL((k_sp_update_f32<4, 8>), dim3(unsigned(nt)), dim3(256), 0, st, W, (const int32_t*)P->d_tgt_pool.p + t0,
-                           (const int32_t*)P->d_tgt_flags.p + t0, (const int32_t*)P->d_src_begin.p + t0, (const int32_t*)P->d_src_a.p,
-                           (const int32_t*)P->d_src_b.p);
+        static const int f32_lds = std::getenv("CX_SPARSE_F32_LDS") ? atoi(std::getenv("CX_SPARSE_F32_LDS")) : 1;  // A/B switch
+        if (f32_lds)
+          hipLaunchKernelGGL((k_sp_update_f32_lds<4>), dim3(unsigned(nt)), dim3(256), 0, st, W, (const int32_t*)P->d_tgt_pool.p + t0,
+                             (const int32_t*)P->d_tgt_flags.p + t0, (const int32_t*)P->d_src_begin.p + t0, (const int32_t*)P->d_src_a.p,
+                             (const int32_t*)P->d_src_b.p);
+        else
+          hipLaunchKernelGGL((k_sp_update_f32<4, 8>), dim3(unsigned(nt)), dim3(256), 0, st, W, (const int32_t*)P->d_tgt_pool.p + t0,
+                             (const int32_t*)P->d_tgt_flags.p + t0, (const int32_t*)P->d_src_begin.p + t0, (const int32_t*)P->d_src_a.p,
+                             (const int32_t*)P->d_src_b.p);
       } else {
       static const int occ = [] { const char* v = std::getenv("CX_SPARSE_UPDATE_OCCUPANCY"); return v ? atoi(v) : 3; }();
 #define CX_SP_UPDATE(K)                                                                                                          \
