@@ -166,8 +166,18 @@ __device__ __forceinline__ void load_operand(const TW* __restrict__ src, int kb,
     for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
+        // Float pool: an unconditional load and the padding selected afterwards -- a load inside a branch, followed by the
+        // float -> double conversion, made every one of these loads a memory round trip of its own (k_sp_panel: 69 s_waitcnt
+        // against 8; 3.9 -> 2.1 ms per Final factorisation, k_sp_diag 3.9 -> 3.5).  Double pool: the conditional load, which the
+        // compiler keeps in flight as it is; the unconditional form costs it 2.5 -> 3.7 ms (panel) and 3.5 -> 3.9 (diag).
+        // Measured per level (tools/sparse_levels.sh), both ways for both pools.
         const int m = 16 * mt + lk + 4 * g, c = 16 * nt + li;
-        X[mt][nt][g] = (m < kb && c < ncols) ? src[size_t(m) * kTile + c] : 0.0;
+        if constexpr (std::is_same_v<TW, double>) {
+          X[mt][nt][g] = (m < kb && c < ncols) ? src[size_t(m) * kTile + c] : 0.0;
+        } else {
+          const TW v = src[size_t(m) * kTile + c];  // (the 32 x 32 block lies inside its 64 x 64 tile whatever kb and ncols are)
+          X[mt][nt][g] = (m < kb && c < ncols) ? double(v) : 0.0;
+        }
       }
 }
 
@@ -213,7 +223,12 @@ __device__ __forceinline__ void load_bop(const TW* __restrict__ Wrow, int kb, in
 #pragma unroll
     for (int nt = 0; nt < 2; ++nt) {
       const int r = 4 * s + lk, c = 16 * nt + li;
-      bop[s][nt] = (r < kb && c < ncols) ? Wrow[size_t(r) * kTile + c] : 0.0;
+      if constexpr (std::is_same_v<TW, double>) {  // (see load_operand)
+        bop[s][nt] = (r < kb && c < ncols) ? Wrow[size_t(r) * kTile + c] : 0.0;
+      } else {
+        const TW v = Wrow[size_t(r) * kTile + c];
+        bop[s][nt] = (r < kb && c < ncols) ? double(v) : 0.0;
+      }
     }
 }
 __device__ __forceinline__ void solve_x(const double (&aop)[8][2], const double (&bop)[8][2], double4_t (&X)[2][2]) {
