@@ -1326,7 +1326,12 @@ __global__ __launch_bounds__(kBlock) void k_pair_items_staged(const int32_t* __r
 // one -- SLOWER again (Eliminate + 1.1 / + 6.1 ms), so it is not the latency of the fetches; launching the items in groups
 // of 2 / 4 / 8 block rows interleaved by block column (CX_PAIR_ROW_GROUP; right operands shared inside a group) -- 16.4 ->
 // 16.3 / 16.2 / 16.2 ms, so it is not the reuse of the right operands either.  What is left is 32.9 GB of random 128-byte
-// line fetches at 2.9 TB/s.
+// line fetches at 2.9 TB/s.  Later in round 3 (rocprofv3 kernel stats, same box): the table in CAMERA-MAJOR order (a cell's
+// pairs then read ascending subsets of two contiguous 0.5 MB blocks instead of rows strewn over 7.4 GB; pair list translated
+// once) -- 10.11 against 10.22 ms per launch, so it is not the locality (or the TLB reach) of the fetches either: not kept.
+// Little's law fits what is seen: a CU holds ~280 pairs in flight (five workgroups x 28 staged + 28 requested, by registers and
+// LDS alike -- LDS-DMA would hold the same), 448 B each = 32 MB chip-wide, at ~3 us of loaded latency = the ~9.4 TB/s the
+// kernel pulls on the CU side (65 % L2 hits).
 __global__ __launch_bounds__(kBlock) void k_row_h(const double* __restrict__ E, const double* __restrict__ F,
                                                   const int32_t* __restrict__ row_pt, const double* __restrict__ ete_inv,
                                                   int64_t O, double* __restrict__ h0, double* __restrict__ h1) {
