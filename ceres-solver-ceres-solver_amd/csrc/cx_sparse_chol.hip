@@ -1324,10 +1324,18 @@ void BuildHostPlan(int C, const int32_t* cell_c1, const int32_t* cell_c2, int64_
         return x.tgt != y.tgt ? x.tgt < y.tgt : (x.level != y.level ? x.level < y.level : x.row < y.row);
       });
       const int32_t split = distributed ? tree_levels : 0;
+      // ... where the level a window opens at is WIDE: a level whose rows produce fewer products than fill the chip twice
+      // (2 x 256 CUs x 5 workgroups) keeps the right-looking schedule -- there a chain of four only lengthens the level
+      // (Final shape, levels 170-186: 12-13 us at window 1 against 23-26 at 4; a dense 51-row S: 2.7 against 3.1 ms)
+      int64_t wide = 2560;
+      if (const char* e = std::getenv("CX_SPARSE_WINDOW_MIN_PRODUCTS")) wide = std::atoll(e);
+      std::vector<int64_t> level_products(size_t(L), 0);
+      for (const Src& x : srcs) level_products[size_t(x.level)]++;
       size_t i = 0;
       while (i < srcs.size()) {
         const int32_t tq = srcs[i].tgt, l0 = srcs[i].level;
-        int32_t close = std::min<int32_t>(l0 + window - 1, vlevel[size_t(row_of_slot[size_t(tq)])] - 1);
+        const int w = level_products[size_t(l0)] >= wide ? window : 1;
+        int32_t close = std::min<int32_t>(l0 + w - 1, vlevel[size_t(row_of_slot[size_t(tq)])] - 1);
         if (l0 < split) close = std::min<int32_t>(close, split - 1);
         size_t j = i;
         while (j < srcs.size() && srcs[j].tgt == tq && srcs[j].level <= close) srcs[j++].level = close;

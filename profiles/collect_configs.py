@@ -19,12 +19,15 @@ RUNS = [
     "--workload final13682 --solver iterative_schur --preconditioner cluster_jacobi --steps 3 --warmup 1",
     "--workload final13682 --solver iterative_schur --preconditioner cluster_tridiagonal --steps 3 --warmup 1",
     "--workload final13682 --solver sparse_schur --steps 3 --warmup 1",
+    "--workload final13682 --solver sparse_schur --mixed --steps 3 --warmup 1",
+    "--workload final13682 --solver sparse_schur --mixed --refinements 1 --steps 3 --warmup 1",
     "--workload dubrovnik356 --solver sparse_schur --steps 10 --warmup 3 --force-tile-sparse",
     "--workload synthetic10M --solver cgnr --steps 10 --warmup 3",
     "--workload synthetic10M --solver cgnr --mixed --steps 10 --warmup 3",
     # the second scene (round 3): the Final sizes with loop closures (5 % of the points also seen half a ring away)
     "--workload final13682_revisit --solver iterative_schur --steps 5 --warmup 2",
     "--workload final13682_revisit --solver sparse_schur --steps 3 --warmup 1",
+    "--workload final13682_revisit --solver sparse_schur --mixed --steps 3 --warmup 1",
     "--workload final13682_revisit --solver iterative_schur --preconditioner cluster_tridiagonal --steps 3 --warmup 1",
 ]
 

@@ -270,7 +270,7 @@ def test_distribution_of_the_tile_sparse_factorisation(C, P, O, seed):
 
 
 @pytest.mark.parametrize("C,P,O,seed", [(700, 5000, 26000, 8), (2000, 20000, 110000, 3)])
-def test_update_windows_of_the_tile_sparse_factorisation(C, P, O, seed):
+def test_update_windows_of_the_tile_sparse_factorisation(C, P, O, seed, monkeypatch):
     """cx_sparse_cholesky_schedule_host: the schedule of the tile-pair updates under an update window (a target's contributions of
     `window` levels subtracted as one chain), checked from its definition on the host: every product of the symbolic factor is
     scheduled exactly once, after its source row is factored and before its target's row is, ascending source rows inside a chain;
@@ -279,7 +279,11 @@ def test_update_windows_of_the_tile_sparse_factorisation(C, P, O, seed):
     bs, _ = cx.bal.build_structure(prob)
     r, c, _, _ = cx.binding.schur_pair_lists_host(bs, P)
     plan = cx.binding.sparse_cholesky_plan_host(C, r, c)
+    # (windows open only at levels wide enough to fill the chip: these small structures have none, so the rule is switched off)
+    wide = cx.binding.sparse_cholesky_schedule_host(C, r, c, window=4)
+    monkeypatch.setenv("CX_SPARSE_WINDOW_MIN_PRODUCTS", "0")
     one = cx.binding.sparse_cholesky_schedule_host(C, r, c, window=1)
+    assert wide["violations"] == 0 and wide["num_chains"] == one["num_chains"]
     assert one["violations"] == 0 and one["num_tile_rows"] == plan["num_tile_rows"]
     assert one["num_products"] == plan["num_tile_pair_updates"]
     chains = [one["num_chains"]]

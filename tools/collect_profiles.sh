@@ -4,7 +4,7 @@
 #   WRITE_SIZE; separate runs, no trace domains besides --kernel-trace) that profiles/make_traffic.py turns into bytes.
 # Everything lands under gpurun_out/prof_rNN/; copy what is to be kept into profiles/.
 set -o pipefail
-R=${CX_ROUND:-02}
+R=${CX_ROUND:-03}
 OUT=$GRAFT_REPO_ROOT/gpurun_out/prof_r$R
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
@@ -16,6 +16,7 @@ run() {  # name, bench args...
 }
 run final13682 --steps 3 --warmup 1
 run final13682_sparse_schur --solver sparse_schur --steps 2 --warmup 1
+run final13682_sparse_schur_mixed --solver sparse_schur --mixed --steps 2 --warmup 1
 run final13682_cluster_tridiagonal --eta 1e-2 --preconditioner cluster_tridiagonal --steps 2 --warmup 1
 run dubrovnik356_dense_schur --workload dubrovnik356 --solver dense_schur --steps 5 --warmup 2
 for c in FETCH_SIZE WRITE_SIZE; do
@@ -24,5 +25,5 @@ for c in FETCH_SIZE WRITE_SIZE; do
   echo "pmc $c done"
 done
 # keep the merged output small: drop the raw traces
-rm -rf $OUT/final13682 $OUT/final13682_sparse_schur $OUT/final13682_cluster_tridiagonal $OUT/dubrovnik356_dense_schur $OUT/pmc_FETCH_SIZE $OUT/pmc_WRITE_SIZE
+rm -rf $OUT/final13682 $OUT/final13682_sparse_schur $OUT/final13682_sparse_schur_mixed $OUT/final13682_cluster_tridiagonal $OUT/dubrovnik356_dense_schur $OUT/pmc_FETCH_SIZE $OUT/pmc_WRITE_SIZE
 ls -la $OUT

@@ -18,7 +18,7 @@ def main():
     runs_dst = os.path.join(ROOT, "profiles", "r%s_config_runs.jsonl" % R)
     if os.path.exists(runs_src):
         shutil.copy(runs_src, runs_dst)
-    for n in ("final13682", "final13682_sparse_schur", "final13682_cluster_tridiagonal", "dubrovnik356_dense_schur"):
+    for n in ("final13682", "final13682_sparse_schur", "final13682_sparse_schur_mixed", "final13682_cluster_tridiagonal", "dubrovnik356_dense_schur"):
         a = os.path.join(SRC, n + "_kernel_stats.csv")
         if os.path.exists(a):
             shutil.copy(a, os.path.join(ROOT, "profiles", "r%s_%s_kernel_stats.csv" % (R, n)))
@@ -71,6 +71,10 @@ def main():
     setrow("| 4 Final-13682 | … CLUSTER_TRIDIAGONAL", "| 4 Final-13682 | … CLUSTER_TRIDIAGONAL (§3e, tile-sparse factorisation) | %.0f ms (%d it) | **%.0f ms (%d it, %.2f ms/it)** [1 080] | %.1f / %.0f / %.2f |" % (r["ms"], r["cg_iterations"], e["ms"], e["cg_iterations"], e["cg_ms_per_iteration"], *ph(r)))
     r = get("final13682 --solver sparse_schur")
     setrow("| 4 Final-13682 | SPARSE_SCHUR", "| 4 Final-13682 | SPARSE_SCHUR (level-scheduled tile-sparse Cholesky, §3d) | **%.1f ms** [143.1] | – | %.1f / %.1f [119.3] / %.2f |" % (r["ms"], *ph(r)))
+    r = get("final13682 --solver sparse_schur --mixed --steps")
+    setrow("| 4 Final-13682 | … `use_mixed_precision_solves` (single", "| 4 Final-13682 | … `use_mixed_precision_solves` (single precision tile pool, §3d) | **%.1f ms** | – | %.1f / %.1f / %.2f |" % (r["ms"], *ph(r)))
+    r = get("final13682 --solver sparse_schur --mixed --refinements 1")
+    setrow("| 4 Final-13682 | … + `max_num_refinement_iterations = 1`", "| 4 Final-13682 | … + `max_num_refinement_iterations = 1` | %.1f ms | – | %.1f / %.1f / %.2f |" % (r["ms"], *ph(r)))
     r = get("synthetic10M --solver cgnr --steps"); e = r["eta_0.01"]
     setrow("| 5 Synthetic-10M | CGNR + JACOBI, fp64", "| 5 Synthetic-10M | CGNR + JACOBI, fp64 | %.2f ms (%d it) | %.2f ms | %.2f / %.2f / – |" % (r["ms"], r["cg_iterations"], e["ms"], ph(r)[0], ph(r)[1]))
     r = get("synthetic10M --solver cgnr --mixed"); e = r["eta_0.01"]
