@@ -4,6 +4,7 @@
 #include <algorithm>
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <numeric>
 #include <random>
 #include <vector>
@@ -107,6 +108,17 @@ static void Exercise(const char* name, const Scene& s) {
   std::vector<int32_t> level(static_cast<size_t>(T)), start(size_t(T) + 1), tcols(static_cast<size_t>(tiles));
   EXPECT(cx_sparse_cholesky_plan_host(C, cell_row.data(), cell_col.data(), num_cells, first.data(), &T, &levels, &tiles, &updates, level.data(),
                                       start.data(), T, tcols.data(), tiles) == CX_OK && start[size_t(T)] == tiles, "%s", cx_last_error());
+  // the update schedule under a window (single plan and rank 1 of 3), with the "wide levels only" rule switched off so that
+  // the windowing code runs on these small scenes
+  setenv("CX_SPARSE_WINDOW_MIN_PRODUCTS", "0", 1);
+  for (int nranks : {1, 3}) {
+    int64_t products = 0, chains = 0, violations = -1;
+    int32_t longest = 0;
+    EXPECT(cx_sparse_cholesky_schedule_host(C, cell_row.data(), cell_col.data(), num_cells, nranks, nranks - 1, 4, &products, &chains, &longest,
+                                            &violations) == T && violations == 0 && (nranks > 1 || products > 0) && chains <= products,
+           "update schedule (%d ranks): %lld violations, %s", nranks, (long long)violations, cx_last_error());
+  }
+  unsetenv("CX_SPARSE_WINDOW_MIN_PRODUCTS");
   std::printf("%-22s %d cameras %d points %lld observations: S %lld cells, %lld pairs, %lld items; tile-sparse plan %d tile rows, %d levels, %lld tiles, %lld updates\n",
               name, C, P, (long long)O, (long long)num_cells, (long long)num_pairs, (long long)num_items, T, levels, (long long)tiles, (long long)updates);
   for (int pre : {CX_CLUSTER_JACOBI, CX_CLUSTER_TRIDIAGONAL})
