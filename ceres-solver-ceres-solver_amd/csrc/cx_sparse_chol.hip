@@ -560,11 +560,13 @@ __global__ __launch_bounds__(256, kWgPerCu) void k_sp_update_f32(float* __restri
 // the two 32-column halves swapped on odd rows, so the four rows a k-step reads (one per 16-lane group) fall on both halves
 // of the 64 banks: a ds_read_b64 of 64 lanes takes its minimum of two passes.  Same products in the same order as
 // k_sp_update_f32: bitwise the same result.
-template <int kWgPerCu>
+template <int kRows, int kWgPerCu>
 __global__ __launch_bounds__(256, kWgPerCu) void k_sp_update_f32_lds(float* __restrict__ W, const int32_t* __restrict__ tgt_pool,
                                                                      const int32_t* __restrict__ tgt_flags, const int32_t* __restrict__ src_begin,
                                                                      const int32_t* __restrict__ src_a, const int32_t* __restrict__ src_b) {
-  __shared__ float lds[2 * kTileDoubles];  // A image | B image
+  constexpr int kPart = kRows * kTile;  // floats of a kRows-row part of a tile (64: the whole tile)
+  constexpr int kParts = kTile / kRows, kPieces = kRows / 16;  // parts per tile; 16-byte pieces per thread and part
+  __shared__ float lds[2 * kPart];  // A image | B image
   typedef float float4v __attribute__((ext_vector_type(4)));
   const int t = blockIdx.x;
   const int tid = threadIdx.x, wave = tid >> 6;
@@ -578,45 +580,44 @@ __global__ __launch_bounds__(256, kWgPerCu) void k_sp_update_f32_lds(float* __re
 #pragma unroll
     for (int b = 0; b < 2; ++b) acc[a][b] = float4_t{0.f, 0.f, 0.f, 0.f};
   const int s0 = src_begin[t], s1 = src_begin[t + 1];
-  // piece j of this thread: float4 number tid + 256 j of a tile = row (tid + 256 j) / 16, columns 4 ((tid + 256 j) % 16) ...
-  float4v ra[4], rb[4];
-  auto request = [&](int s) {
-    const float* pa = W + size_t(src_a[s]) * kTileDoubles + 4 * tid;
-    const float* pb = W + size_t(src_b[s]) * kTileDoubles + 4 * tid;
+  const int nq = kParts * (s1 - s0);
+  // piece j of this thread: float4 number tid + 256 j of a part = row (tid + 256 j) / 16, columns 4 ((tid + 256 j) % 16) ...
+  float4v ra[kPieces], rb[kPieces];
+#define CX_SP_REQUEST(q_)                                                                             \
+  do {                                                                                                \
+    const int s_ = s0 + (q_) / kParts;                                                                \
+    const float* pa_ = W + size_t(src_a[s_]) * kTileDoubles + ((q_) % kParts) * kPart + 4 * tid;      \
+    const float* pb_ = W + size_t(src_b[s_]) * kTileDoubles + ((q_) % kParts) * kPart + 4 * tid;      \
+    _Pragma("unroll") for (int j = 0; j < kPieces; ++j) ra[j] = *reinterpret_cast<const float4v*>(pa_ + 1024 * j); \
+    _Pragma("unroll") for (int j = 0; j < kPieces; ++j) rb[j] = *reinterpret_cast<const float4v*>(pb_ + 1024 * j); \
+  } while (0)
+  if (nq > 0) CX_SP_REQUEST(0);
+  for (int q = 0; q < nq; ++q) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) ra[j] = *reinterpret_cast<const float4v*>(pa + 1024 * j);
-#pragma unroll
-    for (int j = 0; j < 4; ++j) rb[j] = *reinterpret_cast<const float4v*>(pb + 1024 * j);
-  };
-  auto deposit = [&]() {
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
+    for (int j = 0; j < kPieces; ++j) {
       const int idx = tid + 256 * j, k = idx >> 4, c = (idx & 15) << 2;
       const int at = k * kTile + (c ^ ((k & 1) << 5));
       *reinterpret_cast<float4v*>(lds + at) = ra[j];
-      *reinterpret_cast<float4v*>(lds + kTileDoubles + at) = rb[j];
+      *reinterpret_cast<float4v*>(lds + kPart + at) = rb[j];
     }
-  };
-  if (s1 > s0) request(s0);
-  for (int s = s0; s < s1; ++s) {
-    deposit();
     __syncthreads();
-    if (s + 1 < s1) request(s + 1);
+    if (q + 1 < nq) CX_SP_REQUEST(q + 1);
     if (computes) {
+      const int sw = (lk & 1) << 5;  // (k & 1) == (lk & 1)
 #pragma unroll
-      for (int g = 0; g < 16; ++g) {
+      for (int g = 0; g < kRows / 4; ++g) {
         const int k = 4 * g + lk;
-        const int sw = (lk & 1) << 5;  // (k & 1) == (lk & 1)
         const float2_t av = *reinterpret_cast<const float2_t*>(lds + k * kTile + ((32 * qi + 2 * li) ^ sw));
-        const float2_t bv = *reinterpret_cast<const float2_t*>(lds + kTileDoubles + k * kTile + ((32 * qj + 2 * li) ^ sw));
+        const float2_t bv = *reinterpret_cast<const float2_t*>(lds + kPart + k * kTile + ((32 * qj + 2 * li) ^ sw));
         acc[0][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.x, bv.x, acc[0][0], 0, 0, 0);
         acc[0][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.x, bv.y, acc[0][1], 0, 0, 0);
         acc[1][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.y, bv.x, acc[1][0], 0, 0, 0);
         acc[1][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.y, bv.y, acc[1][1], 0, 0, 0);
       }
     }
-    __syncthreads();  // the images are free for the next source
+    __syncthreads();  // the images are free for the next part
   }
+#undef CX_SP_REQUEST
   if (!computes) return;
   float* dst = W + size_t(tgt_pool[t]) * kTileDoubles + size_t(32 * qi) * kTile + 32 * qj;
   const bool upper_only = (flags & 1) && qi == qj;
@@ -635,6 +636,79 @@ __global__ __launch_bounds__(256, kWgPerCu) void k_sp_update_f32_lds(float* __re
       if (!upper_only || j + 1 >= i) v.y -= acc[a][1][g];
       *reinterpret_cast<float2_t*>(dst + size_t(i) * kTile + j) = v;
     }
+}
+
+// The double precision update with both source tiles staged once per workgroup through LDS, as k_sp_update_f32_lds.  The
+// counters (tools/pmc_mfma.sh) said that k_sp_update_slices is NOT bound by the matrix cores: 61-63 busy cycles per
+// v_mfma_f64_16x16x4_f64 (the nominal 64) at 2.2-2.5 GHz, but the pipes busy only 55-60 % of the SIMD cycles on the widest
+// levels (11.3 ns per product; 100 % would be 6.9) -- the wavefronts wait for operands, 128 KB per product through the
+// caches.  Here: 64 KB per product (two 32 KB tiles, 16-byte loads), in 32-row halves: the next half's pieces in registers
+// behind the current 32 products, one 32 KB LDS buffer (four workgroups per CU; whole tiles in a 64 KB buffer, two per CU:
+// 33.4 against 31.5 ms); LDS image row-major with the 16-column blocks swapped in pairs on odd rows, so that the four rows of a
+// k-step spread over all 64 banks (ds_read_b64: two passes, the minimum).  Same products in the same order: bitwise the
+// results of k_sp_update_slices.
+template <int kRows, int kWgPerCu>
+__global__ __launch_bounds__(256, kWgPerCu) void k_sp_update_f64_lds(double* __restrict__ W, const int32_t* __restrict__ tgt_pool,
+                                                                     const int32_t* __restrict__ tgt_flags, const int32_t* __restrict__ src_begin,
+                                                                     const int32_t* __restrict__ src_a, const int32_t* __restrict__ src_b) {
+  constexpr int kHalf = kRows * kTile;  // doubles of a kRows-row part of a tile (32: half)
+  constexpr int kParts = kTile / kRows, kPieces = kRows / 8;  // parts per tile; 16-byte pieces per thread and part
+  __shared__ double lds[2 * kHalf];     // A part | B part: 32 KB at 32 rows
+  typedef double double2v __attribute__((ext_vector_type(2)));
+  const int t = blockIdx.x;
+  const int tid = threadIdx.x, wave = tid >> 6;
+  const int qi = wave >> 1, qj = wave & 1;
+  const int flags = tgt_flags[t];
+  const bool computes = !((flags & 1) && qi == 1 && qj == 0) && !((flags & 2) && qj == 1);  // (every wavefront loads)
+  const int lane = tid & 63, li = lane & 15, lk = lane >> 4;
+  double4_t acc[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b) acc[a][b] = double4_t{0.0, 0.0, 0.0, 0.0};
+  const int s0 = src_begin[t], s1 = src_begin[t + 1];
+  const int nq = kParts * (s1 - s0);  // parts of the sources
+  // piece j of this thread: double2 number tid + 256 j of a half tile = row (tid + 256 j) / 32, columns 2 ((tid + 256 j) % 32), + 1
+  double2v ra[kPieces], rb[kPieces];
+#define CX_SP_REQUEST(q_)                                                                              \
+  do {                                                                                                 \
+    const int s_ = s0 + (q_) / kParts;                                                                 \
+    const double* pa_ = W + size_t(src_a[s_]) * kTileDoubles + ((q_) % kParts) * kHalf + 2 * tid;      \
+    const double* pb_ = W + size_t(src_b[s_]) * kTileDoubles + ((q_) % kParts) * kHalf + 2 * tid;      \
+    _Pragma("unroll") for (int j = 0; j < kPieces; ++j) ra[j] = *reinterpret_cast<const double2v*>(pa_ + 512 * j); \
+    _Pragma("unroll") for (int j = 0; j < kPieces; ++j) rb[j] = *reinterpret_cast<const double2v*>(pb_ + 512 * j); \
+  } while (0)
+  if (nq > 0) CX_SP_REQUEST(0);
+  for (int q = 0; q < nq; ++q) {
+#pragma unroll
+    for (int j = 0; j < kPieces; ++j) {
+      const int idx = tid + 256 * j, k = idx >> 5, c = (idx & 31) << 1;
+      const int at = k * kTile + (c ^ ((k & 1) << 4));
+      *reinterpret_cast<double2v*>(lds + at) = ra[j];
+      *reinterpret_cast<double2v*>(lds + kHalf + at) = rb[j];
+    }
+    __syncthreads();
+    if (q + 1 < nq) CX_SP_REQUEST(q + 1);
+    if (computes) {
+      const int sw = (lk & 1) << 4;  // (k & 1) == (lk & 1)
+#pragma unroll
+      for (int g = 0; g < kRows / 4; ++g) {
+        const double* Ak = lds + (4 * g + lk) * kTile;
+        const double* Bk = Ak + kHalf;
+        const double a0 = Ak[(32 * qi + li) ^ sw], a1 = Ak[(32 * qi + 16 + li) ^ sw];
+        const double b0 = Bk[(32 * qj + li) ^ sw], b1 = Bk[(32 * qj + 16 + li) ^ sw];
+        acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc[0][0], 0, 0, 0);
+        acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, acc[0][1], 0, 0, 0);
+        acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, acc[1][0], 0, 0, 0);
+        acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc[1][1], 0, 0, 0);
+      }
+    }
+    __syncthreads();  // the images are free for the next half
+  }
+#undef CX_SP_REQUEST
+  if (!computes) return;
+  double* dst = W + size_t(tgt_pool[t]) * kTileDoubles + size_t(32 * qi) * kTile + 32 * qj;
+  subtract_block(acc, dst, 32, 32, (flags & 1) && qi == qj);
 }
 
 // (Round 3 A/B, not kept: ONE WAVEFRONT per target tile -- the whole 64 x 64 in 128 accumulator registers, each source tile
@@ -1611,15 +1685,33 @@ int FactorLevels(cx_context* ctx, cx_sp_plan* P, TW* W, int* d_flag) {
     if (nt > 0) {
       if constexpr (std::is_same_v<TW, float>) {
         static const int f32_lds = std::getenv("CX_SPARSE_F32_LDS") ? atoi(std::getenv("CX_SPARSE_F32_LDS")) : 1;  // A/B switch
-        if (f32_lds)
-          hipLaunchKernelGGL((k_sp_update_f32_lds<4>), dim3(unsigned(nt)), dim3(256), 0, st, W, (const int32_t*)P->d_tgt_pool.p + t0,
-                             (const int32_t*)P->d_tgt_flags.p + t0, (const int32_t*)P->d_src_begin.p + t0, (const int32_t*)P->d_src_a.p,
-                             (const int32_t*)P->d_src_b.p);
+#define CX_SP_F32_LDS(R, K)                                                                                                            \
+  hipLaunchKernelGGL((k_sp_update_f32_lds<R, K>), dim3(unsigned(nt)), dim3(256), 0, st, W, (const int32_t*)P->d_tgt_pool.p + t0,         \
+                     (const int32_t*)P->d_tgt_flags.p + t0, (const int32_t*)P->d_src_begin.p + t0, (const int32_t*)P->d_src_a.p,        \
+                     (const int32_t*)P->d_src_b.p)
+        if (f32_lds == 326) CX_SP_F32_LDS(32, 6);
+        else if (f32_lds == 328) CX_SP_F32_LDS(32, 8);
+        else if (f32_lds == 168) CX_SP_F32_LDS(16, 8);
+        else if (f32_lds) CX_SP_F32_LDS(64, 4);
         else
           hipLaunchKernelGGL((k_sp_update_f32<4, 8>), dim3(unsigned(nt)), dim3(256), 0, st, W, (const int32_t*)P->d_tgt_pool.p + t0,
                              (const int32_t*)P->d_tgt_flags.p + t0, (const int32_t*)P->d_src_begin.p + t0, (const int32_t*)P->d_src_a.p,
                              (const int32_t*)P->d_src_b.p);
       } else {
+      static const int f64_lds = std::getenv("CX_SPARSE_F64_LDS") ? atoi(std::getenv("CX_SPARSE_F64_LDS")) : 1;  // A/B switch
+      if (f64_lds) {
+#define CX_SP_F64_LDS(R, K)                                                                                                            \
+  hipLaunchKernelGGL((k_sp_update_f64_lds<R, K>), dim3(unsigned(nt)), dim3(256), 0, st, W, (const int32_t*)P->d_tgt_pool.p + t0,         \
+                     (const int32_t*)P->d_tgt_flags.p + t0, (const int32_t*)P->d_src_begin.p + t0, (const int32_t*)P->d_src_a.p,        \
+                     (const int32_t*)P->d_src_b.p)
+        if (f64_lds == 325) CX_SP_F64_LDS(32, 5);
+        else if (f64_lds == 166) CX_SP_F64_LDS(16, 6);
+        else if (f64_lds == 167) CX_SP_F64_LDS(16, 7);
+        else if (f64_lds == 87) CX_SP_F64_LDS(8, 7);
+        else CX_SP_F64_LDS(32, 4);
+#undef CX_SP_F64_LDS
+        continue;
+      }
       static const int occ = [] { const char* v = std::getenv("CX_SPARSE_UPDATE_OCCUPANCY"); return v ? atoi(v) : 3; }();
 #define CX_SP_UPDATE(K)                                                                                                          \
   hipLaunchKernelGGL(k_sp_update<K>, dim3(unsigned(nt)), dim3(256), 0, st, W, (const int32_t*)P->d_tgt_pool.p + t0,              \
@@ -1638,6 +1730,7 @@ int FactorLevels(cx_context* ctx, cx_sp_plan* P, TW* W, int* d_flag) {
       else CX_SP_UPDATE(2);
 #undef CX_SP_UPDATE
 #undef CX_SP_SLICES
+#undef CX_SP_F32_LDS
       }
     }
   }
