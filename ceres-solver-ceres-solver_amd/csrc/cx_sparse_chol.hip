@@ -555,8 +555,9 @@ __global__ __launch_bounds__(256, kWgPerCu) void k_sp_update_f32(float* __restri
 // bound by the matrix cores (64 v_mfma_f32_16x16x4_f32 per wavefront and source = 2 048 cycles) but by the bytes its four
 // wavefronts pull through the caches: each loads a 32-column half of both tiles, 64 KB per product, 9-10 ns per product on the
 // wide levels = ~7 TB/s on the CU side.  Here the workgroup's 256 threads fetch the two 16 KB tiles once (32 KB per product,
-// 16-byte loads, a wavefront = 1 KB contiguous), the next source's pieces are requested into registers before the current
-// products and written to LDS behind them (one 32 KB buffer, four workgroups per CU).  LDS image: row-major 64 x 64 floats with
+// 16-byte loads, a wavefront = 1 KB contiguous), in parts of kRows rows: the next part's pieces are requested into registers
+// before the current products and written to LDS behind them (whole tiles, 32 KB, four workgroups per CU: reduced solve 19.2 /
+// 45.4 ms on the Final shape / the second scene; **16-row parts, 8 KB, eight per CU: 18.3 / 42.9**).  LDS image: row-major 64 x 64 floats with
 // the two 32-column halves swapped on odd rows, so the four rows a k-step reads (one per 16-lane group) fall on both halves
 // of the 64 banks: a ds_read_b64 of 64 lanes takes its minimum of two passes.  Same products in the same order as
 // k_sp_update_f32: bitwise the same result.
@@ -642,18 +643,21 @@ __global__ __launch_bounds__(256, kWgPerCu) void k_sp_update_f32_lds(float* __re
 // counters (tools/pmc_mfma.sh) said that k_sp_update_slices is NOT bound by the matrix cores: 61-63 busy cycles per
 // v_mfma_f64_16x16x4_f64 (the nominal 64) at 2.2-2.5 GHz, but the pipes busy only 55-60 % of the SIMD cycles on the widest
 // levels (11.3 ns per product; 100 % would be 6.9) -- the wavefronts wait for operands, 128 KB per product through the
-// caches.  Here: 64 KB per product (two 32 KB tiles, 16-byte loads), in 32-row halves: the next half's pieces in registers
-// behind the current 32 products, one 32 KB LDS buffer (four workgroups per CU; whole tiles in a 64 KB buffer, two per CU:
-// 33.4 against 31.5 ms); LDS image row-major with the 16-column blocks swapped in pairs on odd rows, so that the four rows of a
-// k-step spread over all 64 banks (ds_read_b64: two passes, the minimum).  Same products in the same order: bitwise the
-// results of k_sp_update_slices.
+// caches.  Here: 64 KB per product (two 32 KB tiles, 16-byte loads), in parts of kRows rows: the next part's pieces in
+// registers behind the current products, one LDS buffer; LDS image row-major with the 16-column blocks swapped in pairs on odd
+// rows, so that the four rows of a k-step spread over all 64 banks (ds_read_b64: two passes, the minimum).  Same products in
+// the same order: bitwise the results of k_sp_update_slices.  Reduced solve, Final / second scene (k_sp_update_slices: 31.4 /
+// 81.4 ms): whole tiles, 64 KB, two workgroups per CU 33.4 / 87.9; 32-row parts, 32 KB, four per CU 28.9 / 73.6; **16-row
+// parts, 16 KB, six per CU 27.5 / 68.6**; seven per CU (20 B of scratch) or 8-row parts 27.9 / 70.0; two alternating images
+// with one barrier per part instead of two (16 rows, five per CU / 8 rows, six per CU) 29.5 / 75.1 and 28.7 / 72.2 -- what
+// pays is workgroups in flight, not fewer barriers.
 template <int kRows, int kWgPerCu>
 __global__ __launch_bounds__(256, kWgPerCu) void k_sp_update_f64_lds(double* __restrict__ W, const int32_t* __restrict__ tgt_pool,
                                                                      const int32_t* __restrict__ tgt_flags, const int32_t* __restrict__ src_begin,
                                                                      const int32_t* __restrict__ src_a, const int32_t* __restrict__ src_b) {
   constexpr int kHalf = kRows * kTile;  // doubles of a kRows-row part of a tile (32: half)
   constexpr int kParts = kTile / kRows, kPieces = kRows / 8;  // parts per tile; 16-byte pieces per thread and part
-  __shared__ double lds[2 * kHalf];     // A part | B part: 32 KB at 32 rows
+  __shared__ double lds[2 * kHalf];     // A part | B part: 16 KB at 16 rows
   typedef double double2v __attribute__((ext_vector_type(2)));
   const int t = blockIdx.x;
   const int tid = threadIdx.x, wave = tid >> 6;
@@ -703,7 +707,7 @@ __global__ __launch_bounds__(256, kWgPerCu) void k_sp_update_f64_lds(double* __r
         acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc[1][1], 0, 0, 0);
       }
     }
-    __syncthreads();  // the images are free for the next half
+    __syncthreads();  // the images are free for the next part
   }
 #undef CX_SP_REQUEST
   if (!computes) return;
@@ -1689,10 +1693,8 @@ int FactorLevels(cx_context* ctx, cx_sp_plan* P, TW* W, int* d_flag) {
   hipLaunchKernelGGL((k_sp_update_f32_lds<R, K>), dim3(unsigned(nt)), dim3(256), 0, st, W, (const int32_t*)P->d_tgt_pool.p + t0,         \
                      (const int32_t*)P->d_tgt_flags.p + t0, (const int32_t*)P->d_src_begin.p + t0, (const int32_t*)P->d_src_a.p,        \
                      (const int32_t*)P->d_src_b.p)
-        if (f32_lds == 326) CX_SP_F32_LDS(32, 6);
-        else if (f32_lds == 328) CX_SP_F32_LDS(32, 8);
-        else if (f32_lds == 168) CX_SP_F32_LDS(16, 8);
-        else if (f32_lds) CX_SP_F32_LDS(64, 4);
+        if (f32_lds == 644) CX_SP_F32_LDS(64, 4);  // (A/B: whole tiles, four workgroups per CU)
+        else if (f32_lds) CX_SP_F32_LDS(16, 8);
         else
           hipLaunchKernelGGL((k_sp_update_f32<4, 8>), dim3(unsigned(nt)), dim3(256), 0, st, W, (const int32_t*)P->d_tgt_pool.p + t0,
                              (const int32_t*)P->d_tgt_flags.p + t0, (const int32_t*)P->d_src_begin.p + t0, (const int32_t*)P->d_src_a.p,
@@ -1704,11 +1706,8 @@ int FactorLevels(cx_context* ctx, cx_sp_plan* P, TW* W, int* d_flag) {
   hipLaunchKernelGGL((k_sp_update_f64_lds<R, K>), dim3(unsigned(nt)), dim3(256), 0, st, W, (const int32_t*)P->d_tgt_pool.p + t0,         \
                      (const int32_t*)P->d_tgt_flags.p + t0, (const int32_t*)P->d_src_begin.p + t0, (const int32_t*)P->d_src_a.p,        \
                      (const int32_t*)P->d_src_b.p)
-        if (f64_lds == 325) CX_SP_F64_LDS(32, 5);
-        else if (f64_lds == 166) CX_SP_F64_LDS(16, 6);
-        else if (f64_lds == 167) CX_SP_F64_LDS(16, 7);
-        else if (f64_lds == 87) CX_SP_F64_LDS(8, 7);
-        else CX_SP_F64_LDS(32, 4);
+        if (f64_lds == 324) CX_SP_F64_LDS(32, 4);  // (A/B: 32-row parts, four workgroups per CU)
+        else CX_SP_F64_LDS(16, 6);
 #undef CX_SP_F64_LDS
         continue;
       }
