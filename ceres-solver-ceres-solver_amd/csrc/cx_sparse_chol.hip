@@ -18,9 +18,11 @@
 //              permuted positions
 //   numeric    by LEVELS of the tile elimination tree (tile rows of equal height are independent): per level
 //              k_sp_diag (the diagonal tiles: two 32x32 factor + inverse blocks each), k_sp_panel (the rows of
-//              the factor, F(I, J) = U_II^-T W(I, J) on fp64 MFMA, in place) and k_sp_update (every tile that
-//              receives contributions from this level's rows subtracts F(I, Ja)' F(I, Jb) for its sources in
-//              ascending I: a gather, no atomics, bitwise reproducible).  The dependent chain is the tree
+//              the factor, F(I, J) = U_II^-T W(I, J) on fp64 MFMA, in place) and the update (every tile whose
+//              window of contributions closes at this level subtracts F(I, Ja)' F(I, Jb) for its sources in
+//              ascending I: a gather, no atomics, bitwise reproducible; k_sp_update_f64_lds / k_sp_update_f32_lds:
+//              both source tiles staged once per workgroup through LDS).  The pool is double, or float under
+//              use_mixed_precision_solves (every kernel is a template on it).  The dependent chain is the tree
 //              height (about a hundred to a few hundred levels on the Final-13682 shape) instead of n / 32 = 3 848
 //              block steps.
 //   solve      backward substitution by the same levels, top down: one workgroup per tile row gathers
