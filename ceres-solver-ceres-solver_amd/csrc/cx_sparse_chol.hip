@@ -727,6 +727,11 @@ __global__ __launch_bounds__(256, kWgPerCu) void k_sp_update_f64_lds(double* __r
 
 // Backward substitution of a level (top down), part 1: workgroup = one tile F(I, J) right of the diagonal of a row of
 // the level: partial[tile][r] = sum_c F(I, J)[r][c] x_J[c].
+// Lanes run along the COLUMNS of the tile (a wavefront's load is 512 contiguous bytes, as in k_sp_fwd_partial); wavefront w owns
+// rows 16 w ... 16 w + 15, and the 16 x 64 products are summed over the lanes by a halving exchange (8 + 4 + 2 + 1 values
+// swapped with lane ^ 32, 16, 8, 4, then two plain steps): 17 double shuffles instead of 96.  Round 2 had every thread read
+// 16 consecutive doubles of a row -- each load instruction touched 64 lines, and the kernel took twice as long as the forward
+// one on the same tiles (12.6 against 6.2 us per launch in a CLUSTER_TRIDIAGONAL solve).
 template <typename TW>
 __global__ __launch_bounds__(256) void k_sp_bwd_partial(const TW* __restrict__ W, const int32_t* __restrict__ row_tiles,
                                                         const int32_t* __restrict__ panel_pool, const int32_t* __restrict__ valid, int T,
@@ -734,16 +739,34 @@ __global__ __launch_bounds__(256) void k_sp_bwd_partial(const TW* __restrict__ W
   const int q = panel_pool[blockIdx.x];
   const int J = row_tiles[q];
   if (J >= T) return;  // the right-hand-side tile
-  const int t = threadIdx.x, r = t >> 2, part = t & 3;
-  const TW* __restrict__ row = W + size_t(q) * kTileDoubles + size_t(r) * kTile + 16 * part;
-  const double* __restrict__ xj = x + size_t(kTile) * J + 16 * part;
-  const int nvalid = valid[J] - 16 * part;
-  double s = 0.0;
+  const int t = threadIdx.x, c = t & 63, w = t >> 6;
+  const TW* __restrict__ F = W + size_t(q) * kTileDoubles + size_t(16 * w) * kTile + c;
+  TW f[16];
 #pragma unroll
-  for (int c = 0; c < 16; ++c) s += (c < nvalid) ? row[c] * xj[c] : 0.0;
-  s += __shfl_xor(s, 1, 64);
+  for (int i = 0; i < 16; ++i) f[i] = F[size_t(i) * kTile];
+  const double xc = (c < valid[J]) ? x[size_t(kTile) * J + c] : 0.0;
+  double v[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) v[i] = double(f[i]) * xc;
+  // halving exchange: after the step with mask m a lane keeps the rows whose bit (in the order 8, 4, 2, 1 of the row index)
+  // equals its own bit m
+#define CX_SP_HALVE(n, mask)                                              \
+  _Pragma("unroll") for (int i = 0; i < n; ++i) {                          \
+    const bool hi = (c & mask) != 0;                                       \
+    const double keep = hi ? v[i + n] : v[i], send = hi ? v[i] : v[i + n]; \
+    v[i] = keep + __shfl_xor(send, mask, 64);                              \
+  }
+  CX_SP_HALVE(8, 32)
+  CX_SP_HALVE(4, 16)
+  CX_SP_HALVE(2, 8)
+  CX_SP_HALVE(1, 4)
+#undef CX_SP_HALVE
+  double s = v[0];
   s += __shfl_xor(s, 2, 64);
-  if (part == 0) partial[size_t(q) * kTile + r] = s;
+  s += __shfl_xor(s, 1, 64);
+  // this lane's row: bit 3 of the row index from lane bit 5, bit 2 from bit 4, bit 1 from bit 3, bit 0 from bit 2
+  const int row = 16 * w + (((c >> 5) & 1) << 3 | ((c >> 4) & 1) << 2 | ((c >> 3) & 1) << 1 | ((c >> 2) & 1));
+  if ((c & 3) == 0) partial[size_t(q) * kTile + row] = s;
 }
 
 // ... part 2: workgroup = tile row I: y_I (column 0 of the row's last tile) minus the partial sums of its tiles in
