@@ -111,7 +111,7 @@ struct cx_sp_plan {
   DevBuf<int32_t> d_cam_pos, d_valid, d_row_start, d_row_tiles;  // first row of each camera; valid rows per tile row; tile lists
   DevBuf<int32_t> d_level_rows, d_panel_row, d_panel_pool;
   DevBuf<int32_t> d_tgt_pool, d_tgt_flags, d_src_begin, d_src_a, d_src_b;
-  DevBuf<int32_t> d_col_start, d_col_pool;  // transposed index: the tiles (K < I, I) of tile column I, ascending K (forward solves)
+  DevBuf<int32_t> d_col_start, d_col_pool;  // transposed index (forward solves): [T + 1] list ranges of the tile columns (tiles (K < I, I), ascending K); [tiles] every tile's slot in its column's list
   DevBuf<double> d_W, d_x;                  // tile pool (factored in place); vectors, block inverses, partial products
   // use_mixed_precision_solves: the pool is kept (and factored) in single precision, d_W32 instead of d_W; the caller sets f32
   // before cxsp_assemble / cxsp_factor_and_solve*, vectors and the 32 x 32 block inverses stay double

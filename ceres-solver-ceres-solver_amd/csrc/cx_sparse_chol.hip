@@ -838,7 +838,7 @@ template <typename TW>
 __global__ __launch_bounds__(256) void k_sp_fwd_level(const TW* __restrict__ W, const int32_t* __restrict__ row_start,
                                                       const int32_t* __restrict__ level_rows, const int32_t* __restrict__ valid,
                                                       const double* __restrict__ uinv, const int32_t* __restrict__ col_start,
-                                                      const int32_t* __restrict__ col_pool, const double* __restrict__ partial,
+                                                      const double* __restrict__ partial,
                                                       double* __restrict__ y) {
   __shared__ double v1[NB], v2[NB], y1[NB], y2[NB], tmp[NB];
   const int I = level_rows[blockIdx.x];
@@ -854,7 +854,7 @@ __global__ __launch_bounds__(256) void k_sp_fwd_level(const TW* __restrict__ W, 
   if (t < kTile) {
     double s = 0.0;
 #pragma unroll 8
-    for (int p = col_start[I]; p < col_start[I + 1]; ++p) s += partial[size_t(col_pool[p]) * kTile + t];
+    for (int p = col_start[I]; p < col_start[I + 1]; ++p) s += partial[size_t(p) * kTile + t];  // (slots in column order: k_sp_fwd_partial)
     const double v = y[k0 + t] - s;
     if (t < NB) v1[t] = t < kb1 ? v : 0.0;
     else v2[t - NB] = (t - NB) < kb2 ? v : 0.0;
@@ -879,15 +879,18 @@ __global__ __launch_bounds__(256) void k_sp_fwd_level(const TW* __restrict__ W, 
   }
 }
 
-// ... part 2, workgroup = one tile F(K, J) right of the diagonal of a row K of the level: partial[tile][c] =
-// sum_r F(K, J)[r][c] y_K[r], gathered later by tile row J.
+// ... part 2, workgroup = one tile F(K, J) right of the diagonal of a row K of the level: partial[slot][c] =
+// sum_r F(K, J)[r][c] y_K[r], gathered later by tile row J -- slot = the tile's place in the list of tile column J (ascending
+// K), so that row J reads its incoming sums as one contiguous run instead of through an index.
 template <typename TW>
 __global__ __launch_bounds__(256) void k_sp_fwd_partial(const TW* __restrict__ W, const int32_t* __restrict__ row_tiles,
                                                         const int32_t* __restrict__ panel_row, const int32_t* __restrict__ panel_pool,
-                                                        int T, const double* __restrict__ y, double* __restrict__ partial) {
+                                                        const int32_t* __restrict__ col_slot, int T, const double* __restrict__ y,
+                                                        double* __restrict__ partial) {
   __shared__ double red[4][kTile];
   const int q = panel_pool[blockIdx.x];
   if (row_tiles[q] >= T) return;  // the right-hand-side tile
+  const int slot = col_slot[q];
   const int K = panel_row[blockIdx.x];
   const int t = threadIdx.x, c = t & 63, part = t >> 6;
   const TW* __restrict__ F = W + size_t(q) * kTileDoubles + size_t(16 * part) * kTile + c;
@@ -897,7 +900,7 @@ __global__ __launch_bounds__(256) void k_sp_fwd_partial(const TW* __restrict__ W
   for (int r = 0; r < 16; ++r) s += F[size_t(r) * kTile] * yk[r];  // padding rows of y are zero
   red[part][c] = s;
   __syncthreads();
-  if (part == 0) partial[size_t(q) * kTile + c] = (red[0][c] + red[1][c]) + (red[2][c] + red[3][c]);
+  if (part == 0) partial[size_t(slot) * kTile + c] = (red[0][c] + red[1][c]) + (red[2][c] + red[3][c]);
 }
 
 // camera order -> padded elimination order (padding rows zero: memset first)
@@ -1530,7 +1533,11 @@ int cxsp_plan_from_cells(cx_context* ctx, int C, const int32_t* cell_c1, const i
   CX_TRY(P->d_src_a.upload(src_a, st));
   CX_TRY(P->d_src_b.upload(src_b, st));
   CX_TRY(P->d_col_start.upload(col_start, st));
-  CX_TRY(P->d_col_pool.upload(col_pool, st));
+  {  // the device keeps the inverse of the transposed index: for every tile its slot in its column's list
+    std::vector<int32_t> col_slot(static_cast<size_t>(num_tiles), -1);
+    for (size_t p = 0; p < col_pool.size(); ++p) col_slot[size_t(col_pool[p])] = int32_t(p);
+    CX_TRY(P->d_col_pool.upload(col_slot, st));
+  }
   P->h_level_row_begin = lrb;
   P->h_level_panel_begin = lpb;
   P->h_level_tgt_begin = ltb;
@@ -1813,10 +1820,11 @@ int cxsp_solve(cx_context* ctx, cx_sp_plan* P, const double* r, double* z) {
       if (nr > 0)
         hipLaunchKernelGGL(k_sp_fwd_level<TW>, dim3(unsigned(nr)), dim3(256), 0, st, W, (const int32_t*)P->d_row_start.p,
                            rows + r0, (const int32_t*)P->d_valid.p, (const double*)sc.uinv, (const int32_t*)P->d_col_start.p,
-                           (const int32_t*)P->d_col_pool.p, (const double*)sc.partial, sc.xp);
+                           (const double*)sc.partial, sc.xp);
       if (np > 0)
         hipLaunchKernelGGL(k_sp_fwd_partial<TW>, dim3(unsigned(np)), dim3(256), 0, st, W, (const int32_t*)P->d_row_tiles.p,
-                           (const int32_t*)P->d_panel_row.p + p0, (const int32_t*)P->d_panel_pool.p + p0, P->T, (const double*)sc.xp, sc.partial);
+                           (const int32_t*)P->d_panel_row.p + p0, (const int32_t*)P->d_panel_pool.p + p0, (const int32_t*)P->d_col_pool.p, P->T,
+                           (const double*)sc.xp, sc.partial);
       return CX_OK;
     }));
   }
