@@ -253,5 +253,22 @@ def test_config_4_final13682_sparse_schur_on_shards(final):
     assert np.array_equal(xm, xm2)
     assert first["allreduce_calls"] == 6 and tm["allreduce_calls"] == 4      # agreement + presence once; per solve: values, rhs, replicated tiles, solution
     MS.close()
+    # use_mixed_precision_solves on the shards at this size: the float tile pool under the distributed factorisation, unrefined
+    # (single precision error, the same bits as the unsharded float solve's up to the summation order) and with two refinement
+    # steps (the factor then stays whole on every shard; back to the double precision step)
+    S32 = cx.Solver(ctx, type=cx.SPARSE_SCHUR, num_eliminate_blocks=P, use_mixed_precision_solves=1)
+    x32, s32 = S32.solve(A, b, D)
+    S32.close()
+    MS32 = cx.Solver(mctx, type=cx.SPARSE_SCHUR, num_eliminate_blocks=P, use_mixed_precision_solves=1)
+    xm32, sm32 = MS32.solve(mev.jacobian(), mres, D)
+    MS32.close()
+    scale = np.abs(x1).max()
+    e1, em = np.abs(x32 - x1).max() / scale, np.abs(xm32 - x1).max() / scale
+    assert s32.termination_type == sm32.termination_type == cx.SUCCESS
+    assert 1e-10 < e1 < 1e-2 and 1e-10 < em < 1e-2 and em < 10 * e1 + 1e-7, (e1, em)
+    MS32r = cx.Solver(mctx, type=cx.SPARSE_SCHUR, num_eliminate_blocks=P, use_mixed_precision_solves=1, max_num_refinement_iterations=2)
+    xm32r, sm32r = MS32r.solve(mev.jacobian(), mres, D)
+    MS32r.close()
+    assert sm32r.termination_type == cx.SUCCESS and np.abs(xm32r - x1).max() / scale < max(1e-8, 1e-2 * em), (em, np.abs(xm32r - x1).max() / scale)
     mev.close()
     mctx.close()
