@@ -1,0 +1,27 @@
+"""The update kernels of the tile-sparse factorisation that stage their operands through LDS claim the bits of the kernels
+they replaced (cx_sparse_chol.hip: same products in the same order).  The kernel switches are read once per process, so each
+variant runs in a process of its own (tools/sparse_bits.py prints a SHA-1 of the SPARSE_SCHUR step of a 2 000-camera problem)."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _digest(env, *flags):
+    e = dict(os.environ)
+    e.update(env)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "sparse_bits.py"), *flags], env=e, stdout=subprocess.PIPE,
+                         stderr=subprocess.PIPE, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = out.stdout.strip().splitlines()[-1]
+    assert " 0 " in line, line          # termination_type SUCCESS
+    return line.split()[-1]
+
+
+def test_lds_staged_update_kernels_keep_the_bits():
+    assert _digest({"CX_SPARSE_F64_LDS": "1"}) == _digest({"CX_SPARSE_F64_LDS": "0"})                      # k_sp_update_f64_lds == k_sp_update_slices
+    assert _digest({"CX_SPARSE_F32_LDS": "1"}, "--mixed") == _digest({"CX_SPARSE_F32_LDS": "0"}, "--mixed")  # k_sp_update_f32_lds == k_sp_update_f32
