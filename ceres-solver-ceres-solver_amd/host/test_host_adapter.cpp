@@ -224,6 +224,37 @@ static void TestSolversOnHostJacobian() {
     EXPECT(stats.count("LinearSolver::Solve") == 1 && stats.at("LinearSolver::Solve").calls == 1 &&
                absl::ToDoubleSeconds(stats.at("LinearSolver::Solve").time) > 0.0, "%s statistics", c.name);
   }
+  {  // use_mixed_precision_solves / max_num_refinement_iterations (solver.h:572-590) through LinearSolver::Options, as
+     // TrustRegionPreprocessor copies them (trust_region_preprocessor.cc:220-223): the float factor alone is visibly single
+     // precision, with four refinement steps (dense_cholesky_test.cc:86-89) it is the double precision answer again
+    for (LinearSolverType type : {DENSE_SCHUR, SPARSE_SCHUR})
+      for (int refinements : {0, 4}) {
+        LinearSolver::Options options;
+        options.type = type;
+        options.elimination_groups = {kPoints, kCameras};
+        options.use_mixed_precision_solves = true;
+        options.max_num_refinement_iterations = refinements;
+        EXPECT(CxLinearSolver::Supports(options), "mixed precision %d", int(type));
+        CxLinearSolver solver(options);
+        LinearSolver::PerSolveOptions ps;
+        ps.D = D.data();
+        std::vector<double> x(static_cast<size_t>(A->num_cols()));
+        InvalidateArray(A->num_cols(), x.data());
+        LinearSolver::Summary s = solver.Solve(A.get(), b.data(), ps, x.data());
+        double diff = 0.0, scale = 0.0;
+        for (size_t i = 0; i < x.size(); ++i) {
+          diff = std::max(diff, std::abs(x[i] - reference[i]));
+          scale = std::max(scale, std::abs(reference[i]));
+        }
+        diff /= scale;
+        const bool ok = s.termination_type == LinearSolverTerminationType::SUCCESS && IsArrayValid(A->num_cols(), x.data()) &&
+                        (refinements == 0 ? (diff > 1e-11 && diff < 1e-3) : diff < 1e-9) &&
+                        s.message.find("single precision") != std::string::npos;
+        std::printf("%-12s mixed precision, %d refinement steps  %s  max |x - x_dense_schur| / max |x| %.2e  (%s)\n",
+                    type == DENSE_SCHUR ? "DENSE_SCHUR" : "SPARSE_SCHUR", refinements, ok ? "ok  " : "FAIL", diff, s.message.c_str());
+        EXPECT(ok, "mixed precision solve");
+      }
+  }
   {  // the LM call: truncated solve with q_tolerance = eta, step = -x
     LinearSolver::Options options;
     options.type = ITERATIVE_SCHUR;
