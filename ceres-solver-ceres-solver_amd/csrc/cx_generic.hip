@@ -559,6 +559,12 @@ int cxg_solve(cx_solver* S, cx_matrix* A, const double* b, const double* D, doub
       CX_TRY(cx_check_flag(S, "Dense Cholesky factorization failed: the reduced matrix is not positive definite.", summary, &failed));
     }
     if (summary->termination_type == CX_SUCCESS) CX_TRY(G.backsub_chunks(b, S->ete_inv.p, z, x));
+    // use_mixed_precision_solves / max_num_refinement_iterations: the single precision factor and the stored-factor solves of
+    // refinement live in the tile code of the static <2,3,9> layout (cx_solver.hip: SolveDenseSchur239); here the option is
+    // answered, not silently dropped
+    if (summary->termination_type == CX_SUCCESS && (S->opt.use_mixed_precision_solves || S->opt.max_num_refinement_iterations > 0))
+      std::snprintf(summary->message, sizeof(summary->message),
+                    "Success. (dynamic-size structure: double precision dense factorisation, no refinement)");
     return CX_OK;
   }
 

@@ -80,6 +80,14 @@ def test_problem2_comment_goldens_on_device(ctx):
     assert summ.termination_type == cx.SUCCESS
     np.testing.assert_allclose(x, np.array(raw["x"]), atol=5e-5)
     Sv.close()
+    # use_mixed_precision_solves / refinement on a dynamic-size structure (or on the embedded image of one): either honoured
+    # (the float tile pool of the static layout) or answered in the summary message -- never dropped silently; the step stays
+    # the fixture's to the fixture's four decimals either way
+    Sm = cx.Solver(ctx, type=cx.DENSE_SCHUR, num_eliminate_blocks=nelim, use_mixed_precision_solves=1, max_num_refinement_iterations=2)
+    xm, sm = Sm.solve(A, b, None)
+    assert sm.termination_type == cx.SUCCESS and (b"single precision" in sm.message or b"double precision dense" in sm.message), sm.message
+    np.testing.assert_allclose(xm, np.array(raw["x"]), atol=5e-5)
+    Sm.close()
     A.close()
 
 
