@@ -174,6 +174,54 @@ def cpu_baseline(cx, prob, solver_kw, threads, fraction, solver="iterative_schur
     }
 
 
+def boundary_block(cx, ctx, prob, solver_kw, iterations):
+    """What an LM iteration costs THROUGH the Evaluator / SparseMatrix / LinearSolver boundary: the unmodified call
+    sequence of TrustRegionMinimizer with HOST vectors (ceres-solver-ceres-solver_amd/boundary.py, the ctypes twin of
+    host/test_host_adapter --time) on one shard and on four logical shards behind the front, next to the same
+    iterations of the device-resident loop (cx_minimize).  The adapters' three opt-ins are on (fused Jacobi scaling,
+    residual aliasing, zeroed product target) and caller arrays are registered on first sight, as CxSharedContext sets."""
+    cx.host_registration_policy(1)
+    n, m = 3 * prob.num_points + 9 * prob.num_cameras, 2 * prob.num_observations
+    block = {"workload": "LM iterations 1..%d from the start point, ITERATIVE_SCHUR + JACOBI, eta = %g" % (iterations, ETA),
+             "unmodified_caller_floor": {
+                 "h2d_bytes": 8 * 4 * n, "d2h_bytes": 8 * (3 * n + 2 * m),
+                 "what": "state, D, step, candidate state up; residuals, gradient, diag(J'J), step, model residuals down -- every one "
+                         "read or written in HOST memory by TrustRegionMinimizer / LevenbergMarquardtStrategy between the calls"}}
+    for label, devices in (("one_shard", None), ("four_logical_shards", [0, 0, 0, 0])):
+        c = ctx if devices is None else cx.Context(devices=devices)
+        loop = cx.boundary.BoundaryLoop(c, prob, solver_kw, eta=ETA)
+        rep = loop.run(iterations)
+        loop.close()
+        ev = cx.Evaluator(c, prob)
+        S = cx.Solver(c, **solver_kw)
+        opts = cx.binding.minimizer_options(max_num_iterations=iterations, eta=ETA)
+        cx.minimize(ev, S, prob.state(), opts)
+        _, msum, its = cx.minimize(ev, S, prob.state(), opts)
+        S.close()
+        ev.close()
+        resident = [it["iteration_ms"] for it in its[1:iterations + 1]]
+        per = []
+        for k, r in enumerate(rep["per_iteration"]):
+            per.append({"through_interfaces_ms": r["through_interfaces_ms"], "resident_ms": resident[k] if k < len(resident) else None,
+                        "cg_iterations": r["cg_iterations"], "calls_ms": r["calls_ms"], "caller_numpy_ms": r["caller_ms"],
+                        "h2d_bytes": r["h2d_bytes"], "d2h_bytes": r["d2h_bytes"], "h2d_ms": r["h2d_ms"], "d2h_ms": r["d2h_ms"]})
+        both = [(p["through_interfaces_ms"], p["resident_ms"]) for p in per if p["resident_ms"]]
+        block[label] = {
+            "lm_iteration_through_interfaces_ms": rep["lm_iteration_through_interfaces_ms"],
+            "resident_lm_iteration_ms": float(np.mean(resident)) if resident else None,
+            "boundary_overhead_ms": float(np.mean([a - b for a, b in both])) if both else None,
+            "first_iteration_ratio": both[0][0] / both[0][1] if both else None,
+            "h2d_bytes": rep["h2d_bytes"], "d2h_bytes": rep["d2h_bytes"], "transfer_ms": rep["transfer_ms"],
+            "h2d_GBps": rep["h2d_GBps"], "d2h_GBps": rep["d2h_GBps"], "registered_fraction": rep["registered_fraction"],
+            "per_iteration": per, "costs": rep["costs"], "resident_costs": [it["cost"] for it in its[:iterations + 1]],
+        }
+        if devices is not None:
+            c.close()
+    cx.host_registrations_release()
+    cx.host_registration_policy(2)
+    return block
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -199,6 +247,9 @@ def main():
     ap.add_argument("--cpu-threads", type=int, default=0)
     ap.add_argument("--cpu-sample-fraction", type=float, default=1.0,
                     help="part of the points the CPU baseline solves (1.0: the whole workload, ~10 s on 16 threads)")
+    ap.add_argument("--no-boundary", action="store_true",
+                    help="skip the `boundary` block (the LM iteration through the interfaces with host vectors, 1 and 4 shards)")
+    ap.add_argument("--boundary-iterations", type=int, default=3)
     ap.add_argument("--no-sparse-schur", action="store_true",
                     help="skip the SPARSE_SCHUR solve + its CPU baseline that the default Final-13682 line carries (north star: "
                          ">= 10x lower linear-solve ms than host SPARSE_SCHUR)")
@@ -417,6 +468,11 @@ def main():
         sparse["single_precision_factor_ms"] = float(np.median(reps))
         SM.close()
 
+    boundary = None
+    if (world == 1 and args.workload == "final13682" and args.solver == "iterative_schur" and args.preconditioner == "jacobi"
+            and not args.mixed and not args.explicit_schur and not args.no_boundary):
+        boundary = boundary_block(cx, ctx, full, solver_kw, args.boundary_iterations)
+
     out = None
     if rank == 0:
         cpu = None
@@ -458,6 +514,7 @@ def main():
             # keep the camera-major copy of F current, work that round 1 did inside the solve) and the timed solve
             "lm_iteration_ms": values_update["jacobian_eval_ms"] + values_update["scale_columns_ms"] + ms_per_step,
             "sparse_schur": sparse,
+            "boundary": boundary,
             "spmv": spmv,
             "kernels": {k: {"avg_ms": v[0] / max(1, v[1]), "launches_per_solve": v[2] / max(1, args.steps)} for k, v in kstats.items()},
             "roofline": roof,

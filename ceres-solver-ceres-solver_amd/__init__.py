@@ -13,5 +13,6 @@ from . import bal  # noqa: F401
 
 try:  # binding.py needs only ctypes/numpy; the library itself is loaded lazily
     from .binding import *  # noqa: F401,F403
+    from . import binding, boundary  # noqa: F401
 except ImportError:  # pragma: no cover - only during partial checkouts
     raise

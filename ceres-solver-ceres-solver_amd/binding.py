@@ -38,6 +38,7 @@ EXPORTED_SYMBOLS = [
     "cx_implicit_schur_multiply", "cx_dense_cholesky_solve", "cx_evaluator_create_bal", "cx_evaluator_destroy",
     "cx_evaluator_jacobian", "cx_evaluator_row_of_observation", "cx_evaluator_evaluate", "cx_evaluator_set_loss", "cx_minimizer_default_options", "cx_minimize", "cx_schur_sparse_structure", "cx_visibility_structure", "cx_visibility_clusters_host",
     "cx_evaluator_set_camera_model", "cx_evaluator_num_parameters", "cx_evaluator_num_effective_parameters", "cx_evaluator_plus",
+    "cx_matrix_right_multiply_overwrite", "cx_host_registration_policy", "cx_host_register", "cx_host_registrations_release", "cx_transfer_stats_get",
     "cx_evaluator_last_kernel_ms", "cx_evaluator_device_residuals", "cx_evaluator_set_emit_camera_major", "cx_sparse_cholesky_plan_host", "cx_sparse_cholesky_schedule_host", "cx_detect_structure", "cx_partition_points", "cx_stable_schur_ordering",
 ]
 
@@ -63,6 +64,19 @@ class cx_solver_options(ctypes.Structure):
         ("use_explicit_schur_complement", ctypes.c_int32),
         ("visibility_clustering_type", ctypes.c_int32),
         ("reserved", ctypes.c_int32),
+    ]
+
+
+class cx_transfer_stats(ctypes.Structure):
+    _fields_ = [
+        ("h2d_bytes", ctypes.c_int64), ("d2h_bytes", ctypes.c_int64),
+        ("h2d_copies", ctypes.c_int64), ("d2h_copies", ctypes.c_int64),
+        ("h2d_registered_bytes", ctypes.c_int64), ("d2h_registered_bytes", ctypes.c_int64),
+        ("h2d_ms", ctypes.c_double), ("d2h_ms", ctypes.c_double),
+        ("registered_bytes", ctypes.c_int64),
+        ("num_registered", ctypes.c_int32), ("reserved", ctypes.c_int32),
+        ("register_ms", ctypes.c_double),
+        ("num_register_calls", ctypes.c_int64),
     ]
 
 
@@ -202,6 +216,19 @@ def _f64(a):
     return np.ascontiguousarray(a, dtype=np.float64)
 
 
+def host_registration_policy(sightings=2, min_bytes=256 << 10, max_total_bytes=16 << 30):
+    """cx_host_registration_policy: when caller arrays are registered with the HIP runtime (0 never, 1 first sight, 2 second)."""
+    _check(load_library().cx_host_registration_policy(int(sightings), ctypes.c_int64(min_bytes), ctypes.c_int64(max_total_bytes)))
+
+
+def host_register(array):
+    _check(load_library().cx_host_register(_ptr(array), ctypes.c_size_t(array.nbytes)))
+
+
+def host_registrations_release():
+    _check(load_library().cx_host_registrations_release())
+
+
 class Context:
     def __init__(self, device=0, devices=None):
         """device: one GPU.  devices = [d0, d1, ...]: several shards behind one set of handles in this process
@@ -273,6 +300,12 @@ class Context:
 
     def synchronize(self):
         _check(self.lib.cx_synchronize(self._h))
+
+    def transfer_stats(self, reset=False):
+        """What crossed PCIe through this context's calls (cx_transfer_stats_get)."""
+        t = cx_transfer_stats()
+        _check(self.lib.cx_transfer_stats_get(self._h, ctypes.byref(t), int(bool(reset))))
+        return {n: getattr(t, n) for n, _ in cx_transfer_stats._fields_ if n != "reserved"}
 
     def allreduce_sum(self, dev, offset=0, count=None):
         """In-place sum over the ranks of dev[offset:offset+count] (float64 device array)."""

@@ -6,7 +6,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(CSRC, "libcxschur.so")
-SOURCES = ["cx_context.cpp", "cx_ordering.cpp", "cx_matrix.hip", "cx_schur.hip", "cx_solver.hip", "cx_cholesky.hip",
+SOURCES = ["cx_context.cpp", "cx_transfer.cpp", "cx_ordering.cpp", "cx_matrix.hip", "cx_schur.hip", "cx_solver.hip", "cx_cholesky.hip",
            "cx_eval.hip", "cx_generic.hip", "cx_minimizer.hip", "cx_sparse_chol.hip", "cx_visibility.cpp", "cx_band_chol.hip", "cx_multi.hip", "cx_embed.hip"]
 HEADERS = ["cx_internal.h", "cx_kernels.h", "cx_schur.h", "cx_solver_internal.h", "cx_chol_blocks.h", "cx_visibility.h", os.path.join("..", "..", "include", "cxschur.h")]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")

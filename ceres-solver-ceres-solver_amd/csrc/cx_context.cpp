@@ -169,6 +169,7 @@ void cx_context_destroy(cx_context* ctx) {
   if (cxm_is_front(ctx) || ctx->group) cxm_context_destroy_shards(ctx);
   (void)hipSetDevice(ctx->device);
   (void)hipStreamSynchronize(ctx->stream);
+  cx_xfer_destroy(ctx);
   if (ctx->comm && g_rccl.comm_destroy) g_rccl.comm_destroy(ctx->comm);
   for (auto& ev : ctx->ev)
     if (ev) (void)hipEventDestroy(ev);
@@ -237,14 +238,16 @@ int cx_free(cx_context* ctx, void* device_ptr) {
 int cx_memcpy_h2d(cx_context* ctx, void* dst, const void* src, size_t bytes) {
   CX_CHECK_ARG(ctx != nullptr);
   if (bytes == 0) return CX_OK;
-  CX_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ctx->stream));
+  CX_HIP(hipSetDevice(ctx->device));
+  CX_TRY(cx_copy_h2d(ctx, dst, src, bytes));
   CX_HIP(hipStreamSynchronize(ctx->stream));
   return CX_OK;
 }
 int cx_memcpy_d2h(cx_context* ctx, void* dst, const void* src, size_t bytes) {
   CX_CHECK_ARG(ctx != nullptr);
   if (bytes == 0) return CX_OK;
-  CX_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+  CX_HIP(hipSetDevice(ctx->device));
+  CX_TRY(cx_copy_d2h(ctx, dst, src, bytes));
   CX_HIP(hipStreamSynchronize(ctx->stream));
   return CX_OK;
 }
@@ -268,32 +271,3 @@ int cx_device_name(cx_context* ctx, char* out, size_t n) {
 
 }  // extern "C"
 
-// ---------------------------------------------------------- HostOrDevice
-int HostOrDevice::in(const double* u, size_t count, int memspace) {
-  user = const_cast<double*>(u);
-  n = count;
-  is_host = (memspace == CX_HOST);
-  if (!u) { dptr = nullptr; return CX_OK; }
-  if (!is_host) { dptr = user; return CX_OK; }
-  CX_TRY(tmp.alloc(count));
-  CX_HIP(hipMemcpyAsync(tmp.p, u, count * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
-  dptr = tmp.p;
-  return CX_OK;
-}
-int HostOrDevice::inout(double* u, size_t count, int memspace, bool copy_in) {
-  user = u;
-  n = count;
-  is_host = (memspace == CX_HOST);
-  if (!u) { dptr = nullptr; return CX_OK; }
-  if (!is_host) { dptr = user; return CX_OK; }
-  CX_TRY(tmp.alloc(count));
-  if (copy_in) CX_HIP(hipMemcpyAsync(tmp.p, u, count * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
-  dptr = tmp.p;
-  return CX_OK;
-}
-int HostOrDevice::out() {
-  if (!user || !is_host) return CX_OK;
-  CX_HIP(hipMemcpyAsync(user, dptr, n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-  CX_HIP(hipStreamSynchronize(ctx->stream));
-  return CX_OK;
-}

@@ -780,7 +780,9 @@ int cx_evaluator_evaluate(cx_evaluator* e, const double* state, double* cost, do
   const bool with_j = evaluate_jacobian != 0 || gradient != nullptr;
   // Residuals asked for in host memory are produced in the evaluator's own device buffer and copied out, so that
   // they also stay available in HBM (cx_evaluator_device_residuals) for the linear solve that follows.
-  const bool res_to_host = residuals != nullptr && memspace == CX_HOST;
+  const bool res_to_host = residuals != nullptr && cx_is_host_space(memspace);
+  double* res_host = residuals;
+  if (res_to_host && memspace == CX_HOST_SLICES) res_host = reinterpret_cast<const cx_host_slices*>(residuals)->head;  // a front's row slice
   double* res_dev = (memspace == CX_DEVICE) ? residuals : nullptr;
   if (res_to_host || (gradient && !res_dev)) {
     CX_TRY(e->d_res.alloc(size_t(nrows)));
@@ -862,6 +864,18 @@ int cx_evaluator_evaluate(cx_evaluator* e, const double* state, double* cost, do
   }
   CX_HIP(hipGetLastError());
   if (with_j && !scratch_j) { A->ft_valid = ft_out != nullptr; A->f32_valid = false; }
+  // the residuals are final once the evaluation kernel has run: their way back to the caller (the largest copy of an LM
+  // iteration, 16 B per residual block) starts now, on the copy stream, beside the camera-major gather pass and the
+  // gradient product below
+  hipStream_t cs = st;
+  if (res_to_host) {
+    cs = cx_copy_stream(ctx);
+    if (cs != st) {
+      CX_HIP(hipEventRecord(ctx->ev[4], st));
+      CX_HIP(hipStreamWaitEvent(cs, ctx->ev[4], 0));
+    }
+    CX_TRY(cx_copy_d2h(ctx, res_host, res_dev, size_t(nrows) * sizeof(double), cs));
+  }
   // an evaluation that applied the column scale is not followed by a ScaleColumns that would rebuild the camera-major
   // copy: it is rebuilt here, by the gather pass, inside the evaluation's own time
   if (scaled_j && !A->ft_valid) CX_TRY(cx_matrix_ensure_ft(A));
@@ -894,11 +908,10 @@ int cx_evaluator_evaluate(cx_evaluator* e, const double* state, double* cost, do
     if (ctx->nranks > 1) CX_TRY(cx_allreduce_device(ctx, e->d_partial.p + grid, 1));  // shards sum their costs
     CX_HIP(hipMemcpyAsync(cost, e->d_partial.p + grid, sizeof(double), hipMemcpyDeviceToHost, st));
   }
-  CX_HIP(hipEventSynchronize(ctx->ev[7]));
-  CX_HIP(hipEventElapsedTime(&e->last_ms, ctx->ev[6], ctx->ev[7]));
-  if (res_to_host) CX_HIP(hipMemcpyAsync(residuals, res_dev, size_t(nrows) * sizeof(double), hipMemcpyDeviceToHost, st));
-  CX_TRY(hg.out());
+  CX_TRY(hg.out_async(st));
   CX_HIP(hipStreamSynchronize(st));
+  if (cs != st) CX_HIP(hipStreamSynchronize(cs));
+  CX_HIP(hipEventElapsedTime(&e->last_ms, ctx->ev[6], ctx->ev[7]));
   return CX_OK;
 }
 
@@ -924,8 +937,7 @@ int cx_evaluator_set_column_scale(cx_evaluator* e, const double* scale, int32_t 
   CX_HIP(hipSetDevice(ctx->device));
   const size_t n = size_t(3 * int64_t(e->P) + 9 * int64_t(e->C));
   CX_TRY(e->d_col_scale.alloc(n));
-  CX_HIP(hipMemcpyAsync(e->d_col_scale.p, scale, n * sizeof(double), memspace == CX_HOST ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice,
-                        ctx->stream));
+  CX_TRY(cx_vector_in(ctx, e->d_col_scale.p, scale, n, memspace));
   CX_HIP(hipStreamSynchronize(ctx->stream));
   e->has_col_scale = true;
   return CX_OK;

@@ -96,6 +96,8 @@ struct cx_context {
   // context with rank i of shards.size(); the front itself stays a plain context on the first device
   std::vector<cx_context*> shards;
   struct cx_shard_group* group = nullptr;  // worker threads (one per shard) + the in-process exchange step
+  // ---- host <-> device traffic of the calls that take host vectors (cx_transfer.cpp)
+  struct cx_xfer_state* xfer = nullptr;    // staging pool, copy stream, counters; created on first use
 };
 
 // ------------------------------------------------- tile-sparse Cholesky (cx_sparse_chol.hip)
@@ -268,19 +270,67 @@ struct cx_matrix {
   std::vector<std::vector<ValueRun>> part_runs;  // where the values of part i sit in the front's (reference layout) value array
 };
 
+// ------------------------------------------------ host vectors at the boundary (cx_transfer.cpp)
+// Internal memspace value: the pointer is a `const cx_host_slices*` -- a vector handed over as two runs of host memory
+// [head | tail].  The fronts of cx_multi.hip describe a shard's part of the caller's vector that way (the shard's own
+// e-block range followed by the f part every shard sees), so the copies go straight between the caller's array and the
+// shard's device buffer, with no gathered std::vector in between.
+constexpr int32_t CX_HOST_SLICES = 0x51;
+struct cx_host_slices {
+  double* head = nullptr;
+  int64_t nhead = 0;
+  double* tail = nullptr;
+  int64_t ntail = 0;
+  bool skip_tail_out = false;  // outputs: do not copy the tail back (another shard delivers the replica)
+  const double* as_arg() const { return reinterpret_cast<const double*>(this); }
+  double* as_arg() { return reinterpret_cast<double*>(this); }
+};
+inline bool cx_is_host_space(int32_t memspace) { return memspace == CX_HOST || memspace == CX_HOST_SLICES; }
+
+// Copies between caller (host) memory and device memory, enqueued on `st` (NULL: the context stream).  Arrays a caller
+// hands in repeatedly are registered with the HIP runtime (hipHostRegister) by the process-wide registry of
+// cx_transfer.cpp, after which the copy is a DMA at PCIe rate instead of a staged pageable copy; bytes, copies and
+// device-side durations are counted per context (cx_transfer_stats_get).  An H2D copy from registered memory is
+// asynchronous for real: cx_xfer_wait_h2d must run before the call returns to the owner of the source array.
+int cx_copy_h2d(cx_context* ctx, void* dst, const void* src, size_t bytes, hipStream_t st = nullptr);
+int cx_copy_d2h(cx_context* ctx, void* dst, const void* src, size_t bytes, hipStream_t st = nullptr);
+int cx_xfer_wait_h2d(cx_context* ctx);  // blocks until every H2D copy enqueued through cx_copy_h2d has read its source
+// a second stream for copies that overlap work on the context stream (created on first use)
+hipStream_t cx_copy_stream(cx_context* ctx);
+void cx_xfer_destroy(cx_context* ctx);
+// dst[0, count) <- the vector `u` of the given memspace (host, host slices or device), enqueued on the context stream;
+// the reverse for cx_vector_out (host slices: the tail only unless skip_tail_out).  Host copies are counted; the caller waits
+// (cx_xfer_wait_h2d / a stream synchronisation) before it returns
+int cx_vector_in(cx_context* ctx, double* dst, const double* u, size_t count, int32_t memspace);
+int cx_vector_out(cx_context* ctx, double* u, const double* src, size_t count, int32_t memspace);
+// staging buffers: grow-only pool per context, handed out for the duration of one call
+DevBuf<double>* cx_stage_acquire(cx_context* ctx, size_t count);
+void cx_stage_release(cx_context* ctx, DevBuf<double>* b);
+// registry (process-wide): try to make [p, p + bytes) registered memory; true when it is
+bool cx_pin_range(const void* p, size_t bytes);
+
 // upload/download helpers for the (memspace) convention
 struct HostOrDevice {
-  // wraps a user pointer: if host, stages through a device buffer
+  // wraps a user pointer: if host, stages through a device buffer of the context's pool
   cx_context* ctx;
-  DevBuf<double> tmp;
+  DevBuf<double>* tmp = nullptr;
   double* dptr = nullptr;
   double* user = nullptr;
+  cx_host_slices slices;
+  bool sliced = false;
   size_t n = 0;
   bool is_host = false;
   explicit HostOrDevice(cx_context* c) : ctx(c) {}
+  HostOrDevice(const HostOrDevice&) = delete;
+  HostOrDevice& operator=(const HostOrDevice&) = delete;
+  ~HostOrDevice();
   int in(const double* u, size_t count, int memspace);   // read-only input (u may be NULL -> dptr NULL)
   int inout(double* u, size_t count, int memspace, bool copy_in);
-  int out();  // copy back if host
+  int out();  // copy back if host (and wait for it)
+  int out_async(hipStream_t st);  // the same without the wait: the caller synchronises `st` before it returns
+ private:
+  int bind(double* u, size_t count, int memspace);
+  int copy_in();
 };
 
 // ------------------------------------------------ kernels (cx_matrix.hip etc.)

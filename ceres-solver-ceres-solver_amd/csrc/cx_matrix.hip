@@ -997,9 +997,7 @@ int cx_matrix_values_changed(cx_matrix* A) {
 int cx_matrix_set_values(cx_matrix* A, const double* src, int32_t memspace) {
   CX_CHECK_ARG(A && (src || A->nnz == 0));
   if (!A->parts.empty()) return cxm_matrix_set_values(A, src, memspace);
-  if (A->nnz)
-    CX_HIP(hipMemcpyAsync(A->d_values.p, src, size_t(A->nnz) * sizeof(double),
-                          memspace == CX_HOST ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice, A->ctx->stream));
+  if (A->nnz) CX_TRY(cx_vector_in(A->ctx, A->d_values.p, src, size_t(A->nnz), memspace));
   CX_HIP(hipStreamSynchronize(A->ctx->stream));
   A->ft_valid = false;
   A->f32_valid = false;
@@ -1010,7 +1008,7 @@ int cx_matrix_set_values(cx_matrix* A, const double* src, int32_t memspace) {
 int cx_matrix_get_values(const cx_matrix* A, double* dst) {
   CX_CHECK_ARG(A && (dst || A->nnz == 0));
   if (!A->parts.empty()) return cxm_matrix_get_values(A, dst);
-  if (A->nnz) CX_HIP(hipMemcpyAsync(dst, A->d_values.p, size_t(A->nnz) * sizeof(double), hipMemcpyDeviceToHost, A->ctx->stream));
+  if (A->nnz) CX_TRY(cx_copy_d2h(A->ctx, dst, A->d_values.p, size_t(A->nnz) * sizeof(double)));
   CX_HIP(hipStreamSynchronize(A->ctx->stream));
   return CX_OK;
 }
@@ -1031,6 +1029,17 @@ int cx_matrix_right_multiply(cx_matrix* A, const double* x, double* y, int32_t m
   HostOrDevice hx(A->ctx), hy(A->ctx);
   CX_TRY(hx.in(x, size_t(A->num_cols), memspace));
   CX_TRY(hy.inout(y, size_t(A->num_rows), memspace, true));
+  CX_TRY(Timed(A, [&] { return A->embed ? cxe_matrix_op(A, 0, hx.dptr, hy.dptr) : cxk_right_multiply(A, hx.dptr, hy.dptr); }));
+  return hy.out();
+}
+
+int cx_matrix_right_multiply_overwrite(cx_matrix* A, const double* x, double* y, int32_t memspace) {
+  CX_CHECK_ARG(A && x && y);
+  if (!A->parts.empty()) return cxm_matrix_op(A, 4, x, y, memspace);
+  HostOrDevice hx(A->ctx), hy(A->ctx);
+  CX_TRY(hx.in(x, size_t(A->num_cols), memspace));
+  CX_TRY(hy.inout(y, size_t(A->num_rows), memspace, false));  // nothing of y crosses PCIe on the way in
+  CX_HIP(hipMemsetAsync(hy.dptr, 0, size_t(A->num_rows) * sizeof(double), A->ctx->stream));
   CX_TRY(Timed(A, [&] { return A->embed ? cxe_matrix_op(A, 0, hx.dptr, hy.dptr) : cxk_right_multiply(A, hx.dptr, hy.dptr); }));
   return hy.out();
 }

@@ -413,10 +413,10 @@ struct Minimizer {
     CX_TRY(red_out.alloc(4));
     CX_TRY(slots.alloc(size_t(1 + ctx->nranks)));
     DevBuf<double> best;
-    if (memspace == CX_HOST) {
+    if (cx_is_host_space(memspace)) {
       CX_TRY(best.alloc(size_t(n_amb)));
       parameters = best.p;
-      CX_HIP(hipMemcpyAsync(x.p, state, size_t(n_amb) * sizeof(double), hipMemcpyHostToDevice, st));
+      CX_TRY(cx_vector_in(ctx, x.p, state, size_t(n_amb), memspace));
       CX_HIP(hipMemcpyAsync(best.p, x.p, size_t(n_amb) * sizeof(double), hipMemcpyDeviceToDevice, st));
     } else {
       parameters = state;
@@ -527,7 +527,7 @@ struct Minimizer {
     }
     out->num_iterations = num_written;
     out->final_cost = minimum_cost;
-    if (memspace == CX_HOST) CX_HIP(hipMemcpyAsync(state, parameters, size_t(n_amb) * sizeof(double), hipMemcpyDeviceToHost, st));
+    if (cx_is_host_space(memspace)) CX_TRY(cx_vector_out(ctx, state, parameters, size_t(n_amb), memspace));
     CX_HIP(hipStreamSynchronize(st));
     out->total_ms = MsSince(start);
     return CX_OK;
@@ -566,7 +566,7 @@ int cx_minimize(cx_evaluator* e, cx_solver* s, const cx_minimizer_options* optio
     return cxm_minimize(e, s, options, state, memspace, summary, iterations, capacity);
   }
   CX_CHECK_ARG(s->ctx == e->ctx);
-  CX_CHECK_ARG(memspace == CX_HOST || memspace == CX_DEVICE);
+  CX_CHECK_ARG(memspace == CX_HOST || memspace == CX_DEVICE || memspace == CX_HOST_SLICES);
   CX_CHECK_ARG(capacity >= 0 && (iterations != nullptr || capacity == 0));
   // LevenbergMarquardtStrategy's constructor checks (levenberg_marquardt_strategy.cc:62-65)
   CX_CHECK_ARG(options->min_lm_diagonal > 0.0 && options->min_lm_diagonal <= options->max_lm_diagonal);

@@ -179,12 +179,26 @@ std::set<const cx_evaluator*> g_front_evaluators;  // live evaluator fronts (the
 
 int NumShards(const cx_context* ctx) { return int(ctx->shards.size()); }
 
-// v_shard = [v[e range of shard i] | tail], tail = the f (camera) part, tail_len entries starting at tail0
-void GatherCols(const cx_matrix* A, int i, const double* v, int64_t tail0, int64_t tail_len, std::vector<double>* out) {
+// The part of a column-space host vector `v` that shard i works on: [v[e range of shard i] | tail], tail = the f
+// (camera) part every shard sees, tail_len entries starting at tail0.  Nothing is gathered: the descriptor goes to the
+// shard's entry point as a CX_HOST_SLICES vector and the copies run between the caller's array and the shard's device
+// buffer directly.  For an output, only shard 0 delivers the tail (the shards hold replicas of it).
+cx_host_slices ColSlices(const cx_matrix* A, int i, const double* v, int64_t tail0, int64_t tail_len, bool output = false) {
   const int64_t e0 = A->part_ecol0[size_t(i)], e1 = A->part_ecol0[size_t(i) + 1];
-  out->resize(size_t(e1 - e0 + tail_len));
-  std::copy(v + e0, v + e1, out->begin());
-  std::copy(v + tail0, v + tail0 + tail_len, out->begin() + (e1 - e0));
+  cx_host_slices s;
+  s.head = const_cast<double*>(v) + e0;
+  s.nhead = e1 - e0;
+  s.tail = const_cast<double*>(v) + tail0;
+  s.ntail = tail_len;
+  s.skip_tail_out = output && i != 0;
+  return s;
+}
+// a shard's rows of a row-space host vector: one contiguous run
+cx_host_slices RowSlices(const cx_matrix* A, int i, const double* v) {
+  cx_host_slices s;
+  s.head = const_cast<double*>(v) + A->part_row0[size_t(i)];
+  s.nhead = A->part_row0[size_t(i) + 1] - A->part_row0[size_t(i)];
+  return s;
 }
 
 int RequireHost(int32_t memspace, const char* what) {
@@ -431,11 +445,11 @@ void cxm_matrix_destroy(cx_matrix* A) {
 
 int cxm_matrix_set_values(cx_matrix* A, const double* src, int32_t memspace) {
   CX_TRY(RequireHost(memspace, "cx_matrix_set_values"));
+  (void)cx_pin_range(src, size_t(A->nnz) * sizeof(double));
   return A->ctx->group->run([&](int i) -> int {
     cx_matrix* p = A->parts[size_t(i)];
     for (const auto& run : A->part_runs[size_t(i)])
-      CX_HIP(hipMemcpyAsync(p->d_values.p + run.local, src + run.global, size_t(run.len) * sizeof(double), hipMemcpyHostToDevice,
-                            p->ctx->stream));
+      CX_TRY(cx_copy_h2d(p->ctx, p->d_values.p + run.local, src + run.global, size_t(run.len) * sizeof(double)));
     CX_HIP(hipStreamSynchronize(p->ctx->stream));
     return cx_matrix_values_changed(p);
   });
@@ -445,8 +459,7 @@ int cxm_matrix_get_values(const cx_matrix* A, double* dst) {
   return A->ctx->group->run([&](int i) -> int {
     const cx_matrix* p = A->parts[size_t(i)];
     for (const auto& run : A->part_runs[size_t(i)])
-      CX_HIP(hipMemcpyAsync(dst + run.global, p->d_values.p + run.local, size_t(run.len) * sizeof(double), hipMemcpyDeviceToHost,
-                            p->ctx->stream));
+      CX_TRY(cx_copy_d2h(p->ctx, dst + run.global, p->d_values.p + run.local, size_t(run.len) * sizeof(double)));
     CX_HIP(hipStreamSynchronize(p->ctx->stream));
     return CX_OK;
   });
@@ -463,39 +476,47 @@ int cxm_matrix_values_changed(cx_matrix* A) {
 
 int cxm_matrix_op(cx_matrix* A, int op, const double* x, double* y, int32_t memspace) {
   CX_TRY(RequireHost(memspace, "a matrix product"));
-  const int n = int(A->parts.size());
   const int64_t ne = A->num_cols_e, nf = A->num_cols_f;
-  std::vector<std::vector<double>> xin(static_cast<size_t>(n)), yout(static_cast<size_t>(n));
-  CX_TRY(A->ctx->group->run([&](int i) -> int {
+  // the caller's whole arrays are registered before the shards copy their slices of them
+  if (x) (void)cx_pin_range(x, size_t(op == 1 ? A->num_rows : A->num_cols) * sizeof(double));
+  if (y) (void)cx_pin_range(y, size_t(op == 0 || op == 4 ? A->num_rows : A->num_cols) * sizeof(double));
+  return A->ctx->group->run([&](int i) -> int {
     cx_matrix* p = A->parts[size_t(i)];
-    const int64_t r0 = A->part_row0[size_t(i)];
+    cx_context* c = p->ctx;
     switch (op) {
-      case 0:  // y += A x: the shard's rows are a contiguous slice of y
-        GatherCols(A, i, x, ne, nf, &xin[size_t(i)]);
-        return cx_matrix_right_multiply(p, xin[size_t(i)].data(), y + r0, CX_HOST);
-      case 1:  // y += A'x: e part local, f part a partial sum (added below in shard order)
-        yout[size_t(i)].assign(size_t(p->num_cols), 0.0);
-        return cx_matrix_left_multiply(p, x + r0, yout[size_t(i)].data(), CX_HOST);
-      case 2:
-        yout[size_t(i)].assign(size_t(p->num_cols), 0.0);
-        return cx_matrix_squared_column_norm(p, yout[size_t(i)].data(), CX_HOST);
-      default:
-        GatherCols(A, i, x, ne, nf, &xin[size_t(i)]);
-        return cx_matrix_scale_columns(p, xin[size_t(i)].data(), CX_HOST);
+      case 0: {  // y += A x: the shard's rows are a contiguous slice of y
+        cx_host_slices xs = ColSlices(A, i, x, ne, nf), ys = RowSlices(A, i, y);
+        return cx_matrix_right_multiply(p, xs.as_arg(), ys.as_arg(), CX_HOST_SLICES);
+      }
+      case 4: {  // y = A x
+        cx_host_slices xs = ColSlices(A, i, x, ne, nf), ys = RowSlices(A, i, y);
+        return cx_matrix_right_multiply_overwrite(p, xs.as_arg(), ys.as_arg(), CX_HOST_SLICES);
+      }
+      case 1:    // y += A'x: the e part is the shard's own; the f parts are partial sums, added in shard order on top of
+      case 2: {  // the caller's y_f (shard 0 brings it in).  x = diag(A'A): the same without the caller's values
+        CX_HIP(hipSetDevice(c->device));
+        cx_host_slices xs = RowSlices(A, i, x), ys = ColSlices(A, i, y, ne, nf, true);
+        HostOrDevice hx(c), hy(c);
+        if (op == 1) CX_TRY(hx.in(xs.as_arg(), size_t(p->num_rows), CX_HOST_SLICES));
+        CX_TRY(hy.inout(ys.as_arg(), size_t(p->num_cols), CX_HOST_SLICES, false));
+        CX_TRY(cx_matrix_ensure_ft(p));
+        if (op == 1) {
+          CX_TRY(cx_copy_h2d(c, hy.dptr, ys.head, size_t(ys.nhead) * sizeof(double)));
+          if (i == 0) CX_TRY(cx_copy_h2d(c, hy.dptr + ys.nhead, ys.tail, size_t(nf) * sizeof(double)));
+          else CX_HIP(hipMemsetAsync(hy.dptr + ys.nhead, 0, size_t(nf) * sizeof(double), c->stream));
+          CX_TRY(cxk_left_multiply(p, hx.dptr, hy.dptr));
+        } else {
+          CX_TRY(cxk_squared_column_norm(p, hy.dptr));
+        }
+        CX_TRY(cx_allreduce_device(c, hy.dptr + ys.nhead, nf));
+        return hy.out();
+      }
+      default: {
+        cx_host_slices xs = ColSlices(A, i, x, ne, nf);
+        return cx_matrix_scale_columns(p, xs.as_arg(), CX_HOST_SLICES);
+      }
     }
-  }));
-  if (op == 1 || op == 2) {
-    double* dst = y;
-    if (op == 2) std::fill(dst + ne, dst + ne + nf, 0.0);
-    for (int i = 0; i < n; ++i) {
-      const int64_t e0 = A->part_ecol0[size_t(i)], e1 = A->part_ecol0[size_t(i) + 1];
-      const double* v = yout[size_t(i)].data();
-      if (op == 1) for (int64_t k = e0; k < e1; ++k) dst[k] += v[k - e0];
-      else std::copy(v, v + (e1 - e0), dst + e0);
-      for (int64_t k = 0; k < nf; ++k) dst[ne + k] += v[(e1 - e0) + k];
-    }
-  }
-  return CX_OK;
+  });
 }
 
 // ------------------------------------------------------------------ solver
@@ -567,16 +588,21 @@ int cxm_solver_solve(cx_solver* S, cx_matrix* A, const double* b, const cx_per_s
   if (rc != CX_OK) return fatal(rc);
   const int n = int(A->parts.size());
   const int64_t ne = A->num_cols_e, nf = A->num_cols_f;
-  std::vector<std::vector<double>> Ds(static_cast<size_t>(n)), xs(static_cast<size_t>(n));
   std::vector<cx_summary> sums(static_cast<size_t>(n));
+  // whole arrays registered once, by the caller's thread; the shards then copy their slices of them
+  if (!residual_owner) (void)cx_pin_range(b, size_t(A->num_rows) * sizeof(double));
+  if (ps->D) (void)cx_pin_range(ps->D, size_t(A->num_cols) * sizeof(double));
+  (void)cx_pin_range(x, size_t(A->num_cols) * sizeof(double));
   rc = S->ctx->group->run([&](int i) -> int {
     cx_matrix* p = A->parts[size_t(i)];
     cx_per_solve_options psi = *ps;
+    psi.memspace = CX_HOST_SLICES;
+    cx_host_slices Ds, bs = RowSlices(A, i, b), xs = ColSlices(A, i, x, ne, nf, true);
     if (ps->D) {
-      GatherCols(A, i, ps->D, ne, nf, &Ds[size_t(i)]);
-      psi.D = Ds[size_t(i)].data();
+      Ds = ColSlices(A, i, ps->D, ne, nf);
+      psi.D = Ds.as_arg();
     }
-    const double* bi = b + A->part_row0[size_t(i)];
+    const double* bi = bs.as_arg();
     if (residual_owner) {
       bi = cx_evaluator_device_residuals(residual_owner->parts[size_t(i)]);
       if (!bi) {
@@ -584,8 +610,7 @@ int cxm_solver_solve(cx_solver* S, cx_matrix* A, const double* b, const cx_per_s
         return CX_ERR_INVALID_ARGUMENT;
       }
     }
-    xs[size_t(i)].resize(size_t(p->num_cols));
-    return cx_solver_solve(S->parts[size_t(i)], p, bi, &psi, xs[size_t(i)].data(), &sums[size_t(i)]);
+    return cx_solver_solve(S->parts[size_t(i)], p, bi, &psi, xs.as_arg(), &sums[size_t(i)]);
   });
   if (rc != CX_OK) return fatal(rc);
   // the camera-space vectors of the shards are replicas: the same exchange results, the same arithmetic -- so the
@@ -597,11 +622,6 @@ int cxm_solver_solve(cx_solver* S, cx_matrix* A, const double* b, const cx_per_s
       return fatal(CX_ERR_COMM);
     }
   *summary = sums[0];
-  for (int i = 0; i < n; ++i) {
-    const int64_t e0 = A->part_ecol0[size_t(i)], e1 = A->part_ecol0[size_t(i) + 1];
-    std::copy(xs[size_t(i)].begin(), xs[size_t(i)].begin() + (e1 - e0), x + e0);
-  }
-  std::copy(xs[0].end() - nf, xs[0].end(), x + ne);
   // phase times: the slowest shard of each phase; the exchange counters are the same on every shard
   S->timing = S->parts[0]->timing;
   for (int i = 1; i < n; ++i) {
@@ -743,10 +763,10 @@ int cxm_evaluator_set_column_scale(cx_evaluator* e, const double* scale, int32_t
   }
   CX_TRY(RequireHost(memspace, "cx_evaluator_set_column_scale"));
   cx_matrix* A = e->J;
-  std::vector<std::vector<double>> parts(e->parts.size());
+  (void)cx_pin_range(scale, size_t(A->num_cols) * sizeof(double));
   return e->ctx->group->run([&](int i) -> int {
-    GatherCols(A, i, scale, A->num_cols_e, A->num_cols_f, &parts[size_t(i)]);
-    return cx_evaluator_set_column_scale(e->parts[size_t(i)], parts[size_t(i)].data(), CX_HOST);
+    cx_host_slices ss = ColSlices(A, i, scale, A->num_cols_e, A->num_cols_f);
+    return cx_evaluator_set_column_scale(e->parts[size_t(i)], ss.as_arg(), CX_HOST_SLICES);
   });
 }
 
@@ -758,24 +778,20 @@ int cxm_evaluator_evaluate(cx_evaluator* e, const double* state, double* cost, d
   cx_matrix* A = e->J;
   const int n = int(e->parts.size());
   const int64_t ne = A->num_cols_e, nf = A->num_cols_f, ncam = CameraStateSize(e) * e->C;
-  std::vector<std::vector<double>> st(static_cast<size_t>(n)), gr(static_cast<size_t>(n));
   std::vector<double> costs(size_t(n), 0.0);
+  (void)cx_pin_range(state, size_t(ne + ncam) * sizeof(double));
+  if (residuals) (void)cx_pin_range(residuals, size_t(A->num_rows) * sizeof(double));
+  if (gradient) (void)cx_pin_range(gradient, size_t(A->num_cols) * sizeof(double));
   CX_TRY(e->ctx->group->run([&](int i) -> int {
-    GatherCols(A, i, state, ne, ncam, &st[size_t(i)]);
-    if (gradient) gr[size_t(i)].resize(size_t(A->parts[size_t(i)]->num_cols));
+    cx_host_slices ss = ColSlices(A, i, state, ne, ncam), rs, gs;
+    if (residuals) rs = RowSlices(A, i, residuals);
+    if (gradient) gs = ColSlices(A, i, gradient, ne, nf, true);
     // a shard's context has nranks > 1: cost and the camera part of the gradient come back summed over the shards
-    return cx_evaluator_evaluate(e->parts[size_t(i)], st[size_t(i)].data(), cost ? &costs[size_t(i)] : nullptr,
-                                 residuals ? residuals + A->part_row0[size_t(i)] : nullptr,
-                                 gradient ? gr[size_t(i)].data() : nullptr, evaluate_jacobian, CX_HOST);
+    return cx_evaluator_evaluate(e->parts[size_t(i)], ss.as_arg(), cost ? &costs[size_t(i)] : nullptr,
+                                 residuals ? rs.as_arg() : nullptr, gradient ? gs.as_arg() : nullptr, evaluate_jacobian,
+                                 CX_HOST_SLICES);
   }));
   if (cost) *cost = costs[0];
-  if (gradient) {
-    for (int i = 0; i < n; ++i) {
-      const int64_t e0 = A->part_ecol0[size_t(i)], e1 = A->part_ecol0[size_t(i) + 1];
-      std::copy(gr[size_t(i)].begin(), gr[size_t(i)].begin() + (e1 - e0), gradient + e0);
-    }
-    std::copy(gr[0].end() - nf, gr[0].end(), gradient + ne);
-  }
   return CX_OK;
 }
 
@@ -784,19 +800,11 @@ int cxm_evaluator_plus(cx_evaluator* e, const double* x, const double* delta, do
   cx_matrix* A = e->J;
   const int n = int(e->parts.size());
   const int64_t ne = A->num_cols_e, nf = A->num_cols_f, ncam = CameraStateSize(e) * e->C;
-  std::vector<std::vector<double>> xs(static_cast<size_t>(n)), ds(static_cast<size_t>(n)), os(static_cast<size_t>(n));
-  CX_TRY(e->ctx->group->run([&](int i) -> int {
-    GatherCols(A, i, x, ne, ncam, &xs[size_t(i)]);
-    GatherCols(A, i, delta, ne, nf, &ds[size_t(i)]);
-    os[size_t(i)].resize(xs[size_t(i)].size());
-    return cx_evaluator_plus(e->parts[size_t(i)], xs[size_t(i)].data(), ds[size_t(i)].data(), os[size_t(i)].data(), CX_HOST);
-  }));
-  for (int i = 0; i < n; ++i) {
-    const int64_t e0 = A->part_ecol0[size_t(i)], e1 = A->part_ecol0[size_t(i) + 1];
-    std::copy(os[size_t(i)].begin(), os[size_t(i)].begin() + (e1 - e0), x_plus_delta + e0);
-  }
-  std::copy(os[0].end() - ncam, os[0].end(), x_plus_delta + ne);
-  return CX_OK;
+  (void)n;
+  return e->ctx->group->run([&](int i) -> int {
+    cx_host_slices xs = ColSlices(A, i, x, ne, ncam), ds = ColSlices(A, i, delta, ne, nf), os = ColSlices(A, i, x_plus_delta, ne, ncam, true);
+    return cx_evaluator_plus(e->parts[size_t(i)], xs.as_arg(), ds.as_arg(), os.as_arg(), CX_HOST_SLICES);
+  });
 }
 
 const double* cxm_evaluator_device_residuals(const cx_evaluator* e) {
@@ -823,13 +831,12 @@ int cxm_minimize(cx_evaluator* e, cx_solver* s, const cx_minimizer_options* opti
   CX_TRY(EnsureSolverParts(s, A));
   const int n = int(e->parts.size());
   const int64_t ne = A->num_cols_e, ncam = CameraStateSize(e) * e->C;
-  std::vector<std::vector<double>> st(static_cast<size_t>(n));
   std::vector<cx_minimizer_summary> sums(static_cast<size_t>(n));
   std::vector<std::vector<cx_iteration_summary>> its(static_cast<size_t>(n));
   CX_TRY(e->ctx->group->run([&](int i) -> int {
-    GatherCols(A, i, state, ne, ncam, &st[size_t(i)]);
+    cx_host_slices ss = ColSlices(A, i, state, ne, ncam, true);  // in and out: every shard reads the cameras, shard 0 returns them
     its[size_t(i)].resize(size_t(i == 0 ? capacity : 0));
-    return cx_minimize(e->parts[size_t(i)], s->parts[size_t(i)], options, st[size_t(i)].data(), CX_HOST, &sums[size_t(i)],
+    return cx_minimize(e->parts[size_t(i)], s->parts[size_t(i)], options, ss.as_arg(), CX_HOST_SLICES, &sums[size_t(i)],
                        i == 0 && capacity > 0 ? its[0].data() : nullptr, i == 0 ? capacity : 0);
   }));
   for (int i = 1; i < n; ++i)
@@ -839,10 +846,5 @@ int cxm_minimize(cx_evaluator* e, cx_solver* s, const cx_minimizer_options* opti
     }
   *summary = sums[0];
   for (int k = 0; k < capacity && k < sums[0].num_iterations; ++k) iterations[k] = its[0][size_t(k)];
-  for (int i = 0; i < n; ++i) {
-    const int64_t e0 = A->part_ecol0[size_t(i)], e1 = A->part_ecol0[size_t(i) + 1];
-    std::copy(st[size_t(i)].begin(), st[size_t(i)].begin() + (e1 - e0), state + e0);
-  }
-  std::copy(st[0].end() - ncam, st[0].end(), state + ne);
   return CX_OK;
 }

@@ -53,8 +53,30 @@ struct CxEvaluatorHandle {
   bool fuse_scaling = false;
   const double* registered_scale_host = nullptr;
   bool values_carry_registered_scale = false;
+  // three entries of the registered vector (first, middle, last) as they were when it was registered: the cheap check
+  // that the array the caller passes again still holds what the evaluator applies (pointer identity alone would miss a
+  // caller that refills the same array)
+  double registered_scale_probe[3] = {0.0, 0.0, 0.0};
+  int64_t registered_scale_size = 0;
+  void RememberScale(const double* scale, int64_t n) {
+    registered_scale_host = scale;
+    registered_scale_size = n;
+    if (n > 0) {
+      registered_scale_probe[0] = scale[0];
+      registered_scale_probe[1] = scale[n / 2];
+      registered_scale_probe[2] = scale[n - 1];
+    }
+  }
+  bool IsRegisteredScale(const double* scale) const {
+    const int64_t n = registered_scale_size;
+    return scale == registered_scale_host && scale != nullptr &&
+           (n == 0 || (scale[0] == registered_scale_probe[0] && scale[n / 2] == registered_scale_probe[1] && scale[n - 1] == registered_scale_probe[2]));
+  }
   ~CxEvaluatorHandle() {
     if (evaluator) cx_evaluator_destroy(evaluator);
+    // the minimizer's vectors this evaluator's calls were handed (registered with the HIP runtime on first sight,
+    // cx_host_registration_policy) are about to be freed by their owner
+    cx_host_registrations_release();
   }
 };
 
@@ -82,8 +104,18 @@ class CxDeviceJacobian final : public SparseMatrix {
     host_valid_ = host_dirty_ = false;
     CX_ADAPTER_CHECK(cx_matrix_set_zero(matrix_));
   }
+  // When the caller vouches that y is zero whenever it calls RightMultiplyAndAccumulate -- TrustRegionMinimizer does:
+  // model_residuals_.setZero() immediately before the only product it takes (trust_region_minimizer.cc:430-433) -- the
+  // num_rows zeros are not uploaded (464 MB on Final-13682): y = J x is computed into a cleared device vector and
+  // copied back.  Opt-in like the residual aliasing; a few entries of y are sampled anyway, and a non-zero one sends the
+  // call down the accumulating path.
+  void set_assume_zeroed_product_target(bool on) { assume_zeroed_product_target_ = on; }
   void RightMultiplyAndAccumulate(const double* x, double* y) const final {
     Flush();
+    if (assume_zeroed_product_target_ && LooksZero(y, num_rows())) {
+      CX_ADAPTER_CHECK(cx_matrix_right_multiply_overwrite(matrix_, x, y, CX_HOST));
+      return;
+    }
     CX_ADAPTER_CHECK(cx_matrix_right_multiply(matrix_, x, y, CX_HOST));
   }
   void LeftMultiplyAndAccumulate(const double* x, double* y) const final {
@@ -97,7 +129,7 @@ class CxDeviceJacobian final : public SparseMatrix {
   void ScaleColumns(const double* scale) final {
     Flush();
     if (handle_->fuse_scaling && handle_->evaluator != nullptr) {
-      if (handle_->registered_scale_host == scale && handle_->values_carry_registered_scale) {
+      if (handle_->values_carry_registered_scale && handle_->IsRegisteredScale(scale)) {
         handle_->values_carry_registered_scale = false;  // the evaluation already wrote J diag(scale): this call's work is done
         return;
       }
@@ -105,8 +137,14 @@ class CxDeviceJacobian final : public SparseMatrix {
         host_valid_ = false;
         CX_ADAPTER_CHECK(cx_matrix_scale_columns(matrix_, scale, CX_HOST));
         CX_ADAPTER_CHECK(cx_evaluator_set_column_scale(handle_->evaluator, scale, CX_HOST));
-        handle_->registered_scale_host = scale;
+        handle_->RememberScale(scale, num_cols());
         return;
+      }
+      if (handle_->values_carry_registered_scale) {
+        // the values already carry the registered scale and the caller now brings ANOTHER vector (or new contents):
+        // the promise behind set_fuse_jacobi_scaling is broken and the product of both scalings is not what was asked for
+        std::fprintf(stderr, "cxschur: ScaleColumns with a vector other than the one registered by set_fuse_jacobi_scaling\n");
+        std::abort();
       }
     }
     host_valid_ = false;
@@ -162,7 +200,15 @@ class CxDeviceJacobian final : public SparseMatrix {
       }
   }
 
+  static bool LooksZero(const double* y, int64_t n) {
+    const int64_t stride = n > 64 ? n / 64 : 1;
+    for (int64_t i = 0; i < n; i += stride)
+      if (y[i] != 0.0) return false;
+    return n == 0 || y[n - 1] == 0.0;
+  }
+
   std::shared_ptr<CxEvaluatorHandle> handle_;
+  bool assume_zeroed_product_target_ = false;
   cx_matrix* matrix_;  // owned by the evaluator behind handle_
   std::unique_ptr<CompressedRowBlockStructure> block_structure_;
   mutable std::vector<double> host_values_;

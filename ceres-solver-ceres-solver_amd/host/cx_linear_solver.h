@@ -79,6 +79,11 @@ inline cx_context* CxSharedContext() {
                                        : cx_context_create_multi(int(r.devices.size()), r.devices.data(), &ctx);
   if (rc != CX_OK) return nullptr;  // not cached: a later call may succeed (or report again)
   r.contexts.emplace(r.devices, ctx);
+  // The arrays TrustRegionMinimizer / LevenbergMarquardtStrategy hand to Evaluate / Solve / the Jacobian's products live
+  // for the whole minimisation (trust_region_minimizer.cc:181-203): register them with the HIP runtime the first time
+  // they are seen, so that every later copy is a DMA at PCIe rate (the library's own default waits for the second
+  // sighting).  CX_PIN in the environment overrides (0 = never register).
+  if (std::getenv("CX_PIN") == nullptr) cx_host_registration_policy(1, int64_t(256) << 10, int64_t(16) << 30);
   return ctx;
 }
 
@@ -115,6 +120,8 @@ class CxLinearSolver final : public LinearSolver {
   ~CxLinearSolver() override {
     if (solver_) cx_solver_destroy(solver_);
     if (owned_matrix_) cx_matrix_destroy(owned_matrix_);
+    // b / D / x / values() arrays registered on first sight belong to a caller that is about to free them
+    cx_host_registrations_release();
   }
   CxLinearSolver(const CxLinearSolver&) = delete;
   void operator=(const CxLinearSolver&) = delete;
@@ -159,6 +166,7 @@ class CxLinearSolver final : public LinearSolver {
 
     cx_matrix* matrix = nullptr;
     const double* device_b = nullptr;
+    int64_t uploaded_values_bytes = 0;
     if (device_jacobian != nullptr) {
       matrix = device_jacobian->device_matrix();  // values are in HBM already
       if (alias_evaluator_residuals_ && device_jacobian->handle()->last_residuals_host == b)
@@ -171,6 +179,7 @@ class CxLinearSolver final : public LinearSolver {
       // values change every LM iteration: upload them verbatim (same cell layout)
       if (cx_matrix_set_values(owned_matrix_, host_jacobian->values(), CX_HOST) != CX_OK) return Fatal(&summary);
       matrix = owned_matrix_;
+      uploaded_values_bytes = int64_t(host_jacobian->num_nonzeros()) * int64_t(sizeof(double));
     } else {
       return Fatal(&summary, "the Jacobian is neither a BlockSparseMatrix nor a CxDeviceJacobian");
     }
@@ -192,6 +201,14 @@ class CxLinearSolver final : public LinearSolver {
     summary.num_iterations = s.num_iterations;
     summary.termination_type = static_cast<LinearSolverTerminationType>(s.termination_type);
     summary.message = s.message;
+    if (uploaded_values_bytes > 0) {
+      // said once per Solve, where Solver::Summary / the iteration log will show it: this Jacobian is a host matrix (the
+      // evaluator is not CxBalEvaluator) and its values cross PCIe every Solve
+      char note[160];
+      std::snprintf(note, sizeof(note), " [cxschur: host BlockSparseMatrix, %.1f MB of values uploaded for this Solve]", double(uploaded_values_bytes) / 1e6);
+      summary.message += note;
+    }
+    host_values_uploaded_bytes_ += uploaded_values_bytes;
     cx_solver_last_timing(solver_, &timing_);
     aliased_last_b_ = device_b != nullptr;
     return summary;
@@ -202,6 +219,7 @@ class CxLinearSolver final : public LinearSolver {
 
   const cx_solve_timing& last_timing() const { return timing_; }  // device-side phase times of the last Solve
   bool last_solve_aliased_residuals() const { return aliased_last_b_; }
+  int64_t host_values_uploaded_bytes() const { return host_values_uploaded_bytes_; }  // over the life of this solver
 
  private:
   bool TranslateOptions(int num_eliminate_blocks, cx_solver_options* o, LinearSolver::Summary* summary) const {
@@ -258,6 +276,7 @@ class CxLinearSolver final : public LinearSolver {
   cx_solve_timing timing_{};
   bool alias_evaluator_residuals_ = false;
   bool aliased_last_b_ = false;
+  int64_t host_values_uploaded_bytes_ = 0;
   ExecutionSummary execution_summary_;
 };
 

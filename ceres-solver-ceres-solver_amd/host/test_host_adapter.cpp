@@ -17,6 +17,7 @@
 // Needs a gfx950 device.  Exit code 0 = all checks passed.
 #include <functional>
 #include <algorithm>
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <numeric>
@@ -476,9 +477,29 @@ struct LmTrace {
   bool ok = true;
 };
 
+// Wall time of the loop, split by the call that crosses the boundary (--time mode): iterations after the first
+// `skip_iterations` are accumulated.  "caller" is everything between the calls -- the reference's own Eigen expressions.
+struct LoopClock {
+  int skip_iterations = 0;
+  int timed_iterations = 0;
+  double evaluate_jacobian_ms = 0, evaluate_cost_ms = 0, squared_column_norm_ms = 0, scale_columns_ms = 0, solve_ms = 0,
+         model_cost_product_ms = 0, total_ms = 0;
+  std::function<void()> on_timing_starts;  // called once, when the first timed iteration begins
+};
+
 static LmTrace RunTrustRegionLoop(Evaluator* evaluator, SparseMatrix* jacobian, LinearSolver* linear_solver, std::vector<double> x,
-                                  int max_iterations, double eta) {
+                                  int max_iterations, double eta, LoopClock* clock = nullptr) {
   LmTrace trace;
+  using SteadyClock = std::chrono::steady_clock;
+  bool timing = false;
+  auto timed = [&](double LoopClock::*slot, auto&& call) {
+    if (!timing) return call();
+    const auto t0 = SteadyClock::now();
+    auto r = call();
+    clock->*slot += std::chrono::duration<double, std::milli>(SteadyClock::now() - t0).count();
+    return r;
+  };
+  SteadyClock::time_point timing_started;
   const int num_parameters = evaluator->NumParameters(), num_effective = evaluator->NumEffectiveParameters();
   const int num_residuals = evaluator->NumResiduals();
   std::vector<double> residuals(static_cast<size_t>(num_residuals)), gradient(static_cast<size_t>(num_effective)), scaling(static_cast<size_t>(num_effective)),
@@ -492,20 +513,29 @@ static LmTrace RunTrustRegionLoop(Evaluator* evaluator, SparseMatrix* jacobian, 
   auto evaluate_gradient_and_jacobian = [&](bool first) {
     Evaluator::EvaluateOptions evaluate_options;
     evaluate_options.new_evaluation_point = true;
-    if (!evaluator->Evaluate(evaluate_options, x.data(), &cost, residuals.data(), gradient.data(), jacobian)) return false;
+    if (!timed(&LoopClock::evaluate_jacobian_ms, [&] { return evaluator->Evaluate(evaluate_options, x.data(), &cost, residuals.data(), gradient.data(), jacobian); })) return false;
     if (first) {
       jacobian->SquaredColumnNorm(scaling.data());
       for (auto& s : scaling) s = 1.0 / (1.0 + std::sqrt(s));
     }
-    jacobian->ScaleColumns(scaling.data(), nullptr, 1);
+    timed(&LoopClock::scale_columns_ms, [&] { jacobian->ScaleColumns(scaling.data(), nullptr, 1); return true; });
     return true;
   };
   if (!evaluate_gradient_and_jacobian(true)) { trace.ok = false; return trace; }
   trace.costs.push_back(cost);
   for (int iteration = 1; iteration <= max_iterations; ++iteration) {
+    if (clock != nullptr && !timing && iteration > clock->skip_iterations) {
+      if (clock->on_timing_starts) clock->on_timing_starts();
+      timing = true;
+      timing_started = SteadyClock::now();
+    }
+    if (timing) {
+      clock->timed_iterations = iteration - 1 - clock->skip_iterations;
+      clock->total_ms = std::chrono::duration<double, std::milli>(SteadyClock::now() - timing_started).count();
+    }
     // LevenbergMarquardtStrategy::ComputeStep (levenberg_marquardt_strategy.cc:69-156)
     if (!reuse_diagonal) {
-      jacobian->SquaredColumnNorm(diagonal.data(), nullptr, 1);
+      timed(&LoopClock::squared_column_norm_ms, [&] { jacobian->SquaredColumnNorm(diagonal.data(), nullptr, 1); return true; });
       for (auto& d : diagonal) d = std::min(std::max(d, min_diagonal), max_diagonal);
     }
     for (int i = 0; i < num_effective; ++i) lm_diagonal[size_t(i)] = std::sqrt(diagonal[size_t(i)] / radius);
@@ -514,7 +544,7 @@ static LmTrace RunTrustRegionLoop(Evaluator* evaluator, SparseMatrix* jacobian, 
     solve_options.q_tolerance = eta;
     solve_options.r_tolerance = -1.0;
     InvalidateArray(num_effective, step.data());
-    LinearSolver::Summary summary = linear_solver->Solve(jacobian, residuals.data(), solve_options, step.data());
+    LinearSolver::Summary summary = timed(&LoopClock::solve_ms, [&] { return linear_solver->Solve(jacobian, residuals.data(), solve_options, step.data()); });
     if (summary.termination_type == LinearSolverTerminationType::FATAL_ERROR) { trace.ok = false; std::printf("  %s\n", summary.message.c_str()); return trace; }
     bool step_is_valid = false;
     if (summary.termination_type != LinearSolverTerminationType::FAILURE && IsArrayValid(num_effective, step.data())) {
@@ -523,7 +553,7 @@ static LmTrace RunTrustRegionLoop(Evaluator* evaluator, SparseMatrix* jacobian, 
       trace.linear_iterations.push_back(summary.num_iterations);
       // TrustRegionMinimizer::ComputeTrustRegionStep (trust_region_minimizer.cc:381-463)
       std::fill(model_residuals.begin(), model_residuals.end(), 0.0);
-      jacobian->RightMultiplyAndAccumulate(step.data(), model_residuals.data(), nullptr, 1);
+      timed(&LoopClock::model_cost_product_ms, [&] { jacobian->RightMultiplyAndAccumulate(step.data(), model_residuals.data(), nullptr, 1); return true; });
       double model_cost_change = 0.0;
       for (int i = 0; i < num_residuals; ++i) model_cost_change -= model_residuals[size_t(i)] * (residuals[size_t(i)] + model_residuals[size_t(i)] / 2.0);
       step_is_valid = model_cost_change > 0.0;
@@ -532,7 +562,7 @@ static LmTrace RunTrustRegionLoop(Evaluator* evaluator, SparseMatrix* jacobian, 
         // ComputeCandidatePointAndEvaluateCost (:720-748): cost only
         double candidate_cost = 0.0;
         if (!evaluator->Plus(x.data(), delta.data(), candidate.data()) ||
-            !evaluator->Evaluate(candidate.data(), &candidate_cost, nullptr, nullptr, nullptr)) { trace.ok = false; return trace; }
+            !timed(&LoopClock::evaluate_cost_ms, [&] { return evaluator->Evaluate(candidate.data(), &candidate_cost, nullptr, nullptr, nullptr); })) { trace.ok = false; return trace; }
         const double relative_decrease = (cost - candidate_cost) / model_cost_change;  // TrustRegionStepEvaluator, monotonic
         if (relative_decrease > min_relative_decrease) {
           // HandleSuccessfulStep (:790-812) + LevenbergMarquardtStrategy::StepAccepted (:158-166)
@@ -553,6 +583,10 @@ static LmTrace RunTrustRegionLoop(Evaluator* evaluator, SparseMatrix* jacobian, 
     reuse_diagonal = true;
     ++trace.num_unsuccessful;
     (void)step_is_valid;
+  }
+  if (timing) {
+    clock->timed_iterations = max_iterations - clock->skip_iterations;
+    clock->total_ms = std::chrono::duration<double, std::milli>(SteadyClock::now() - timing_started).count();
   }
   trace.final_state = x;
   return trace;
@@ -694,6 +728,32 @@ static void TestEvaluatorToSolverThroughTheInterfaces() {
            "fused Jacobi scaling must not change a bit of the loop (%zu vs %zu accepted)", t.costs.size(), device_trace.costs.size());
     EXPECT(static_cast<CxDeviceJacobian*>(jacobian3.get())->num_downloads() == 0, "fused scaling keeps J in HBM");
   }
+
+  // (ii c) the boundary's transfer machinery changes no bit: caller arrays registered with the HIP runtime (first
+  // sight, what CxSharedContext sets) or not at all, and the model-cost product into a target the caller has just zeroed
+  // taken as y = J x (set_assume_zeroed_product_target) -- all three opt-ins on, as a TrustRegionMinimizer build would
+  for (int registration = 0; registration <= 1; ++registration) {
+    cx_host_registration_policy(registration, 1024, int64_t(1) << 30);  // small arrays here: register from 1 KiB
+    std::unique_ptr<Evaluator> evaluator4 = CxBalEvaluator::TryCreate(evaluator_options, &bal.program, &why);
+    static_cast<CxBalEvaluator*>(evaluator4.get())->set_fuse_jacobi_scaling(true);
+    std::unique_ptr<SparseMatrix> jacobian4 = evaluator4->CreateJacobian();
+    static_cast<CxDeviceJacobian*>(jacobian4.get())->set_assume_zeroed_product_target(true);
+    CxLinearSolver solver4(solver_options);
+    solver4.set_alias_evaluator_residuals(true);
+    cx_transfer_stats before{}, after{};
+    cx_transfer_stats_get(CxSharedContext(), &before, 1);
+    LmTrace t = RunTrustRegionLoop(evaluator4.get(), jacobian4.get(), &solver4, x0, kIterations, kEta);
+    cx_transfer_stats_get(CxSharedContext(), &after, 0);
+    EXPECT(t.ok && t.costs == device_trace.costs && t.linear_iterations == device_trace.linear_iterations,
+           "registration policy %d + zeroed product target + aliasing + fused scaling must not change a bit of the loop", registration);
+    const double registered = double(after.h2d_registered_bytes + after.d2h_registered_bytes) / double(after.h2d_bytes + after.d2h_bytes);
+    std::printf("  registration policy %d: %.2f MB H2D, %.2f MB D2H over the loop, %.0f %% through registered arrays (%d arrays, %.1f ms registering)\n",
+                registration, after.h2d_bytes / 1e6, after.d2h_bytes / 1e6, 100.0 * registered, after.num_registered, after.register_ms);
+    EXPECT(registration == 0 ? registered == 0.0 : registered > 0.9, "registered share of the traffic: %.3f", registered);
+    // the zeroed target saves the upload of num_rows doubles per product: H2D per iteration stays below 4 column vectors
+    EXPECT(double(after.h2d_bytes) < double(kIterations + 1) * 8.0 * (4.5 * evaluator4->NumEffectiveParameters()), "H2D bytes %lld", (long long)after.h2d_bytes);
+  }
+  cx_host_registration_policy(1, int64_t(256) << 10, int64_t(16) << 30);
 
   // (iii) the reference-style path: host BlockSparseMatrix, host products, values uploaded on every Solve
   HostJacobianEvaluator host_evaluator(evaluator.get());
@@ -932,7 +992,96 @@ static void TestRobustAndQuaternionPrograms() {
   }
 }
 
-int main() {
+// ------------------------------------------------------------------------------------------------ --time
+// What one LM iteration costs THROUGH the interfaces at a given size: the unmodified call sequence of RunTrustRegionLoop
+// on CxBalEvaluator / CxDeviceJacobian / CxLinearSolver with host vectors, wall ms per call kind, bytes across PCIe.
+//   test_host_adapter --time --problem FILE [--iterations N] [--warmup W] [--eta X] [--shards S] [--plain]
+// FILE (written by tools/boundary_timing.py from a bal.py preset): int64 C, P, O; int32 camera[O]; int32 point[O]
+// (non-decreasing: the Schur order); double xy[2 O]; double state[3 P + 9 C] (points, then cameras).
+// --plain switches the three opt-ins off (fused scaling, residual aliasing, zeroed product target).
+static int TimeBoundary(int argc, char** argv) {
+  const char* path = nullptr;
+  int iterations = 4, warmup = 1, shards = 1;
+  double eta = 0.1;
+  bool plain = false;
+  for (int i = 1; i < argc; ++i) {
+    const std::string a = argv[i];
+    if (a == "--problem" && i + 1 < argc) path = argv[++i];
+    else if (a == "--iterations" && i + 1 < argc) iterations = std::atoi(argv[++i]);
+    else if (a == "--warmup" && i + 1 < argc) warmup = std::atoi(argv[++i]);
+    else if (a == "--shards" && i + 1 < argc) shards = std::atoi(argv[++i]);
+    else if (a == "--eta" && i + 1 < argc) eta = std::atof(argv[++i]);
+    else if (a == "--plain") plain = true;
+  }
+  if (path == nullptr) { std::fprintf(stderr, "--time needs --problem FILE\n"); return 2; }
+  FILE* f = std::fopen(path, "rb");
+  if (!f) { std::fprintf(stderr, "cannot open %s\n", path); return 2; }
+  int64_t header[3];
+  if (std::fread(header, sizeof(int64_t), 3, f) != 3) { std::fprintf(stderr, "short file\n"); return 2; }
+  const int64_t C = header[0], P = header[1], O = header[2];
+  std::vector<int32_t> cam(static_cast<size_t>(O)), pt(static_cast<size_t>(O));
+  std::vector<double> xy(static_cast<size_t>(2 * O)), state(static_cast<size_t>(3 * P + 9 * C));
+  if (std::fread(cam.data(), 4, size_t(O), f) != size_t(O) || std::fread(pt.data(), 4, size_t(O), f) != size_t(O) ||
+      std::fread(xy.data(), 8, size_t(2 * O), f) != size_t(2 * O) || std::fread(state.data(), 8, state.size(), f) != state.size()) {
+    std::fprintf(stderr, "short file\n");
+    return 2;
+  }
+  std::fclose(f);
+  if (shards > 1) CxSetDevices(std::vector<int>(size_t(shards), 0));  // logical shards on device 0
+  CxBalProblemView view;
+  view.num_cameras = int32_t(C);
+  view.num_points = int32_t(P);
+  view.num_observations = O;
+  view.camera_index = cam.data();
+  view.point_index = pt.data();
+  view.observations_xy = xy.data();
+  Evaluator::Options evaluator_options;
+  evaluator_options.linear_solver_type = ITERATIVE_SCHUR;
+  evaluator_options.num_eliminate_blocks = int(P);
+  std::string error;
+  std::unique_ptr<CxBalEvaluator> evaluator = CxBalEvaluator::Create(evaluator_options, view, &error);
+  if (!evaluator) { std::fprintf(stderr, "CxBalEvaluator::Create: %s\n", error.c_str()); return 1; }
+  if (!plain) evaluator->set_fuse_jacobi_scaling(true);
+  std::unique_ptr<SparseMatrix> jacobian = evaluator->CreateJacobian();
+  if (!plain) static_cast<CxDeviceJacobian*>(jacobian.get())->set_assume_zeroed_product_target(true);
+  LinearSolver::Options solver_options;
+  solver_options.type = ITERATIVE_SCHUR;
+  solver_options.preconditioner_type = JACOBI;
+  solver_options.elimination_groups = {int(P), int(C)};
+  solver_options.min_num_iterations = 0;
+  solver_options.max_num_iterations = 500;
+  CxLinearSolver solver(solver_options);
+  if (!plain) solver.set_alias_evaluator_residuals(true);
+  cx_context* ctx = CxSharedContext();
+  LoopClock clock;
+  clock.skip_iterations = warmup;
+  clock.on_timing_starts = [&] { cx_transfer_stats t; cx_transfer_stats_get(ctx, &t, 1); };
+  LmTrace trace = RunTrustRegionLoop(evaluator.get(), jacobian.get(), &solver, state, warmup + iterations, eta, &clock);
+  if (!trace.ok) { std::fprintf(stderr, "the loop failed\n"); return 1; }
+  cx_transfer_stats t;
+  cx_transfer_stats_get(ctx, &t, 0);
+  const double k = double(std::max(1, clock.timed_iterations));
+  const double inside = clock.evaluate_jacobian_ms + clock.evaluate_cost_ms + clock.squared_column_norm_ms + clock.scale_columns_ms +
+                        clock.solve_ms + clock.model_cost_product_ms;
+  std::printf("{\"through\": \"CxBalEvaluator / CxDeviceJacobian / CxLinearSolver (host vectors)\", \"cameras\": %lld, \"points\": %lld, "
+              "\"residual_blocks\": %lld, \"shards\": %d, \"opt_ins\": %s, \"iterations\": %d, \"accepted\": %d, "
+              "\"lm_iteration_through_interfaces_ms\": %.3f, \"calls_ms\": {\"evaluate_jacobian_ms\": %.3f, \"evaluate_cost_ms\": %.3f, "
+              "\"squared_column_norm_ms\": %.3f, \"scale_columns_ms\": %.3f, \"solve_ms\": %.3f, \"model_cost_product_ms\": %.3f}, "
+              "\"caller_ms\": %.3f, \"wall_ms_per_iteration\": %.3f, \"h2d_bytes\": %.0f, \"d2h_bytes\": %.0f, \"h2d_ms\": %.3f, "
+              "\"d2h_ms\": %.3f, \"transfer_ms\": %.3f, \"registered_fraction\": %.4f, \"registered_arrays\": %d, "
+              "\"register_ms_total\": %.1f, \"final_cost\": %.17g, \"cg_iterations_last\": %d}\n",
+              (long long)C, (long long)P, (long long)O, shards, plain ? "false" : "true", clock.timed_iterations, trace.num_successful,
+              inside / k, clock.evaluate_jacobian_ms / k, clock.evaluate_cost_ms / k, clock.squared_column_norm_ms / k, clock.scale_columns_ms / k,
+              clock.solve_ms / k, clock.model_cost_product_ms / k, (clock.total_ms - inside) / k, clock.total_ms / k, t.h2d_bytes / k, t.d2h_bytes / k,
+              t.h2d_ms / k, t.d2h_ms / k, (t.h2d_ms + t.d2h_ms) / k,
+              double(t.h2d_registered_bytes + t.d2h_registered_bytes) / std::max(1.0, double(t.h2d_bytes + t.d2h_bytes)), t.num_registered, t.register_ms,
+              trace.costs.empty() ? 0.0 : trace.costs.back(), trace.linear_iterations.empty() ? 0 : trace.linear_iterations.back());
+  return 0;
+}
+
+int main(int argc, char** argv) {
+  for (int i = 1; i < argc; ++i)
+    if (std::string(argv[i]) == "--time") return TimeBoundary(argc, argv);
   TestSolversOnHostJacobian();
   TestEvaluatorToSolverThroughTheInterfaces();
   TestShardsBehindTheInterfaces();

@@ -235,6 +235,39 @@ int cx_context_num_shards(const cx_context* ctx);   /* 1 for a plain context */
  * e-block and the first row block of every shard (n + 1 entries each; either array may be NULL). */
 int cx_matrix_shard_layout(const cx_matrix* A, int32_t* e_block_bounds, int32_t* row_block_bounds, int32_t capacity);
 
+/* ---- host vectors at the boundary.
+ * LinearSolver::Solve and Evaluator::Evaluate hand over HOST arrays (linear_solver.h:363-390, evaluator.h:120-150), and
+ * TrustRegionMinimizer / LevenbergMarquardtStrategy pass the same long-lived arrays every LM iteration
+ * (trust_region_minimizer.cc:181-203, levenberg_marquardt_strategy.cc:77-99).  The library registers such arrays with the
+ * HIP runtime (hipHostRegister) so that their copies run as DMA at PCIe rate instead of through pageable bounce
+ * buffers.  The registry is process-wide, keeps at most 64 arrays / max_total_bytes (least recently used go first) and
+ * only ever touches a range inside a call that was handed that range.
+ *   sightings        0: never register; 1: the first time an array is handed in; 2 (library default): the second time
+ *                    -- a caller whose arrays do not live longer than one call pays nothing;
+ *   min_bytes        smaller arrays stay pageable (default 256 KiB);
+ *   max_total_bytes  default 16 GiB.
+ * Environment (read once, an explicit call wins): CX_PIN=0|1|2, CX_PIN_MIN_KB, CX_PIN_MAX_MB.
+ * cx_host_register pins one array now; cx_host_registrations_release unregisters everything -- call it before the
+ * arrays are freed (the host adapters do, in their destructors). */
+int cx_host_registration_policy(int32_t sightings, int64_t min_bytes, int64_t max_total_bytes);
+int cx_host_register(const void* host_ptr, size_t bytes);
+int cx_host_registrations_release(void);
+/* What crossed PCIe through this context's calls since the last reset (a multi-shard front: bytes and copies summed
+ * over the shards, durations of the slowest shard).  *_ms are device-side durations of the copies (HIP events on the
+ * stream each copy ran on), *_registered_bytes the part that went to / from registered memory. */
+typedef struct {
+  int64_t h2d_bytes, d2h_bytes;
+  int64_t h2d_copies, d2h_copies;
+  int64_t h2d_registered_bytes, d2h_registered_bytes;
+  double h2d_ms, d2h_ms;
+  int64_t registered_bytes;      /* registry: bytes registered now */
+  int32_t num_registered;        /* registry: arrays registered now */
+  int32_t reserved;
+  double register_ms;            /* host time spent in hipHostRegister since the last reset */
+  int64_t num_register_calls;
+} cx_transfer_stats;
+int cx_transfer_stats_get(cx_context* ctx, cx_transfer_stats* out, int32_t reset);
+
 int cx_malloc(cx_context* ctx, size_t bytes, void** device_ptr);
 int cx_free(cx_context* ctx, void* device_ptr);
 int cx_memcpy_h2d(cx_context* ctx, void* dst_device, const void* src_host, size_t bytes);
@@ -279,6 +312,11 @@ int cx_matrix_values_changed(cx_matrix* A);
 int cx_matrix_set_zero(cx_matrix* A);
 /* y += A x   BlockSparseMatrix::RightMultiplyAndAccumulate (block_sparse_matrix.cc:239-274) */
 int cx_matrix_right_multiply(cx_matrix* A, const double* x, double* y, int32_t memspace);
+/* y = A x: the product for a caller that knows y to be zero beforehand -- TrustRegionMinimizer's model cost
+ * (trust_region_minimizer.cc:430-433: model_residuals_.setZero() immediately before RightMultiplyAndAccumulate).  With
+ * host vectors it saves the upload of num_rows zeros; the bits of y equal those of zero-filling y and calling
+ * cx_matrix_right_multiply. */
+int cx_matrix_right_multiply_overwrite(cx_matrix* A, const double* x, double* y, int32_t memspace);
 /* y += A' x  BlockSparseMatrix::LeftMultiplyAndAccumulate (block_sparse_matrix.cc:278-349) */
 int cx_matrix_left_multiply(cx_matrix* A, const double* x, double* y, int32_t memspace);
 /* x = diag(A'A)  BlockSparseMatrix::SquaredColumnNorm (block_sparse_matrix.cc:351-401) */
