@@ -179,8 +179,8 @@ def boundary_block(cx, ctx, prob, solver_kw, iterations):
     sequence of TrustRegionMinimizer with HOST vectors (ceres-solver-ceres-solver_amd/boundary.py, the ctypes twin of
     host/test_host_adapter --time) on one shard and on four logical shards behind the front, next to the same
     iterations of the device-resident loop (cx_minimize).  The adapters' three opt-ins are on (fused Jacobi scaling,
-    residual aliasing, zeroed product target) and caller arrays are registered on first sight, as CxSharedContext sets."""
-    cx.host_registration_policy(1)
+    residual aliasing, zeroed product target) and the loop's vectors are registered with the HIP runtime on first sight
+    (CxRegisterCallerArrays: the loop owns their lifetime and releases the registrations before they are freed)."""
     n, m = 3 * prob.num_points + 9 * prob.num_cameras, 2 * prob.num_observations
     block = {"workload": "LM iterations 1..%d from the start point, ITERATIVE_SCHUR + JACOBI, eta = %g" % (iterations, ETA),
              "unmodified_caller_floor": {
@@ -189,9 +189,9 @@ def boundary_block(cx, ctx, prob, solver_kw, iterations):
                          "read or written in HOST memory by TrustRegionMinimizer / LevenbergMarquardtStrategy between the calls"}}
     for label, devices in (("one_shard", None), ("four_logical_shards", [0, 0, 0, 0])):
         c = ctx if devices is None else cx.Context(devices=devices)
-        loop = cx.boundary.BoundaryLoop(c, prob, solver_kw, eta=ETA)
+        loop = cx.boundary.BoundaryLoop(c, prob, solver_kw, eta=ETA, register_arrays=1)   # its vectors live until close()
         rep = loop.run(iterations)
-        loop.close()
+        loop.close()                         # registrations released, policy back to "never"
         ev = cx.Evaluator(c, prob)
         S = cx.Solver(c, **solver_kw)
         opts = cx.binding.minimizer_options(max_num_iterations=iterations, eta=ETA)
@@ -217,8 +217,6 @@ def boundary_block(cx, ctx, prob, solver_kw, iterations):
         }
         if devices is not None:
             c.close()
-    cx.host_registrations_release()
-    cx.host_registration_policy(2)
     return block
 
 

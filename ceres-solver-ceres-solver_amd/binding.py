@@ -216,8 +216,10 @@ def _f64(a):
     return np.ascontiguousarray(a, dtype=np.float64)
 
 
-def host_registration_policy(sightings=2, min_bytes=256 << 10, max_total_bytes=16 << 30):
-    """cx_host_registration_policy: when caller arrays are registered with the HIP runtime (0 never, 1 first sight, 2 second)."""
+def host_registration_policy(sightings=0, min_bytes=256 << 10, max_total_bytes=16 << 30):
+    """cx_host_registration_policy: when caller arrays are registered with the HIP runtime (0 never -- the default --, 1 first
+    sight, 2 second).  Switching it on is a promise: every array handed to the library stays allocated until
+    host_registrations_release()."""
     _check(load_library().cx_host_registration_policy(int(sightings), ctypes.c_int64(min_bytes), ctypes.c_int64(max_total_bytes)))
 
 

@@ -26,11 +26,15 @@ def _p(a):
 
 
 class BoundaryLoop:
-    def __init__(self, ctx, problem, solver_kw, eta=0.1, fuse_scaling=True, alias_residuals=True, zeroed_target=True):
+    def __init__(self, ctx, problem, solver_kw, eta=0.1, fuse_scaling=True, alias_residuals=True, zeroed_target=True,
+                 register_arrays=0):
         """fuse_scaling / alias_residuals / zeroed_target are the adapters' three opt-ins:
         CxBalEvaluator::set_fuse_jacobi_scaling, CxLinearSolver::set_alias_evaluator_residuals and
-        CxDeviceJacobian::set_assume_zeroed_product_target."""
+        CxDeviceJacobian::set_assume_zeroed_product_target.  register_arrays: cx_host_registration_policy's `sightings`
+        for the life of this object (its vectors live as long as it does; close() releases the registrations)."""
         self.ctx, self.lib, self.problem = ctx, ctx.lib, problem
+        self.register_arrays = int(register_arrays)
+        B.host_registration_policy(self.register_arrays, 4096, 16 << 30)
         self.ev = B.Evaluator(ctx, problem)
         self.J = self.ev.jacobian()
         self.S = B.Solver(ctx, **solver_kw)
@@ -63,6 +67,8 @@ class BoundaryLoop:
     def close(self):
         self.S.close()
         self.ev.close()
+        B.host_registrations_release()   # before the vectors can be freed
+        B.host_registration_policy(0)
 
     # ---- timing
     def _timed(self, key, fn):
@@ -154,7 +160,10 @@ class BoundaryLoop:
                 boundary("model_cost_product_ms", lambda: B._check(lib.cx_matrix_right_multiply(self.J._h, _p(self.step), _p(self.model_residuals), B.HOST)))
             np.multiply(self.model_residuals, 0.5, out=self.tmp_rows)
             self.tmp_rows += self.residuals
-            model_cost_change = -float(np.dot(self.model_residuals, self.tmp_rows))
+            # (no BLAS here on purpose: the worker threads a threaded ddot leaves spinning steal the cores the HIP runtime's
+            # copy threads need, and the evaluation that follows was measured anywhere between 14 and 87 ms because of it)
+            np.multiply(self.tmp_rows, self.model_residuals, out=self.tmp_rows)
+            model_cost_change = -float(self.tmp_rows.sum())
             if model_cost_change > 0.0:
                 np.multiply(self.step, self.scaling, out=self.delta)
                 np.add(self.x, self.delta, out=self.candidate)  # Evaluator::Plus, Euclidean blocks (host, as CxBalEvaluator::Plus)

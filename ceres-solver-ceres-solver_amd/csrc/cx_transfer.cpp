@@ -4,10 +4,18 @@
 // TrustRegionMinimizer allocates its vectors once (trust_region_minimizer.cc:181-203: x_, candidate_x_, gradient_,
 // residuals_, model_residuals_, trust_region_step_, delta_, jacobian_scaling_) and LevenbergMarquardtStrategy its
 // diagonal_ / lm_diagonal_ once (levenberg_marquardt_strategy.cc:77-99), then hands the same arrays to every call of an
-// LM iteration.  Copying them as pageable memory goes through the runtime's bounce buffers at a fraction of the PCIe
-// rate, so this file keeps a process-wide registry of caller arrays registered with the HIP runtime (hipHostRegister:
-// the pages are pinned and mapped once, later copies are plain DMA), a grow-only pool of device staging buffers per
-// context (no hipMalloc / hipFree per call) and per-context counters of what crossed PCIe.
+// LM iteration.  This file keeps a grow-only pool of device staging buffers per context (no hipMalloc / hipFree per
+// call), per-context counters of what crossed PCIe, and -- OPT-IN -- a process-wide registry of caller arrays registered
+// with the HIP runtime (hipHostRegister: the pages are pinned and mapped once, later copies are plain DMA that do not
+// block the calling thread).
+//
+// Why opt-in (measured, round 4, Final-13682 vectors on the MI355X boxes of this pool): pageable copies of arrays this
+// size already run at the PCIe rate (55 GB/s either way; the runtime pins the pages of a large copy in place), so
+// registration saves host time only (about 3 ms of a 31 ms iteration's boundary calls).  And a registration cannot see
+// its array die: a registered range that the owner frees (munmap) and whose addresses come back with the next
+// allocation still looks registered to the runtime, and the DMA into it faults the GPU.  So nothing is registered unless
+// the caller vouches for the lifetime of what it hands in (cx_host_registration_policy / cx_host_register) and calls
+// cx_host_registrations_release before those arrays are freed.
 #include <algorithm>
 #include <chrono>
 #include <cstdlib>
@@ -36,7 +44,7 @@ struct PinRegistry {
   uint64_t clock = 0;
   size_t total_bytes = 0;
   // policy (cx_host_registration_policy / CX_PIN_* in the environment)
-  int sightings_needed = 2;           // register an array the n-th time it is handed in; 0 = never
+  int sightings_needed = 0;           // register an array the n-th time it is handed in; 0 = never (the default)
   size_t min_bytes = size_t(256) << 10;
   size_t max_total_bytes = size_t(16) << 30;
   size_t max_entries = 64;
@@ -390,7 +398,6 @@ int cx_host_register(const void* p, size_t bytes) {
   r.read_env();
   const int keep = r.sightings_needed;
   const size_t keep_min = r.min_bytes;
-  if (keep == 0) return CX_OK;  // registration is switched off: not an error, the copies stay pageable
   r.sightings_needed = 1;
   r.min_bytes = 1;
   const bool ok = r.pin(p, bytes);

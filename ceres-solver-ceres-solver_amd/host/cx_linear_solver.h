@@ -51,6 +51,14 @@ struct CxContextRegistry {
   }
 };
 
+// Register the arrays the minimizer hands to Evaluate / Solve / the Jacobian's products with the HIP runtime the first
+// time they are seen (cx_host_registration_policy).  A Ceres tree may switch this on: TrustRegionMinimizer and
+// LevenbergMarquardtStrategy allocate those vectors once and keep them until Minimize returns
+// (trust_region_minimizer.cc:181-203), after which no call reaches this library before the evaluator and the solver are
+// destroyed -- and their destructors release the registrations.  Off by default: it buys host time only (pageable copies
+// of such vectors already run at the PCIe rate), and a registered array that is freed early faults the GPU.
+inline void CxRegisterCallerArrays(bool on) { cx_host_registration_policy(on ? 1 : 0, int64_t(256) << 10, int64_t(16) << 30); }
+
 inline void CxSetDevices(const std::vector<int>& devices) {
   CxContextRegistry& r = CxContextRegistry::Get();
   std::lock_guard<std::mutex> lock(r.mutex);
@@ -79,11 +87,6 @@ inline cx_context* CxSharedContext() {
                                        : cx_context_create_multi(int(r.devices.size()), r.devices.data(), &ctx);
   if (rc != CX_OK) return nullptr;  // not cached: a later call may succeed (or report again)
   r.contexts.emplace(r.devices, ctx);
-  // The arrays TrustRegionMinimizer / LevenbergMarquardtStrategy hand to Evaluate / Solve / the Jacobian's products live
-  // for the whole minimisation (trust_region_minimizer.cc:181-203): register them with the HIP runtime the first time
-  // they are seen, so that every later copy is a DMA at PCIe rate (the library's own default waits for the second
-  // sighting).  CX_PIN in the environment overrides (0 = never register).
-  if (std::getenv("CX_PIN") == nullptr) cx_host_registration_policy(1, int64_t(256) << 10, int64_t(16) << 30);
   return ctx;
 }
 

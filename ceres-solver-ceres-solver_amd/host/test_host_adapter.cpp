@@ -753,7 +753,7 @@ static void TestEvaluatorToSolverThroughTheInterfaces() {
     // the zeroed target saves the upload of num_rows doubles per product: H2D per iteration stays below 4 column vectors
     EXPECT(double(after.h2d_bytes) < double(kIterations + 1) * 8.0 * (4.5 * evaluator4->NumEffectiveParameters()), "H2D bytes %lld", (long long)after.h2d_bytes);
   }
-  cx_host_registration_policy(1, int64_t(256) << 10, int64_t(16) << 30);
+  cx_host_registration_policy(0, int64_t(256) << 10, int64_t(16) << 30);
 
   // (iii) the reference-style path: host BlockSparseMatrix, host products, values uploaded on every Solve
   HostJacobianEvaluator host_evaluator(evaluator.get());
@@ -1028,6 +1028,7 @@ static int TimeBoundary(int argc, char** argv) {
   }
   std::fclose(f);
   if (shards > 1) CxSetDevices(std::vector<int>(size_t(shards), 0));  // logical shards on device 0
+  if (std::getenv("CX_PIN") == nullptr) CxRegisterCallerArrays(true);  // the loop's vectors live until it returns; CX_PIN=0 for the A/B
   CxBalProblemView view;
   view.num_cameras = int32_t(C);
   view.num_points = int32_t(P);

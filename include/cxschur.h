@@ -238,17 +238,19 @@ int cx_matrix_shard_layout(const cx_matrix* A, int32_t* e_block_bounds, int32_t*
 /* ---- host vectors at the boundary.
  * LinearSolver::Solve and Evaluator::Evaluate hand over HOST arrays (linear_solver.h:363-390, evaluator.h:120-150), and
  * TrustRegionMinimizer / LevenbergMarquardtStrategy pass the same long-lived arrays every LM iteration
- * (trust_region_minimizer.cc:181-203, levenberg_marquardt_strategy.cc:77-99).  The library registers such arrays with the
- * HIP runtime (hipHostRegister) so that their copies run as DMA at PCIe rate instead of through pageable bounce
- * buffers.  The registry is process-wide, keeps at most 64 arrays / max_total_bytes (least recently used go first) and
- * only ever touches a range inside a call that was handed that range.
- *   sightings        0: never register; 1: the first time an array is handed in; 2 (library default): the second time
- *                    -- a caller whose arrays do not live longer than one call pays nothing;
+ * (trust_region_minimizer.cc:181-203, levenberg_marquardt_strategy.cc:77-99).  A caller that can vouch for the lifetime
+ * of those arrays may have the library register them with the HIP runtime (hipHostRegister): their copies then are plain
+ * DMA that do not block the calling thread.  OFF by default, for two measured reasons: pageable
+ * copies of vectors this size already run at the PCIe rate on MI355X hosts (the runtime pins a large copy's pages in
+ * place), and a registration cannot see its array die -- a registered range that is freed and whose addresses come back
+ * with a later allocation faults the GPU when it is copied.  THE CONTRACT of switching it on: every array handed to the
+ * library stays allocated until cx_host_registrations_release() has been called (the host adapters call it in their
+ * destructors; TrustRegionMinimizer's vectors live until Minimize returns).
+ *   sightings        0 (default): never register; 1: the first time an array is handed in; 2: the second time;
  *   min_bytes        smaller arrays stay pageable (default 256 KiB);
- *   max_total_bytes  default 16 GiB.
+ *   max_total_bytes  default 16 GiB; at most 64 arrays, least recently used go first.
  * Environment (read once, an explicit call wins): CX_PIN=0|1|2, CX_PIN_MIN_KB, CX_PIN_MAX_MB.
- * cx_host_register pins one array now; cx_host_registrations_release unregisters everything -- call it before the
- * arrays are freed (the host adapters do, in their destructors). */
+ * cx_host_register pins one array now (whatever the policy); cx_host_registrations_release unregisters everything. */
 int cx_host_registration_policy(int32_t sightings, int64_t min_bytes, int64_t max_total_bytes);
 int cx_host_register(const void* host_ptr, size_t bytes);
 int cx_host_registrations_release(void);
