@@ -38,6 +38,7 @@ EXPORTED_SYMBOLS = [
     "cx_implicit_schur_multiply", "cx_dense_cholesky_solve", "cx_evaluator_create_bal", "cx_evaluator_destroy",
     "cx_evaluator_jacobian", "cx_evaluator_row_of_observation", "cx_evaluator_evaluate", "cx_evaluator_set_loss", "cx_minimizer_default_options", "cx_minimize", "cx_schur_sparse_structure", "cx_visibility_structure", "cx_visibility_clusters_host",
     "cx_evaluator_set_camera_model", "cx_evaluator_num_parameters", "cx_evaluator_num_effective_parameters", "cx_evaluator_plus",
+    "cx_context_set_comm_timeout", "cx_debug_inject_failure", "cx_debug_stall_stream", "cx_debug_force_rank_count",
     "cx_matrix_right_multiply_overwrite", "cx_host_registration_policy", "cx_host_register", "cx_host_registrations_release", "cx_transfer_stats_get",
     "cx_evaluator_last_kernel_ms", "cx_evaluator_device_residuals", "cx_evaluator_set_emit_camera_major", "cx_sparse_cholesky_plan_host", "cx_sparse_cholesky_schedule_host", "cx_detect_structure", "cx_partition_points", "cx_stable_schur_ordering",
 ]
@@ -302,6 +303,16 @@ class Context:
 
     def synchronize(self):
         _check(self.lib.cx_synchronize(self._h))
+
+    def set_comm_timeout(self, seconds):
+        _check(self.lib.cx_context_set_comm_timeout(self._h, ctypes.c_double(seconds)))
+
+    def inject_failure(self, shard, nth_collective):
+        """Test hook: shard `shard` fails right before the nth collective it enters from now on (-1 clears)."""
+        _check(self.lib.cx_debug_inject_failure(self._h, int(shard), ctypes.c_int64(nth_collective)))
+
+    def stall_stream(self, milliseconds):
+        _check(self.lib.cx_debug_stall_stream(self._h, int(milliseconds)))
 
     def transfer_stats(self, reset=False):
         """What crossed PCIe through this context's calls (cx_transfer_stats_get)."""

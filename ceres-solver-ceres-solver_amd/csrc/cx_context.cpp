@@ -3,6 +3,8 @@
 #include <dlfcn.h>
 
 #include <chrono>
+#include <cstdlib>
+#include <thread>
 
 #include "cx_internal.h"
 
@@ -24,6 +26,7 @@ using GetUniqueIdFn = int (*)(UniqueId*);
 using CommInitRankFn = int (*)(void**, int, UniqueId, int);
 using AllReduceFn = int (*)(const void*, void*, size_t, int, int, void*, hipStream_t);
 using CommDestroyFn = int (*)(void*);
+using CommAbortFn = int (*)(void*);
 using GetErrorStringFn = const char* (*)(int);
 struct Rccl {
   void* handle = nullptr;
@@ -31,6 +34,7 @@ struct Rccl {
   CommInitRankFn comm_init_rank = nullptr;
   AllReduceFn all_reduce = nullptr;
   CommDestroyFn comm_destroy = nullptr;
+  CommAbortFn comm_abort = nullptr;
   GetErrorStringFn error_string = nullptr;
 } g_rccl;
 constexpr int kNcclFloat64 = 8;  // rccl.h:467
@@ -52,6 +56,7 @@ int LoadRccl() {
   g_rccl.comm_init_rank = reinterpret_cast<CommInitRankFn>(dlsym(h, "ncclCommInitRank"));
   g_rccl.all_reduce = reinterpret_cast<AllReduceFn>(dlsym(h, "ncclAllReduce"));
   g_rccl.comm_destroy = reinterpret_cast<CommDestroyFn>(dlsym(h, "ncclCommDestroy"));
+  g_rccl.comm_abort = reinterpret_cast<CommAbortFn>(dlsym(h, "ncclCommAbort"));
   g_rccl.error_string = reinterpret_cast<GetErrorStringFn>(dlsym(h, "ncclGetErrorString"));
   if (!g_rccl.get_unique_id || !g_rccl.comm_init_rank || !g_rccl.all_reduce || !g_rccl.comm_destroy) {
     cx_set_error("librccl lacks a required symbol");
@@ -67,11 +72,133 @@ int RcclCheck(int rc, const char* what) {
 }
 }  // namespace
 
+// ---------------------------------------------------------------- a collective must not be able to hang the caller
+// RCCL collectives are enqueued; a rank whose peer never arrives (the peer failed locally and returned, or died) shows it
+// at the next wait on the stream, which would block for good.  On a context with an RCCL communicator of several ranks
+// every such wait polls with a deadline instead (cx_stream_sync / cx_event_sync, used by all code a sharded solve runs
+// through); when the deadline passes the communicator is aborted -- ncclCommAbort makes the stuck collective's kernel
+// leave -- the context is marked broken and the call returns CX_ERR_COMM, which the callers turn into FATAL_ERROR.
+// Nothing is retried and no process is re-executed.  CX_COMM_TIMEOUT_S (default 120) or cx_context_set_comm_timeout.
+static double CommTimeout(const cx_context* ctx) {
+  if (ctx->comm_timeout_s > 0.0) return ctx->comm_timeout_s;
+  static const double from_env = [] {
+    const char* e = std::getenv("CX_COMM_TIMEOUT_S");
+    const double v = e ? std::atof(e) : 0.0;
+    return v > 0.0 ? v : 120.0;
+  }();
+  return from_env;
+}
+
+double cx_comm_timeout(const cx_context* ctx) { return CommTimeout(ctx); }
+
+int cx_read_back(cx_context* ctx, void* host, const void* dev, size_t bytes, hipStream_t st) {
+  if (!st) st = ctx->stream;
+  if (ctx->comm && ctx->nranks > 1) CX_TRY(cx_stream_sync(ctx, st));
+  CX_HIP(hipMemcpyAsync(host, dev, bytes, hipMemcpyDeviceToHost, st));
+  CX_HIP(hipStreamSynchronize(st));
+  return CX_OK;
+}
+
+int cx_comm_abort(cx_context* ctx) {
+  if (!ctx) return CX_OK;
+  void* comm = ctx->comm;
+  ctx->comm = nullptr;
+  ctx->comm_broken = ctx->comm_broken || ctx->nranks > 1;
+  if (comm) {
+    if (g_rccl.comm_abort) g_rccl.comm_abort(comm);
+    else if (g_rccl.comm_destroy) g_rccl.comm_destroy(comm);
+  }
+  return CX_OK;
+}
+
+template <typename Ready>
+static int BoundedWait(cx_context* ctx, hipStream_t drain, Ready ready, const char* what) {
+  const double limit = CommTimeout(ctx);
+  const auto t0 = std::chrono::steady_clock::now();
+  for (long spins = 0;; ++spins) {
+    const hipError_t q = ready();
+    if (q == hipSuccess) return CX_OK;
+    if (q != hipErrorNotReady) {
+      cx_set_error("%s failed: %s", what, hipGetErrorString(q));
+      return CX_ERR_HIP;
+    }
+    if (spins > 4000) std::this_thread::sleep_for(std::chrono::microseconds(50));
+    if ((spins & 127) == 127 && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > limit) break;
+  }
+  // no progress for `limit` seconds: the exchange step is waiting for a rank that will not come
+  cx_comm_abort(ctx);
+  // the aborted collective leaves its kernel; give the stream a bounded time to drain so that later frees are safe
+  const auto t1 = std::chrono::steady_clock::now();
+  while (hipStreamQuery(drain) == hipErrorNotReady && std::chrono::duration<double>(std::chrono::steady_clock::now() - t1).count() < 10.0)
+    std::this_thread::sleep_for(std::chrono::milliseconds(1));
+  cx_set_error("rank %d of %d: no progress on the stream for %.3g s -- a peer never reached the exchange step (it failed or died); "
+               "communicator aborted, this context cannot run sharded work any more", ctx->rank, ctx->nranks, limit);
+  return CX_ERR_COMM;
+}
+
+int cx_stream_sync(cx_context* ctx, hipStream_t st) {
+  if (!st) st = ctx->stream;
+  if (!(ctx->comm && ctx->nranks > 1)) {
+    CX_HIP(hipStreamSynchronize(st));
+    return CX_OK;
+  }
+  return BoundedWait(ctx, st, [&] { return hipStreamQuery(st); }, "hipStreamQuery");
+}
+
+int cx_event_sync(cx_context* ctx, hipEvent_t ev) {
+  if (!(ctx->comm && ctx->nranks > 1)) {
+    CX_HIP(hipEventSynchronize(ev));
+    return CX_OK;
+  }
+  return BoundedWait(ctx, ctx->stream, [&] { return hipEventQuery(ev); }, "hipEventQuery");
+}
+
+static int AllReduce(cx_context* ctx, double* p, int64_t n, bool even_single_rank);
+
+// Every rank says whether it is still healthy; all of them learn whether any is not.  Called where a sharded phase is
+// about to start exchanging (after argument checks, allocations and input copies -- the places a rank fails on its own):
+// a rank that failed still takes part, with its flag set, and ALL ranks leave the call with an error together instead of
+// the healthy ones waiting inside the first collective.
+int cx_comm_agree(cx_context* ctx, int local_rc) {
+  if (ctx->nranks <= 1) return local_rc;
+  if (ctx->comm_broken) {
+    if (local_rc == CX_OK) cx_set_error("the communicator of this context was aborted after a lost rank");
+    return local_rc != CX_OK ? local_rc : CX_ERR_COMM;
+  }
+  std::string keep = local_rc != CX_OK ? cx_last_error() : "";
+  int rc = ctx->agree.alloc(1);
+  double flag = local_rc != CX_OK ? 1.0 : 0.0;
+  if (rc == CX_OK && hipMemcpyAsync(ctx->agree.p, &flag, sizeof(double), hipMemcpyHostToDevice, ctx->stream) != hipSuccess) rc = CX_ERR_HIP;
+  if (rc == CX_OK) rc = AllReduce(ctx, ctx->agree.p, 1, false);
+  if (rc == CX_OK && hipMemcpyAsync(&flag, ctx->agree.p, sizeof(double), hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) rc = CX_ERR_HIP;
+  if (rc == CX_OK) rc = cx_stream_sync(ctx, ctx->stream);
+  if (local_rc != CX_OK) {
+    cx_set_error("%s", keep.c_str());
+    return local_rc;
+  }
+  if (rc != CX_OK) return rc;
+  if (flag != 0.0) {
+    cx_set_error("rank %d of %d: another rank failed before the exchange step of this call; all ranks return together", ctx->rank, ctx->nranks);
+    return CX_ERR_COMM;
+  }
+  return CX_OK;
+}
+
 static int AllReduce(cx_context* ctx, double* p, int64_t n, bool even_single_rank) {
   if (n == 0) return CX_OK;
   // with one rank the sum is the identity: skipped inside the solvers, but cx_allreduce_sum still goes through
   // RCCL when a communicator exists, so that the call path can be exercised on a one-GPU box
   if (ctx->nranks <= 1 && !(even_single_rank && ctx->comm)) return CX_OK;
+  if (ctx->comm_broken) {
+    cx_set_error("the communicator of this context was aborted after a lost rank");
+    return CX_ERR_COMM;
+  }
+  // failure injection (cx_debug_inject_failure): this rank "fails locally" right before its n-th collective from now
+  if (ctx->fail_countdown >= 0 && ctx->fail_countdown-- == 0) {
+    ctx->fail_countdown = -1;
+    cx_set_error("injected failure before a collective (cx_debug_inject_failure)");
+    return CX_ERR_HIP;
+  }
   ctx->ar_calls += 1;
   ctx->ar_bytes += n * int64_t(sizeof(double));
   if (ctx->allreduce_cb) {
@@ -217,6 +344,41 @@ int cx_context_set_comm_callback(cx_context* ctx, int rank, int nranks, cx_allre
   return CX_OK;
 }
 
+int cx_context_set_comm_timeout(cx_context* ctx, double seconds) {
+  CX_CHECK_ARG(ctx != nullptr && seconds >= 0.0);
+  ctx->comm_timeout_s = seconds;
+  for (cx_context* shard : ctx->shards)
+    if (shard) shard->comm_timeout_s = seconds;
+  return CX_OK;
+}
+
+int cx_debug_inject_failure(cx_context* ctx, int32_t shard, int64_t nth_collective) {
+  CX_CHECK_ARG(ctx != nullptr && nth_collective >= -1);
+  cx_context* target = ctx;
+  if (!ctx->shards.empty()) {
+    CX_CHECK_ARG(shard >= 0 && shard < int32_t(ctx->shards.size()));
+    target = ctx->shards[size_t(shard)];
+  }
+  target->fail_countdown = nth_collective;
+  return CX_OK;
+}
+
+int cx_debug_force_rank_count(cx_context* ctx, int32_t nranks) {
+  CX_CHECK_ARG(ctx != nullptr && nranks >= 1);
+  ctx->nranks = nranks;
+  return CX_OK;
+}
+
+static void StallCallback(void* user) {
+  std::this_thread::sleep_for(std::chrono::milliseconds(reinterpret_cast<intptr_t>(user)));
+}
+int cx_debug_stall_stream(cx_context* ctx, int32_t milliseconds) {
+  CX_CHECK_ARG(ctx != nullptr && milliseconds >= 0);
+  CX_HIP(hipSetDevice(ctx->device));
+  CX_HIP(hipLaunchHostFunc(ctx->stream, StallCallback, reinterpret_cast<void*>(intptr_t(milliseconds))));
+  return CX_OK;
+}
+
 int cx_context_rank(const cx_context* ctx) { return ctx ? ctx->rank : 0; }
 int cx_context_num_ranks(const cx_context* ctx) { return ctx ? ctx->nranks : 1; }
 
@@ -258,8 +420,7 @@ int cx_memset_zero(cx_context* ctx, void* p, size_t bytes) {
 }
 int cx_synchronize(cx_context* ctx) {
   CX_CHECK_ARG(ctx != nullptr);
-  CX_HIP(hipStreamSynchronize(ctx->stream));
-  return CX_OK;
+  return cx_stream_sync(ctx, ctx->stream);
 }
 void* cx_context_stream(cx_context* ctx) { return ctx ? ctx->stream : nullptr; }
 

@@ -775,8 +775,11 @@ int cx_evaluator_evaluate(cx_evaluator* e, const double* state, double* cost, do
   const int64_t ncols = A->num_cols, nrows = A->num_rows;
   HostOrDevice hs(ctx), hg(ctx);
   const int64_t nstate = 3 * int64_t(e->P) + (e->camera_model == CX_CAMERA_ANGLE_AXIS ? 9 : 10) * int64_t(e->C);
-  CX_TRY(hs.in(state, size_t(nstate), memspace));
-  CX_TRY(hg.inout(gradient, size_t(ncols), memspace, false));
+  int staged = hs.in(state, size_t(nstate), memspace);
+  if (staged == CX_OK) staged = hg.inout(gradient, size_t(ncols), memspace, false);
+  // sharded: cost and gradient are summed over the ranks below; a rank that could not stage its inputs says so first
+  if (cost != nullptr || gradient != nullptr) CX_TRY(cx_comm_agree(ctx, staged));
+  else CX_TRY(staged);
   const bool with_j = evaluate_jacobian != 0 || gradient != nullptr;
   // Residuals asked for in host memory are produced in the evaluator's own device buffer and copied out, so that
   // they also stay available in HBM (cx_evaluator_device_residuals) for the linear solve that follows.
@@ -906,11 +909,11 @@ int cx_evaluator_evaluate(cx_evaluator* e, const double* state, double* cost, do
   }
   if (cost) {
     if (ctx->nranks > 1) CX_TRY(cx_allreduce_device(ctx, e->d_partial.p + grid, 1));  // shards sum their costs
-    CX_HIP(hipMemcpyAsync(cost, e->d_partial.p + grid, sizeof(double), hipMemcpyDeviceToHost, st));
+    CX_TRY(cx_read_back(ctx, cost, e->d_partial.p + grid, sizeof(double), st));
   }
   CX_TRY(hg.out_async(st));
-  CX_HIP(hipStreamSynchronize(st));
-  if (cs != st) CX_HIP(hipStreamSynchronize(cs));
+  CX_TRY(cx_stream_sync(ctx, st));
+  if (cs != st) CX_TRY(cx_stream_sync(ctx, cs));
   CX_HIP(hipEventElapsedTime(&e->last_ms, ctx->ev[6], ctx->ev[7]));
   return CX_OK;
 }
@@ -938,7 +941,7 @@ int cx_evaluator_set_column_scale(cx_evaluator* e, const double* scale, int32_t 
   const size_t n = size_t(3 * int64_t(e->P) + 9 * int64_t(e->C));
   CX_TRY(e->d_col_scale.alloc(n));
   CX_TRY(cx_vector_in(ctx, e->d_col_scale.p, scale, n, memspace));
-  CX_HIP(hipStreamSynchronize(ctx->stream));
+  CX_TRY(cx_stream_sync(ctx, ctx->stream));
   e->has_col_scale = true;
   return CX_OK;
 }
@@ -967,7 +970,7 @@ int cx_evaluator_plus(cx_evaluator* e, const double* x, const double* delta, dou
   CX_TRY(ho.inout(x_plus_delta, size_t(cx_evaluator_num_parameters(e)), memspace, false));
   CX_TRY(cxe_plus(e, hx.dptr, hd.dptr, 1.0, ho.dptr));
   CX_TRY(ho.out());
-  CX_HIP(hipStreamSynchronize(ctx->stream));
+  CX_TRY(cx_stream_sync(ctx, ctx->stream));
   return CX_OK;
 }
 

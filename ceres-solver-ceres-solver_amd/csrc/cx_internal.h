@@ -83,6 +83,10 @@ struct cx_context {
   void* allreduce_cb_user = nullptr;
   int rank = 0;
   int nranks = 1;
+  bool comm_broken = false;        // the communicator was aborted after a lost rank (cx_comm_abort): no sharded work any more
+  double comm_timeout_s = 0.0;     // 0: CX_COMM_TIMEOUT_S or 120 s
+  int64_t fail_countdown = -1;     // cx_debug_inject_failure: fail before the n-th collective from now (-1: off)
+  DevBuf<double> agree;            // one word for cx_comm_agree
   double allreduce_host_ms = 0.0;
   // device-side timing of the exchange step: event pairs around the collectives since cx_allreduce_reset()
   static constexpr int kTimedCollectives = 256;
@@ -356,6 +360,18 @@ int cxk_ft_multiply(cx_matrix* A, const double* t, double* y_f, bool accumulate)
 int cxk_ft_partials(cx_matrix* A, const double* t);
 
 int cx_allreduce_device(cx_context* ctx, double* p, int64_t n);
+// waits that cannot hang on a lost rank (cx_context.cpp): plain waits on a context without an RCCL communicator of
+// several ranks, polling with a deadline + ncclCommAbort otherwise.  st == NULL: the context stream
+int cx_stream_sync(cx_context* ctx, hipStream_t st);
+int cx_event_sync(cx_context* ctx, hipEvent_t ev);
+int cx_comm_abort(cx_context* ctx);
+double cx_comm_timeout(const cx_context* ctx);  // seconds a wait on a sharded context may see no progress
+// host <- device for the scalars the control flow reads (pageable host memory): a pageable copy blocks inside the runtime
+// until the stream has drained, so the bounded wait comes first, then the copy, then the wait for the copy
+int cx_read_back(cx_context* ctx, void* host, const void* dev, size_t bytes, hipStream_t st = nullptr);
+// all ranks learn whether any of them has failed so far in this call (local_rc != CX_OK); returns local_rc when that is
+// an error, CX_ERR_COMM when only another rank failed, CX_OK when all are healthy.  One rank: returns local_rc
+int cx_comm_agree(cx_context* ctx, int local_rc);
 // statistics of the collectives since the last reset; collect waits for the recorded events (call after the stream
 // has been synchronised) and returns the device time, extrapolated when more collectives ran than were timed
 void cx_allreduce_reset(cx_context* ctx);

@@ -860,7 +860,7 @@ static int Timed(cx_matrix* A, Fn body) {
   CX_HIP(hipEventRecord(ctx->ev[0], ctx->stream));
   CX_TRY(body());
   CX_HIP(hipEventRecord(ctx->ev[1], ctx->stream));
-  CX_HIP(hipEventSynchronize(ctx->ev[1]));
+  CX_TRY(cx_event_sync(ctx, ctx->ev[1]));
   CX_HIP(hipEventElapsedTime(&A->last_ms, ctx->ev[0], ctx->ev[1]));
   return CX_OK;
 }
@@ -998,7 +998,7 @@ int cx_matrix_set_values(cx_matrix* A, const double* src, int32_t memspace) {
   CX_CHECK_ARG(A && (src || A->nnz == 0));
   if (!A->parts.empty()) return cxm_matrix_set_values(A, src, memspace);
   if (A->nnz) CX_TRY(cx_vector_in(A->ctx, A->d_values.p, src, size_t(A->nnz), memspace));
-  CX_HIP(hipStreamSynchronize(A->ctx->stream));
+  CX_TRY(cx_stream_sync(A->ctx, A->ctx->stream));
   A->ft_valid = false;
   A->f32_valid = false;
   if (A->embed) A->embed->dirty = true;
@@ -1009,7 +1009,7 @@ int cx_matrix_get_values(const cx_matrix* A, double* dst) {
   CX_CHECK_ARG(A && (dst || A->nnz == 0));
   if (!A->parts.empty()) return cxm_matrix_get_values(A, dst);
   if (A->nnz) CX_TRY(cx_copy_d2h(A->ctx, dst, A->d_values.p, size_t(A->nnz) * sizeof(double)));
-  CX_HIP(hipStreamSynchronize(A->ctx->stream));
+  CX_TRY(cx_stream_sync(A->ctx, A->ctx->stream));
   return CX_OK;
 }
 

@@ -237,8 +237,8 @@ struct Minimizer {
     double h[4] = {0, 0, 0, 0};
     if (ctx->nranks <= 1) {
       CX_TRY(pass(a, b, len, red_out.p));
-      CX_HIP(hipMemcpyAsync(h, red_out.p, 2 * sizeof(double), hipMemcpyDeviceToHost, st));
-      CX_HIP(hipStreamSynchronize(st));
+      CX_TRY(cx_read_back(ctx, h, red_out.p, 2 * sizeof(double), st));
+      CX_TRY(cx_stream_sync(ctx, st));
       v0 = h[0];
       v1 = h[1];
       return CX_OK;
@@ -250,9 +250,9 @@ struct Minimizer {
     if (len > len_local) CX_TRY(pass(a + len_local, b + len_local, len - len_local, red_out.p + 2));
     else CX_HIP(hipMemsetAsync(red_out.p + 2, 0, 2 * sizeof(double), st));
     std::vector<double> hs(size_t(1 + ctx->nranks));
-    CX_HIP(hipMemcpyAsync(hs.data(), slots.p, hs.size() * sizeof(double), hipMemcpyDeviceToHost, st));
-    CX_HIP(hipMemcpyAsync(h, red_out.p + 2, 2 * sizeof(double), hipMemcpyDeviceToHost, st));
-    CX_HIP(hipStreamSynchronize(st));
+    CX_TRY(cx_read_back(ctx, hs.data(), slots.p, hs.size() * sizeof(double), st));
+    CX_TRY(cx_read_back(ctx, h, red_out.p + 2, 2 * sizeof(double), st));
+    CX_TRY(cx_stream_sync(ctx, st));
     v0 = hs[0] + h[0];
     v1 = h[1];
     for (int r = 0; r < ctx->nranks; ++r) v1 = (MODE == RED_GRADIENT) ? std::max(v1, hs[1 + r]) : v1 + hs[1 + r];
@@ -528,7 +528,7 @@ struct Minimizer {
     out->num_iterations = num_written;
     out->final_cost = minimum_cost;
     if (cx_is_host_space(memspace)) CX_TRY(cx_vector_out(ctx, state, parameters, size_t(n_amb), memspace));
-    CX_HIP(hipStreamSynchronize(st));
+    CX_TRY(cx_stream_sync(ctx, st));
     out->total_ms = MsSince(start);
     return CX_OK;
   }

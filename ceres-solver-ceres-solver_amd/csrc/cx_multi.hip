@@ -22,6 +22,7 @@
 #include <string>
 #include <thread>
 
+#include "cx_shard_group.h"
 #include "cx_solver_internal.h"
 
 namespace {
@@ -41,137 +42,46 @@ __global__ void k_sum_shards(ShardPtrs ptrs, int n, int64_t len) {
 
 }  // namespace
 
-struct cx_shard_group {
-  int n = 0;
+// cx_context::group points at this: the plain threading (cx_shard_group.h, sanitizer-tested on the CPU) plus what the
+// device side of a front needs
+struct cx_front_group : cx_shard_group {
   std::vector<int> devices;
-  std::vector<std::thread> threads;
-  // ---- job dispatch: run(fn) executes fn(shard) on every worker thread and waits for all of them
-  std::mutex run_mutex;  // one front call at a time
-  std::mutex m;
-  std::condition_variable cv_start, cv_done;
-  uint64_t gen = 0;
-  int pending = 0;
-  bool stop = false;
-  const std::function<int(int)>* job = nullptr;
-  std::vector<int> rc;
-  std::vector<std::string> err;
-  // ---- in-process exchange step (logical shards sharing one device)
-  bool inproc = false;
-  std::mutex bm;
-  std::condition_variable bcv;
-  int arrived = 0;
-  uint64_t bgen = 0;
-  bool aborted = false;
-  double* ptrs[kMaxShards] = {};
-  int64_t lens[kMaxShards] = {};
+  bool inproc = false;           // logical shards on one device: the exchange step is the in-process sum below
   hipStream_t stream0 = nullptr;
-  struct CbUser { cx_shard_group* g; int rank; } users[kMaxShards];
-
-  int barrier() {
-    std::unique_lock<std::mutex> lk(bm);
-    if (aborted) return -1;
-    const uint64_t g0 = bgen;
-    if (++arrived == n) {
-      arrived = 0;
-      ++bgen;
-      bcv.notify_all();
-      return 0;
-    }
-    bcv.wait(lk, [&] { return bgen != g0 || aborted; });
-    return (bgen != g0) ? 0 : -1;
-  }
-  void abort_exchange() {
-    std::lock_guard<std::mutex> lk(bm);
-    aborted = true;
-    bcv.notify_all();
-  }
-
-  void worker(int i) {
-    (void)hipSetDevice(devices[size_t(i)]);
-    uint64_t seen = 0;
-    for (;;) {
-      const std::function<int(int)>* fn = nullptr;
-      {
-        std::unique_lock<std::mutex> lk(m);
-        cv_start.wait(lk, [&] { return stop || gen != seen; });
-        if (stop) return;
-        seen = gen;
-        fn = job;
-      }
-      int r = (*fn)(i);
-      if (r != CX_OK) {
-        err[size_t(i)] = cx_last_error();
-        // a shard that fails will not reach the next exchange step: release the others instead of letting them wait
-        // (in-process transport only; with RCCL a rank-local failure before a collective cannot be undone from here)
-        if (inproc) abort_exchange();
-      }
-      {
-        std::lock_guard<std::mutex> lk(m);
-        rc[size_t(i)] = r;
-        if (--pending == 0) cv_done.notify_one();
-      }
-    }
-  }
-
-  int run(const std::function<int(int)>& fn) {
-    std::lock_guard<std::mutex> serial(run_mutex);
-    {
-      std::unique_lock<std::mutex> lk(m);
-      job = &fn;
-      pending = n;
-      ++gen;
-      cv_start.notify_all();
-      cv_done.wait(lk, [&] { return pending == 0; });
-    }
-    {
-      std::lock_guard<std::mutex> lk(bm);
-      aborted = false;
-      arrived = 0;
-    }
-    // report the failure that started it, not the CX_ERR_COMM of the shards that were released from the barrier
-    int first = CX_OK, first_i = -1;
-    for (int i = 0; i < n; ++i) {
-      if (rc[size_t(i)] == CX_OK) continue;
-      if (first == CX_OK || (first == CX_ERR_COMM && rc[size_t(i)] != CX_ERR_COMM)) { first = rc[size_t(i)]; first_i = i; }
-    }
-    if (first != CX_OK) cx_set_error("shard %d: %s", first_i, err[size_t(first_i)].c_str());
-    return first;
-  }
-
-  ~cx_shard_group() {
-    {
-      std::lock_guard<std::mutex> lk(m);
-      stop = true;
-      cv_start.notify_all();
-    }
-    for (auto& t : threads)
-      if (t.joinable()) t.join();
-  }
+  struct CbUser { cx_front_group* g; int rank; } users[kMaxShards];
+  cx_context* front = nullptr;
+  bool broken = false;           // RCCL transport: a shard failed and the communicators were aborted
 };
+static_assert(cx_shard_group::kOk == CX_OK && cx_shard_group::kCommError == CX_ERR_COMM, "codes of cx_shard_group.h");
+
+static cx_front_group* Group(const cx_context* ctx) { return static_cast<cx_front_group*>(ctx->group); }
+
+// run fn(shard) on every worker of the front's group; the first failing shard's error becomes this thread's last error
+static int RunShards(const cx_context* ctx, const std::function<int(int)>& fn) {
+  cx_front_group* g = Group(ctx);
+  if (g->broken) {
+    cx_set_error("this multi-shard context lost a shard in an earlier call and its communicators were aborted: create a new context");
+    return CX_ERR_COMM;
+  }
+  int failed = -1;
+  std::string message;
+  const int rc = g->run(fn, &failed, &message);
+  if (rc != CX_OK) cx_set_error("shard %d: %s", failed, message.c_str());
+  return rc;
+}
 
 namespace {
 
 // the exchange step of a logical shard (cx_context::allreduce_cb): called with the shard's stream drained
 int InprocAllReduce(double* p, int64_t len, void* user) {
-  auto* u = static_cast<cx_shard_group::CbUser*>(user);
-  cx_shard_group* g = u->g;
-  g->ptrs[u->rank] = p;
-  g->lens[u->rank] = len;
-  if (g->barrier() != 0) return -1;
-  int ok = 0;
-  if (u->rank == 0) {
-    for (int r = 1; r < g->n; ++r)
-      if (g->lens[r] != len) ok = -1;  // the shards disagree about the collective: a bug, not a transient
-    if (ok == 0) {
-      ShardPtrs ptrs;
-      for (int r = 0; r < g->n; ++r) ptrs.p[r] = g->ptrs[r];
-      hipLaunchKernelGGL(k_sum_shards, dim3(unsigned((len + 255) / 256)), dim3(256), 0, g->stream0, ptrs, g->n, len);
-      if (hipGetLastError() != hipSuccess || hipStreamSynchronize(g->stream0) != hipSuccess) ok = -1;
-    }
-    if (ok != 0) g->abort_exchange();
-  }
-  if (g->barrier() != 0) return -1;
-  return ok;
+  auto* u = static_cast<cx_front_group::CbUser*>(user);
+  cx_front_group* g = u->g;
+  return g->exchange(u->rank, p, len, [g](double* const* bufs, int n, int64_t count) -> int {
+    ShardPtrs ptrs;
+    for (int r = 0; r < n; ++r) ptrs.p[r] = bufs[r];
+    hipLaunchKernelGGL(k_sum_shards, dim3(unsigned((count + 255) / 256)), dim3(256), 0, g->stream0, ptrs, n, count);
+    return (hipGetLastError() != hipSuccess || hipStreamSynchronize(g->stream0) != hipSuccess) ? -1 : 0;
+  });
 }
 
 std::mutex g_front_evaluators_mutex;
@@ -226,15 +136,26 @@ extern "C" int cx_context_create_multi(int num_shards, const int* device_ids, cx
   }
   cx_context* front = nullptr;
   CX_TRY(cx_context_create(device_ids[0], &front));
-  auto* g = new cx_shard_group;
-  g->n = num_shards;
+  auto* g = new cx_front_group;
   g->devices.assign(device_ids, device_ids + num_shards);
-  g->rc.assign(size_t(num_shards), CX_OK);
-  g->err.resize(size_t(num_shards));
   g->inproc = num_shards > 1 && same;
+  g->front = front;
+  g->on_thread_start = [g](int i) { (void)hipSetDevice(g->devices[size_t(i)]); };
+  g->last_error = [] { return cx_last_error(); };
+  // RCCL between the shards: a shard that fails leaves the others inside (or on their way into) a collective that can
+  // never complete.  The failing worker aborts every shard's communicator -- ncclCommAbort is made for exactly this: it
+  // ends the collectives the other shards' streams are stuck in -- so their jobs come back with an error instead of
+  // never; the front is unusable from then on (RunShards says so).  In-process transport: abort_exchange() has already
+  // released the rendezvous and the next call starts clean.
+  g->on_failure = [g](int) {
+    if (g->inproc || g->n <= 1) return;
+    g->broken = true;
+    for (cx_context* shard : g->front->shards)
+      if (shard) cx_comm_abort(shard);
+  };
   front->group = g;
   front->shards.assign(size_t(num_shards), nullptr);
-  for (int i = 0; i < num_shards; ++i) g->threads.emplace_back([g, i] { g->worker(i); });
+  g->start(num_shards);
   int rc = g->run([&](int i) { return cx_context_create(device_ids[i], &front->shards[size_t(i)]); });
   if (rc == CX_OK && num_shards > 1) {
     if (g->inproc) {
@@ -285,11 +206,11 @@ extern "C" int cx_matrix_shard_layout(const cx_matrix* A, int32_t* e_block_bound
 // called by cx_context_destroy for a front, before the front's own stream goes
 void cxm_context_destroy_shards(cx_context* front) {
   if (front->group) {
-    front->group->run([&](int i) {
+    Group(front)->run([&](int i) {
       cx_context_destroy(front->shards[size_t(i)]);
       return CX_OK;
     });
-    delete front->group;
+    delete Group(front);
     front->group = nullptr;
   }
   front->shards.clear();
@@ -351,7 +272,7 @@ int cxm_matrix_create(cx_context* ctx, const cx_block_structure* bs, int32_t nel
       return CX_ERR_INVALID_ARGUMENT;
     }
   std::vector<int64_t> part_nnz(size_t(n), 0);
-  rc = ctx->group->run([&](int i) -> int {
+  rc = RunShards(ctx, [&](int i) -> int {
     const int32_t r0 = A->part_rowblk0[size_t(i)], r1 = A->part_rowblk0[size_t(i) + 1];
     const int32_t e0 = A->part_e0[size_t(i)], e1 = A->part_e0[size_t(i) + 1], ne = e1 - e0;
     const int32_t c0 = bs->row_cell_begin[r0], c1 = bs->row_cell_begin[r1];
@@ -435,7 +356,7 @@ int cxm_matrix_create(cx_context* ctx, const cx_block_structure* bs, int32_t nel
 void cxm_matrix_destroy(cx_matrix* A) {
   if (!A) return;
   if (A->parts_owned && A->ctx->group)
-    A->ctx->group->run([&](int i) {
+    Group(A->ctx)->run([&](int i) {
       if (A->parts[size_t(i)]) cx_matrix_destroy(A->parts[size_t(i)]);
       return CX_OK;
     });
@@ -446,7 +367,7 @@ void cxm_matrix_destroy(cx_matrix* A) {
 int cxm_matrix_set_values(cx_matrix* A, const double* src, int32_t memspace) {
   CX_TRY(RequireHost(memspace, "cx_matrix_set_values"));
   (void)cx_pin_range(src, size_t(A->nnz) * sizeof(double));
-  return A->ctx->group->run([&](int i) -> int {
+  return RunShards(A->ctx, [&](int i) -> int {
     cx_matrix* p = A->parts[size_t(i)];
     for (const auto& run : A->part_runs[size_t(i)])
       CX_TRY(cx_copy_h2d(p->ctx, p->d_values.p + run.local, src + run.global, size_t(run.len) * sizeof(double)));
@@ -456,7 +377,7 @@ int cxm_matrix_set_values(cx_matrix* A, const double* src, int32_t memspace) {
 }
 
 int cxm_matrix_get_values(const cx_matrix* A, double* dst) {
-  return A->ctx->group->run([&](int i) -> int {
+  return RunShards(A->ctx, [&](int i) -> int {
     const cx_matrix* p = A->parts[size_t(i)];
     for (const auto& run : A->part_runs[size_t(i)])
       CX_TRY(cx_copy_d2h(p->ctx, dst + run.global, p->d_values.p + run.local, size_t(run.len) * sizeof(double)));
@@ -466,7 +387,7 @@ int cxm_matrix_get_values(const cx_matrix* A, double* dst) {
 }
 
 int cxm_matrix_set_zero(cx_matrix* A) {
-  return A->ctx->group->run([&](int i) { return cx_matrix_set_zero(A->parts[size_t(i)]); });
+  return RunShards(A->ctx, [&](int i) { return cx_matrix_set_zero(A->parts[size_t(i)]); });
 }
 
 int cxm_matrix_values_changed(cx_matrix* A) {
@@ -480,7 +401,7 @@ int cxm_matrix_op(cx_matrix* A, int op, const double* x, double* y, int32_t mems
   // the caller's whole arrays are registered before the shards copy their slices of them
   if (x) (void)cx_pin_range(x, size_t(op == 1 ? A->num_rows : A->num_cols) * sizeof(double));
   if (y) (void)cx_pin_range(y, size_t(op == 0 || op == 4 ? A->num_rows : A->num_cols) * sizeof(double));
-  return A->ctx->group->run([&](int i) -> int {
+  return RunShards(A->ctx, [&](int i) -> int {
     cx_matrix* p = A->parts[size_t(i)];
     cx_context* c = p->ctx;
     switch (op) {
@@ -522,7 +443,7 @@ int cxm_matrix_op(cx_matrix* A, int op, const double* x, double* y, int32_t mems
 // ------------------------------------------------------------------ solver
 static void DestroySolverParts(cx_solver* S) {
   if (S->parts.empty()) return;
-  S->ctx->group->run([&](int i) {
+  Group(S->ctx)->run([&](int i) {
     if (S->parts[size_t(i)]) cx_solver_destroy(S->parts[size_t(i)]);
     return CX_OK;
   });
@@ -543,7 +464,7 @@ static int EnsureSolverParts(cx_solver* S, const cx_matrix* A) {
   DestroySolverParts(S);
   const int n = int(A->parts.size());
   S->parts.assign(size_t(n), nullptr);
-  int rc = S->ctx->group->run([&](int i) {
+  int rc = RunShards(S->ctx, [&](int i) {
     cx_solver_options o = S->opt;
     o.num_eliminate_blocks = A->parts[size_t(i)]->nelim;  // the shard's own e-blocks
     return cx_solver_create(S->ctx->shards[size_t(i)], &o, &S->parts[size_t(i)]);
@@ -593,7 +514,7 @@ int cxm_solver_solve(cx_solver* S, cx_matrix* A, const double* b, const cx_per_s
   if (!residual_owner) (void)cx_pin_range(b, size_t(A->num_rows) * sizeof(double));
   if (ps->D) (void)cx_pin_range(ps->D, size_t(A->num_cols) * sizeof(double));
   (void)cx_pin_range(x, size_t(A->num_cols) * sizeof(double));
-  rc = S->ctx->group->run([&](int i) -> int {
+  rc = RunShards(S->ctx, [&](int i) -> int {
     cx_matrix* p = A->parts[size_t(i)];
     cx_per_solve_options psi = *ps;
     psi.memspace = CX_HOST_SLICES;
@@ -682,7 +603,7 @@ int cxm_evaluator_create_bal(cx_context* ctx, int32_t C, int32_t P, int64_t O, c
   e->P = P;
   e->O = O;
   e->parts.assign(size_t(n), nullptr);
-  int rc = ctx->group->run([&](int i) {
+  int rc = RunShards(ctx, [&](int i) {
     return cx_evaluator_create_bal(ctx->shards[size_t(i)], C, bounds[size_t(i) + 1] - bounds[size_t(i)], int64_t(cams[size_t(i)].size()),
                                    cams[size_t(i)].data(), pts[size_t(i)].data(), xy[size_t(i)].data(), &e->parts[size_t(i)]);
   });
@@ -740,7 +661,7 @@ void cxm_evaluator_destroy(cx_evaluator* e) {
     g_front_evaluators.erase(e);
   }
   if (e->J) cxm_matrix_destroy(e->J);  // the front only: the parts belong to the shards' evaluators
-  e->ctx->group->run([&](int i) {
+  Group(e->ctx)->run([&](int i) {
     if (e->parts[size_t(i)]) cx_evaluator_destroy(e->parts[size_t(i)]);
     return CX_OK;
   });
@@ -764,7 +685,7 @@ int cxm_evaluator_set_column_scale(cx_evaluator* e, const double* scale, int32_t
   CX_TRY(RequireHost(memspace, "cx_evaluator_set_column_scale"));
   cx_matrix* A = e->J;
   (void)cx_pin_range(scale, size_t(A->num_cols) * sizeof(double));
-  return e->ctx->group->run([&](int i) -> int {
+  return RunShards(e->ctx, [&](int i) -> int {
     cx_host_slices ss = ColSlices(A, i, scale, A->num_cols_e, A->num_cols_f);
     return cx_evaluator_set_column_scale(e->parts[size_t(i)], ss.as_arg(), CX_HOST_SLICES);
   });
@@ -782,7 +703,7 @@ int cxm_evaluator_evaluate(cx_evaluator* e, const double* state, double* cost, d
   (void)cx_pin_range(state, size_t(ne + ncam) * sizeof(double));
   if (residuals) (void)cx_pin_range(residuals, size_t(A->num_rows) * sizeof(double));
   if (gradient) (void)cx_pin_range(gradient, size_t(A->num_cols) * sizeof(double));
-  CX_TRY(e->ctx->group->run([&](int i) -> int {
+  CX_TRY(RunShards(e->ctx, [&](int i) -> int {
     cx_host_slices ss = ColSlices(A, i, state, ne, ncam), rs, gs;
     if (residuals) rs = RowSlices(A, i, residuals);
     if (gradient) gs = ColSlices(A, i, gradient, ne, nf, true);
@@ -801,7 +722,7 @@ int cxm_evaluator_plus(cx_evaluator* e, const double* x, const double* delta, do
   const int n = int(e->parts.size());
   const int64_t ne = A->num_cols_e, nf = A->num_cols_f, ncam = CameraStateSize(e) * e->C;
   (void)n;
-  return e->ctx->group->run([&](int i) -> int {
+  return RunShards(e->ctx, [&](int i) -> int {
     cx_host_slices xs = ColSlices(A, i, x, ne, ncam), ds = ColSlices(A, i, delta, ne, nf), os = ColSlices(A, i, x_plus_delta, ne, ncam, true);
     return cx_evaluator_plus(e->parts[size_t(i)], xs.as_arg(), ds.as_arg(), os.as_arg(), CX_HOST_SLICES);
   });
@@ -833,7 +754,7 @@ int cxm_minimize(cx_evaluator* e, cx_solver* s, const cx_minimizer_options* opti
   const int64_t ne = A->num_cols_e, ncam = CameraStateSize(e) * e->C;
   std::vector<cx_minimizer_summary> sums(static_cast<size_t>(n));
   std::vector<std::vector<cx_iteration_summary>> its(static_cast<size_t>(n));
-  CX_TRY(e->ctx->group->run([&](int i) -> int {
+  CX_TRY(RunShards(e->ctx, [&](int i) -> int {
     cx_host_slices ss = ColSlices(A, i, state, ne, ncam, true);  // in and out: every shard reads the cameras, shard 0 returns them
     its[size_t(i)].resize(size_t(i == 0 ? capacity : 0));
     return cx_minimize(e->parts[size_t(i)], s->parts[size_t(i)], options, ss.as_arg(), CX_HOST_SLICES, &sums[size_t(i)],

@@ -426,8 +426,8 @@ struct CgDriver {
   }
 
   int read_state(CgState* h) {
-    CX_HIP(hipMemcpyAsync(h, S->state.p, sizeof(CgState), hipMemcpyDeviceToHost, st));
-    CX_HIP(hipStreamSynchronize(st));
+    CX_TRY(cx_read_back(S->ctx, h, S->state.p, sizeof(CgState), st));
+    CX_TRY(cx_stream_sync(S->ctx, st));
     return CX_OK;
   }
 
@@ -492,9 +492,13 @@ struct CgDriver {
           cx_set_error("CG iteration %d was never published (stream idle): %s", iter, hipGetErrorString(hipGetLastError()));
           return CX_ERR_HIP;
         }
-        if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 120.0) {
-          cx_set_error("timed out waiting for CG iteration %d", iter);
-          return CX_ERR_HIP;
+        if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > cx_comm_timeout(S->ctx)) {
+          // on a sharded context this is a peer that never reached the iteration's exchange step: end the collective
+          // this rank's stream is stuck in (cx_comm_abort) instead of leaving it there
+          const bool sharded = S->ctx->comm != nullptr && S->ctx->nranks > 1;
+          if (sharded) cx_comm_abort(S->ctx);
+          cx_set_error("timed out waiting for CG iteration %d%s", iter, sharded ? " (a peer rank never reached the exchange step; communicator aborted)" : "");
+          return sharded ? CX_ERR_COMM : CX_ERR_HIP;
         }
       }
     }
@@ -558,9 +562,9 @@ struct CgDriver {
       CX_TRY(dot2(rhs, rhs, nullptr, nullptr, FIN_STORE, 0, ds));
       int precond_flag = 0, precond_flag2 = 0;
       if (preconditioner_failed)
-        CX_HIP(hipMemcpyAsync(&precond_flag, preconditioner_failed, sizeof(int), hipMemcpyDeviceToHost, st));
+        CX_TRY(cx_read_back(S->ctx, &precond_flag, preconditioner_failed, sizeof(int), st));
       if (preconditioner_failed2)
-        CX_HIP(hipMemcpyAsync(&precond_flag2, preconditioner_failed2, sizeof(int), hipMemcpyDeviceToHost, st));
+        CX_TRY(cx_read_back(S->ctx, &precond_flag2, preconditioner_failed2, sizeof(int), st));
       CX_TRY(read_state(&h));  // this path waits for the device anyway
       if (precond_flag || precond_flag2) {
         summary->termination_type = CX_FAILURE;
@@ -611,7 +615,7 @@ struct CgDriver {
       if (h.flag != CG_RUNNING) break;
       CX_TRY(enqueue_tail(iter, lhs, rhs, x, p, r, z, tmp, ds));
     }
-    CX_HIP(hipStreamSynchronize(st));
+    CX_TRY(cx_stream_sync(S->ctx, st));
     summary->num_iterations = h.iter;
     switch (h.flag) {
       case CG_CONVERGED_Q:
@@ -780,8 +784,8 @@ struct SpseOp : LinOp {
     hipLaunchKernelGGL(k_dot2_final, dim3(1), dim3(256), 0, st, (const double*)S->partial.p, nb, int(FIN_STORE), 0, 0,
                        S->spse_state.p, (CgState*)nullptr, 0);
     CgState h;
-    CX_HIP(hipMemcpyAsync(&h, S->spse_state.p, sizeof(h), hipMemcpyDeviceToHost, st));
-    CX_HIP(hipStreamSynchronize(st));
+    CX_TRY(cx_read_back(S->ctx, &h, S->spse_state.p, sizeof(h), st));
+    CX_TRY(cx_stream_sync(S->ctx, st));
     *out = std::sqrt(h.s0);
     return CX_OK;
   }
@@ -925,8 +929,8 @@ struct Stopwatch {
 
 int CheckFlag(cx_solver* S, const char* what, cx_summary* summary, bool* failed) {
   int h = 0;
-  CX_HIP(hipMemcpyAsync(&h, S->flag.p, sizeof(int), hipMemcpyDeviceToHost, S->ctx->stream));
-  CX_HIP(hipStreamSynchronize(S->ctx->stream));
+  CX_TRY(cx_read_back(S->ctx, &h, S->flag.p, sizeof(int), S->ctx->stream));
+  CX_TRY(cx_stream_sync(S->ctx, S->ctx->stream));
   *failed = (h != 0);
   if (h != 0) {
     summary->termination_type = CX_FAILURE;
@@ -1024,8 +1028,8 @@ int SolveIterativeSchur239(cx_solver* S, cx_matrix* A, const double* b, const do
       // "If it works, great, otherwise we scale all the cells in the preconditioner corresponding to the edges
       // in the degree-2 forest and that guarantees positive definiteness" (:331-360) -- the one host check
       int failed = 0;
-      CX_HIP(hipMemcpyAsync(&failed, vis_flag, sizeof(int), hipMemcpyDeviceToHost, st));
-      CX_HIP(hipStreamSynchronize(st));
+      CX_TRY(cx_read_back(S->ctx, &failed, vis_flag, sizeof(int), st));
+      CX_TRY(cx_stream_sync(S->ctx, st));
       if (failed) {
         CX_HIP(hipMemsetAsync(vis_flag, 0, sizeof(int), st));
         CX_TRY(cxv_factor(A, vis_plan, D, true, vis_flag));
@@ -1488,9 +1492,11 @@ int cx_solver_solve(cx_solver* S, cx_matrix* A, const double* b, const cx_per_so
   S->ktimer.reset();
   cx_allreduce_reset(ctx);
   HostOrDevice hb(ctx), hD(ctx), hx(ctx);
-  CX_TRY(hb.in(b, size_t(A->num_rows), ps->b_on_device ? CX_DEVICE : ps->memspace));
-  CX_TRY(hD.in(ps->D, size_t(A->num_cols), ps->memspace));
-  CX_TRY(hx.inout(x, size_t(A->num_cols), ps->memspace, false));
+  int staged = hb.in(b, size_t(A->num_rows), ps->b_on_device ? CX_DEVICE : ps->memspace);
+  if (staged == CX_OK) staged = hD.in(ps->D, size_t(A->num_cols), ps->memspace);
+  if (staged == CX_OK) staged = hx.inout(x, size_t(A->num_cols), ps->memspace, false);
+  // sharded: a rank that could not stage its inputs says so before anybody enters the solve's first collective
+  CX_TRY(cx_comm_agree(ctx, staged));
   CX_HIP(hipEventRecord(ctx->ev[4], ctx->stream));
   // "std::fill(x, x + A->num_cols(), 0.0)" (schur_complement_solver.cc:137): whatever a failed solve leaves
   // unwritten is zero, in the caller's host buffer as well (the staging copy is not initialised otherwise)
@@ -1527,7 +1533,7 @@ int cx_solver_solve(cx_solver* S, cx_matrix* A, const double* b, const cx_per_so
     return rc;
   }
   CX_HIP(hipEventRecord(ctx->ev[5], ctx->stream));
-  CX_HIP(hipEventSynchronize(ctx->ev[5]));
+  CX_TRY(cx_event_sync(ctx, ctx->ev[5]));
   float ms = 0.f;
   CX_HIP(hipEventElapsedTime(&ms, ctx->ev[4], ctx->ev[5]));
   S->timing.total_ms = ms;
@@ -1580,7 +1586,7 @@ int cx_schur_eliminate_dense(cx_context* ctx, cx_matrix* A, const double* b, con
     cx_solver tmp;
     tmp.ctx = ctx;
     CX_TRY(cxg_eliminate_dense(&tmp, A, hb.dptr, hD.dptr, hl.dptr, hb.dptr ? hr.dptr : nullptr));
-    CX_HIP(hipStreamSynchronize(ctx->stream));
+    CX_TRY(cx_stream_sync(ctx, ctx->stream));
   }
   CX_TRY(hl.out());
   return hr.out();
@@ -1599,7 +1605,7 @@ int cx_schur_back_substitute(cx_context* ctx, cx_matrix* A, const double* b, con
     cx_solver tmp;
     tmp.ctx = ctx;
     CX_TRY(cxg_back_substitute(&tmp, A, hb.dptr, hD.dptr, hz.dptr, hx.dptr));
-    CX_HIP(hipStreamSynchronize(ctx->stream));
+    CX_TRY(cx_stream_sync(ctx, ctx->stream));
     return hx.out();
   }
   DevBuf<double> ete;
@@ -1630,7 +1636,7 @@ int cx_implicit_schur_multiply(cx_context* ctx, cx_matrix* A, const double* D, c
     cx_solver tmp;
     tmp.ctx = ctx;
     CX_TRY(cxg_implicit_schur_multiply(&tmp, A, hD.dptr, hb.dptr, hx.dptr, hy.dptr, hb.dptr ? hr.dptr : nullptr));
-    CX_HIP(hipStreamSynchronize(ctx->stream));
+    CX_TRY(cx_stream_sync(ctx, ctx->stream));
     if (hx.dptr && hy.dptr) CX_TRY(hy.out());
     if (hb.dptr) CX_TRY(hr.out());
     return CX_OK;
@@ -1659,7 +1665,7 @@ int cx_implicit_schur_multiply(cx_context* ctx, cx_matrix* A, const double* D, c
     CX_TRY(cxk_ft_multiply(A, rows.p, hr.dptr, false));
     CX_TRY(hr.out());
   }
-  CX_HIP(hipStreamSynchronize(ctx->stream));
+  CX_TRY(cx_stream_sync(ctx, ctx->stream));
   return CX_OK;
 }
 
@@ -1675,8 +1681,8 @@ int cx_dense_cholesky_solve(cx_context* ctx, int32_t n, double* lhs, const doubl
   CX_TRY(hx.inout(x, size_t(n), memspace, false));
   if (n > 0) CX_TRY(cxd_cholesky_solve(ctx, n, hl.dptr, hr.dptr, hx.dptr, flag.p));
   int h = 0;
-  CX_HIP(hipMemcpyAsync(&h, flag.p, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
-  CX_HIP(hipStreamSynchronize(ctx->stream));
+  CX_TRY(cx_read_back(ctx, &h, flag.p, sizeof(int), ctx->stream));
+  CX_TRY(cx_stream_sync(ctx, ctx->stream));
   if (summary) {
     std::memset(summary, 0, sizeof(*summary));
     summary->num_iterations = 1;

@@ -1926,8 +1926,8 @@ int cxsp_build_plan_sharded(cx_matrix* A) {
   CX_HIP(hipMemcpyAsync(agree.p, &failed_here, sizeof(double), hipMemcpyHostToDevice, st));
   CX_TRY(cx_allreduce_device(ctx, agree.p, 1));
   double failed_anywhere = 0.0;
-  CX_HIP(hipMemcpyAsync(&failed_anywhere, agree.p, sizeof(double), hipMemcpyDeviceToHost, st));
-  CX_HIP(hipStreamSynchronize(st));
+  CX_TRY(cx_read_back(ctx, &failed_anywhere, agree.p, sizeof(double), st));
+  CX_TRY(cx_stream_sync(ctx, st));
   if (local_rc != CX_OK) {
     cx_set_error("%s", local_error.c_str());
     return local_rc;
@@ -1947,8 +1947,8 @@ int cxsp_build_plan_sharded(cx_matrix* A) {
   CX_HIP(hipGetLastError());
   CX_TRY(cx_allreduce_device(ctx, present.p, int64_t(C) * C + 1));
   std::vector<double> h(size_t(C) * C + 1);
-  CX_HIP(hipMemcpyAsync(h.data(), present.p, h.size() * sizeof(double), hipMemcpyDeviceToHost, st));
-  CX_HIP(hipStreamSynchronize(st));
+  CX_TRY(cx_read_back(ctx, h.data(), present.p, h.size() * sizeof(double), st));
+  CX_TRY(cx_stream_sync(ctx, st));
   if (h[size_t(C) * C] > 0.0) { P->state = 2; return CX_OK; }
   std::vector<int32_t> u1, u2, local_to_union(size_t(A->num_cells), 0);
   {

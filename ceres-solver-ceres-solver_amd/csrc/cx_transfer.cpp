@@ -371,9 +371,11 @@ int HostOrDevice::out_async(hipStream_t st) {
 
 int HostOrDevice::out() {
   if (!user || !is_host) return CX_OK;
+  // (a copy into pageable memory blocks inside the runtime until the stream has drained: on a sharded context the wait
+  // that cannot hang on a lost rank comes first)
+  if (ctx->comm && ctx->nranks > 1) CX_TRY(cx_stream_sync(ctx, ctx->stream));
   CX_TRY(out_async(ctx->stream));
-  CX_HIP(hipStreamSynchronize(ctx->stream));
-  return CX_OK;
+  return cx_stream_sync(ctx, ctx->stream);
 }
 
 // ------------------------------------------------------------------ C ABI

@@ -112,8 +112,8 @@ int SumOverRanks(cx_context* ctx, std::vector<double>* host) {
   DevBuf<double> tmp;
   CX_TRY(tmp.upload(*host, ctx->stream));
   CX_TRY(cx_allreduce_device(ctx, tmp.p, int64_t(host->size())));
-  CX_HIP(hipMemcpyAsync(host->data(), tmp.p, host->size() * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-  CX_HIP(hipStreamSynchronize(ctx->stream));
+  CX_TRY(cx_read_back(ctx, host->data(), tmp.p, host->size() * sizeof(double), ctx->stream));
+  CX_TRY(cx_stream_sync(ctx, ctx->stream));
   return CX_OK;
 }
 

@@ -213,6 +213,25 @@ int cx_context_rank(const cx_context* ctx);
 int cx_context_num_ranks(const cx_context* ctx);
 /* sum-all-reduce of n doubles in place on the context's stream (exposed for tests) */
 int cx_allreduce_sum(cx_context* ctx, double* device_ptr, int64_t n);
+/* A sharded call cannot hang on a lost rank.  (1) Where a sharded phase starts (cx_solver_solve, cx_evaluator_evaluate
+ * after their inputs are staged; the structure exchange of a sharded SPARSE_SCHUR) every rank first tells the others
+ * whether it is still healthy -- a rank that failed locally still takes part, flag set, and ALL ranks return an error
+ * together.  (2) On an RCCL communicator every wait polls with a deadline; when no progress is seen for `seconds`
+ * (default: CX_COMM_TIMEOUT_S in the environment, else 120) the communicator is aborted (ncclCommAbort ends the
+ * collective the stream is stuck in), the context is marked broken and the call returns CX_ERR_COMM -- FATAL_ERROR in
+ * the summary, which makes TrustRegionMinimizer stop (trust_region_minimizer.cc:404-411).  Nothing is retried.  (3) In a
+ * multi-shard front the worker of a failing shard releases the others at once (in-process transport) or aborts every
+ * shard's communicator (RCCL); an RCCL front is unusable afterwards and says so. */
+int cx_context_set_comm_timeout(cx_context* ctx, double seconds);
+/* Test hooks.  cx_debug_inject_failure: the context (on a multi-shard front: its shard `shard`) fails locally right
+ * before the nth collective it enters from now on (0 = the next one; -1 clears) -- how the tests make one shard drop
+ * out in the middle of a solve.  cx_debug_stall_stream: a host callback that sleeps that long is enqueued on the
+ * context stream (a stream that makes no progress, for the deadline test). */
+int cx_debug_inject_failure(cx_context* ctx, int32_t shard, int64_t nth_collective);
+int cx_debug_stall_stream(cx_context* ctx, int32_t milliseconds);
+/* ... and the context reports (and waits as if it had) that many ranks: on a one-GPU box RCCL forms one-rank
+ * communicators only, this makes the deadline path of a several-rank communicator reachable there. */
+int cx_debug_force_rank_count(cx_context* ctx, int32_t nranks);
 
 /* Several GPUs behind ONE set of handles in ONE process -- how a Solver::Solve caller (one process, one ContextImpl,
  * context_impl.h:74-83; LinearSolver::Solve and Evaluator::Evaluate called with whole vectors, linear_solver.h:363-390,

@@ -24,4 +24,20 @@ def test_host_planners_are_clean_under_asan_ubsan_and_tsan():
         assert "ALL OK" in log and log.rstrip().endswith("exit 0"), log[-3000:]
         for bad in ("ERROR: AddressSanitizer", "ERROR: LeakSanitizer", "runtime error:", "WARNING: ThreadSanitizer", "FAILED"):
             assert bad not in log, log[-3000:]
-        shutil.copy(os.path.join(SAN, "out", name + ".log"), os.path.join(ROOT, "profiles", "r03_sanitizer_%s.log" % name))
+        shutil.copy(os.path.join(SAN, "out", name + ".log"), os.path.join(ROOT, "profiles", "r04_sanitizer_%s.log" % name))
+
+
+@pytest.mark.skipif(not os.path.exists("/opt/rocm/lib/llvm/bin/clang++"), reason="needs the ROCm clang with its sanitizer runtimes")
+def test_shard_group_threading_is_clean_under_asan_ubsan_and_tsan():
+    """the multi-shard front's threading (csrc/cx_shard_group.h -- job dispatch, the rendezvous of the
+    in-process exchange step, the abort path) driven with dummy jobs: clean runs, one shard failing before / between /
+    after the exchange steps, a failing combine step, a length mismatch, a late failure while the others wait, runs after
+    failed runs, destruction while idle.  Every scenario must return, naming the shard that failed first."""
+    out = subprocess.run(["make", "-s", "-C", SAN, "check-shard-group"], capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
+    for name in ("asan", "tsan"):
+        log = open(os.path.join(SAN, "out", "shard_group_%s.log" % name)).read()
+        assert "ALL OK" in log and log.rstrip().endswith("exit 0"), log[-3000:]
+        for bad in ("ERROR: AddressSanitizer", "ERROR: LeakSanitizer", "runtime error:", "WARNING: ThreadSanitizer", "FAILED"):
+            assert bad not in log, log[-3000:]
+        shutil.copy(os.path.join(SAN, "out", "shard_group_%s.log" % name), os.path.join(ROOT, "profiles", "r04_sanitizer_shard_group_%s.log" % name))
