@@ -197,6 +197,8 @@ struct cx_matrix {
   DevBuf<double> d_t_partial;                    // [segments][16] partial sums of the columns that have several segments
   DevBuf<double> d_t_partial_blocks;             // [segments][256] the same for the block diagonal
   int32_t num_t_segments = 0;
+  int32_t t_max_col_size = 0;                    // widest column block (wider than 64: A'x takes the scatter kernel)
+  int32_t t_stride = 16;                         // doubles per segment in d_t_partial
   bool transpose_ready = false;
 
   // values

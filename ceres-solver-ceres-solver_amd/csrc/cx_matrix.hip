@@ -365,19 +365,26 @@ __global__ void kg_left(const cx_block* __restrict__ rows, const cx_block* __res
 // power of two), lane j of group g sums column j over the entries g, g + groups, ... of the segment, the group sums are
 // added by a fixed butterfly.  A column with one segment is finished there; the others leave a partial sum per segment and
 // kg_left_finish adds them in segment order.  No atomics, the same bits every time.
+// Block sizes: a column block of up to 64 scalars fits the lane groups (cs_pad <= 64: at least one group); the per-segment
+// partial sums are `stride` apart, stride = the largest padded column block of the matrix (16 for everything the reference
+// instantiates).  Matrices with a wider column block take the scatter kernel kg_left (cxk_generic_left_multiply).  A
+// transposed entry packs its row block's size into the low 30 bits and the e-cell flag above them.
 constexpr int kTransposeSegment = 128;
+constexpr int kMetaEBit = 30;
+constexpr int kMetaSizeMask = (1 << kMetaEBit) - 1;
+constexpr int kGatherMaxColSize = 64;
 __global__ __launch_bounds__(256) void kg_left_gather(const cx_block* __restrict__ cols, const int32_t* __restrict__ seg_begin,
                                                       const int32_t* __restrict__ seg_col, const int32_t* __restrict__ col_seg,
                                                       const int32_t* __restrict__ t_pos, const int32_t* __restrict__ t_rp,
                                                       const int32_t* __restrict__ t_meta, const double* __restrict__ values,
                                                       const double* __restrict__ x, double* __restrict__ y, double* __restrict__ partial,
-                                                      int num_segments, int first_col, int end_col, int sel, int col_off) {
+                                                      int num_segments, int first_col, int end_col, int sel, int col_off, int stride) {
   const int s = int(blockIdx.x) * 4 + int(threadIdx.x >> 6);
   if (s >= num_segments) return;
   const int cb = seg_col[s];
   if (cb < first_col || cb >= end_col) return;
   const int lane = threadIdx.x & 63;
-  const int cs = cols[cb].size;
+  const int cs = cols[cb].size;  // <= kGatherMaxColSize (checked on the host)
   int cs_pad = 1;
   while (cs_pad < cs) cs_pad <<= 1;
   const int groups = 64 / cs_pad, g = lane / cs_pad, j = lane - g * cs_pad;
@@ -385,9 +392,9 @@ __global__ __launch_bounds__(256) void kg_left_gather(const cx_block* __restrict
   if (j < cs) {
     for (int k = seg_begin[s] + g; k < seg_begin[s + 1]; k += groups) {
       const int meta = t_meta[k];
-      const bool is_e_cell = (meta >> 8) != 0;
+      const bool is_e_cell = (meta >> kMetaEBit) != 0;
       if ((sel == 1 && !is_e_cell) || (sel == 2 && is_e_cell)) continue;
-      const int rs = meta & 0xff;
+      const int rs = meta & kMetaSizeMask;
       const double* m = values + t_pos[k] + j;
       const double* xr = x + t_rp[k];
       double sum = 0.0;
@@ -398,18 +405,21 @@ __global__ __launch_bounds__(256) void kg_left_gather(const cx_block* __restrict
   for (int off = cs_pad; off < 64; off <<= 1) acc += __shfl_xor(acc, off, 64);
   if (g == 0 && j < cs) {
     if (col_seg[cb + 1] - col_seg[cb] == 1) y[cols[cb].position - col_off + j] += acc;
-    else partial[int64_t(s) * 16 + j] = acc;
+    else partial[int64_t(s) * stride + j] = acc;
   }
 }
 __global__ void kg_left_finish(const cx_block* __restrict__ cols, const int32_t* __restrict__ col_seg, const double* __restrict__ partial,
-                               double* __restrict__ y, int first_col, int end_col, int col_off) {
-  const int t = blockIdx.x * blockDim.x + threadIdx.x;
-  const int cb = first_col + t / 16, j = t & 15;
-  if (cb >= end_col || j >= cols[cb].size) return;
+                               double* __restrict__ y, int first_col, int end_col, int col_off, int stride) {
+  const int64_t t = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  const int64_t c = t / stride;
+  const int j = int(t - c * stride);
+  if (c >= end_col - first_col) return;
+  const int cb = first_col + int(c);
+  if (j >= cols[cb].size) return;
   const int s0 = col_seg[cb], s1 = col_seg[cb + 1];
   if (s1 - s0 <= 1) return;
   double v = 0.0;
-  for (int s = s0; s < s1; ++s) v += partial[int64_t(s) * 16 + j];
+  for (int s = s0; s < s1; ++s) v += partial[int64_t(s) * stride + j];
   y[cols[cb].position - col_off + j] += v;
 }
 
@@ -742,9 +752,9 @@ __global__ __launch_bounds__(256) void kg_blockdiag_gather(const cx_block* __res
   double acc[4] = {0.0, 0.0, 0.0, 0.0};  // cs <= 16: at most four entries per lane
   for (int k = seg_begin[s]; k < seg_begin[s + 1]; ++k) {
     const int meta = t_meta[k];
-    const bool is_e_cell = (meta >> 8) != 0;
+    const bool is_e_cell = (meta >> kMetaEBit) != 0;
     if ((sel == 1 && !is_e_cell) || (sel == 2 && is_e_cell)) continue;
-    const int rs = meta & 0xff;
+    const int rs = meta & kMetaSizeMask;
     const double* m = values + t_pos[k];
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
@@ -792,8 +802,13 @@ int cxk_build_transpose(cx_matrix* A) {
       pos[size_t(slot)] = A->cells[size_t(c)].position;
       rp[size_t(slot)] = A->rows[size_t(r)].position;
       const bool is_e_cell = r < A->num_row_blocks_e && c == A->rcb[size_t(r)];
-      meta[size_t(slot)] = A->rows[size_t(r)].size | (is_e_cell ? 1 << 8 : 0);
+      meta[size_t(slot)] = A->rows[size_t(r)].size | (is_e_cell ? 1 << kMetaEBit : 0);
     }
+  int32_t max_cs = 1;
+  for (const cx_block& c : A->cols) max_cs = std::max(max_cs, c.size);
+  A->t_max_col_size = max_cs;
+  A->t_stride = 16;  // partial sums of a segment: padded size of the widest column block the gather kernels take
+  while (A->t_stride < std::min(max_cs, kGatherMaxColSize)) A->t_stride <<= 1;
   std::vector<int32_t> seg_begin, seg_col, col_seg(size_t(A->Cb) + 1, 0);
   for (int c = 0; c < A->Cb; ++c) {
     col_seg[size_t(c)] = int32_t(seg_col.size());
@@ -812,7 +827,7 @@ int cxk_build_transpose(cx_matrix* A) {
   CX_TRY(A->d_t_seg_col.upload(seg_col, st));
   CX_TRY(A->d_t_col_seg.upload(col_seg, st));
   A->num_t_segments = int32_t(seg_col.size());
-  CX_TRY(A->d_t_partial.alloc(size_t(std::max(A->num_t_segments, 1)) * 16));
+  CX_TRY(A->d_t_partial.alloc(size_t(std::max(A->num_t_segments, 1)) * size_t(A->t_stride)));
   A->transpose_ready = true;
   return CX_OK;
 }
@@ -826,12 +841,19 @@ int cxk_generic_left_multiply(cx_matrix* A, int sel, int col_off, const double* 
   const int end = sel == 1 ? A->nelim : A->Cb;
   if (end <= first || A->num_t_segments == 0) return CX_OK;
   hipStream_t st = A->ctx->stream;
+  if (A->t_max_col_size > kGatherMaxColSize) {
+    // a column block wider than a wavefront's lane groups: the scatter form (atomic adds; not bitwise repeatable) takes any size
+    hipLaunchKernelGGL(kg_left, dim3(grid_for(A->R, 128)), dim3(128), 0, st, A->d_rows.p, A->d_cols.p, A->d_rcb.p, A->d_cells.p,
+                       A->d_values.p, x, y, A->R, A->num_row_blocks_e, sel, col_off);
+    CX_HIP(hipGetLastError());
+    return CX_OK;
+  }
   hipLaunchKernelGGL(kg_left_gather, dim3(unsigned((A->num_t_segments + 3) / 4)), dim3(256), 0, st, (const cx_block*)A->d_cols.p,
                      (const int32_t*)A->d_t_seg_begin.p, (const int32_t*)A->d_t_seg_col.p, (const int32_t*)A->d_t_col_seg.p,
                      (const int32_t*)A->d_t_pos.p, (const int32_t*)A->d_t_rp.p, (const int32_t*)A->d_t_meta.p, (const double*)A->d_values.p,
-                     x, y, A->d_t_partial.p, A->num_t_segments, first, end, sel, col_off);
-  hipLaunchKernelGGL(kg_left_finish, dim3(unsigned((int64_t(end - first) * 16 + 255) / 256)), dim3(256), 0, st, (const cx_block*)A->d_cols.p,
-                     (const int32_t*)A->d_t_col_seg.p, (const double*)A->d_t_partial.p, y, first, end, col_off);
+                     x, y, A->d_t_partial.p, A->num_t_segments, first, end, sel, col_off, A->t_stride);
+  hipLaunchKernelGGL(kg_left_finish, dim3(unsigned((int64_t(end - first) * A->t_stride + 255) / 256)), dim3(256), 0, st, (const cx_block*)A->d_cols.p,
+                     (const int32_t*)A->d_t_col_seg.p, (const double*)A->d_t_partial.p, y, first, end, col_off, A->t_stride);
   CX_HIP(hipGetLastError());
   return CX_OK;
 }
@@ -839,6 +861,11 @@ int cxk_generic_left_multiply(cx_matrix* A, int sel, int col_off, const double* 
 int cxk_generic_block_diagonal(cx_matrix* A, int sel, int first, int count, int64_t off0, double* blocks) {
   if (count <= 0) return CX_OK;
   CX_TRY(cxk_build_transpose(A));
+  for (int c = first; c < first + count; ++c)
+    if (A->cols[size_t(c)].size > 16) {  // four entries per lane: blocks of up to 16 x 16
+      cx_set_error("block diagonal of a %d-wide column block: the dynamic-size kernels take blocks of up to 16", A->cols[size_t(c)].size);
+      return CX_ERR_UNSUPPORTED;
+    }
   CX_TRY(A->d_t_partial_blocks.alloc(size_t(std::max(A->num_t_segments, 1)) * 256));
   hipStream_t st = A->ctx->stream;
   if (A->num_t_segments > 0)

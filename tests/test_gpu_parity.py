@@ -413,6 +413,42 @@ def test_generic_layout_products(ctx, oracle):
         A.close()
 
 
+@pytest.mark.parametrize("wide", [20, 33, 64, 70, 300])
+def test_generic_products_with_wide_column_blocks(ctx, oracle, wide):
+    """the gather form of y += A'x assumed column blocks of at most 16 scalars.  A shared calibration
+    block of 20 (or 33, 64) parameters seen by more than 128 rows -- several gather segments, partial sums `stride` apart --
+    must give the oracle's product; blocks wider than 64 take the scatter kernel; a row block of 300 scalars keeps its size
+    (it used to be packed into 8 bits)."""
+    rng = np.random.default_rng(wide)
+    rows, pos = [], 0
+    num_e = 40
+    col_sizes = [3] * num_e + [wide, 5]
+    row_size = 300 if wide == 300 else 2
+    for r in range(400):
+        e = r % num_e
+        cells = [(e, pos)]
+        pos += row_size * 3
+        cells.append((num_e, pos))          # every row sees the wide block: 400 cells > three segments of 128
+        pos += row_size * wide
+        if r % 3 == 0:
+            cells.append((num_e + 1, pos))
+            pos += row_size * 5
+        rows.append((row_size, cells))
+    bs = cx.BlockStructure.from_rows(col_sizes, rows)
+    values = rng.standard_normal(pos)
+    A = cx.Matrix(ctx, bs, 0)
+    assert not A.is_static_239
+    A.set_values(values)
+    x, y = rng.standard_normal(bs.num_cols), rng.standard_normal(bs.num_rows)
+    assert relerr(A.right_multiply(x), oracle.right_multiply(bs, values, x)) < 1e-13
+    lt = A.left_multiply(y)
+    assert relerr(lt, oracle.left_multiply(bs, values, y)) < 1e-13
+    if wide <= 64:
+        assert np.array_equal(lt, A.left_multiply(y))   # the gather form is repeatable to the bit
+    assert relerr(A.squared_column_norm(), oracle.squared_column_norm(bs, values)) < 1e-13
+    A.close()
+
+
 def test_host_adapter_cpp():
     """The C++ adapter behind the mirrored LinearSolver interface (host/cx_linear_solver.h):
     every solver type against the normal equations, and the LM call sequence."""
