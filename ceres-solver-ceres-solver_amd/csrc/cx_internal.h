@@ -244,6 +244,7 @@ struct cx_matrix {
   int64_t num_items = 0;
   int64_t num_cells = 0;
   DevBuf<double> d_elim_bg0, d_elim_bg1, d_elim_bg2;  // per row B = E'F (3x9) and G = (E'E)^-1 B, 3 x 18 doubles
+  DevBuf<float> d_elim_h32;                           // [O][32] the one-table operand H = K'B in single precision (mixed solves)
   // tile-sparse Cholesky of S (cx_sparse_chol.hip)
   cx_sp_plan sp;
   int pairs_state = 0;                   // 0 not built, 1 ready, 2 too many pairs (atomic path)

@@ -21,11 +21,14 @@ int cxs_eliminate_dense(cx_matrix* A, const double* b, const double* D, bool add
 // the same elimination into the block-sparse upper-stored S of the matrix (A->d_S, cell list A->d_cell_*;
 // D_f^2 NOT added, see k_pair_cells); CX_ERR_UNSUPPORTED when the pair list is too large to build
 int cxs_build_pair_lists(cx_matrix* A);
-int cxs_eliminate_sparse(cx_matrix* A, const double* b, const double* D, double* rhs);
+int cxs_eliminate_sparse(cx_matrix* A, const double* b, const double* D, double* rhs, bool f32_operands = false);
 // the two halves of the gather elimination on their own (tile-sparse SPARSE_SCHUR): per-item pair sums, F'F
 // diagonal blocks and (E'E + D^2)^-1 into the matrix' scratch; rhs = F'(b - E (E'E)^-1 E'b)
 // item_ids (device, optional): only these work items are summed (the cells a visibility preconditioner keeps)
-int cxs_assemble_pair_items(cx_matrix* A, const double* D, const int32_t* item_ids = nullptr, int64_t num_selected = 0);
+// f32_operands (use_mixed_precision_solves: the cells feed a single precision factor): the per-row operand H = K'B is kept
+// in float, one 128-byte line per row, products and sums in double
+int cxs_assemble_pair_items(cx_matrix* A, const double* D, const int32_t* item_ids = nullptr, int64_t num_selected = 0,
+                            bool f32_operands = false);
 int cxs_eliminate_rhs(cx_matrix* A, const double* b, double* rhs);
 // tile-sparse Cholesky (cx_sparse_chol.hip).  For the explicit S of a matrix: plan into A->sp, then assemble + factor
 // + solve in one call.

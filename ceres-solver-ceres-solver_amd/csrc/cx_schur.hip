@@ -1478,6 +1478,163 @@ __global__ __launch_bounds__(kBlock, CX_PAIR_H_OCCUPANCY) void k_pair_items_h(co
 #undef CX_PAIR_FETCH
 }
 
+// ---- Round 4, use_mixed_precision_solves: the operand table in SINGLE precision.  The factor these cells feed is fp32 anyway
+// (cx_sparse_chol.hip, float tile pool), so H = K'B is rounded to float when it is written: 27 floats = 108 bytes, padded to
+// one aligned 128-byte line per row -- an operand is ONE line instead of two, the table 3.7 GB instead of 7.4 GB on the Final
+// shape.  Products of two floats are exact in double, and the sums stay double: S differs from the fp64 assembly by the
+// rounding of H (relative 6e-8 per entry), below what the single precision factorisation does to it afterwards.
+__global__ __launch_bounds__(kBlock) void k_row_h32(const double* __restrict__ E, const double* __restrict__ F,
+                                                    const int32_t* __restrict__ row_pt, const double* __restrict__ ete_inv,
+                                                    int64_t O, float* __restrict__ hf) {
+  __shared__ double lds[kBlock * 18];
+  const int64_t r0 = int64_t(blockIdx.x) * kBlock;
+  const int nvalid = int(min(int64_t(kBlock), O - r0));
+  const int tid = threadIdx.x;
+  double f[18], e[6];
+  stage_cells<18>(F + 18 * r0, nvalid, lds, f);
+  stage_cells<6>(E + 6 * r0, nvalid, lds, e);
+  double packed[16];  // 32 floats as 16 eight-byte pieces (the row's 128-byte line; entries 27..31 are zero)
+#pragma unroll
+  for (int k = 0; k < 16; ++k) packed[k] = 0.0;
+  if (tid < nvalid) {
+    const double* m = ete_inv + 9 * int64_t(row_pt[r0 + tid]);
+    const double k00 = sqrt(m[0]);
+    const double k10 = m[3] / k00, k20 = m[6] / k00;
+    const double k11 = sqrt(m[4] - k10 * k10);
+    const double k21 = (m[7] - k20 * k10) / k11;
+    const double k22 = sqrt(m[8] - k20 * k20 - k21 * k21);
+    float H[32];
+#pragma unroll
+    for (int k = 27; k < 32; ++k) H[k] = 0.f;
+#pragma unroll
+    for (int a = 0; a < 9; ++a) {
+      const double b0 = e[0] * f[a] + e[3] * f[9 + a];  // B = E'F, as k_row_h
+      const double b1 = e[1] * f[a] + e[4] * f[9 + a];
+      const double b2 = e[2] * f[a] + e[5] * f[9 + a];
+      H[a] = float(k00 * b0 + k10 * b1 + k20 * b2);     // H = K'B, rounded once
+      H[9 + a] = float(k11 * b1 + k21 * b2);
+      H[18 + a] = float(k22 * b2);
+    }
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+      const float2 two = make_float2(H[2 * k], H[2 * k + 1]);
+      packed[k] = __builtin_bit_cast(double, two);
+    }
+  }
+  unstage_cells<16>(reinterpret_cast<double*>(hf) + 16 * r0, nvalid, lds, packed);
+}
+
+// k_pair_items_h on the float table: per pair 7 + 7 sixteen-byte pieces (one line per row), 56 pairs per step -- the same
+// number of lines in flight per workgroup as the fp64 kernel's 28 pairs of four lines -- staged one step ahead; every
+// group of 9 threads takes two pairs of a step.  Sum of H_ri' H_rj in double.
+constexpr int kPairGroups32 = 2 * kPairGroups;
+constexpr int kPairOperand32 = 28;                    // staged floats per operand (7 pieces of 4)
+constexpr int kPairPieces32 = kPairGroups32 * 14;     // 16-byte pieces per step
+template <int OCC>
+__global__ __launch_bounds__(kBlock, OCC) void k_pair_items_h32(const int32_t* __restrict__ pair_rows, const int64_t* __restrict__ item_begin,
+                                                         const int32_t* __restrict__ item_ids, const float* __restrict__ hf,
+                                                         double* __restrict__ item_partial, int num_launch_items) {
+  constexpr int kStage = kPairGroups32 * 2 * kPairOperand32;  // floats per buffer
+  constexpr int kLdsBytes = (2 * kStage * 4 > kPairGroups * 81 * 8) ? 2 * kStage * 4 : kPairGroups * 81 * 8;
+  __shared__ double lds[kLdsBytes / 8];
+  float* ldsf = reinterpret_cast<float*>(lds);
+  const int tid = threadIdx.x;
+  const int slot = num_launch_items > 0 ? xcd_segment(num_launch_items) : int(blockIdx.x);
+  if (slot < 0) return;
+  const int64_t item = item_ids ? int64_t(item_ids[slot]) : int64_t(slot);
+  const int64_t p0 = item_begin[item], p1 = item_begin[item + 1];
+  const int steps = int((p1 - p0 + kPairGroups32 - 1) / kPairGroups32);
+  // the (up to four) pieces this thread moves per step, packed: pair slot g (bits 0-5, 63 = none), piece of the row's line
+  // (6-8), right operand (9), place in the staging buffer in floats (10-21)
+  int piece[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int q = tid + i * kBlock;
+    const int g = q / 14, w = q - g * 14;
+    const int operand = w / 7, pc = w - operand * 7;
+    const int dst = (g * 2 + operand) * kPairOperand32 + 4 * pc;
+    piece[i] = (q < kPairPieces32 ? g : 63) | (pc << 6) | (operand << 9) | (dst << 10);
+  }
+#define CX_PAIR_ROW(i, step, out)                                                                     \
+  do {                                                                                                \
+    const int g_ = piece[i] & 63;                                                                     \
+    const int64_t k_ = p0 + int64_t(step) * kPairGroups32 + g_;                                       \
+    out = (g_ != 63 && k_ < p1) ? pair_rows[2 * k_ + ((piece[i] >> 9) & 1)] : -1;                     \
+  } while (0)
+#define CX_PAIR_FETCH(i, row, out)                                                                    \
+  do {                                                                                                \
+    out = (row) < 0 ? make_float4(0.f, 0.f, 0.f, 0.f)                                                 \
+                    : *reinterpret_cast<const float4*>(hf + 32 * int64_t(row) + 4 * ((piece[i] >> 6) & 7)); \
+  } while (0)
+  int32_t rows_next[4];
+  float4 v[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) CX_PAIR_ROW(i, 0, rows_next[i]);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) CX_PAIR_FETCH(i, rows_next[i], v[i]);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    if (steps > 1) CX_PAIR_ROW(i, 1, rows_next[i]);
+    else rows_next[i] = -1;
+  }
+  const int g = tid / 9, sub = tid - g * 9;
+  const int a0 = 3 * (sub / 3), c0 = 3 * (sub - 3 * (sub / 3));
+  double acc[9];
+#pragma unroll
+  for (int k = 0; k < 9; ++k) acc[k] = 0.0;
+  for (int s = 0; s < steps; ++s) {
+    float* buf = ldsf + (s & 1) * kStage;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      if ((piece[i] & 63) != 63) *reinterpret_cast<float4*>(buf + (piece[i] >> 10)) = v[i];
+    __syncthreads();
+    if (s + 1 < steps) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) CX_PAIR_FETCH(i, rows_next[i], v[i]);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        if (s + 2 < steps) CX_PAIR_ROW(i, s + 2, rows_next[i]);
+        else rows_next[i] = -1;
+      }
+    }
+    if (g < kPairGroups) {
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int pair = g + h * kPairGroups;  // ascending pair order inside a group's sum: g, then g + 28
+        if (p0 + int64_t(s) * kPairGroups32 + pair < p1) {
+          const float* Hl = buf + (pair * 2) * kPairOperand32;
+          const float* Hr = Hl + kPairOperand32;
+#pragma unroll
+          for (int q = 0; q < 3; ++q) {
+            const double b0 = double(Hl[9 * q + a0]), b1 = double(Hl[9 * q + a0 + 1]), b2 = double(Hl[9 * q + a0 + 2]);
+            const double g0 = double(Hr[9 * q + c0]), g1 = double(Hr[9 * q + c0 + 1]), g2 = double(Hr[9 * q + c0 + 2]);
+            acc[0] += b0 * g0; acc[1] += b0 * g1; acc[2] += b0 * g2;
+            acc[3] += b1 * g0; acc[4] += b1 * g1; acc[5] += b1 * g2;
+            acc[6] += b2 * g0; acc[7] += b2 * g1; acc[8] += b2 * g2;
+          }
+        }
+      }
+    }
+  }
+  __syncthreads();  // the staging buffers become the groups' partial sums
+  double* part = lds;
+  if (g < kPairGroups) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+      for (int j = 0; j < 3; ++j) part[g * 81 + (a0 + i) * 9 + c0 + j] = acc[i * 3 + j];
+  }
+  __syncthreads();
+  if (tid < 81) {
+    double v81 = 0.0;
+#pragma unroll 4
+    for (int q = 0; q < kPairGroups; ++q) v81 += part[q * 81 + tid];
+    item_partial[item * 81 + tid] = v81;
+  }
+#undef CX_PAIR_ROW
+#undef CX_PAIR_FETCH
+}
+
 // Stage 2, 81 threads per non-zero cell (c1 <= c2): [c1 == c2] F'F - sum of the cell's items, written either
 // into the dense row-major lhs (pre-zeroed; D_f^2 added on the diagonal -- the reference's dense S) or
 // into the cell-major sparse value array (81 contiguous doubles per cell, D_f^2 NOT added: the sparse
@@ -1642,7 +1799,7 @@ int cxs_block9_add_diag_invert(cx_context* ctx, double* blocks, const double* Df
 
 // Gather assembly shared by the dense and the block-sparse explicit S: (E'E + D_e^2)^-1 (closed-form inverse
 // of InvertPSDMatrix<3>), B / G of every row, F'F diagonal blocks, per-item pair sums.
-int cxs_assemble_pair_items(cx_matrix* A, const double* D, const int32_t* item_ids, int64_t num_selected) {
+int cxs_assemble_pair_items(cx_matrix* A, const double* D, const int32_t* item_ids, int64_t num_selected, bool f32_operands) {
   hipStream_t st = A->ctx->stream;
   CX_TRY(A->d_elim_ete.alloc(size_t(std::max<int64_t>(9 * int64_t(A->P), 1))));
   CX_TRY(A->d_elim_diag.alloc(size_t(std::max<int64_t>(81 * int64_t(A->C), 1))));
@@ -1650,6 +1807,31 @@ int cxs_assemble_pair_items(cx_matrix* A, const double* D, const int32_t* item_i
   // E'E + D^2 shows as Inf/NaN in S and ends the solve in the Cholesky factorisation, as in the reference
   CX_TRY(cxs_compute_ete_inverse(A, D, nullptr, A->d_elim_ete.p, nullptr, false, nullptr));
   static const bool one_table = std::getenv("CX_PAIR_BG") == nullptr && std::getenv("CX_PAIR_ITEMS_DIRECT") == nullptr;  // A/B switch
+  static const bool allow_f32 = std::getenv("CX_PAIR_H64") == nullptr;  // A/B switch: fp64 operands under a float factor
+  if (one_table && f32_operands && allow_f32) {  // round 4: the same on a float table, one 128-byte line per row
+    CX_TRY(A->d_elim_h32.alloc(size_t(std::max<int64_t>(32 * A->O, 1))));
+    if (A->O > 0)
+      hipLaunchKernelGGL(k_row_h32, dim3(grid_for(A->O, kBlock)), dim3(kBlock), 0, st, (const double*)A->d_values.p,
+                         (const double*)(A->d_values.p + 6 * A->O), (const int32_t*)A->d_row_pt.p, (const double*)A->d_elim_ete.p,
+                         A->O, A->d_elim_h32.p);
+    CX_TRY(cxs_camera_block_diagonal(A, A->d_elim_diag.p));
+    const int32_t* ids = item_ids ? item_ids : (A->d_item_order.n > 0 && A->d_item_order.p ? (const int32_t*)A->d_item_order.p : nullptr);
+    const int64_t n_items = item_ids ? num_selected : A->num_items;
+    static const bool xcd = std::getenv("CX_NO_XCD_ITEMS") == nullptr;
+    static const int occ = std::getenv("CX_PAIR_H32_OCC") ? std::atoi(std::getenv("CX_PAIR_H32_OCC")) : 5;  // A/B switch
+    if (n_items > 0) {
+      if (occ == 4)
+        hipLaunchKernelGGL(k_pair_items_h32<4>, dim3(unsigned(xcd ? xcd_grid(int(n_items)) : n_items)), dim3(kBlock), 0, st,
+                           (const int32_t*)A->d_pair_rows.p, (const int64_t*)A->d_item_begin.p, ids, (const float*)A->d_elim_h32.p,
+                           A->d_item_partial.p, xcd ? int(n_items) : 0);
+      else
+        hipLaunchKernelGGL(k_pair_items_h32<5>, dim3(unsigned(xcd ? xcd_grid(int(n_items)) : n_items)), dim3(kBlock), 0, st,
+                           (const int32_t*)A->d_pair_rows.p, (const int64_t*)A->d_item_begin.p, ids, (const float*)A->d_elim_h32.p,
+                           A->d_item_partial.p, xcd ? int(n_items) : 0);
+    }
+    CX_HIP(hipGetLastError());
+    return CX_OK;
+  }
   if (one_table) {  // round 3: H = K'B, one operand table (k_row_h / k_pair_items_h)
     const size_t rows16 = size_t(std::max<int64_t>(16 * A->O, 1));
     CX_TRY(A->d_elim_bg0.alloc(rows16));
@@ -1743,14 +1925,14 @@ int cxs_eliminate_dense(cx_matrix* A, const double* b, const double* D, bool add
   return cxs_eliminate_rhs(A, b, rhs);
 }
 
-int cxs_eliminate_sparse(cx_matrix* A, const double* b, const double* D, double* rhs) {
+int cxs_eliminate_sparse(cx_matrix* A, const double* b, const double* D, double* rhs, bool f32_operands) {
   CX_TRY(cxs_build_pair_lists(A));
   if (A->pairs_state != 1) {
     cx_set_error("the explicit Schur complement of this structure needs more than 2^28 row pairs");
     return CX_ERR_UNSUPPORTED;
   }
   CX_TRY(A->d_S.alloc(size_t(std::max<int64_t>(A->num_cells, 1)) * 81));
-  CX_TRY(cxs_assemble_pair_items(A, D));
+  CX_TRY(cxs_assemble_pair_items(A, D, nullptr, 0, f32_operands));
   if (A->num_cells > 0)
     hipLaunchKernelGGL(k_pair_cells, dim3(unsigned((A->num_cells + 2) / 3)), dim3(3 * 81), 0, A->ctx->stream,
                        (const int32_t*)A->d_cell_c1.p, (const int32_t*)A->d_cell_c2.p, (const int32_t*)A->d_cell_item_start.p,

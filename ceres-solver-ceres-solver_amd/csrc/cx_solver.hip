@@ -1241,13 +1241,16 @@ int SolveSparseSchur239(cx_solver* S, cx_matrix* A, const double* b, const doubl
   CX_HIP(hipMemsetAsync(S->flag.p, 0, sizeof(int), st));
   CX_TRY(sw.start());
   const bool sharded = ctx->nranks > 1;
+  // use_mixed_precision_solves: the cells go into a single precision tile pool, so the row operands of their assembly are
+  // kept in single precision too (one 128-byte line per operand instead of two; products and sums stay double)
+  const bool f32_operands = S->opt.use_mixed_precision_solves != 0;
   if (sharded) {
     // every rank eliminates its own points into its own S cells; the cells (in the order of the ranks' common cell
     // list) and the right-hand side are summed over the ranks, factorisation and triangular solves are replicated
-    CX_TRY(cxs_eliminate_sparse(A, b, D, S->v_rhs.p));
+    CX_TRY(cxs_eliminate_sparse(A, b, D, S->v_rhs.p, f32_operands));
     CX_TRY(cx_allreduce_device(ctx, S->v_rhs.p, nf));
   } else {
-    CX_TRY(cxs_assemble_pair_items(A, D));
+    CX_TRY(cxs_assemble_pair_items(A, D, nullptr, 0, f32_operands));
     CX_TRY(cxs_eliminate_rhs(A, b, S->v_rhs.p));
   }
   CX_TRY(sw.stop(&S->timing.eliminate_ms));
