@@ -9,7 +9,7 @@ problems, build script).  There is no CPU fallback: every operation raises if
 the HIP library is missing or reports an error.
 """
 from .structure import BLOCK_DTYPE, CELL_DTYPE, BlockStructure  # noqa: F401
-from . import bal  # noqa: F401
+from . import bal, dumps  # noqa: F401
 
 try:  # binding.py needs only ctypes/numpy; the library itself is loaded lazily
     from .binding import *  # noqa: F401,F403
