@@ -39,10 +39,28 @@ struct DotTail {
   int ring_slots, op, iter;
 };
 
+// Small problems (vectors of at most kSmallCgMax entries, one rank): the camera-sized rest of a CG iteration -- the end of
+// the operator application with p.q, the x / r update with the Q test, the preconditioner with r.z and the new search
+// direction -- runs as ONE single-workgroup kernel (k_cg_small_tail, cx_solver.hip) instead of four launches with ticket
+// reductions.  An operator takes part by handing over where its product's partial sums lie.
+constexpr int kSmallCgMax = 4096;
+struct SmallProduct {
+  const double* partial9 = nullptr;       // [segments][9] per-segment partial sums of F't
+  const int32_t* cam_seg_start = nullptr;  // [C + 1]
+  const double* d = nullptr;               // LM diagonal of the camera part (may be NULL)
+};
+
 struct LinOp {
   virtual ~LinOp() = default;
   virtual int64_t size() const = 0;
   virtual int apply(const double* x, double* y) = 0;  // y = A x
+  // small-problem form: run the product of x up to its per-segment partial sums and say where they are (false: no such form)
+  virtual bool small_partials(const double* x, SmallProduct* out, int* rc) {
+    (void)x; (void)out; (void)rc;
+    return false;
+  }
+  // a block-Jacobi preconditioner's inverted 9x9 blocks (NULL: not of that kind)
+  virtual const double* block9_inverse() const { return nullptr; }
   // y = A x and the CG dot product x.y with its scalar step in the operator's last kernel;
   // *done = false when the operator has no fused form (the caller then applies and reduces).
   virtual int apply_dot(const double* x, double* y, const DotTail& tail, bool* done) {
@@ -69,13 +87,16 @@ struct KernelTimer {
       created = true;
     }
     ++launches[slot];
-    if (count[slot] < kMaxSamples) CX_HIP(hipEventRecord(ev[slot][count[slot]][0], st));
+    if (count[slot] < max_samples) CX_HIP(hipEventRecord(ev[slot][count[slot]][0], st));
     return CX_OK;
   }
   int end(int slot, hipStream_t st) {
-    if (count[slot] < kMaxSamples) { CX_HIP(hipEventRecord(ev[slot][count[slot]][1], st)); ++count[slot]; }
+    if (count[slot] < max_samples) { CX_HIP(hipEventRecord(ev[slot][count[slot]][1], st)); ++count[slot]; }
     return CX_OK;
   }
+  // how many launches per slot are bracketed by events in a solve (each pair costs the host two enqueues and the queue
+  // two markers: a launch-bound small solve samples less)
+  int max_samples = kMaxSamples;
   int collect() {  // call after the stream has been synchronised
     for (int s = 0; s < kSlots; ++s) {
       total_ms[s] = 0.0;

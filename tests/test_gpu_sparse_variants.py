@@ -25,3 +25,20 @@ def _digest(env, *flags):
 def test_lds_staged_update_kernels_keep_the_bits():
     assert _digest({"CX_SPARSE_F64_LDS": "1"}) == _digest({"CX_SPARSE_F64_LDS": "0"})                      # k_sp_update_f64_lds == k_sp_update_slices
     assert _digest({"CX_SPARSE_F32_LDS": "1"}, "--mixed") == _digest({"CX_SPARSE_F32_LDS": "0"}, "--mixed")  # k_sp_update_f32_lds == k_sp_update_f32
+
+
+def test_single_workgroup_cg_tail_keeps_the_bits():
+    """problems whose camera vectors have at most 4 096 entries close a CG iteration (and open the next)
+    in ONE single-workgroup launch (k_cg_small_tail) instead of four ticket-finished ones -- with the same sums in the same
+    order: steps and iteration counts of tools/small_cg_bits.py are those of the general path, to the last bit."""
+    def run(env):
+        e = dict(os.environ)
+        e.update(env)
+        out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "small_cg_bits.py")], env=e, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                             text=True, timeout=600)
+        assert out.returncode == 0, out.stderr[-2000:]
+        return out.stdout.strip().splitlines()[-2:]
+    fused, general = run({}), run({"CX_NO_SMALL_CG": "1"})
+    assert fused == general, (fused, general)
+    assert "(0, " in fused[0]      # SUCCESS somewhere, and more than one residual reset period was crossed
+    assert any(int(t.split(")")[0]) > 20 for t in fused[0].split(", ")[1::2])

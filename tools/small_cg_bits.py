@@ -1,0 +1,37 @@
+#!/usr/bin/env python3
+"""SHA-1 of the ITERATIVE_SCHUR steps of a few small problems (ladybug49 preset and two synthetic ones; JACOBI and
+SCHUR_JACOBI, eta 0.1 / 1e-3 / 1e-8 so that residual resets happen) plus their iteration counts: the single-workgroup CG
+tail of small problems (k_cg_small_tail) must give the bits of the general path (CX_NO_SMALL_CG=1).  One process per
+variant: the switch is read once."""
+import hashlib
+import importlib.util
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+pkg = os.path.join(ROOT, "ceres-solver-ceres-solver_amd")
+spec = importlib.util.spec_from_file_location("cxschur", os.path.join(pkg, "__init__.py"), submodule_search_locations=[pkg])
+cx = importlib.util.module_from_spec(spec)
+sys.modules["cxschur"] = cx
+spec.loader.exec_module(cx)
+
+h = hashlib.sha1()
+its = []
+ctx = cx.Context(0)
+for prob in (cx.bal.make_preset("ladybug49"), cx.bal.make_bal_like(7, 300, 1400, seed=3), cx.bal.make_bal_like(455, 9000, 60000, seed=4)):
+    ev = cx.Evaluator(ctx, prob)
+    _, res, _ = ev.evaluate(prob.state())
+    A = ev.jacobian()
+    D = np.sqrt(np.clip(A.squared_column_norm(), 1e-6, 1e32) / 1e4)
+    for pre in (cx.JACOBI, cx.SCHUR_JACOBI):
+        for eta in (0.1, 1e-3, 1e-8):
+            S = cx.Solver(ctx, type=cx.ITERATIVE_SCHUR, preconditioner_type=pre, num_eliminate_blocks=prob.num_points, max_num_iterations=120)
+            x, s = S.solve(A, res, D, r_tolerance=-1.0, q_tolerance=eta)
+            h.update(x.tobytes())
+            its.append((int(s.termination_type), int(s.num_iterations)))
+            S.close()
+    ev.close()
+print(its)
+print(h.hexdigest())
