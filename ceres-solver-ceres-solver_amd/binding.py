@@ -22,6 +22,7 @@ CAMERA_ANGLE_AXIS, CAMERA_QUATERNION_MANIFOLD = 0, 1
 IDENTITY, JACOBI, SCHUR_JACOBI, SCHUR_POWER_SERIES_EXPANSION, CLUSTER_JACOBI, CLUSTER_TRIDIAGONAL = 0, 1, 2, 3, 4, 5
 CANONICAL_VIEWS, SINGLE_LINKAGE = 0, 1
 SUCCESS, NO_CONVERGENCE, FAILURE, FATAL_ERROR = 0, 1, 2, 3
+NOTE_DOUBLE_PRECISION_FACTOR, NOTE_SPSE_INITIALIZATION_SKIPPED = 1, 2
 
 # every symbol include/cxschur.h declares (tests check that the library exports them all)
 EXPORTED_SYMBOLS = [
@@ -97,6 +98,8 @@ class cx_summary(ctypes.Structure):
         ("num_iterations", ctypes.c_int32),
         ("termination_type", ctypes.c_int32),
         ("message", ctypes.c_char * 256),
+        ("notes", ctypes.c_int32),
+        ("reserved", ctypes.c_int32),
     ]
 
 

@@ -290,6 +290,110 @@ __global__ void kg_chunk_eliminate(GStruct g, const int32_t* __restrict__ chunk_
   }
 }
 
+// ---- the same elimination as a GATHER (round 4): no atomics, every cell of S summed in a fixed order.
+// Per f cell q of an e-row: B_q = E_r' F_q and G_q = (E'E + D_e^2)^-1 B_q (kg_fcell_bg); then one wavefront per cell
+// (b1 <= b2) of S walks the cell's products in list order -- + F_i' F_j for two f cells of one row (EBlockRowOuterProduct /
+// NoEBlockRowsUpdate), - B_i' G_j for two f cells of one chunk (ChunkOuterProduct) -- and writes the cell once.
+__global__ void kg_fcell_bg(GStruct g, const int32_t* __restrict__ fcell, int num_fcells, const double* __restrict__ values,
+                            const int64_t* __restrict__ blk_off, const double* __restrict__ ete_inv, double* __restrict__ bg) {
+  const int q = blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= num_fcells) return;
+  const int r = fcell[4 * q], c = fcell[4 * q + 1];
+  const cx_cell ecell = g.cells[g.rcb[r]], fc = g.cells[c];
+  const int rs = g.rows[r].size, es = g.cols[ecell.block_id].size, fs = g.cols[fc.block_id].size;
+  const double* E = values + ecell.position;
+  const double* F = values + fc.position;
+  const double* inv = ete_inv + blk_off[ecell.block_id];
+  double* B = bg + fcell[4 * q + 2];
+  double* G = bg + fcell[4 * q + 3];
+  for (int a = 0; a < fs; ++a) {
+    double u[kMaxBlock];
+    for (int k = 0; k < es; ++k) {
+      double v = 0.0;
+      for (int i = 0; i < rs; ++i) v += E[i * es + k] * F[i * fs + a];
+      u[k] = v;
+      B[k * fs + a] = v;
+    }
+    for (int k = 0; k < es; ++k) {
+      double v = 0.0;
+      for (int t = 0; t < es; ++t) v += inv[k * es + t] * u[t];
+      G[k * fs + a] = v;
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void kg_gather_cells(const int32_t* __restrict__ target, const int32_t* __restrict__ tuple_begin,
+                                                       const int32_t* __restrict__ tuples, int num_targets,
+                                                       const double* __restrict__ values, const double* __restrict__ bg,
+                                                       const double* __restrict__ Df, double* __restrict__ lhs, int64_t n) {
+  const int t = int(blockIdx.x) * 4 + int(threadIdx.x >> 6);
+  if (t >= num_targets) return;
+  const int lane = threadIdx.x & 63;
+  const int p1 = target[4 * t], p2 = target[4 * t + 1], s1 = target[4 * t + 2], s2 = target[4 * t + 3];
+  const int entries = s1 * s2;
+  double acc[4] = {0.0, 0.0, 0.0, 0.0};  // blocks of up to 16 x 16: four entries per lane
+  for (int k = tuple_begin[t]; k < tuple_begin[t + 1]; ++k) {
+    const int kind = tuples[4 * k + 3], inner = tuples[4 * k + 2];
+    const double* X = (kind ? bg : values) + tuples[4 * k];
+    const double* Y = (kind ? bg : values) + tuples[4 * k + 1];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int e = lane + 64 * q;
+      if (e < entries) {
+        const int a = e / s2, c = e - a * s2;
+        double sum = 0.0;
+        for (int i = 0; i < inner; ++i) sum += X[i * s1 + a] * Y[i * s2 + c];
+        acc[q] += kind ? -sum : sum;
+      }
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int e = lane + 64 * q;
+    if (e < entries) {
+      const int a = e / s2, c = e - a * s2;
+      double v = acc[q];
+      if (Df && p1 + a == p2 + c) v += Df[p1 + a] * Df[p1 + a];
+      lhs[int64_t(p1 + a) * n + p2 + c] = v;
+    }
+  }
+}
+
+// s = b - E (E'E + D^2)^-1 E'b for the rows of a chunk (the vector UpdateRhs multiplies by F', :379-420); rows without an
+// e block keep b.  One thread per chunk, sums in row order.
+__global__ void kg_chunk_rhs_rows(GStruct g, const int32_t* __restrict__ chunk_start, int num_chunks, const double* __restrict__ values,
+                                  const double* __restrict__ b, const int64_t* __restrict__ blk_off, const double* __restrict__ ete_inv,
+                                  double* __restrict__ s) {
+  const int ch = blockIdx.x * blockDim.x + threadIdx.x;
+  if (ch >= num_chunks) return;
+  const int r0 = chunk_start[ch], r1 = chunk_start[ch + 1];
+  const int eb = g.cells[g.rcb[r0]].block_id;
+  const int es = g.cols[eb].size;
+  const double* inv = ete_inv + blk_off[eb];
+  double gsum[kMaxBlock], invg[kMaxBlock];
+  for (int k = 0; k < es; ++k) gsum[k] = 0.0;
+  for (int r = r0; r < r1; ++r) {
+    const double* E = values + g.cells[g.rcb[r]].position;
+    const int rs = g.rows[r].size, rp = g.rows[r].position;
+    for (int k = 0; k < es; ++k)
+      for (int i = 0; i < rs; ++i) gsum[k] += E[i * es + k] * b[rp + i];
+  }
+  for (int k = 0; k < es; ++k) {
+    double v = 0.0;
+    for (int q = 0; q < es; ++q) v += inv[k * es + q] * gsum[q];
+    invg[k] = v;
+  }
+  for (int r = r0; r < r1; ++r) {
+    const double* E = values + g.cells[g.rcb[r]].position;
+    const int rs = g.rows[r].size, rp = g.rows[r].position;
+    for (int i = 0; i < rs; ++i) {
+      double v = b[rp + i];
+      for (int k = 0; k < es; ++k) v -= E[i * es + k] * invg[k];
+      s[rp + i] = v;
+    }
+  }
+}
+
 // SchurEliminator::BackSubstitute (:307-373): y_e = (E'E + D^2)^-1 sum E_i'(b_i - F_i z)
 __global__ void kg_chunk_backsub(GStruct g, const int32_t* __restrict__ chunk_start, int num_chunks,
                                  const double* __restrict__ values, const double* __restrict__ b,
@@ -337,12 +441,28 @@ __global__ void kg_sub(const double* __restrict__ a, const double* __restrict__ 
   const int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
   if (i < n) out[i] = a[i] - bvec[i];
 }
+// out = rhs - S z for a dense symmetric S of which the upper triangle is valid (row-major, n x n); one thread per row
+__global__ void kg_sym_residual(const double* __restrict__ S, int64_t n, const double* __restrict__ rhs, const double* __restrict__ z,
+                                double* __restrict__ out) {
+  const int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  double s = 0.0;
+  for (int64_t j = 0; j < i; ++j) s += S[j * n + i] * z[j];
+  for (int64_t j = i; j < n; ++j) s += S[i * n + j] * z[j];
+  out[i] = rhs[i] - s;
+}
+__global__ void kg_axpy(double* __restrict__ y, const double* __restrict__ x, int64_t n) {
+  const int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i < n) y[i] += x[i];
+}
 __global__ void kg_negate(double* __restrict__ a, int64_t n) {
   const int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
   if (i < n) a[i] = -a[i];
 }
 
 // ------------------------------------------------------------------- host side
+int PrepareGenericGather(cx_matrix* A);
+
 struct Generic {
   cx_solver* S;
   cx_matrix* A;
@@ -385,6 +505,11 @@ struct Generic {
   }
   // SchurEliminator::Eliminate into dense lhs (n = nf); ete_inv must hold (E'E + D_e^2)^-1
   int eliminate(const double* b, const double* D, const double* ete_inv, bool add_df, double* lhs, double* rhs) {
+    static const bool atomics = std::getenv("CX_GENERIC_ATOMICS") != nullptr;  // A/B switch: the scatter kernels
+    if (!atomics) {
+      CX_TRY(PrepareGenericGather(A));
+      if (A->gather_state == 1) return eliminate_gather(b, D, ete_inv, add_df, lhs, rhs);
+    }
     CX_TRY(zero(lhs, nf * nf));
     if (rhs) CX_TRY(zero(rhs, nf));
     if (D && add_df && nf) hipLaunchKernelGGL(kg_add_diag_sq, dim3(grid_for(nf, 256)), dim3(256), 0, st, lhs, nf, D + ne);
@@ -392,6 +517,31 @@ struct Generic {
     if (A->num_chunks) hipLaunchKernelGGL(kg_chunk_eliminate, dim3(grid_for(A->num_chunks, 64)), dim3(64), 0, st, g,
                                           (const int32_t*)A->d_chunk_start.p, A->num_chunks, (const double*)A->d_values.p, b,
                                           (const int64_t*)A->d_blk_off.p, ete_inv, lhs, nf, rhs, int(ne));
+    CX_HIP(hipGetLastError());
+    return CX_OK;
+  }
+  // the same without atomics: every cell of S gathered in a fixed order (kg_gather_cells), the right-hand side through the
+  // transposed index (F's with s = b - E (E'E)^-1 E'b): the same bits every time
+  int eliminate_gather(const double* b, const double* D, const double* ete_inv, bool add_df, double* lhs, double* rhs) {
+    CX_TRY(zero(lhs, nf * nf));
+    if (D && add_df && nf) hipLaunchKernelGGL(kg_add_diag_sq, dim3(grid_for(nf, 256)), dim3(256), 0, st, lhs, nf, D + ne);  // blocks no row touches
+    if (A->g_num_fcells)
+      hipLaunchKernelGGL(kg_fcell_bg, dim3(grid_for(A->g_num_fcells, 64)), dim3(64), 0, st, g, (const int32_t*)A->d_g_fcell.p, A->g_num_fcells,
+                         (const double*)A->d_values.p, (const int64_t*)A->d_blk_off.p, ete_inv, A->d_g_bg.p);
+    if (A->g_num_targets)
+      hipLaunchKernelGGL(kg_gather_cells, dim3(grid_for(A->g_num_targets, 4)), dim3(256), 0, st, (const int32_t*)A->d_g_target.p,
+                         (const int32_t*)A->d_g_tuple_begin.p, (const int32_t*)A->d_g_tuples.p, A->g_num_targets, (const double*)A->d_values.p,
+                         (const double*)A->d_g_bg.p, (D && add_df) ? D + ne : (const double*)nullptr, lhs, nf);
+    if (rhs) {
+      CX_TRY(S->v_rows.alloc(size_t(std::max<int64_t>(A->num_rows, 1))));
+      double* s = S->v_rows.p;
+      CX_HIP(hipMemcpyAsync(s, b, size_t(A->num_rows) * sizeof(double), hipMemcpyDeviceToDevice, st));
+      if (A->num_chunks)
+        hipLaunchKernelGGL(kg_chunk_rhs_rows, dim3(grid_for(A->num_chunks, 64)), dim3(64), 0, st, g, (const int32_t*)A->d_chunk_start.p,
+                           A->num_chunks, (const double*)A->d_values.p, b, (const int64_t*)A->d_blk_off.p, ete_inv, s);
+      CX_TRY(zero(rhs, nf));
+      CX_TRY(mult(SEL_F, true, s, rhs));
+    }
     CX_HIP(hipGetLastError());
     return CX_OK;
   }
@@ -448,6 +598,44 @@ struct GenericIdentityOp : LinOp {
   }
 };
 
+// PowerSeriesExpansionPreconditioner (power_series_expansion_preconditioner.cc:57-84) on the dynamic-size operators:
+// y = sum_{k = 0 .. max_iterations} Z^k (F'F)^-1 x, Z = (F'F)^-1 F'E (E'E)^-1 E'F (InversePowerSeriesOperatorRightMultiply-
+// Accumulate, implicit_schur_complement.cc:146-177), a fixed number of terms (the preconditioner's tolerance is 0,
+// iterative_schur_complement_solver.cc:178-186).  blocks: the inverted diagonal blocks of F'F (+ D_f^2).
+struct GenericSpseOp : LinOp {
+  Generic* G;
+  const double* ftf_inv;
+  const double* ete_inv;
+  int max_iterations;
+  double *tmp_rows, *tmp_e, *tmp_e2, *series, *previous, *tmp_f;
+  int64_t size() const override { return G->nf; }
+  int apply(const double* x, double* y) override {
+    Generic& q = *G;
+    const int64_t n = q.nf;
+    const int first = q.g.nelim, count = q.nfb, pos0 = int(q.ne);
+    CX_TRY(q.blockdiag_mult(first, count, pos0, ftf_inv, x, y));
+    CX_HIP(hipMemcpyAsync(previous, y, size_t(n) * sizeof(double), hipMemcpyDeviceToDevice, q.st));
+    double* prev = previous;
+    double* ser = series;
+    for (int i = 1; i <= max_iterations; ++i) {
+      CX_TRY(q.zero(tmp_rows, q.A->num_rows));
+      CX_TRY(q.mult(SEL_F, false, prev, tmp_rows));
+      CX_TRY(q.zero(tmp_e, q.ne));
+      CX_TRY(q.mult(SEL_E, true, tmp_rows, tmp_e));
+      CX_TRY(q.blockdiag_mult(0, q.g.nelim, 0, ete_inv, tmp_e, tmp_e2));
+      CX_TRY(q.zero(tmp_rows, q.A->num_rows));
+      CX_TRY(q.mult(SEL_E, false, tmp_e2, tmp_rows));
+      CX_TRY(q.zero(tmp_f, n));
+      CX_TRY(q.mult(SEL_F, true, tmp_rows, tmp_f));
+      CX_TRY(q.blockdiag_mult(first, count, pos0, ftf_inv, tmp_f, ser));
+      if (n) hipLaunchKernelGGL(kg_axpy, dim3(grid_for(n, 256)), dim3(256), 0, q.st, y, (const double*)ser, n);
+      std::swap(prev, ser);
+    }
+    CX_HIP(hipGetLastError());
+    return CX_OK;
+  }
+};
+
 struct GenericCgnrOp : LinOp {
   Generic* G;
   const double* D;
@@ -464,6 +652,92 @@ struct GenericCgnrOp : LinOp {
     return CX_OK;
   }
 };
+
+// The product lists of the gather eliminator, from the structure alone (once per matrix).
+int PrepareGenericGather(cx_matrix* A) {
+  if (A->gather_state != 0) return CX_OK;
+  const int nelim = A->nelim, nre = A->num_row_blocks_e;
+  const int64_t f_pos0 = A->num_cols_e;
+  // f cells of e-rows and their B / G slots
+  std::vector<int32_t> fcell;
+  std::vector<int32_t> q_of_cell(A->cells.size(), -1);
+  int64_t bg = 0;
+  for (int r = 0; r < nre; ++r) {
+    const int es = A->cols[size_t(A->cells[size_t(A->rcb[size_t(r)])].block_id)].size;
+    for (int c = A->rcb[size_t(r)] + 1; c < A->rcb[size_t(r) + 1]; ++c) {
+      const int fs = A->cols[size_t(A->cells[size_t(c)].block_id)].size;
+      q_of_cell[size_t(c)] = int32_t(fcell.size() / 4);
+      fcell.insert(fcell.end(), {int32_t(r), int32_t(c), int32_t(bg), int32_t(bg + int64_t(es) * fs)});
+      bg += 2 * int64_t(es) * fs;
+      if (bg >= (int64_t(1) << 31)) { A->gather_state = 2; return CX_OK; }
+    }
+  }
+  struct Product { int64_t key; int32_t x, y, inner, kind; };
+  std::vector<Product> products;
+  const int64_t kMaxProducts = int64_t(1) << 26;
+  auto key_of = [&](int b1, int b2) { return int64_t(b1) * (int64_t(A->Cb) + 1) + b2; };
+  // + F_i' F_j over the f cells of every row (cells i <= j in row order)
+  for (int r = 0; r < A->R; ++r) {
+    int cb = A->rcb[size_t(r)], ce = A->rcb[size_t(r) + 1];
+    if (r < nre) cb = std::min(ce, cb + 1);
+    for (int i = cb; i < ce; ++i)
+      for (int j = i; j < ce; ++j) {
+        const cx_cell& ci = A->cells[size_t(i)];
+        const cx_cell& cj = A->cells[size_t(j)];
+        products.push_back({key_of(ci.block_id, cj.block_id), ci.position, cj.position, A->rows[size_t(r)].size, 0});
+      }
+    if (int64_t(products.size()) > kMaxProducts) { A->gather_state = 2; return CX_OK; }
+  }
+  // - B_i' G_j over the f cells of every chunk, blocks b1 <= b2 (both orders when they are equal, as ChunkOuterProduct)
+  {
+    int r = 0;
+    while (r < nre) {
+      const int id = A->cells[size_t(A->rcb[size_t(r)])].block_id;
+      const int r0 = r;
+      while (r < nre && A->cells[size_t(A->rcb[size_t(r)])].block_id == id) ++r;
+      const int es = A->cols[size_t(id)].size;
+      for (int ri = r0; ri < r; ++ri)
+        for (int ci = A->rcb[size_t(ri)] + 1; ci < A->rcb[size_t(ri) + 1]; ++ci)
+          for (int rj = r0; rj < r; ++rj)
+            for (int cj = A->rcb[size_t(rj)] + 1; cj < A->rcb[size_t(rj) + 1]; ++cj) {
+              const int b1 = A->cells[size_t(ci)].block_id, b2 = A->cells[size_t(cj)].block_id;
+              if (b1 > b2) continue;
+              products.push_back({key_of(b1, b2), fcell[size_t(4 * q_of_cell[size_t(ci)] + 2)], fcell[size_t(4 * q_of_cell[size_t(cj)] + 3)], es, 1});
+            }
+      if (int64_t(products.size()) > kMaxProducts) { A->gather_state = 2; return CX_OK; }
+    }
+  }
+  std::stable_sort(products.begin(), products.end(), [](const Product& a, const Product& b) { return a.key < b.key; });
+  std::vector<int32_t> target, tuple_begin, tuples;
+  tuples.reserve(products.size() * 4);
+  for (size_t k = 0; k < products.size(); ++k) {
+    if (k == 0 || products[k].key != products[k - 1].key) {
+      const int b1 = int(products[k].key / (int64_t(A->Cb) + 1)), b2 = int(products[k].key % (int64_t(A->Cb) + 1));
+      if (b1 < nelim || b2 < nelim) {
+        cx_set_error("an f cell of row products lies in an e-block column");
+        return CX_ERR_INVALID_ARGUMENT;
+      }
+      target.insert(target.end(), {int32_t(A->cols[size_t(b1)].position - f_pos0), int32_t(A->cols[size_t(b2)].position - f_pos0),
+                                   A->cols[size_t(b1)].size, A->cols[size_t(b2)].size});
+      tuple_begin.push_back(int32_t(k));
+    }
+    tuples.insert(tuples.end(), {products[k].x, products[k].y, products[k].inner, products[k].kind});
+  }
+  tuple_begin.push_back(int32_t(products.size()));
+  hipStream_t st = A->ctx->stream;
+  A->g_num_targets = int32_t(target.size() / 4);
+  A->g_num_fcells = int32_t(fcell.size() / 4);
+  if (target.empty()) target.assign(4, 0);
+  if (tuples.empty()) tuples.assign(4, 0);
+  if (fcell.empty()) fcell.assign(4, 0);
+  CX_TRY(A->d_g_target.upload(target, st));
+  CX_TRY(A->d_g_tuple_begin.upload(tuple_begin, st));
+  CX_TRY(A->d_g_tuples.upload(tuples, st));
+  CX_TRY(A->d_g_fcell.upload(fcell, st));
+  CX_TRY(A->d_g_bg.alloc(size_t(std::max<int64_t>(bg, 1))));
+  A->gather_state = 1;
+  return CX_OK;
+}
 
 int PrepareGeneric(cx_matrix* A) {
   if (A->generic_ready) return CX_OK;
@@ -554,17 +828,39 @@ int cxg_solve(cx_solver* S, cx_matrix* A, const double* b, const double* D, doub
     summary->num_iterations = 0;
     std::snprintf(summary->message, sizeof(summary->message), "Success.");
     if (G.nf > 0) {
+      if (S->opt.max_num_refinement_iterations > 0) {  // refinement needs S itself beside its factor
+        CX_TRY(S->lhs_copy.alloc(size_t(G.nf * G.nf)));
+        CX_HIP(hipMemcpyAsync(S->lhs_copy.p, S->lhs.p, size_t(G.nf * G.nf) * sizeof(double), hipMemcpyDeviceToDevice, st));
+      }
       CX_TRY(cxd_cholesky_solve(ctx, int(G.nf), S->lhs.p, S->v_rhs.p, z, S->flag.p));
       summary->num_iterations = 1;
       CX_TRY(cx_check_flag(S, "Dense Cholesky factorization failed: the reduced matrix is not positive definite.", summary, &failed));
     }
+    // max_num_refinement_iterations (RefinedDenseCholesky -> DenseIterativeRefiner::Refine, dense_cholesky.cc:122-128,
+    // iterative_refiner.cc:80-103): residual = rhs - S z in double, z += S^-1 residual, a fixed number of times.  The dense
+    // kernel factors in place and solves inside the factorisation, so a step factors a fresh copy of S -- the same factor
+    // every time (this is the correctness path of the dynamic-size structures, not a fast one).
+    const int refinements = std::max(0, S->opt.max_num_refinement_iterations);
+    if (summary->termination_type == CX_SUCCESS && refinements > 0 && G.nf > 0) {
+      CX_TRY(S->v_p.alloc(size_t(G.nf)));
+      CX_TRY(S->v_tmp.alloc(size_t(G.nf)));
+      for (int it = 0; it < refinements; ++it) {
+        hipLaunchKernelGGL(kg_sym_residual, dim3(grid_for(G.nf, 64)), dim3(64), 0, st, (const double*)S->lhs_copy.p, G.nf,
+                           (const double*)S->v_rhs.p, (const double*)z, S->v_p.p);
+        CX_HIP(hipMemcpyAsync(S->lhs.p, S->lhs_copy.p, size_t(G.nf * G.nf) * sizeof(double), hipMemcpyDeviceToDevice, st));
+        CX_TRY(cxd_cholesky_solve(ctx, int(G.nf), S->lhs.p, S->v_p.p, S->v_tmp.p, S->flag.p));
+        hipLaunchKernelGGL(kg_axpy, dim3(grid_for(G.nf, 256)), dim3(256), 0, st, z, (const double*)S->v_tmp.p, G.nf);
+      }
+      CX_HIP(hipGetLastError());
+    }
     if (summary->termination_type == CX_SUCCESS) CX_TRY(G.backsub_chunks(b, S->ete_inv.p, z, x));
-    // use_mixed_precision_solves / max_num_refinement_iterations: the single precision factor and the stored-factor solves of
-    // refinement live in the tile code of the static <2,3,9> layout (cx_solver.hip: SolveDenseSchur239); here the option is
-    // answered, not silently dropped
-    if (summary->termination_type == CX_SUCCESS && (S->opt.use_mixed_precision_solves || S->opt.max_num_refinement_iterations > 0))
-      std::snprintf(summary->message, sizeof(summary->message),
-                    "Success. (dynamic-size structure: double precision dense factorisation, no refinement)");
+    // use_mixed_precision_solves: the single precision factor lives in the tile code of the static <2,3,9> layout
+    // (cx_solver.hip: SolveDenseSchur239); here the factor is double -- said in the message and in summary->notes
+    if (summary->termination_type == CX_SUCCESS && (S->opt.use_mixed_precision_solves || refinements > 0)) {
+      if (S->opt.use_mixed_precision_solves) summary->notes |= CX_NOTE_DOUBLE_PRECISION_FACTOR;
+      std::snprintf(summary->message, sizeof(summary->message), "Success. (dynamic-size structure: double precision dense factorisation, %d refinement step%s)",
+                    refinements, refinements == 1 ? "" : "s");
+    }
     return CX_OK;
   }
 
@@ -607,8 +903,13 @@ int cxg_solve(cx_solver* S, cx_matrix* A, const double* b, const double* D, doub
     hipLaunchKernelGGL(kg_blockdiag_invert, dim3(grid_for(G.nfb, 64)), dim3(64), 0, st, (const cx_block*)A->d_cols.p,
                        (const int64_t*)A->d_blk_off.p, G.off_f, A->nelim, G.nfb, sharded ? D : (const double*)nullptr, S->cam_blocks.p, S->flag.p);
     CX_HIP(hipGetLastError());
+  } else if (o.preconditioner_type == CX_SCHUR_POWER_SERIES_EXPANSION) {
+    CX_TRY(G.block_diag_inverse(SEL_F, A->nelim, G.nfb, D, S->cam_blocks.p, true));  // (F'F + D_f^2)^-1, as for JACOBI
+    CX_TRY(S->v_spse.alloc(size_t(std::max<int64_t>(3 * G.nf, 1))));
+    CX_TRY(S->v_spse_rows.alloc(size_t(std::max<int64_t>(A->num_rows + 2 * G.ne, 1))));
   } else if (o.preconditioner_type != CX_IDENTITY) {
-    cx_set_error("preconditioner %d is not available for ITERATIVE_SCHUR on the device", o.preconditioner_type);
+    cx_set_error("preconditioner %d on a dynamic-size structure: the visibility based preconditioners exist for the static <2,3,9> "
+                 "layout (and the structures embedded in it) only", o.preconditioner_type);
     return CX_ERR_UNSUPPORTED;
   }
   CX_TRY(cx_check_flag(S, "Preconditioner update failed.", summary, &failed));
@@ -617,7 +918,15 @@ int cxg_solve(cx_solver* S, cx_matrix* A, const double* b, const double* D, doub
   lhs.G = &G; lhs.D = D; lhs.tmp_rows = tmp_rows; lhs.tmp_e = tmp_e; lhs.tmp_e2 = tmp_e2; lhs.ete_inv = S->ete_inv.p;
   GenericBlockDiagOp bd; bd.G = &G; bd.first = A->nelim; bd.count = G.nfb; bd.pos0 = int(G.ne); bd.blocks = S->cam_blocks.p; bd.n = G.nf;
   GenericIdentityOp id; id.G = &G; id.n = G.nf;
-  LinOp& pre = (o.preconditioner_type == CX_IDENTITY) ? static_cast<LinOp&>(id) : static_cast<LinOp&>(bd);
+  GenericSpseOp spse;
+  spse.G = &G; spse.ftf_inv = S->cam_blocks.p; spse.ete_inv = S->ete_inv.p; spse.max_iterations = o.max_num_spse_iterations;
+  if (o.preconditioner_type == CX_SCHUR_POWER_SERIES_EXPANSION) {  // its own temporaries: the operator's are live inside CG
+    spse.tmp_rows = S->v_spse_rows.p; spse.tmp_e = S->v_spse_rows.p + A->num_rows; spse.tmp_e2 = spse.tmp_e + G.ne;
+    spse.series = S->v_spse.p; spse.previous = S->v_spse.p + G.nf; spse.tmp_f = S->v_spse.p + 2 * G.nf;
+  }
+  LinOp& pre = (o.preconditioner_type == CX_IDENTITY) ? static_cast<LinOp&>(id)
+               : (o.preconditioner_type == CX_SCHUR_POWER_SERIES_EXPANSION) ? static_cast<LinOp&>(spse) : static_cast<LinOp&>(bd);
+  if (o.use_spse_initialization) summary->notes |= CX_NOTE_SPSE_INITIALIZATION_SKIPPED;  // CG starts from zero here
   CX_TRY(G.zero(S->v_x.p, G.nf));
   CX_TRY(cx_cg_run(S, G.nf, G.nf, lhs, pre, S->v_rhs.p, S->v_x.p, true, r_tol, q_tol, summary));
   if (summary->termination_type != CX_FAILURE && summary->termination_type != CX_FATAL_ERROR) {

@@ -186,6 +186,16 @@ struct cx_matrix {
   std::vector<int64_t> blk_off;   // packed size^2 offsets of the column blocks, [Cb+1]
   DevBuf<int64_t> d_blk_off;
   bool generic_ready = false;
+  // gather form of the dynamic-size eliminator (cx_generic.hip: PrepareGenericGather): the cells (b1 <= b2) of S that any
+  // row or chunk touches, and per cell the products that update it, in a fixed order -- the role of the static path's
+  // pair lists.  0 not built, 1 ready, 2 too many products (the scatter kernels with atomics are used)
+  int gather_state = 0;
+  int32_t g_num_targets = 0, g_num_fcells = 0;
+  DevBuf<int32_t> d_g_target;      // [targets][4] first scalar row / column of the cell in S, its sizes s1, s2
+  DevBuf<int32_t> d_g_tuple_begin; // [targets + 1]
+  DevBuf<int32_t> d_g_tuples;      // [tuples][4] X position, Y position, inner dimension, kind (0: +F_i'F_j from the values, 1: -B_i'G_j from d_g_bg)
+  DevBuf<int32_t> d_g_fcell;       // [fcells][4] row block, cell index, offset of B in d_g_bg, offset of G
+  DevBuf<double> d_g_bg;           // per f cell of an e-row: B = E'F and G = (E'E + D^2)^-1 B
   // transposed index of the dynamic-size structure (the reference's transpose block structure, block_sparse_matrix.cc:784-808):
   // the cells of every column block in ascending row order -- what lets A'x be a gather with a fixed summation order instead
   // of atomics (cx_matrix.hip: cxk_build_transpose)

@@ -1609,6 +1609,7 @@ int SolveDenseSchur239(cx_solver* S, cx_matrix* A, const double* b, const double
   }
   CX_TRY(sw.stop(&S->timing.back_substitute_ms));
   // (reached with use_mixed_precision_solves / refinement only when no tile plan could be built for this structure)
+  if (wants_tiles && summary->termination_type == CX_SUCCESS && S->opt.use_mixed_precision_solves) summary->notes |= CX_NOTE_DOUBLE_PRECISION_FACTOR;
   if (wants_tiles && summary->termination_type == CX_SUCCESS)
     std::snprintf(summary->message, sizeof(summary->message),
                   "Success. (no tile plan for this structure: double precision dense factorisation, no refinement)");

@@ -122,7 +122,8 @@ struct cx_solver {
   DevBuf<double> v_p, v_r, v_z, v_tmp, v_x, v_rhs, v_rows, v_rows2, v_cols;
   DevBuf<double> ete_inv, cam_blocks, pt_blocks, g_e, lhs, partial, v_pack;
   DevBuf<CgState> state, spse_state;
-  DevBuf<double> v_spse;
+  DevBuf<double> v_spse, v_spse_rows;
+  DevBuf<double> lhs_copy;  // dynamic-size DENSE / SPARSE_SCHUR with refinement: S beside its factor
   CgState* ring_h = nullptr;  // host-pinned, device-visible ring of published CG states
   CgState* ring_d = nullptr;
   DevBuf<int> flag;

@@ -204,6 +204,7 @@ class CxLinearSolver final : public LinearSolver {
     summary.num_iterations = s.num_iterations;
     summary.termination_type = static_cast<LinearSolverTerminationType>(s.termination_type);
     summary.message = s.message;
+    last_notes_ = s.notes;  // CX_NOTE_*: options answered differently from how they were asked (the message says so in words)
     if (uploaded_values_bytes > 0) {
       // said once per Solve, where Solver::Summary / the iteration log will show it: this Jacobian is a host matrix (the
       // evaluator is not CxBalEvaluator) and its values cross PCIe every Solve
@@ -222,6 +223,7 @@ class CxLinearSolver final : public LinearSolver {
 
   const cx_solve_timing& last_timing() const { return timing_; }  // device-side phase times of the last Solve
   bool last_solve_aliased_residuals() const { return aliased_last_b_; }
+  int last_notes() const { return last_notes_; }
   int64_t host_values_uploaded_bytes() const { return host_values_uploaded_bytes_; }  // over the life of this solver
 
  private:
@@ -279,6 +281,7 @@ class CxLinearSolver final : public LinearSolver {
   cx_solve_timing timing_{};
   bool alias_evaluator_residuals_ = false;
   bool aliased_last_b_ = false;
+  int last_notes_ = 0;
   int64_t host_values_uploaded_bytes_ = 0;
   ExecutionSummary execution_summary_;
 };

@@ -148,12 +148,19 @@ typedef struct {
                           * left in HBM, cx_evaluator_device_residuals) */
 } cx_per_solve_options;
 
-/* LinearSolver::Summary (linear_solver.h:320-326) */
+/* LinearSolver::Summary (linear_solver.h:320-326) + notes: options that were answered differently from how they were
+ * asked, machine-readable (the message says the same in words; the host adapter logs them):
+ *   CX_NOTE_DOUBLE_PRECISION_FACTOR      use_mixed_precision_solves on a dynamic-size structure (or a dense S no tile plan
+ *                                        fits): the factorisation ran in double precision -- more accurate than asked, not faster;
+ *   CX_NOTE_SPSE_INITIALIZATION_SKIPPED  use_spse_initialization on a dynamic-size structure: CG started from zero. */
+enum { CX_NOTE_DOUBLE_PRECISION_FACTOR = 1, CX_NOTE_SPSE_INITIALIZATION_SKIPPED = 2 };
 typedef struct {
   double residual_norm;
   int32_t num_iterations;
   int32_t termination_type;  /* cx_termination */
   char message[256];
+  int32_t notes;             /* CX_NOTE_* bits */
+  int32_t reserved;
 } cx_summary;
 
 /* Phase timings of the last solve in milliseconds (device time, HIP events);
