@@ -39,7 +39,7 @@ EXPORTED_SYMBOLS = [
     "cx_implicit_schur_multiply", "cx_dense_cholesky_solve", "cx_evaluator_create_bal", "cx_evaluator_destroy",
     "cx_evaluator_jacobian", "cx_evaluator_row_of_observation", "cx_evaluator_evaluate", "cx_evaluator_set_loss", "cx_minimizer_default_options", "cx_minimize", "cx_schur_sparse_structure", "cx_visibility_structure", "cx_visibility_clusters_host",
     "cx_evaluator_set_camera_model", "cx_evaluator_num_parameters", "cx_evaluator_num_effective_parameters", "cx_evaluator_plus",
-    "cx_context_set_comm_timeout", "cx_debug_inject_failure", "cx_debug_stall_stream", "cx_debug_force_rank_count",
+    "cx_context_set_comm_timeout", "cx_debug_inject_failure", "cx_debug_stall_stream", "cx_debug_force_rank_count", "cx_evaluator_device_residuals_match",
     "cx_matrix_right_multiply_overwrite", "cx_host_registration_policy", "cx_host_register", "cx_host_registrations_release", "cx_transfer_stats_get",
     "cx_evaluator_last_kernel_ms", "cx_evaluator_device_residuals", "cx_evaluator_set_emit_camera_major", "cx_sparse_cholesky_plan_host", "cx_sparse_cholesky_schedule_host", "cx_detect_structure", "cx_partition_points", "cx_stable_schur_ordering",
 ]

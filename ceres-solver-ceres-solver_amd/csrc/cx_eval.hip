@@ -923,6 +923,44 @@ const double* cx_evaluator_device_residuals(const cx_evaluator* e) {
   return (e && e->res_valid) ? e->d_res.p : nullptr;
 }
 
+// 64 entries of the device copy, evenly spread (first and last included), for the check below
+__global__ void k_sample_vector(const double* __restrict__ v, int64_t n, double* __restrict__ out) {
+  const int t = threadIdx.x;
+  if (t < 64) out[t] = v[n <= 64 ? min(int64_t(t), n - 1) : (int64_t(t) * (n - 1)) / 63];
+}
+
+int cx_evaluator_device_residuals_match(cx_evaluator* e, const double* host_residuals, int32_t* match) {
+  CX_CHECK_ARG(e != nullptr && host_residuals != nullptr && match != nullptr);
+  *match = 0;
+  if (!e->parts.empty()) {  // a front: every shard checks its own rows
+    int32_t all = 1;
+    const cx_matrix* A = e->J;
+    for (size_t i = 0; i < e->parts.size() && all; ++i) {
+      int32_t m = 0;
+      CX_TRY(cx_evaluator_device_residuals_match(e->parts[i], host_residuals + A->part_row0[i], &m));
+      all = all && m;
+    }
+    *match = all;
+    return CX_OK;
+  }
+  if (!e->res_valid || e->d_res.p == nullptr) return CX_OK;
+  cx_context* ctx = e->ctx;
+  CX_HIP(hipSetDevice(ctx->device));
+  const int64_t n = e->J->num_rows;
+  if (n == 0) { *match = 1; return CX_OK; }
+  CX_TRY(e->d_sample.alloc(64));
+  hipLaunchKernelGGL(k_sample_vector, dim3(1), dim3(64), 0, ctx->stream, (const double*)e->d_res.p, n, e->d_sample.p);
+  double got[64];
+  CX_TRY(cx_read_back(ctx, got, e->d_sample.p, sizeof(got)));
+  int32_t same = 1;
+  for (int t = 0; t < 64 && same; ++t) {
+    const int64_t i = n <= 64 ? std::min<int64_t>(t, n - 1) : (int64_t(t) * (n - 1)) / 63;
+    same = std::memcmp(&got[t], &host_residuals[i], sizeof(double)) == 0;
+  }
+  *match = same;
+  return CX_OK;
+}
+
 int cx_evaluator_set_emit_camera_major(cx_evaluator* e, int32_t on) {
   CX_CHECK_ARG(e != nullptr);
   e->emit_ft = on != 0;

@@ -400,6 +400,7 @@ struct cx_evaluator {
   DevBuf<double> d_obs;              // [2O] in row order
   DevBuf<double> d_partial, d_state, d_res;
   DevBuf<double> d_scratch_values, d_scratch_Ft;  // J of a gradient-only evaluation (the matrix keeps its values)
+  DevBuf<double> d_sample;           // 64 sampled entries (cx_evaluator_device_residuals_match)
   DevBuf<double> d_col_scale;        // [3P + 9C] column scales applied by Jacobian evaluations (cx_evaluator_set_column_scale)
   bool has_col_scale = false;
   bool emit_ft = true;               // Jacobian evaluations also write the camera-major copy of F (cx_matrix::d_Ft)

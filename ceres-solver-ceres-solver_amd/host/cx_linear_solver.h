@@ -143,9 +143,11 @@ class CxLinearSolver final : public LinearSolver {
   // When the right-hand side handed to Solve is the very host array the CxBalEvaluator behind the Jacobian last
   // wrote its residuals to -- which is what LevenbergMarquardtStrategy::ComputeStep passes
   // (levenberg_marquardt_strategy.cc:113, trust_region_minimizer.cc:404-408) -- use the copy the evaluator kept in
-  // HBM instead of uploading 2 * num_residual_blocks doubles again.  Off by default: LinearSolver::Solve promises
-  // nothing about who owns b, so the caller has to vouch that it does not modify the residual array between
-  // Evaluate and Solve (TrustRegionMinimizer does not).
+  // HBM instead of uploading 2 * num_residual_blocks doubles again.  LinearSolver::Solve promises nothing about who
+  // owns b (TrustRegionMinimizer does not modify the residual array between Evaluate and Solve, another caller might).
+  // Round 4: ON by default, because the pointer alone is not trusted: before the device copy is used, 64 entries of it spread over
+  // the vector are compared bit for bit with the host array (cx_evaluator_device_residuals_match: a 512-byte copy); a
+  // caller that has touched its residuals between Evaluate and Solve gets them uploaded as before.
   void set_alias_evaluator_residuals(bool on) { alias_evaluator_residuals_ = on; }
 
   LinearSolver::Summary Solve(LinearOperator* A, const double* b, const LinearSolver::PerSolveOptions& per_solve_options,
@@ -172,8 +174,11 @@ class CxLinearSolver final : public LinearSolver {
     int64_t uploaded_values_bytes = 0;
     if (device_jacobian != nullptr) {
       matrix = device_jacobian->device_matrix();  // values are in HBM already
-      if (alias_evaluator_residuals_ && device_jacobian->handle()->last_residuals_host == b)
-        device_b = cx_evaluator_device_residuals(device_jacobian->handle()->evaluator);
+      if (alias_evaluator_residuals_ && device_jacobian->handle()->last_residuals_host == b) {
+        int32_t same = 0;
+        if (cx_evaluator_device_residuals_match(device_jacobian->handle()->evaluator, b, &same) == CX_OK && same)
+          device_b = cx_evaluator_device_residuals(device_jacobian->handle()->evaluator);
+      }
     } else if (auto* host_jacobian = dynamic_cast<BlockSparseMatrix*>(A)) {
       if (owned_matrix_ == nullptr) {  // structure is fixed for the life of the solver (linear_solver.h:137-142)
         CxFlatStructure flat(*host_jacobian->block_structure());
@@ -279,7 +284,7 @@ class CxLinearSolver final : public LinearSolver {
   cx_matrix* owned_matrix_ = nullptr;  // only for host BlockSparseMatrix Jacobians
   cx_solver* solver_ = nullptr;
   cx_solve_timing timing_{};
-  bool alias_evaluator_residuals_ = false;
+  bool alias_evaluator_residuals_ = true;
   bool aliased_last_b_ = false;
   int last_notes_ = 0;
   int64_t host_values_uploaded_bytes_ = 0;

@@ -705,15 +705,35 @@ static void TestEvaluatorToSolverThroughTheInterfaces() {
   EXPECT(device_solver.Statistics().at("LinearSolver::Solve").calls == device_trace.num_successful + device_trace.num_unsuccessful,
          "LinearSolver::Solve call count");
 
-  // (ii) the same loop with the residual vector aliased to the evaluator's device copy: identical arithmetic
+  // (ii) the residual vector is aliased to the evaluator's device copy by default (round 4: the pointer match is backed by
+  // a sampled bit-for-bit comparison): identical arithmetic with it switched off ...
+  EXPECT(device_solver.last_solve_aliased_residuals(), "residual aliasing is the default");
   {
     std::unique_ptr<Evaluator> evaluator2 = CxBalEvaluator::TryCreate(evaluator_options, &bal.program, &why);
     std::unique_ptr<SparseMatrix> jacobian2 = evaluator2->CreateJacobian();
-    CxLinearSolver aliasing_solver(solver_options);
-    aliasing_solver.set_alias_evaluator_residuals(true);
-    LmTrace t = RunTrustRegionLoop(evaluator2.get(), jacobian2.get(), &aliasing_solver, x0, kIterations, kEta);
-    EXPECT(t.ok && aliasing_solver.last_solve_aliased_residuals(), "residual aliasing was not taken");
+    CxLinearSolver uploading_solver(solver_options);
+    uploading_solver.set_alias_evaluator_residuals(false);
+    LmTrace t = RunTrustRegionLoop(evaluator2.get(), jacobian2.get(), &uploading_solver, x0, kIterations, kEta);
+    EXPECT(t.ok && !uploading_solver.last_solve_aliased_residuals(), "aliasing switched off must upload b");
     EXPECT(t.costs == device_trace.costs && t.linear_iterations == device_trace.linear_iterations, "aliased residuals change nothing");
+    // ... and a caller that HAS touched its residual array between Evaluate and Solve gets its own b, not the stale copy
+    std::vector<double> residuals(static_cast<size_t>(evaluator2->NumResiduals())), step_a(x0.size()), step_b(x0.size()), D(x0.size(), 1.0);
+    double cost = 0.0;
+    Evaluator::EvaluateOptions eo;
+    EXPECT(evaluator2->Evaluate(eo, x0.data(), &cost, residuals.data(), nullptr, jacobian2.get()), "evaluate");
+    CxLinearSolver solver_a(solver_options), solver_b(solver_options);
+    LinearSolver::PerSolveOptions ps;
+    ps.D = D.data();
+    ps.q_tolerance = 1e-6;
+    ps.r_tolerance = -1.0;
+    solver_a.Solve(jacobian2.get(), residuals.data(), ps, step_a.data());
+    EXPECT(solver_a.last_solve_aliased_residuals(), "untouched residuals are aliased");
+    for (size_t i = 0; i < residuals.size(); ++i) residuals[i] *= 2.0;
+    solver_b.Solve(jacobian2.get(), residuals.data(), ps, step_b.data());
+    EXPECT(!solver_b.last_solve_aliased_residuals(), "modified residuals must not be aliased");
+    double worst = 0.0, scale = 0.0;
+    for (size_t i = 0; i < step_a.size(); ++i) { worst = std::max(worst, std::abs(step_b[i] - 2.0 * step_a[i])); scale = std::max(scale, std::abs(step_a[i])); }
+    EXPECT(worst <= 1e-4 * scale, "the solve of the doubled residuals is twice the step: %.3e vs scale %.3e", worst, scale);
   }
 
   // (ii b) Jacobi scaling folded into the evaluation (set_fuse_jacobi_scaling): J carries the same bits as after
@@ -1052,7 +1072,7 @@ static int TimeBoundary(int argc, char** argv) {
   solver_options.min_num_iterations = 0;
   solver_options.max_num_iterations = 500;
   CxLinearSolver solver(solver_options);
-  if (!plain) solver.set_alias_evaluator_residuals(true);
+  solver.set_alias_evaluator_residuals(!plain);
   cx_context* ctx = CxSharedContext();
   LoopClock clock;
   clock.skip_iterations = warmup;

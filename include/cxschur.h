@@ -482,6 +482,11 @@ int cx_evaluator_set_column_scale(cx_evaluator* e, const double* scale, int32_t 
  * cx_per_solve_options.b_on_device = 1, without a second trip across PCIe.  Valid until the next evaluate that
  * produces residuals. */
 const double* cx_evaluator_device_residuals(const cx_evaluator* e);
+/* *match = 1 when the host array still holds what the device copy holds: 64 entries spread over the vector (first and last
+ * included) are brought back and compared bit for bit -- a 512-byte copy instead of the 16 bytes per residual block that
+ * re-uploading b costs.  What lets the host adapter alias b to the device copy BY DEFAULT: LinearSolver::Solve promises
+ * nothing about who owns b, so the adapter does not take the pointer's word for it. */
+int cx_evaluator_device_residuals_match(cx_evaluator* e, const double* host_residuals, int32_t* match);
 
 /* -------------------------------------------------------------- minimizer */
 
