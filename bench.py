@@ -280,7 +280,18 @@ def main():
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="gloo", rank=rank, world_size=world)   # control plane only
+        # control plane only.  (Gloo announces its connections on STDOUT -- "[Gloo] Rank 0 is connected to 1 peer ranks" -- and
+        # stdout is where the ONE JSON line goes: file descriptor 1 points at stderr while the process group forms.)
+        sys.stdout.flush()
+        saved_stdout = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+            dist.barrier()
+        finally:
+            sys.stdout.flush()
+            os.dup2(saved_stdout, 1)
+            os.close(saved_stdout)
     ctx = cx.Context(local_rank)
     if world > 1 and os.environ.get("CX_BENCH_TRANSPORT") == "gloo":
         # rehearsal only (several ranks sharing one GPU, where RCCL refuses to form a communicator): the

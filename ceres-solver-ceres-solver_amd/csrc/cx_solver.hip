@@ -796,7 +796,7 @@ struct CgDriver {
     // (CX_NO_SMALL_CG=1: the general path, for A/B runs and the bit-equality test).
     static const bool small_allowed = std::getenv("CX_NO_SMALL_CG") == nullptr;
     SmallProduct probe;
-    if (small_allowed && fused() && n <= kSmallCgMax && pre.block9_inverse() != nullptr) {
+    if (small_allowed && ctx->nranks <= 1 && fused() && n <= kSmallCgMax && pre.block9_inverse() != nullptr) {  // (one rank: a speculative iteration must not enter a collective)
       CX_TRY(enqueue_head(1, pre, p, r, z, ds));
       bool small_ok = true;
       int last_enqueued = 0;

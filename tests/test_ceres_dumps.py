@@ -78,7 +78,10 @@ def test_dumped_system_through_the_c_abi(solver, oracle):
     # parity: the oracle's exact solve of the same loaded values; the dumped x (six decimals of a system whose values had
     # more) only as far as the format's rounding allows
     x_r, _ = oracle.solve(bs, values, d["b"], d["D"], oracle.make_options(type=oracle.DENSE_SCHUR, num_eliminate_blocks=nelim))
-    assert np.abs(x - x_r).max() <= (1e-10 if solver in ("DENSE_SCHUR", "SPARSE_SCHUR") else 1e-6) * np.abs(x_r).max(), solver
+    # (direct solves to rounding; the CG solvers as far as 2000 iterations at r_tolerance 1e-12 take them -- CGNR works on
+    # the squared condition number)
+    tol = {"DENSE_SCHUR": 1e-10, "SPARSE_SCHUR": 1e-10, "ITERATIVE_SCHUR": 1e-6, "CGNR": 2e-5}[solver]
+    assert np.abs(x - x_r).max() <= tol * np.abs(x_r).max(), solver
     assert np.abs(x - d["x"]).max() <= 5e-4 * np.abs(d["x"]).max(), solver
     S.close()
     A.close()
