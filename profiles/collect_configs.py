@@ -37,7 +37,7 @@ def bench(args, eta):
     if "--force-tile-sparse" in args:      # SPARSE_SCHUR stays dense below 512 cameras unless told otherwise
         env["CX_SPARSE_CHOLESKY"] = "1"
         args = args.replace(" --force-tile-sparse", "")
-    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--no-cpu-baseline", "--no-sparse-schur", "--eta", str(eta)] + args.split()
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--no-cpu-baseline", "--no-sparse-schur", "--no-boundary", "--eta", str(eta)] + args.split()
     out = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True, check=True, env=env).stdout
     return json.loads([l for l in out.splitlines() if l.startswith("{")][-1])
 

@@ -4,7 +4,7 @@ set -o pipefail
 OUT=$GRAFT_REPO_ROOT/gpurun_out/pmc_sparse
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/fetch -- python3 $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --no-sparse-schur --solver sparse_schur --steps 1 --warmup 1 > /dev/null 2> $OUT/fetch.err
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/fetch -- python3 $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --no-sparse-schur --solver sparse_schur $BENCH_ARGS --steps 1 --warmup 1 > /dev/null 2> $OUT/fetch.err
 cp $(ls $OUT/fetch/*/*counter_collection.csv | head -1) $OUT/fetch.csv && rm -rf $OUT/fetch
 python3 - <<PY
 import csv, collections
