@@ -25,6 +25,7 @@ struct UniqueId { char internal[128]; };
 using GetUniqueIdFn = int (*)(UniqueId*);
 using CommInitRankFn = int (*)(void**, int, UniqueId, int);
 using AllReduceFn = int (*)(const void*, void*, size_t, int, int, void*, hipStream_t);
+using ReduceScatterFn = int (*)(const void*, void*, size_t, int, int, void*, hipStream_t);
 using CommDestroyFn = int (*)(void*);
 using CommAbortFn = int (*)(void*);
 using GetErrorStringFn = const char* (*)(int);
@@ -33,6 +34,7 @@ struct Rccl {
   GetUniqueIdFn get_unique_id = nullptr;
   CommInitRankFn comm_init_rank = nullptr;
   AllReduceFn all_reduce = nullptr;
+  ReduceScatterFn reduce_scatter = nullptr;
   CommDestroyFn comm_destroy = nullptr;
   CommAbortFn comm_abort = nullptr;
   GetErrorStringFn error_string = nullptr;
@@ -55,6 +57,7 @@ int LoadRccl() {
   g_rccl.get_unique_id = reinterpret_cast<GetUniqueIdFn>(dlsym(h, "ncclGetUniqueId"));
   g_rccl.comm_init_rank = reinterpret_cast<CommInitRankFn>(dlsym(h, "ncclCommInitRank"));
   g_rccl.all_reduce = reinterpret_cast<AllReduceFn>(dlsym(h, "ncclAllReduce"));
+  g_rccl.reduce_scatter = reinterpret_cast<ReduceScatterFn>(dlsym(h, "ncclReduceScatter"));
   g_rccl.comm_destroy = reinterpret_cast<CommDestroyFn>(dlsym(h, "ncclCommDestroy"));
   g_rccl.comm_abort = reinterpret_cast<CommAbortFn>(dlsym(h, "ncclCommAbort"));
   g_rccl.error_string = reinterpret_cast<GetErrorStringFn>(dlsym(h, "ncclGetErrorString"));
@@ -259,6 +262,46 @@ int cx_allreduce_collect(cx_context* ctx, double* device_ms, double* host_ms, do
 }
 
 int cx_allreduce_device(cx_context* ctx, double* p, int64_t n) { return AllReduce(ctx, p, n, false); }
+
+int cx_reduce_scatter_device(cx_context* ctx, double* send, double* recv, int64_t count) {
+  if (count == 0) return CX_OK;
+  if (ctx->nranks <= 1) {
+    CX_HIP(hipMemcpyAsync(recv, send, size_t(count) * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+    return CX_OK;
+  }
+  if (ctx->comm_broken) {
+    cx_set_error("the communicator of this context was aborted after a lost rank");
+    return CX_ERR_COMM;
+  }
+  const int64_t total = count * ctx->nranks;
+  const bool native = ctx->reduce_scatter_cb != nullptr || (ctx->allreduce_cb == nullptr && ctx->comm != nullptr && g_rccl.reduce_scatter != nullptr);
+  if (!native) {  // a transport that only sums whole buffers: sum, keep the own range
+    CX_TRY(AllReduce(ctx, send, total, false));
+    CX_HIP(hipMemcpyAsync(recv, send + int64_t(ctx->rank) * count, size_t(count) * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+    return CX_OK;
+  }
+  if (ctx->fail_countdown >= 0 && ctx->fail_countdown-- == 0) {
+    ctx->fail_countdown = -1;
+    cx_set_error("injected failure before a collective (cx_debug_inject_failure)");
+    return CX_ERR_HIP;
+  }
+  ctx->ar_calls += 1;
+  ctx->ar_bytes += total * int64_t(sizeof(double)) / 2;  // what it moves, in all-reduce terms
+  if (ctx->reduce_scatter_cb) {
+    CX_HIP(hipStreamSynchronize(ctx->stream));
+    auto t0 = std::chrono::steady_clock::now();
+    if (ctx->reduce_scatter_cb(send, recv, count, ctx->allreduce_cb_user) != 0) {
+      cx_set_error("reduce-scatter callback failed");
+      return CX_ERR_COMM;
+    }
+    ctx->allreduce_host_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    return CX_OK;
+  }
+  auto t0 = std::chrono::steady_clock::now();
+  const int rc = g_rccl.reduce_scatter(send, recv, size_t(count), kNcclFloat64, kNcclSum, ctx->comm, ctx->stream);
+  ctx->allreduce_host_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+  return RcclCheck(rc, "ncclReduceScatter");
+}
 
 extern "C" {
 

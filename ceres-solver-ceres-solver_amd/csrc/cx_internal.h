@@ -81,6 +81,9 @@ struct cx_context {
   void* comm = nullptr;
   int (*allreduce_cb)(double*, int64_t, void*) = nullptr;  // rehearsal transport (cx_context_set_comm_callback)
   void* allreduce_cb_user = nullptr;
+  // in-process transport of a multi-shard front: recv[0, count) = sum over the ranks of send[rank * count ...) (NULL: a
+  // callback transport without it sums the whole send buffer and keeps its own range)
+  int (*reduce_scatter_cb)(double*, double*, int64_t, void*) = nullptr;
   int rank = 0;
   int nranks = 1;
   bool comm_broken = false;        // the communicator was aborted after a lost rank (cx_comm_abort): no sharded work any more
@@ -123,6 +126,8 @@ struct cx_sp_plan {
   // before cxsp_assemble / cxsp_factor_and_solve*, vectors and the 32 x 32 block inverses stay double
   bool f32 = false;
   bool replicate = false;  // sharded: keep the whole factor on every rank (refinement solves need cxsp_solve), see cxsp_build_plan_sharded
+  bool built_replicate = false;                 // how the current plan was built (the option may differ from solve to solve)
+  std::vector<int32_t> h_union_c1, h_union_c2;  // the union cell list, kept so that re-planning needs no second exchange
   DevBuf<float> d_W32;
   // sharded matrix (points over ranks): the plan is built from the UNION of the ranks' S cells; a rank scatters its own
   // cell values into the common cell-major array, which is summed over the ranks and assembled into the pool
@@ -136,6 +141,12 @@ struct cx_sp_plan {
   DevBuf<int32_t> d_shared_tiles;    // pool slots of the replicated rows' tiles (summed over the ranks at the split)
   DevBuf<int32_t> d_row_keep;        // [T] 1: this rank contributes the row's part of the solution to the final sum
   DevBuf<double> d_exchange;         // packed shared tiles + one slot for the not-positive-definite flag
+  // cell values by owner (round 4): [nranks][rs_chunk_cells] union cell ids (-1 padding), rank r's range = the cells its
+  // tile rows (rank 0: and the replicated rows) are assembled from -- the ranges of the reduce-scatter of a solve
+  int64_t rs_chunk_cells = 0;
+  DevBuf<int32_t> d_rs_cells;
+  DevBuf<int32_t> d_cell_mine;       // [union cells] 1: this rank assembles the cell
+  DevBuf<double> d_rs_send, d_rs_recv;
   std::vector<int64_t> h_work_per_rank;
   int64_t h_work_shared = 0;
 };
@@ -373,6 +384,10 @@ int cxk_ft_multiply(cx_matrix* A, const double* t, double* y_f, bool accumulate)
 int cxk_ft_partials(cx_matrix* A, const double* t);
 
 int cx_allreduce_device(cx_context* ctx, double* p, int64_t n);
+// recv[0, count) = sum over the ranks q of send_q[rank * count, (rank + 1) * count): every rank contributes nranks * count
+// doubles and receives the sum of its own range only (ncclReduceScatter; half the traffic of an all-reduce of the same
+// buffer, and counted so in the exchange statistics).  send may be overwritten.
+int cx_reduce_scatter_device(cx_context* ctx, double* send, double* recv, int64_t count);
 // waits that cannot hang on a lost rank (cx_context.cpp): plain waits on a context without an RCCL communicator of
 // several ranks, polling with a deadline + ncclCommAbort otherwise.  st == NULL: the context stream
 int cx_stream_sync(cx_context* ctx, hipStream_t st);

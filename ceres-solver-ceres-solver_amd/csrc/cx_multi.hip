@@ -40,6 +40,16 @@ __global__ void k_sum_shards(ShardPtrs ptrs, int n, int64_t len) {
   for (int r = 0; r < n; ++r) ptrs.p[r][i] = s;
 }
 
+// recv_r[k] = sum over the shards q of send_q[r * count + k], added in rank order
+__global__ void k_reduce_scatter_shards(ShardPtrs send, ShardPtrs recv, int n, int64_t count) {
+  const int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i >= int64_t(n) * count) return;
+  const int r = int(i / count);
+  double s = send.p[0][i];
+  for (int q = 1; q < n; ++q) s += send.p[q][i];
+  recv.p[r][i - int64_t(r) * count] = s;
+}
+
 }  // namespace
 
 // cx_context::group points at this: the plain threading (cx_shard_group.h, sanitizer-tested on the CPU) plus what the
@@ -80,6 +90,18 @@ int InprocAllReduce(double* p, int64_t len, void* user) {
     ShardPtrs ptrs;
     for (int r = 0; r < n; ++r) ptrs.p[r] = bufs[r];
     hipLaunchKernelGGL(k_sum_shards, dim3(unsigned((count + 255) / 256)), dim3(256), 0, g->stream0, ptrs, n, count);
+    return (hipGetLastError() != hipSuccess || hipStreamSynchronize(g->stream0) != hipSuccess) ? -1 : 0;
+  });
+}
+
+int InprocReduceScatter(double* send, double* recv, int64_t count, void* user) {
+  auto* u = static_cast<cx_front_group::CbUser*>(user);
+  cx_front_group* g = u->g;
+  return g->exchange2(u->rank, send, recv, count, [g](double* const* sends, double* const* recvs, int n, int64_t cnt) -> int {
+    ShardPtrs a, b;
+    for (int r = 0; r < n; ++r) { a.p[r] = sends[r]; b.p[r] = recvs[r]; }
+    const int64_t total = int64_t(n) * cnt;
+    hipLaunchKernelGGL(k_reduce_scatter_shards, dim3(unsigned((total + 255) / 256)), dim3(256), 0, g->stream0, a, b, n, cnt);
     return (hipGetLastError() != hipSuccess || hipStreamSynchronize(g->stream0) != hipSuccess) ? -1 : 0;
   });
 }
@@ -164,6 +186,7 @@ extern "C" int cx_context_create_multi(int num_shards, const int* device_ids, cx
         g->users[i] = {g, i};
         rc = cx_context_set_comm_callback(front->shards[size_t(i)], i, num_shards, InprocAllReduce, &g->users[i]);
         if (rc != CX_OK) break;
+        front->shards[size_t(i)]->reduce_scatter_cb = InprocReduceScatter;
       }
     } else {
       char id[128];

@@ -51,6 +51,7 @@ struct cx_shard_group {
   uint64_t bgen = 0;
   bool aborted = false;
   double* ptrs[kMaxShards] = {};
+  double* ptrs2[kMaxShards] = {};  // a second buffer per shard (reduce-scatter: where the shard's own range of the sum goes)
   int64_t lens[kMaxShards] = {};
 
   void start(int num_shards) {
@@ -83,9 +84,15 @@ struct cx_shard_group {
   // The in-process all-reduce as a protocol: deposit, meet, shard 0 runs `combine` over the deposited buffers, meet.
   // combine returns 0 on success; on failure the exchange is aborted for everybody.
   int exchange(int rank, double* p, int64_t len, const std::function<int(double* const*, int, int64_t)>& combine) {
+    return exchange2(rank, p, nullptr, len, [&](double* const* a, double* const*, int n_, int64_t l) { return combine(a, n_, l); });
+  }
+  // the same with two buffers per shard (combine sees both arrays)
+  int exchange2(int rank, double* p, double* q, int64_t len,
+                const std::function<int(double* const*, double* const*, int, int64_t)>& combine) {
     {
       std::lock_guard<std::mutex> lk(bm);
       ptrs[rank] = p;
+      ptrs2[rank] = q;
       lens[rank] = len;
     }
     if (barrier() != 0) return -1;
@@ -96,7 +103,7 @@ struct cx_shard_group {
         for (int r = 1; r < n; ++r)
           if (lens[r] != len) ok = -1;  // the shards disagree about the collective: a bug, not a transient
       }
-      if (ok == 0) ok = combine(ptrs, n, len);
+      if (ok == 0) ok = combine(ptrs, ptrs2, n, len);
       if (ok != 0) abort_exchange();
     }
     if (barrier() != 0) return -1;

@@ -99,12 +99,13 @@ __global__ __launch_bounds__(3 * 81) void k_sp_assemble(const int32_t* __restric
 // right-hand side (camera order) -> column 0 of every tile row's last tile
 template <typename TW>
 __global__ void k_sp_rhs(const double* __restrict__ rhs, const int32_t* __restrict__ cam_pos, const int32_t* __restrict__ row_start,
-                         TW* __restrict__ W, int C) {
+                         TW* __restrict__ W, int C, const int32_t* __restrict__ row_keep = nullptr) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= 9 * C) return;
   const int c = i / 9, a = i - 9 * c;
   const int row = cam_pos[c] + a;
   const int I = row >> 6;
+  if (row_keep && !row_keep[I]) return;  // (distributed: a replicated row's right-hand side enters the sum at the split once, on rank 0)
   W[size_t(row_start[I + 1] - 1) * kTileDoubles + (row & 63) * kTile] = TW(rhs[i]);
 }
 
@@ -1556,6 +1557,46 @@ int cxsp_plan_from_cells(cx_context* ctx, int C, const int32_t* cell_c1, const i
     P->num_shared_tiles = int64_t(shared_tiles.size());
     CX_TRY(P->d_shared_tiles.upload(shared_tiles, st));
     CX_TRY(P->d_row_keep.upload(keep, st));
+    // Round 4: who needs which cell of S.  A cell's entries land in the tile rows of its camera that comes first in the
+    // elimination order (one row, or two when the camera's nine rows straddle a 64-row boundary); the rank that factors
+    // such a row needs the cell summed over the ranks, a replicated row's assembled values count on rank 0 only
+    // (cxsp_factor_and_solve_sharded) -- nobody else needs the cell at all.  The ranks' lists, padded to the longest, are
+    // the ranges of ONE reduce-scatter that replaces the all-reduce of every cell to every rank.
+    {
+      const int nr = ctx->nranks;
+      std::vector<std::vector<int32_t>> need(static_cast<size_t>(nr));
+      // cells of rows with an owner first; then the cells that only replicated rows need, each to the rank with the shortest
+      // list so far (any ONE rank may bring such a cell into the sum at the split).  A cell that straddles an owned and a
+      // replicated row goes to that owner alone -- it would assemble the replicated row's part anyway.
+      std::vector<int64_t> only_shared;
+      for (int64_t k = 0; k < num_cells; ++k) {
+        const int32_t p0 = std::min(layout.cam_row[size_t(cell_c1[k])], layout.cam_row[size_t(cell_c2[k])]);
+        const int32_t o0 = H.owner[size_t(p0 >> 6)], o1 = H.owner[size_t((p0 + 8) >> 6)];
+        if (o0 < 0 && o1 < 0) { only_shared.push_back(k); continue; }
+        if (o0 >= 0) need[size_t(o0)].push_back(int32_t(k));
+        if (o1 >= 0 && o1 != o0) need[size_t(o1)].push_back(int32_t(k));
+      }
+      for (int64_t k : only_shared) {
+        int best = 0;
+        for (int r = 1; r < nr; ++r)
+          if (need[size_t(r)].size() < need[size_t(best)].size()) best = r;
+        need[size_t(best)].push_back(int32_t(k));
+      }
+      std::vector<int32_t> mine(static_cast<size_t>(std::max<int64_t>(num_cells, 1)), 0);
+      for (int32_t k : need[size_t(ctx->rank)]) mine[size_t(k)] = 1;
+      CX_TRY(P->d_cell_mine.upload(mine, st));
+      size_t chunk = 1;
+      for (const auto& v : need) chunk = std::max(chunk, v.size());
+      std::vector<int32_t> send_cells(size_t(nr) * chunk, -1);
+      for (int r = 0; r < nr; ++r) std::copy(need[size_t(r)].begin(), need[size_t(r)].end(), send_cells.begin() + int64_t(size_t(r) * chunk));
+      P->rs_chunk_cells = int64_t(chunk);
+      CX_TRY(P->d_rs_cells.upload(send_cells, st));
+      if (std::getenv("CX_SPARSE_CHOLESKY_VERBOSE")) {
+        std::fprintf(stderr, "[cxschur] cell values by owner, rank %d: %lld cells in the union, ranges of %lld cells (", ctx->rank, (long long)num_cells, (long long)chunk);
+        for (const auto& v : need) std::fprintf(stderr, " %zu", v.size());
+        std::fprintf(stderr, " ): %.2f GB into the reduce-scatter instead of %.2f GB all-reduced\n", double(nr) * double(chunk) * 648e-9, double(num_cells) * 648e-9);
+      }
+    }
     P->h_work_per_rank = H.work_per_rank;
     P->h_work_shared = H.work_shared;
     if (std::getenv("CX_SPARSE_CHOLESKY_VERBOSE")) {
@@ -1598,10 +1639,14 @@ int WithPool(cx_sp_plan* P, F&& f) {
 }
 int AllocPool(cx_sp_plan* P, hipStream_t st) {
   const size_t pool = size_t(P->num_tiles) * kTileDoubles;
+  // (f32 is a per-solve option: a matrix solved now with one pool, now with the other keeps only the one in use -- the
+  // other's gigabytes go back to the allocator after the stream has drained, which hipFree waits for)
   if (P->f32) {
+    P->d_W.release();
     CX_TRY(P->d_W32.alloc(pool));
     CX_HIP(hipMemsetAsync(P->d_W32.p, 0, pool * sizeof(float), st));
   } else {
+    P->d_W32.release();
     CX_TRY(P->d_W.alloc(pool));
     CX_HIP(hipMemsetAsync(P->d_W.p, 0, pool * sizeof(double), st));
   }
@@ -1868,6 +1913,22 @@ __global__ void k_sp_mark_cells(const int32_t* __restrict__ c1, const int32_t* _
   if (k < num_cells) present[int64_t(c1[k]) * C + c2[k]] = 1.0;
 }
 // this rank's cell values into their slots of the union's cell-major array (81 doubles per cell)
+// the reduce-scatter of the cell values by owner: pack the ranks' ranges out of the (local) union array, unpack the own
+// range of the sum back into it
+__global__ void k_sp_pack_cells(const double* __restrict__ values, const int32_t* __restrict__ cells, int64_t n, double* __restrict__ packed) {
+  const int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i >= n * 81) return;
+  const int64_t k = i / 81;
+  const int32_t c = cells[k];
+  packed[i] = c >= 0 ? values[int64_t(c) * 81 + (i - k * 81)] : 0.0;
+}
+__global__ void k_sp_unpack_cells(const double* __restrict__ packed, const int32_t* __restrict__ cells, int64_t n, double* __restrict__ values) {
+  const int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i >= n * 81) return;
+  const int64_t k = i / 81;
+  const int32_t c = cells[k];
+  if (c >= 0) values[int64_t(c) * 81 + (i - k * 81)] = packed[i];
+}
 __global__ void k_sp_scatter_cells(const double* __restrict__ local, const int32_t* __restrict__ local_to_union, int64_t num_cells,
                                    double* __restrict__ values) {
   const int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
@@ -1881,9 +1942,10 @@ __global__ __launch_bounds__(3 * 81) void k_sp_assemble_values(const int32_t* __
                                                                const double* __restrict__ values, const double* __restrict__ Df,
                                                                const int32_t* __restrict__ cam_pos, const int32_t* __restrict__ row_start,
                                                                const int32_t* __restrict__ row_tiles, TW* __restrict__ W,
-                                                               int64_t num_cells) {
+                                                               int64_t num_cells, const int32_t* __restrict__ mine = nullptr) {
   const int64_t cell = int64_t(blockIdx.x) * 3 + threadIdx.x / 81;
   if (cell >= num_cells) return;
+  if (mine && !mine[cell]) return;  // (cell values by owner: another rank assembles this cell, D_f^2 included)
   const int el = threadIdx.x % 81;
   const int c1 = cell_c1[cell], c2 = cell_c2[cell];
   const int a = el / 9, c = el - a * 9;
@@ -1905,9 +1967,16 @@ int cxsp_build_plan_sharded(cx_matrix* A) {
   cx_sp_plan* P = &A->sp;
   // (the solves with a stored factor that iterative refinement needs, cxsp_solve, exist for a whole factor only: a plan that
   // was distributed is rebuilt when the caller now wants the factor replicated -- the same decision on every rank)
-  if (P->state == 1 && P->replicate && P->level_split >= 0) P->state = 0;
-  if (P->state != 0) return CX_OK;
+  // Round 4: and back -- an unrefined solve after a refined one gets its distributed factorisation again.  The
+  // flag is a per-solve option kept on the matrix' plan, so the plan remembers how it was built; re-planning uses the
+  // union cell list kept on the host (no second presence exchange), the same on every rank.
   cx_context* ctx = A->ctx;
+  if (P->state == 1 && P->built_replicate != P->replicate && !P->h_union_c1.empty()) {
+    P->built_replicate = P->replicate;
+    P->state = 0;
+    return cxsp_plan_from_cells(ctx, A->C, P->h_union_c1.data(), P->h_union_c2.data(), P->num_union_cells, P, /*distribute=*/!P->replicate);
+  }
+  if (P->state != 0) return CX_OK;
   hipStream_t st = ctx->stream;
   const int C = A->C;
   if (int64_t(C) > 16384) {  // (the same on every rank: all of them return here)
@@ -1970,7 +2039,11 @@ int cxsp_build_plan_sharded(cx_matrix* A) {
   CX_TRY(P->d_union_c1.upload(u1, st));
   CX_TRY(P->d_union_c2.upload(u2, st));
   CX_TRY(P->d_local_to_union.upload(local_to_union, st));
-  return cxsp_plan_from_cells(ctx, C, u1.data(), u2.data(), P->num_union_cells, P, /*distribute=*/!P->replicate);
+  P->built_replicate = P->replicate;
+  const int rc = cxsp_plan_from_cells(ctx, C, u1.data(), u2.data(), P->num_union_cells, P, /*distribute=*/!P->replicate);
+  P->h_union_c1.swap(u1);
+  P->h_union_c2.swap(u2);
+  return rc;
 }
 
 int cxsp_factor_and_solve_sharded(cx_matrix* A, const double* Df, const double* rhs, double* z, int* d_flag) {
@@ -1986,11 +2059,39 @@ int cxsp_factor_and_solve_sharded(cx_matrix* A, const double* Df, const double* 
     hipLaunchKernelGGL(k_sp_scatter_cells, dim3(unsigned((A->num_cells * 81 + 255) / 256)), dim3(256), 0, st, (const double*)A->d_S.p,
                        (const int32_t*)P->d_local_to_union.p, A->num_cells, P->d_union_values.p);
   CX_HIP(hipGetLastError());
-  CX_TRY(cx_allreduce_device(ctx, P->d_union_values.p, int64_t(count)));
-  CX_TRY(AllocPool(P, st));
   const bool distributed = P->level_split >= 0;
+  static const bool by_owner = !(std::getenv("CX_SPARSE_CELLS_BY_OWNER") && std::atoi(std::getenv("CX_SPARSE_CELLS_BY_OWNER")) == 0);  // A/B switch
+  if (distributed && by_owner && P->rs_chunk_cells > 0) {
+    // every tile row has ONE owner: a rank receives the sum of the cells its own rows (rank 0: and the replicated rows)
+    // are assembled from, nothing else -- a reduce-scatter over the ranks' cell lists instead of the all-reduce of all cells
+    const int64_t chunk = P->rs_chunk_cells, total = chunk * ctx->nranks;
+    CX_TRY(P->d_rs_send.alloc(size_t(total) * 81));
+    CX_TRY(P->d_rs_recv.alloc(size_t(chunk) * 81));
+    hipLaunchKernelGGL(k_sp_pack_cells, dim3(unsigned((total * 81 + 255) / 256)), dim3(256), 0, st, (const double*)P->d_union_values.p,
+                       (const int32_t*)P->d_rs_cells.p, total, P->d_rs_send.p);
+    CX_HIP(hipGetLastError());
+    CX_TRY(cx_reduce_scatter_device(ctx, P->d_rs_send.p, P->d_rs_recv.p, chunk * 81));
+    hipLaunchKernelGGL(k_sp_unpack_cells, dim3(unsigned((chunk * 81 + 255) / 256)), dim3(256), 0, st, (const double*)P->d_rs_recv.p,
+                       (const int32_t*)P->d_rs_cells.p + int64_t(ctx->rank) * chunk, chunk, P->d_union_values.p);
+    CX_HIP(hipGetLastError());
+  } else {
+    CX_TRY(cx_allreduce_device(ctx, P->d_union_values.p, int64_t(count)));
+  }
+  CX_TRY(AllocPool(P, st));
+  const bool cells_by_owner = distributed && by_owner && P->rs_chunk_cells > 0;
   CX_TRY(WithPool(P, [&](auto* W) -> int {
     using TW = std::remove_pointer_t<decltype(W)>;
+    if (cells_by_owner) {
+      // every rank assembles the cells of its own range only (the pool starts from zeros) and the right-hand side of the rows
+      // it keeps: what the replicated rows' tiles hold over the ranks then sums to the assembled values exactly once
+      hipLaunchKernelGGL(k_sp_assemble_values<TW>, dim3(unsigned((P->num_union_cells + 2) / 3)), dim3(3 * 81), 0, st,
+                         (const int32_t*)P->d_union_c1.p, (const int32_t*)P->d_union_c2.p, (const double*)P->d_union_values.p, Df,
+                         (const int32_t*)P->d_cam_pos.p, (const int32_t*)P->d_row_start.p, (const int32_t*)P->d_row_tiles.p, W,
+                         P->num_union_cells, (const int32_t*)P->d_cell_mine.p);
+      hipLaunchKernelGGL(k_sp_rhs<TW>, dim3((n + 255) / 256), dim3(256), 0, st, rhs, (const int32_t*)P->d_cam_pos.p,
+                         (const int32_t*)P->d_row_start.p, W, C, (const int32_t*)P->d_row_keep.p);
+      return CX_OK;
+    }
     hipLaunchKernelGGL(k_sp_assemble_values<TW>, dim3(unsigned((P->num_union_cells + 2) / 3)), dim3(3 * 81), 0, st,
                        (const int32_t*)P->d_union_c1.p, (const int32_t*)P->d_union_c2.p, (const double*)P->d_union_values.p, Df,
                        (const int32_t*)P->d_cam_pos.p, (const int32_t*)P->d_row_start.p, (const int32_t*)P->d_row_tiles.p, W,

@@ -146,6 +146,9 @@ def test_sparse_schur_700_cameras_through_the_front(oracle):
     x, s = S.solve(ev.jacobian(bs), res, D)
     assert s.termination_type == s_r.termination_type
     assert np.abs(x - x_r).max() <= 1e-8 * np.abs(x_r).max()
+    x_again, _ = S.solve(ev.jacobian(bs), res, D)
+    plain_calls = S.timing()["allreduce_calls"]       # per solve on the distributed plan (the first solve also exchanged the structure)
+    assert np.array_equal(x, x_again)
     # use_mixed_precision_solves on shards: the float tile pool under the distributed factorisation (the exchange of the
     # replicated tiles converts to double and back); with refinement steps the factor is kept whole on every shard (the plan is
     # rebuilt: stored-factor sweeps need it) and the step comes back to double precision
@@ -156,8 +159,14 @@ def test_sparse_schur_700_cameras_through_the_front(oracle):
     S32r = cx.Solver(ctx, type=cx.SPARSE_SCHUR, num_eliminate_blocks=P, use_mixed_precision_solves=1, max_num_refinement_iterations=3)
     x32r, s32r = S32r.solve(ev.jacobian(bs), res, D)
     assert s32r.termination_type == cx.SUCCESS and np.abs(x32r - x_r).max() <= max(1e-8, 1e-3 * e32) * np.abs(x_r).max()
-    x2, s2 = S.solve(ev.jacobian(bs), res, D)          # (and the double precision solver on the rebuilt, replicated plan)
+    refined_calls = S32r.timing()["allreduce_calls"]
+    # round 4: the unrefined solver gets its DISTRIBUTED factorisation back after the refined one (the plan
+    # remembers how it was built and re-plans from the union cell list it kept: no second structure exchange) -- the same
+    # collectives per solve and the same bits as before the refined solve
+    x2, s2 = S.solve(ev.jacobian(bs), res, D)
     assert np.abs(x2 - x_r).max() <= 1e-8 * np.abs(x_r).max()
+    assert S.timing()["allreduce_calls"] == plain_calls and np.array_equal(x2, x_again), (S.timing()["allreduce_calls"], plain_calls)
+    assert refined_calls == 3 + 3                # health agreement, cell values, right-hand side + one product per refinement step: no exchange of replicated tiles, no solution sum
     S32.close()
     S32r.close()
     S.close()
