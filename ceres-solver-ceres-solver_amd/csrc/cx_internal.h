@@ -146,6 +146,10 @@ struct cx_sp_plan {
   int64_t rs_chunk_cells = 0;
   DevBuf<int32_t> d_rs_cells;
   DevBuf<int32_t> d_cell_mine;       // [union cells] 1: this rank assembles the cell
+  // stored-factor sweeps on the distributed factor: per replicated row with incoming products from owned rows, their slots
+  int32_t xs_count = 0;
+  DevBuf<int32_t> d_xs_begin, d_xs_slots;
+  DevBuf<double> d_xs_t;
   DevBuf<double> d_rs_send, d_rs_recv;
   std::vector<int64_t> h_work_per_rank;
   int64_t h_work_shared = 0;

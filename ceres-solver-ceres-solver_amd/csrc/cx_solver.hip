@@ -1553,7 +1553,10 @@ int SolveDenseSchur239(cx_solver* S, cx_matrix* A, const double* b, const double
     // On a sharded matrix the plan comes from the union of the ranks' cells, so every rank decides the same.
     const bool forced = std::getenv("CX_SPARSE_CHOLESKY") != nullptr || wants_tiles;
     if (forced || A->C >= kSparseCholeskyMinCameras) {
-      A->sp.replicate = S->opt.max_num_refinement_iterations > 0;
+      // (round 3 kept the factor whole on every rank when refinement was asked for; round 4: the stored-factor sweeps run on
+      // the distributed factor, CX_SPARSE_REFINE_REPLICATED=1 keeps the old form for A/B runs)
+      static const bool refine_replicated = std::getenv("CX_SPARSE_REFINE_REPLICATED") != nullptr;
+      A->sp.replicate = refine_replicated && S->opt.max_num_refinement_iterations > 0;
       if (ctx->nranks > 1) CX_TRY(cxsp_build_plan_sharded(A));
       else CX_TRY(cxsp_build_plan(A));
       if (A->sp.state == 1) {

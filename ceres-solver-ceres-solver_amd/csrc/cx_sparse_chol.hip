@@ -1582,6 +1582,32 @@ int cxsp_plan_from_cells(cx_context* ctx, int C, const int32_t* cell_c1, const i
           if (need[size_t(r)].size() < need[size_t(best)].size()) best = r;
         need[size_t(best)].push_back(int32_t(k));
       }
+      // Round 4, stored-factor sweeps on a distributed factor (cxsp_solve): the forward sweep of a replicated row J sums
+      // the partial products F(K,J)' y_K of ALL rows K < J -- those of rows with an owner exist on their owner only.  Per
+      // replicated row the slots of such tiles, in ascending K: their sum is formed per rank, summed over the ranks and put
+      // back into the first of them (k_sp_fwd_gather_shared / k_sp_fwd_scatter_shared).
+      {
+        std::vector<int32_t> row_of_tile(static_cast<size_t>(num_tiles), -1);
+        for (int K = 0; K < T; ++K)
+          for (int32_t q = row_start[size_t(K)]; q < row_start[size_t(K) + 1]; ++q) row_of_tile[size_t(q)] = K;
+        std::vector<int32_t> xs_rows, xs_begin(1, 0), xs_slots;
+        for (int J = 0; J < T; ++J) {
+          if (H.owner[size_t(J)] >= 0) continue;
+          const size_t before = xs_slots.size();
+          for (int32_t pslot = col_start[size_t(J)]; pslot < col_start[size_t(J) + 1]; ++pslot)
+            if (H.owner[size_t(row_of_tile[size_t(col_pool[size_t(pslot)])])] >= 0) xs_slots.push_back(pslot);
+          if (xs_slots.size() > before) {
+            xs_rows.push_back(J);
+            xs_begin.push_back(int32_t(xs_slots.size()));
+          }
+        }
+        P->xs_count = int32_t(xs_rows.size());
+        if (xs_slots.empty()) xs_slots.push_back(0);
+        if (xs_rows.empty()) xs_rows.push_back(0);
+        CX_TRY(P->d_xs_begin.upload(xs_begin, st));
+        CX_TRY(P->d_xs_slots.upload(xs_slots, st));
+        CX_TRY(P->d_xs_t.alloc(size_t(std::max(P->xs_count, 1)) * kTile));
+      }
       std::vector<int32_t> mine(static_cast<size_t>(std::max<int64_t>(num_cells, 1)), 0);
       for (int32_t k : need[size_t(ctx->rank)]) mine[size_t(k)] = 1;
       CX_TRY(P->d_cell_mine.upload(mine, st));
@@ -1846,17 +1872,48 @@ int BackwardSweep(cx_context* ctx, cx_sp_plan* P, const Scratch& sc, int y_in_x)
 }
 }  // namespace
 
-// z = M^-1 r with the stored factor M = U'U (r, z in camera order): U' y = r bottom up, U x = y top down
+namespace {
+// t[j] = sum of the listed partial-product slots of replicated row j (list order: ascending source row)
+__global__ void k_sp_fwd_gather_shared(const int32_t* __restrict__ begin, const int32_t* __restrict__ slots, const double* __restrict__ partial,
+                                       double* __restrict__ t) {
+  const int j = blockIdx.x, lane = threadIdx.x;
+  double s = 0.0;
+  for (int p = begin[j]; p < begin[j + 1]; ++p) s += partial[size_t(slots[p]) * kTile + lane];
+  t[size_t(j) * kTile + lane] = s;
+}
+// ... and back: the first listed slot takes the sum over the ranks, the others zero
+__global__ void k_sp_fwd_scatter_shared(const int32_t* __restrict__ begin, const int32_t* __restrict__ slots, const double* __restrict__ t,
+                                        double* __restrict__ partial) {
+  const int j = blockIdx.x, lane = threadIdx.x;
+  for (int p = begin[j]; p < begin[j + 1]; ++p) partial[size_t(slots[p]) * kTile + lane] = (p == begin[j]) ? t[size_t(j) * kTile + lane] : 0.0;
+}
+}  // namespace
+
+// z = M^-1 r with the stored factor M = U'U (r, z in camera order): U' y = r bottom up, U x = y top down.
+// On a distributed factor (round 4): every rank sweeps its own rows and the replicated top; at the split the replicated rows'
+// incoming partial sums from owned rows are summed over the ranks (one collective of 64 doubles per such row), the top is
+// swept on every rank, the backward sweep needs nothing from other ranks, and the solution is the sum of the rows each rank
+// keeps (one collective of 64 T doubles, as in cxsp_factor_and_solve_sharded).
 int cxsp_solve(cx_context* ctx, cx_sp_plan* P, const double* r, double* z) {
   hipStream_t st = ctx->stream;
   const int C = P->C, n = 9 * C;
   if (n == 0) return CX_OK;
   Scratch sc;
   CX_TRY(GetScratch(P, &sc));
+  const bool distributed = P->level_split >= 0 && ctx->nranks > 1;
   CX_HIP(hipMemsetAsync(sc.xp, 0, size_t(P->T) * kTile * sizeof(double), st));
+  if (distributed) CX_HIP(hipMemsetAsync(sc.partial, 0, size_t(P->num_tiles) * kTile * sizeof(double), st));  // (other ranks' rows: no products here)
   hipLaunchKernelGGL(k_sp_permute, dim3((n + 255) / 256), dim3(256), 0, st, r, (const int32_t*)P->d_cam_pos.p, sc.xp, C);
   const int32_t* rows = P->d_level_rows.p;
   for (int l = 0; l < P->num_levels; ++l) {
+    if (distributed && l == P->level_split && P->xs_count > 0) {
+      hipLaunchKernelGGL(k_sp_fwd_gather_shared, dim3(unsigned(P->xs_count)), dim3(kTile), 0, st, (const int32_t*)P->d_xs_begin.p,
+                         (const int32_t*)P->d_xs_slots.p, (const double*)sc.partial, P->d_xs_t.p);
+      CX_HIP(hipGetLastError());
+      CX_TRY(cx_allreduce_device(ctx, P->d_xs_t.p, int64_t(P->xs_count) * kTile));
+      hipLaunchKernelGGL(k_sp_fwd_scatter_shared, dim3(unsigned(P->xs_count)), dim3(kTile), 0, st, (const int32_t*)P->d_xs_begin.p,
+                         (const int32_t*)P->d_xs_slots.p, (const double*)P->d_xs_t.p, sc.partial);
+    }
     const int r0 = P->h_level_row_begin[size_t(l)], nr = P->h_level_row_begin[size_t(l) + 1] - r0;
     const int p0 = P->h_level_panel_begin[size_t(l)], np = P->h_level_panel_begin[size_t(l) + 1] - p0;
     CX_TRY(WithPool(P, [&](auto* Wp) -> int {
@@ -1874,6 +1931,11 @@ int cxsp_solve(cx_context* ctx, cx_sp_plan* P, const double* r, double* z) {
     }));
   }
   CX_TRY(BackwardSweep(ctx, P, sc, 1));
+  if (distributed) {
+    const int64_t npad = int64_t(P->T) * kTile;
+    hipLaunchKernelGGL(k_sp_mask_rows, dim3(unsigned((npad + 255) / 256)), dim3(256), 0, st, sc.xp, (const int32_t*)P->d_row_keep.p, npad);
+    CX_TRY(cx_allreduce_device(ctx, sc.xp, npad));
+  }
   hipLaunchKernelGGL(k_sp_unpermute, dim3((n + 255) / 256), dim3(256), 0, st, (const double*)sc.xp, (const int32_t*)P->d_cam_pos.p, z, C);
   CX_HIP(hipGetLastError());
   return CX_OK;
