@@ -14,7 +14,8 @@ int cxs_chunk_pass(cx_matrix* A, int mode, const double* ete_inv, const double* 
 int cxs_camera_block_diagonal(cx_matrix* A, double* blocks);
 // fused set-up of the implicit Schur complement (k_chunk_init + k_cam_init), see cx_schur.hip
 int cxs_implicit_init(cx_matrix* A, const double* D, const double* b, bool want_blocks, bool with_schur,
-                      double* ete_inv, double* rows_scratch, double* blocks, double* rhs_out, int* d_flag);
+                      double* ete_inv, double* rows_scratch, double* blocks, double* rhs_out, int* d_flag,
+                      bool defer_reduce = false);
 int cxs_block9_add_diag_invert(cx_context* ctx, double* blocks, const double* Df, int C, int* d_flag);
 // dense lhs (9C x 9C row-major, upper block triangle) and rhs of the reduced system
 int cxs_eliminate_dense(cx_matrix* A, const double* b, const double* D, bool add_df, double* lhs, double* rhs);

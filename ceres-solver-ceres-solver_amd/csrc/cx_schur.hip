@@ -1962,8 +1962,10 @@ int cxs_sparse_diagonal(cx_matrix* A, double* blocks) {
 // Fused ImplicitSchurComplement::Init for the static layout: ete_inv[9P], the inverse of the
 // per-camera preconditioner blocks is left to the caller (blocks[81C] = F'F or S diagonal blocks,
 // D_f^2 not yet added), rhs_out[9C] = F'(b - E (E'E)^-1 E'b).
+// defer_reduce: stop at the per-segment partial sums (A->d_partials: 45 per segment, A->d_partials9: 9 per segment); the
+// caller's next kernel adds them up (small problems: k_cg_small_setup, cx_solver.hip).
 int cxs_implicit_init(cx_matrix* A, const double* D, const double* b, bool want_blocks, bool with_schur,
-                      double* ete_inv, double* rows_scratch, double* blocks, double* rhs_out, int* d_flag) {
+                      double* ete_inv, double* rows_scratch, double* blocks, double* rhs_out, int* d_flag, bool defer_reduce) {
   hipStream_t st = A->ctx->stream;
   if (A->num_tiles == 0 || A->num_segs == 0) {
     if (want_blocks) CX_HIP(hipMemsetAsync(blocks, 0, 81 * size_t(A->C) * sizeof(double), st));
@@ -1984,11 +1986,13 @@ int cxs_implicit_init(cx_matrix* A, const double* D, const double* b, bool want_
     hipLaunchKernelGGL(k_cam_init<false>, dim3(xcd_grid(A->num_segs)), dim3(kBlock), 0, st, F, E, A->d_cam_rows.p,
                        A->d_row_pt.p, A->d_seg_begin.p, (const double*)ete_inv, (const double*)rows_scratch, (const double*)A->d_Ft.p,
                        A->d_partials.p, A->d_partials9.p, A->num_segs);
-  if (want_blocks)
-    hipLaunchKernelGGL(k_cam_diag_reduce, dim3(grid_for(int64_t(A->C) * 45, 256)), dim3(256), 0, st,
-                       (const double*)A->d_partials.p, A->d_cam_seg_start.p, blocks, A->C);
-  hipLaunchKernelGGL(k_sum_segments9, dim3(grid_for(int64_t(A->C) * 9, 256)), dim3(256), 0, st,
-                     (const double*)A->d_partials9.p, A->d_cam_seg_start.p, rhs_out, A->C);
+  if (!defer_reduce) {
+    if (want_blocks)
+      hipLaunchKernelGGL(k_cam_diag_reduce, dim3(grid_for(int64_t(A->C) * 45, 256)), dim3(256), 0, st,
+                         (const double*)A->d_partials.p, A->d_cam_seg_start.p, blocks, A->C);
+    hipLaunchKernelGGL(k_sum_segments9, dim3(grid_for(int64_t(A->C) * 9, 256)), dim3(256), 0, st,
+                       (const double*)A->d_partials9.p, A->d_cam_seg_start.p, rhs_out, A->C);
+  }
   CX_HIP(hipGetLastError());
   return CX_OK;
 }

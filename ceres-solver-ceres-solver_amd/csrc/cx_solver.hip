@@ -473,6 +473,165 @@ __global__ __launch_bounds__(1024) void k_cg_small_tail(SmallTail a) {
   if (publish_rho) publish(pub_rho, a.iter + 1);
 }
 
+// ---- small problems, the set-up: everything between the two passes over J of ImplicitSchurComplement::Init and the first
+// product of the CG run, in one workgroup (n <= kSmallSetupMax entries, so one entry per thread).  It replaces
+// k_cam_diag_reduce, k_sum_segments9, k_block9_add_diag_invert, the zeroing of x, the upload of the initial state,
+// k_dot2_fused(rhs, rhs), k_cg_prologue, the copy r = rhs, k_blockdiag9_dot and k_update_p of iteration 1 -- with their
+// arithmetic, entry by entry and sum by sum (the virtual-workgroup bookkeeping of k_cg_small_tail; rhs.rhs is the one
+// reduction whose kernel walks a 256-thread workgroup over 1024 entries, so threads 0..255 replay that loop).
+__global__ __launch_bounds__(1024) void k_cg_small_setup(SmallSetup su, CgState init, double* __restrict__ rhs,
+                                                         double* __restrict__ x, double* __restrict__ r, double* __restrict__ p,
+                                                         int n, int* __restrict__ not_pd, const int* __restrict__ failed2,
+                                                         CgState* __restrict__ st, CgState* __restrict__ ring, int ring_slots) {
+  constexpr int kMaxC = (kSmallSetupMax + 8) / 9;
+  __shared__ double slab[kMaxC * 81];  // per camera: the block's upper triangle, then its Cholesky factor in place
+  __shared__ double rl[1024];
+  __shared__ double sc0[64];
+  __shared__ CgState ls;
+  __shared__ int bad;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int C = su.C, G = (n + 255) / 256;
+  if (tid == 0) {
+    ls = init;
+    bad = 0;
+  }
+  // (1) the cameras' blocks: sum of the segment partials  (k_cam_diag_reduce)
+  for (int idx = tid; idx < C * 45; idx += 1024) {
+    const int c = idx / 45, k = idx - c * 45;
+    double s = 0.0;
+    for (int sg = su.cam_seg_start[c]; sg < su.cam_seg_start[c + 1]; ++sg) s += su.partial45[int64_t(sg) * 45 + k];
+    int a = 0, rem = k;
+    while (rem >= 9 - a) { rem -= 9 - a; ++a; }
+    slab[c * 81 + a * 9 + a + rem] = s;
+  }
+  // (2) rhs = sum of the segment partials (k_sum_segments9) ; r = rhs ; x = 0
+  {
+    double s = 0.0;
+    if (tid < n) {
+      const int c = tid / 9, k = tid - c * 9;
+      for (int sg = su.cam_seg_start[c]; sg < su.cam_seg_start[c + 1]; ++sg) s += su.partial9[int64_t(sg) * 9 + k];
+      rhs[tid] = s;
+      r[tid] = s;
+      x[tid] = 0.0;
+    }
+    rl[tid] = s;
+  }
+  __syncthreads();
+  // (3a) rhs.rhs  (k_dot2_fused on one workgroup of 256: thread t adds entries t, t + 256, ...)
+  if (tid < 256) {
+    double s0 = 0.0;
+    for (int i = tid; i < n; i += 256) s0 += rl[i] * rl[i];
+    const double ws = wave_sum(s0);
+    if (lane == 0) sc0[wave] = ws;
+  }
+  // (3b) blocks <- (blocks + diag(D^2))^-1 through LLT (k_block9_add_diag_invert; the factor overwrites the triangle it was
+  // computed from).  Nine threads per camera, counted from the far end of the workgroup: the first of them factors, then
+  // each solves U'U x = e_col for its own column -- the arithmetic of every entry is that of the one-thread-per-camera
+  // kernel, only the nine columns no longer wait for each other.
+  const int inv_t = 1023 - tid, inv_c = inv_t / 9, inv_col = inv_t - inv_c * 9;
+  if (inv_c < C && inv_col == 0) {
+    double* U = slab + inv_c * 81;
+    bool ok = true;
+    for (int j = 0; j < 9; ++j) {
+      for (int i = 0; i <= j; ++i) {
+        double s = U[i * 9 + j];
+        if (i == j && su.Df) s += su.Df[9 * int64_t(inv_c) + j] * su.Df[9 * int64_t(inv_c) + j];
+        for (int k = 0; k < i; ++k) s -= U[k * 9 + i] * U[k * 9 + j];
+        if (i == j) {
+          if (!(s > 0.0)) ok = false;
+          U[i * 9 + i] = sqrt(s);
+        } else {
+          U[i * 9 + j] = s / U[i * 9 + i];
+        }
+      }
+    }
+    if (!ok) {
+      *not_pd = 1;
+      bad = 1;
+    }
+  }
+  __syncthreads();
+  if (inv_c < C) {
+    const double* U = slab + inv_c * 81;
+    double* X = su.blocks + int64_t(inv_c) * 81;
+    double y[9], xc[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) {
+      double s = (i == inv_col) ? 1.0 : 0.0;
+#pragma unroll
+      for (int k = 0; k < i; ++k) s -= U[k * 9 + i] * y[k];
+      y[i] = s / U[i * 9 + i];
+    }
+#pragma unroll
+    for (int i = 8; i >= 0; --i) {
+      double s = y[i];
+#pragma unroll
+      for (int k = i + 1; k < 9; ++k) s -= U[i * 9 + k] * xc[k];
+      xc[i] = s / U[i * 9 + i];
+    }
+#pragma unroll
+    for (int i = 0; i < 9; ++i) X[i * 9 + inv_col] = xc[i];
+  }
+  __syncthreads();
+  // (3c) the prologue  (k_cg_prologue)
+  if (tid == 0) {
+    const double tot = ((sc0[0] + sc0[1]) + sc0[2]) + sc0[3];
+    ls.s0 = tot;
+    ls.s1 = 0.0;
+    const double norm_rhs = sqrt(tot);
+    ls.norm_r = norm_rhs;
+    if (bad || *not_pd || (failed2 && *failed2)) {
+      ls.flag = CG_FAIL_PRECONDITIONER;
+    } else if (norm_rhs == 0.0) {
+      ls.flag = CG_ZERO_RHS;
+    } else {
+      ls.tol_r = ls.tol_r * norm_rhs;
+      if (ls.min_iter == 0 && norm_rhs <= ls.tol_r) ls.flag = CG_CONVERGED_AT_START;
+    }
+    if (ls.flag != CG_RUNNING) ls.iter = 0;
+  }
+  __syncthreads();
+  const bool stopped_at_start = ls.flag != CG_RUNNING;
+  int published_as = 0;
+  if (!stopped_at_start) {
+    // (4) head of iteration 1: z = blockdiag(M) r ; r.z  (k_blockdiag9_dot) ; p = z  (k_update_p)
+    double zv = 0.0, s0 = 0.0;
+    if (tid < n) {
+      const int blk = tid / 9, row = tid - blk * 9;
+      const double* m = su.blocks + int64_t(blk) * 81 + row * 9;
+      const double* rv = rl + blk * 9;
+      double s = 0.0;
+#pragma unroll
+      for (int kk = 0; kk < 9; ++kk) s += m[kk] * rv[kk];
+      zv = s;
+      s0 += rv[row] * s;
+    }
+    const double ws = wave_sum(s0);
+    if (lane == 0) sc0[wave] = ws;
+    __syncthreads();
+    if (wave == 0) {
+      const double tot = small_total(sc0, lane, G);
+      if (lane == 0) cg_scalar_step(tot, 0.0, FIN_RHO, 1, 0, &ls, nullptr, 0);
+    }
+    __syncthreads();
+    if (ls.flag == 0) {
+      if (tid < n) p[tid] = zv;
+    } else {
+      published_as = 1;  // a failure of the r.z step: iteration 1 (cg_scalar_step)
+    }
+  } else {
+    published_as = 1;  // the prologue publishes a run that ended before it began where the host expects the first outcome
+  }
+  if (tid != 0) return;
+  *st = ls;
+  if (published_as) {
+    CgState* slot = ring + (published_as % ring_slots);
+    *slot = ls;
+    __threadfence_system();
+    __hip_atomic_store(&slot->seq, published_as, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+}
+
 // p = z (first iteration) or z + beta p
 __global__ void k_update_p(double* __restrict__ p, const double* __restrict__ z, int64_t n, int iter,
                            const CgState* __restrict__ st) {
@@ -566,6 +725,17 @@ __global__ __launch_bounds__(kBlock) void k_point_jacobi(const double* __restric
 
 namespace {
 
+bool SmallCgAllowed() {
+  static const bool allowed = std::getenv("CX_NO_SMALL_CG") == nullptr;
+  return allowed;
+}
+// k_cg_small_setup: one rank, at most kSmallSetupMax reduced unknowns (CX_NO_SMALL_SETUP=1: the separate launches, for A/B
+// runs and the bit-equality test)
+bool SmallSetupEligible(const cx_context* ctx, int64_t n) {
+  static const bool allowed = std::getenv("CX_NO_SMALL_SETUP") == nullptr;
+  return allowed && SmallCgAllowed() && ctx->nranks <= 1 && n > 0 && n <= kSmallSetupMax;
+}
+
 struct CgDriver {
   cx_solver* S;
   cx_context* ctx;
@@ -578,6 +748,9 @@ struct CgDriver {
   // ends the run before the first iteration (no host check, no synchronisation, in between)
   const int* preconditioner_failed = nullptr;
   const int* preconditioner_failed2 = nullptr;  // a second, independently raised flag (factorisation of a visibility preconditioner)
+  // small problems: the caller stopped its set-up at the segment partial sums; the run's first launch finishes it
+  // (k_cg_small_setup).  Only with SmallSetupEligible(); blocks, rhs and x are then OUTPUTS of that launch.
+  const SmallSetup* small_setup = nullptr;
 
   // vectors replicated on every rank (or a single rank): dot products need no exchange
   bool fused() const { return !(ctx->nranks > 1 && shared0 < n); }
@@ -724,7 +897,25 @@ struct CgDriver {
     CgState h{};
     CgState* init = S->ring_h + kRingSlots;  // pinned staging slot of the initial device state
     double tol_r = 0.0;
-    if (zero_initial) {
+    const bool small_loop = SmallCgAllowed() && ctx->nranks <= 1 && fused() && n <= kSmallCgMax && pre.block9_inverse() != nullptr;  // (one rank: a speculative iteration must not enter a collective)
+    if (small_setup && !(zero_initial && small_loop && n <= kSmallSetupMax && pre.block9_inverse() == small_setup->blocks)) {
+      cx_set_error("internal: fused small set-up requested for a run that cannot take it");
+      return CX_ERR_INVALID_ARGUMENT;
+    }
+    if (small_setup) {
+      CgState first{};
+      first.rho = 1.0;
+      first.Q0 = 0.0;
+      first.tol_r = r_tol;  // relative; the prologue inside the kernel scales it by |rhs|
+      first.q_tol = q_tol;
+      first.min_iter = o.min_num_iterations;
+      first.max_iter = o.max_num_iterations;
+      first.flag = CG_RUNNING;
+      first.seq = -1;
+      hipLaunchKernelGGL(k_cg_small_setup, dim3(1), dim3(1024), 0, st, *small_setup, first, const_cast<double*>(rhs), x, r, p, int(n),
+                         const_cast<int*>(preconditioner_failed), preconditioner_failed2, ds, S->ring_d, kRingSlots);
+      CX_HIP(hipGetLastError());
+    } else if (zero_initial) {
       // x = 0: r = rhs, Q0 = 0; |rhs|, the absolute tolerance and the "nothing to do" cases are the device
       // prologue's business -- the host goes straight on to enqueue the first iteration
       *init = CgState{};
@@ -794,10 +985,9 @@ struct CgDriver {
     // Small problems: see k_cg_small_tail.  One launch after the operator's passes closes iteration i and opens i + 1;
     // every kernel looks at the termination flag, so a whole iteration is enqueued ahead of the host's look at the ring
     // (CX_NO_SMALL_CG=1: the general path, for A/B runs and the bit-equality test).
-    static const bool small_allowed = std::getenv("CX_NO_SMALL_CG") == nullptr;
     SmallProduct probe;
-    if (small_allowed && ctx->nranks <= 1 && fused() && n <= kSmallCgMax && pre.block9_inverse() != nullptr) {  // (one rank: a speculative iteration must not enter a collective)
-      CX_TRY(enqueue_head(1, pre, p, r, z, ds));
+    if (small_loop) {
+      if (!small_setup) CX_TRY(enqueue_head(1, pre, p, r, z, ds));  // (k_cg_small_setup has opened iteration 1)
       bool small_ok = true;
       int last_enqueued = 0;
       for (int iter = 1;; ++iter) {
@@ -835,7 +1025,10 @@ struct CgDriver {
       CX_TRY(enqueue_tail(iter, lhs, rhs, x, p, r, z, tmp, ds));
     }
     }
-    CX_TRY(cx_stream_sync(S->ctx, st));
+    // the outcome is in h (read from the ring); what is still queued behind it are speculative launches that see the flag and
+    // do nothing, so the caller's next launches simply follow them.  A sharded run waits here: this is where a peer that
+    // never reached the exchange step is noticed (cx_stream_sync is bounded on a sharded context).
+    if (ctx->nranks > 1) CX_TRY(cx_stream_sync(S->ctx, st));
     summary->num_iterations = h.iter;
     switch (h.flag) {
       case CG_CONVERGED_Q:
@@ -1152,11 +1345,11 @@ struct Stopwatch {
   cx_solver* S;
   hipStream_t st;
   int start() {
-    if (S->num_pending >= 4) return CX_OK;
+    if (!S->diag || S->num_pending >= 4) return CX_OK;
     return hipEventRecord(S->ctx->ev[8 + 2 * S->num_pending], st) == hipSuccess ? CX_OK : CX_ERR_HIP;
   }
   int stop(double* ms) {
-    if (S->num_pending >= 4) return CX_OK;
+    if (!S->diag || S->num_pending >= 4) return CX_OK;
     if (hipEventRecord(S->ctx->ev[9 + 2 * S->num_pending], st) != hipSuccess) return CX_ERR_HIP;
     S->pending_ms[S->num_pending++] = ms;
     return CX_OK;
@@ -1243,8 +1436,12 @@ int SolveIterativeSchur239(cx_solver* S, cx_matrix* A, const double* b, const do
     return CX_ERR_UNSUPPORTED;
   }
   CX_TRY(S->cam_blocks.alloc(81 * size_t(std::max(A->C, 1))));
+  // small problems with a block-Jacobi preconditioner: the two passes stop at their segment partial sums and the CG run's
+  // first launch does the rest of the set-up (k_cg_small_setup)
+  const bool small_setup = SmallSetupEligible(ctx, nf) && !o.use_spse_initialization && A->num_tiles > 0 && A->num_segs > 0 &&
+                           (o.preconditioner_type == CX_JACOBI || o.preconditioner_type == CX_SCHUR_JACOBI);
   CX_TRY(cxs_implicit_init(A, D, b, want_blocks, o.preconditioner_type == CX_SCHUR_JACOBI, S->ete_inv.p, S->v_rows.p,
-                           S->cam_blocks.p, S->v_rhs.p, S->flag.p));
+                           S->cam_blocks.p, S->v_rhs.p, S->flag.p, small_setup));
   if (ctx->nranks > 1 && A->C > 0) {
     const int per = want_blocks ? 54 : 9;
     const int64_t count = int64_t(A->C) * per;
@@ -1256,7 +1453,7 @@ int SolveIterativeSchur239(cx_solver* S, cx_matrix* A, const double* b, const do
                        S->v_rhs.p, A->C, want_blocks ? 1 : 0);
     CX_HIP(hipGetLastError());
   }
-  if (want_blocks) CX_TRY(cxs_block9_add_diag_invert(ctx, S->cam_blocks.p, D ? D + ne : nullptr, A->C, S->flag.p));
+  if (want_blocks && !small_setup) CX_TRY(cxs_block9_add_diag_invert(ctx, S->cam_blocks.p, D ? D + ne : nullptr, A->C, S->flag.p));
   if (visibility) {
     // VisibilityBasedPreconditioner::UpdateImpl (visibility_based_preconditioner.cc:321-364)
     CX_TRY(cxv_factor(A, vis_plan, D, false, vis_flag));
@@ -1277,7 +1474,7 @@ int SolveIterativeSchur239(cx_solver* S, cx_matrix* A, const double* b, const do
   // the run before the first iteration ("Preconditioner update failed.") -- no host check in between
 
   CX_TRY(sw.start());
-  CX_HIP(hipMemsetAsync(S->v_x.p, 0, nf * sizeof(double), st));
+  if (!small_setup) CX_HIP(hipMemsetAsync(S->v_x.p, 0, nf * sizeof(double), st));
   ImplicitSchurOp lhs;
   lhs.S = S; lhs.A = A; lhs.D = D;
   BlockDiag9Op bd;
@@ -1304,6 +1501,16 @@ int SolveIterativeSchur239(cx_solver* S, cx_matrix* A, const double* b, const do
   CgDriver cg{S, ctx, st, nf, nf};
   cg.preconditioner_failed = S->flag.p;
   cg.preconditioner_failed2 = vis_flag;
+  SmallSetup setup;
+  if (small_setup) {
+    setup.partial45 = A->d_partials.p;
+    setup.partial9 = A->d_partials9.p;
+    setup.cam_seg_start = A->d_cam_seg_start.p;
+    setup.Df = D ? D + ne : nullptr;
+    setup.blocks = S->cam_blocks.p;
+    setup.C = A->C;
+    cg.small_setup = &setup;
+  }
   CX_TRY(S->state.alloc(1));
   // use_mixed_precision_solves: S x inside CG streams fp32 copies of the cells (fp64 accumulation, fp64
   // vectors); set-up, right-hand side and back substitution stay on the fp64 values.  Not in the reference
@@ -1730,14 +1937,22 @@ int cx_solver_solve(cx_solver* S, cx_matrix* A, const double* b, const cx_per_so
   const cx_solver_options& o = S->opt;
   if (o.type != CX_CGNR) CX_CHECK_ARG(o.num_eliminate_blocks == A->nelim);
   std::memset(summary, 0, sizeof(*summary));
-  S->timing = cx_solve_timing{};
-  S->num_pending = 0;
-  S->ktimer.reset();
+  const bool launch_bound = ctx->nranks <= 1 && A->num_cols_f <= kSmallCgMax;
   {
-    static const int forced = std::getenv("CX_KTIMER_SAMPLES") ? std::atoi(std::getenv("CX_KTIMER_SAMPLES")) : -1;  // A/B switch
-    // small problems are bound by their launches (a solve is some 30 enqueues): one sampled launch per kernel reports its time
-    S->ktimer.max_samples = forced >= 0 ? std::min(forced, int(KernelTimer::kMaxSamples)) : (A->num_cols_f <= kSmallCgMax ? 1 : int(KernelTimer::kMaxSamples));
+    static const int period = std::getenv("CX_DIAG_PERIOD") ? std::max(1, std::atoi(std::getenv("CX_DIAG_PERIOD"))) : int(cx_solver::kDiagPeriod);
+    S->diag = !launch_bound || (S->num_solves % period) == 0;  // see cx_solver::diag
+    ++S->num_solves;
   }
+  S->num_pending = 0;
+  S->ktimer.enabled = S->diag;
+  if (S->diag) {
+    S->timing = cx_solve_timing{};
+    S->ktimer.reset();
+    static const int forced = std::getenv("CX_KTIMER_SAMPLES") ? std::atoi(std::getenv("CX_KTIMER_SAMPLES")) : -1;  // A/B switch
+    // small problems are bound by their launches: one sampled launch per kernel reports its time
+    S->ktimer.max_samples = forced >= 0 ? std::min(forced, int(KernelTimer::kMaxSamples)) : (launch_bound ? 1 : int(KernelTimer::kMaxSamples));
+  }
+  const auto host_t0 = std::chrono::steady_clock::now();
   cx_allreduce_reset(ctx);
   HostOrDevice hb(ctx), hD(ctx), hx(ctx);
   int staged = hb.in(b, size_t(A->num_rows), ps->b_on_device ? CX_DEVICE : ps->memspace);
@@ -1745,7 +1960,7 @@ int cx_solver_solve(cx_solver* S, cx_matrix* A, const double* b, const cx_per_so
   if (staged == CX_OK) staged = hx.inout(x, size_t(A->num_cols), ps->memspace, false);
   // sharded: a rank that could not stage its inputs says so before anybody enters the solve's first collective
   CX_TRY(cx_comm_agree(ctx, staged));
-  CX_HIP(hipEventRecord(ctx->ev[4], ctx->stream));
+  if (S->diag) CX_HIP(hipEventRecord(ctx->ev[4], ctx->stream));
   // "std::fill(x, x + A->num_cols(), 0.0)" (schur_complement_solver.cc:137): whatever a failed solve leaves
   // unwritten is zero, in the caller's host buffer as well (the staging copy is not initialised otherwise)
   CX_HIP(hipMemsetAsync(hx.dptr, 0, size_t(A->num_cols) * sizeof(double), ctx->stream));
@@ -1779,6 +1994,11 @@ int cx_solver_solve(cx_solver* S, cx_matrix* A, const double* b, const cx_per_so
     summary->termination_type = CX_FATAL_ERROR;
     std::snprintf(summary->message, sizeof(summary->message), "%s", cx_last_error());
     return rc;
+  }
+  if (!S->diag) {
+    CX_TRY(cx_stream_sync(ctx, ctx->stream));
+    S->timing.total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - host_t0).count();
+    return hx.out();
   }
   CX_HIP(hipEventRecord(ctx->ev[5], ctx->stream));
   CX_TRY(cx_event_sync(ctx, ctx->ev[5]));

@@ -50,6 +50,19 @@ struct SmallProduct {
   const double* d = nullptr;               // LM diagonal of the camera part (may be NULL)
 };
 
+// The set-up of such a run in one launch too (k_cg_small_setup, vectors of at most kSmallSetupMax entries): the segment
+// partial sums cxs_implicit_init(..., defer_reduce) left behind become the block-Jacobi blocks and the reduced right-hand
+// side, the blocks are inverted, and the CG prologue and the head of iteration 1 follow.
+constexpr int kSmallSetupMax = 1024;
+struct SmallSetup {
+  const double* partial45 = nullptr;       // [segments][45] packed upper triangles of the cameras' 9x9 blocks
+  const double* partial9 = nullptr;        // [segments][9] the reduced right-hand side
+  const int32_t* cam_seg_start = nullptr;  // [C + 1]
+  const double* Df = nullptr;              // LM diagonal of the camera part (may be NULL)
+  double* blocks = nullptr;                // [C][81] out: the inverted blocks
+  int C = 0;
+};
+
 struct LinOp {
   virtual ~LinOp() = default;
   virtual int64_t size() const = 0;
@@ -86,18 +99,23 @@ struct KernelTimer {
       for (auto& a : ev) for (auto& b : a) for (auto& e : b) CX_HIP(hipEventCreate(&e));
       created = true;
     }
+    if (!enabled) return CX_OK;
     ++launches[slot];
     if (count[slot] < max_samples) CX_HIP(hipEventRecord(ev[slot][count[slot]][0], st));
     return CX_OK;
   }
   int end(int slot, hipStream_t st) {
+    if (!enabled) return CX_OK;
     if (count[slot] < max_samples) { CX_HIP(hipEventRecord(ev[slot][count[slot]][1], st)); ++count[slot]; }
     return CX_OK;
   }
+  // false: a solve that takes no samples and keeps the numbers of the last one that did (cx_solver::diag)
+  bool enabled = true;
   // how many launches per slot are bracketed by events in a solve (each pair costs the host two enqueues and the queue
   // two markers: a launch-bound small solve samples less)
   int max_samples = kMaxSamples;
   int collect() {  // call after the stream has been synchronised
+    if (!enabled) return CX_OK;
     for (int s = 0; s < kSlots; ++s) {
       total_ms[s] = 0.0;
       for (int i = 0; i < count[s]; ++i) {
@@ -131,6 +149,14 @@ struct cx_solver {
   // phase timings are read back once, at the end of the solve (no synchronisation between the phases)
   double* pending_ms[4] = {};
   int num_pending = 0;
+  // Launch-bound solves (at most kSmallCgMax reduced unknowns on one rank: some twenty enqueues of 2-17 us kernels).  Every
+  // event record is a marker in the queue that costs about as much as one of those kernels -- the ten of a solve's phase
+  // timings and kernel samples were 40 us of a 0.2 ms Ladybug-49 solve -- so such a solver takes them on its first solve and
+  // on every kDiagPeriod-th after it (CX_DIAG_PERIOD=n overrides, 1 = always); in between cx_solver_last_timing() keeps the
+  // phases of the last sampled solve, refreshes total_ms from the host clock, and cx_solver_kernel_stats() keeps its samples.
+  static constexpr int kDiagPeriod = 16;
+  int64_t num_solves = 0;
+  bool diag = true;
   // front on a multi-shard context (cx_multi.hip): one solver per shard, created at the first solve of a matrix
   std::vector<cx_solver*> parts;
   const cx_matrix* parts_for = nullptr;

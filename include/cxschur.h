@@ -371,8 +371,12 @@ void cx_solver_default_options(cx_solver_options* options);
  * b has num_rows entries, x num_cols; x is fully overwritten. */
 int cx_solver_solve(cx_solver* s, cx_matrix* A, const double* b,
                     const cx_per_solve_options* per_solve, double* x, cx_summary* summary);
+/* Phase times of the last solve.  A launch-bound solver (one rank, at most 4096 reduced unknowns: some twenty enqueues of
+ * 2-17 us kernels, where every timing event costs about as much as a kernel) takes phase times and kernel samples on its
+ * first solve and on every 16th after it (CX_DIAG_PERIOD=n in the environment: every n-th, 1 = always); in between the
+ * phases and kernel samples of the last sampled solve stay, and total_ms is host wall time around the solve. */
 int cx_solver_last_timing(const cx_solver* s, cx_solve_timing* out);
-/* per-kernel device times of the last solve (ExecutionSummary of the reference is host
+/* per-kernel device times of the last (sampled, see above) solve (ExecutionSummary of the reference is host
  * wall time per phase, execution_summary.h:45-83; this is its device-side counterpart) */
 int cx_solver_kernel_stats(const cx_solver* s, cx_kernel_stat* out, int32_t capacity, int32_t* count);
 

@@ -40,5 +40,7 @@ def test_single_workgroup_cg_tail_keeps_the_bits():
         return out.stdout.strip().splitlines()[-2:]
     fused, general = run({}), run({"CX_NO_SMALL_CG": "1"})
     assert fused == general, (fused, general)
+    # ... and the set-up of the smallest ones (k_cg_small_setup: ten launches and copies in one) keeps them too
+    assert run({"CX_NO_SMALL_SETUP": "1"}) == fused
     assert "(0, " in fused[0]      # SUCCESS somewhere, and more than one residual reset period was crossed
     assert any(int(t.split(")")[0]) > 20 for t in fused[0].split(", ")[1::2])

@@ -1,8 +1,9 @@
 #!/usr/bin/env python3
 """SHA-1 of the ITERATIVE_SCHUR steps of a few small problems (ladybug49 preset and two synthetic ones; JACOBI and
 SCHUR_JACOBI, eta 0.1 / 1e-3 / 1e-8 so that residual resets happen) plus their iteration counts: the single-workgroup CG
-tail of small problems (k_cg_small_tail) must give the bits of the general path (CX_NO_SMALL_CG=1).  One process per
-variant: the switch is read once."""
+tail of small problems (k_cg_small_tail) and the single-launch set-up of the smallest (k_cg_small_setup, at most 1024 reduced
+unknowns: 113 cameras) must give the bits of the general path (CX_NO_SMALL_CG=1 / CX_NO_SMALL_SETUP=1).  Also runs that end
+in the prologue: a zero right-hand side, and a tolerance met at the start.  One process per variant: the switches are read once."""
 import hashlib
 import importlib.util
 import os
@@ -20,7 +21,8 @@ spec.loader.exec_module(cx)
 h = hashlib.sha1()
 its = []
 ctx = cx.Context(0)
-for prob in (cx.bal.make_preset("ladybug49"), cx.bal.make_bal_like(7, 300, 1400, seed=3), cx.bal.make_bal_like(455, 9000, 60000, seed=4)):
+for prob in (cx.bal.make_preset("ladybug49"), cx.bal.make_bal_like(7, 300, 1400, seed=3), cx.bal.make_bal_like(113, 2500, 16000, seed=5),
+             cx.bal.make_bal_like(455, 9000, 60000, seed=4)):
     ev = cx.Evaluator(ctx, prob)
     _, res, _ = ev.evaluate(prob.state())
     A = ev.jacobian()
@@ -32,6 +34,12 @@ for prob in (cx.bal.make_preset("ladybug49"), cx.bal.make_bal_like(7, 300, 1400,
             h.update(x.tobytes())
             its.append((int(s.termination_type), int(s.num_iterations)))
             S.close()
+    S = cx.Solver(ctx, type=cx.ITERATIVE_SCHUR, preconditioner_type=cx.JACOBI, num_eliminate_blocks=prob.num_points, max_num_iterations=120)
+    for rhs, rtol in ((np.zeros_like(res), -1.0), (res, 10.0)):   # |b| = 0 ; |r| <= r_tolerance |b| before the first iteration
+        x, s = S.solve(A, rhs, D, r_tolerance=rtol, q_tolerance=0.1)
+        h.update(x.tobytes())
+        its.append((int(s.termination_type), int(s.num_iterations)))
+    S.close()
     ev.close()
 print(its)
 print(h.hexdigest())
