@@ -29,6 +29,8 @@ import time
 import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
+# the host driver of this pool supports dmabuf IPC only: RCCL between processes needs this before the runtime starts
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 
 def _load(name, path, search=None):
