@@ -108,7 +108,7 @@ class cx_summary(ctypes.Structure):
 class cx_solve_timing(ctypes.Structure):
     _fields_ = [(n, ctypes.c_double) for n in
                 ("setup_ms", "eliminate_ms", "reduced_solve_ms", "back_substitute_ms", "total_ms", "allreduce_ms",
-                 "allreduce_host_ms", "allreduce_calls", "allreduce_bytes")]
+                 "allreduce_host_ms", "allreduce_calls", "allreduce_bytes", "sampled")]
 
 
 class cx_kernel_stat(ctypes.Structure):

@@ -377,13 +377,15 @@ int cxk_generic_block_diagonal(cx_matrix* A, int sel, int first, int count, int6
 int cx_matrix_ensure_f32(cx_matrix* A);
 
 // all of these enqueue on ctx->stream and work on device pointers
-int cxk_right_multiply(cx_matrix* A, const double* x, double* y);
-int cxk_left_multiply(cx_matrix* A, const double* x, double* y);
+int cxk_right_multiply(cx_matrix* A, const double* x, double* y, bool accumulate = true);
+int cxk_left_multiply(cx_matrix* A, const double* x, double* y, bool accumulate = true, const double* d = nullptr,
+                      const double* dx = nullptr, bool* folded = nullptr);
 int cxk_squared_column_norm(cx_matrix* A, double* x);
 int cxk_scale_columns(cx_matrix* A, const double* scale);
 
 // y_f (+)= F' t  for the static path; t is row-sized
-int cxk_ft_multiply(cx_matrix* A, const double* t, double* y_f, bool accumulate);
+int cxk_ft_multiply(cx_matrix* A, const double* t, double* y_f, bool accumulate, const double* d_f = nullptr,
+                    const double* x_f = nullptr);
 // first half of it: the per-segment partial sums only (A->d_partials, 9 per segment)
 int cxk_ft_partials(cx_matrix* A, const double* t);
 

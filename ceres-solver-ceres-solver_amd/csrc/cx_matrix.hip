@@ -79,7 +79,10 @@ __global__ __launch_bounds__(kBlock) void k_left_e_239(const T* __restrict__ E,
                                                        const int32_t* __restrict__ pt_start,
                                                        const double* __restrict__ x,
                                                        double* __restrict__ ye, int accumulate,
-                                                       const int* __restrict__ stop) {
+                                                       const int* __restrict__ stop,
+                                                       const double* __restrict__ d = nullptr,
+                                                       const double* __restrict__ dx = nullptr) {
+  // d != nullptr: + diag(d)^2 dx on top (the LM diagonal of CGNR's (J'J + D'D) x, point part)
   __shared__ double lds[kBlock * 6];
   if (stop && *stop) return;
   __shared__ double w[kBlock * 3];
@@ -107,6 +110,13 @@ __global__ __launch_bounds__(kBlock) void k_left_e_239(const T* __restrict__ E,
         s2 += w[j * 3 + 2];
       }
       double* yp = ye + 3 * int64_t(p);
+      if (d) {
+        const double* dp = d + 3 * int64_t(p);
+        const double* xp = dx + 3 * int64_t(p);
+        s0 += dp[0] * dp[0] * xp[0];
+        s1 += dp[1] * dp[1] * xp[1];
+        s2 += dp[2] * dp[2] * xp[2];
+      }
       if (accumulate) { yp[0] += s0; yp[1] += s1; yp[2] += s2; }
       else { yp[0] = s0; yp[1] = s1; yp[2] = s2; }
     }
@@ -123,6 +133,13 @@ __global__ __launch_bounds__(kBlock) void k_left_e_239(const T* __restrict__ E,
     block_sum<3>(s, red);
     if (tid == 0) {
       double* yp = ye + 3 * int64_t(p0);
+      if (d) {
+        const double* dp = d + 3 * int64_t(p0);
+        const double* xp = dx + 3 * int64_t(p0);
+        s[0] += dp[0] * dp[0] * xp[0];
+        s[1] += dp[1] * dp[1] * xp[1];
+        s[2] += dp[2] * dp[2] * xp[2];
+      }
       if (accumulate) { yp[0] += s[0]; yp[1] += s[1]; yp[2] += s[2]; }
       else { yp[0] = s[0]; yp[1] = s[1]; yp[2] = s[2]; }
     }
@@ -640,26 +657,27 @@ int cxk_ft_partials(cx_matrix* A, const double* t) {
   return CX_OK;
 }
 
-int cxk_ft_multiply(cx_matrix* A, const double* t, double* yf, bool accumulate) {
+int cxk_ft_multiply(cx_matrix* A, const double* t, double* yf, bool accumulate, const double* d_f, const double* x_f) {
   CX_TRY(cxk_ft_partials(A, t));
   hipLaunchKernelGGL(k_cam_reduce9, dim3(grid_for(int64_t(A->C) * 9, 256)), dim3(256), 0, A->ctx->stream,
-                     A->d_partials.p, A->d_cam_seg_start.p, yf, A->C, accumulate ? 1 : 0,
-                     (const double*)nullptr, (const double*)nullptr, A->stop);
+                     A->d_partials.p, A->d_cam_seg_start.p, yf, A->C, accumulate ? 1 : 0, d_f, x_f, A->stop);
   CX_HIP(hipGetLastError());
   return CX_OK;
 }
 
-int cxk_right_multiply(cx_matrix* A, const double* x, double* y) {
+int cxk_right_multiply(cx_matrix* A, const double* x, double* y, bool accumulate) {
   hipStream_t st = A->ctx->stream;
+  const int acc = accumulate ? 1 : 0;
+  if (!accumulate && !A->is239) CX_HIP(hipMemsetAsync(y, 0, size_t(A->num_rows) * sizeof(double), st));
   if (A->is239) {
     if (A->use_f32)
       hipLaunchKernelGGL(k_right_239<float>, dim3(grid_for(A->O, kBlock)), dim3(kBlock), 0, st, (const float*)A->d_vals32.p,
                          (const float*)(A->d_vals32.p + 6 * A->O), A->d_row_pt.p, A->d_row_cam.p, x, x + 3 * int64_t(A->P), y,
-                         A->O, 1, 1, 1, A->stop);
+                         A->O, 1, 1, acc, A->stop);
     else
       hipLaunchKernelGGL(k_right_239<double>, dim3(grid_for(A->O, kBlock)), dim3(kBlock), 0, st, (const double*)A->d_values.p,
                          (const double*)(A->d_values.p + 6 * A->O), A->d_row_pt.p, A->d_row_cam.p, x, x + 3 * int64_t(A->P), y,
-                         A->O, 1, 1, 1, A->stop);
+                         A->O, 1, 1, acc, A->stop);
   } else if (A->R > 0) {
     hipLaunchKernelGGL(kg_right, dim3(grid_for(A->R, 128)), dim3(128), 0, st, A->d_rows.p, A->d_cols.p,
                        A->d_rcb.p, A->d_cells.p, A->d_values.p, x, y, A->R, A->num_row_blocks_e, 0, 0);
@@ -668,16 +686,24 @@ int cxk_right_multiply(cx_matrix* A, const double* x, double* y) {
   return CX_OK;
 }
 
-int cxk_left_multiply(cx_matrix* A, const double* x, double* y) {
+// accumulate = false: y = A'x (the static kernels write every entry themselves: their tiles cover all points, empty ones
+// included, and the camera reduction writes every camera; the dynamic-size path zeroes y first).
+// d != nullptr: y (+)= A'x + diag(d)^2 dx in the same launches (static layout; *folded says whether it happened).
+int cxk_left_multiply(cx_matrix* A, const double* x, double* y, bool accumulate, const double* d, const double* dx, bool* folded) {
   hipStream_t st = A->ctx->stream;
+  if (folded) *folded = false;
+  if (!accumulate && !A->is239) CX_HIP(hipMemsetAsync(y, 0, size_t(A->num_cols) * sizeof(double), st));
   if (A->is239) {
+    const int acc = accumulate ? 1 : 0;
+    const int64_t ne = 3 * int64_t(A->P);
     if (A->use_f32)
       hipLaunchKernelGGL(k_left_e_239<float>, dim3(A->num_tiles), dim3(kBlock), 0, st, (const float*)A->d_vals32.p,
-                         A->d_tile_row.p, A->d_tile_pt.p, A->d_pt_start.p, x, y, 1, A->stop);
+                         A->d_tile_row.p, A->d_tile_pt.p, A->d_pt_start.p, x, y, acc, A->stop, d, dx);
     else
       hipLaunchKernelGGL(k_left_e_239<double>, dim3(A->num_tiles), dim3(kBlock), 0, st, (const double*)A->d_values.p,
-                         A->d_tile_row.p, A->d_tile_pt.p, A->d_pt_start.p, x, y, 1, A->stop);
-    CX_TRY(cxk_ft_multiply(A, x, y + 3 * int64_t(A->P), true));
+                         A->d_tile_row.p, A->d_tile_pt.p, A->d_pt_start.p, x, y, acc, A->stop, d, dx);
+    CX_TRY(cxk_ft_multiply(A, x, y + ne, accumulate, d ? d + ne : nullptr, d ? dx + ne : nullptr));
+    if (folded && d) *folded = true;
   } else if (A->R > 0) {
     static const bool atomics = std::getenv("CX_GENERIC_ATOMICS") != nullptr;  // A/B switch: round 1's scatter form
     if (atomics)

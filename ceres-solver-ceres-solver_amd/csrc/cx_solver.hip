@@ -212,6 +212,38 @@ __global__ __launch_bounds__(256) void k_blockdiag9_dot(const double* __restrict
   dot2_finish(s0, 0.0, t, red);
 }
 
+// CGNR's block Jacobi preconditioner and rho in one launch: z = blockdiag(M) r with 3x3 blocks on the first ne entries and
+// 9x9 blocks behind them (k_blockdiag_multiply<3>, <9>), s0 = r.z summed exactly as k_dot2_fused(r, z) sums it (same grid,
+// same strided loop), so the fusion does not change a bit of the iteration.
+__global__ __launch_bounds__(256) void k_cgnr_jacobi_dot(const double* __restrict__ pt_blocks, const double* __restrict__ cam_blocks,
+                                                         const double* __restrict__ r, double* __restrict__ z, int64_t ne, int64_t n,
+                                                         DotTail t) {
+  __shared__ double red[8];
+  if (t.st->flag) return;
+  double s0 = 0.0;
+  for (int64_t i = int64_t(blockIdx.x) * 256 + threadIdx.x; i < n; i += int64_t(gridDim.x) * 256) {
+    double s = 0.0;
+    if (i < ne) {
+      const int64_t blk = i / 3;
+      const int row = int(i - blk * 3);
+      const double* m = pt_blocks + blk * 9 + row * 3;
+      const double* rv = r + blk * 3;
+#pragma unroll
+      for (int k = 0; k < 3; ++k) s += m[k] * rv[k];
+    } else {
+      const int64_t j = i - ne, blk = j / 9;
+      const int row = int(j - blk * 9);
+      const double* m = cam_blocks + blk * 81 + row * 9;
+      const double* rv = r + ne + blk * 9;
+#pragma unroll
+      for (int k = 0; k < 9; ++k) s += m[k] * rv[k];
+    }
+    z[i] = s;
+    s0 += r[i] * s;
+  }
+  dot2_finish(s0, 0.0, t, red);
+}
+
 // y[9c+k] = sum of camera c's segment partials (segment order) + d^2 x ; s0 = x.y
 // (second half of F't, the LM diagonal and p.q of the implicit Schur product in one launch)
 __global__ __launch_bounds__(256) void k_cam_reduce9_dot(const double* __restrict__ partial9,
@@ -1301,25 +1333,44 @@ struct IdentityOp : LinOp {
   }
 };
 
+bool CgnrPlain() {
+  static const bool plain = std::getenv("CX_CGNR_PLAIN") != nullptr;
+  return plain;
+}
+
 // (J'J + D'D) x   (CgnrLinearOperator, cgnr_solver.cc:98-114)
 struct CgnrOp : LinOp {
   cx_solver* S;
   cx_matrix* A;
   const double* D;
   int64_t size() const override { return A->num_cols; }
+  // t = J x and y = J't + D^2 x, both written outright: no zeroing of t or y beforehand, and on one rank the LM diagonal
+  // rides in the kernels that write y (k_left_e_239 for the points, k_cam_reduce9 for the cameras) -- four launches where
+  // round 3 had two memsets, the two products and k_add_d2x.  Sharded: the cameras' part of J't is summed over the ranks
+  // first, D^2 x is added once after that.
   int apply(const double* x, double* y) override {
     cx_context* ctx = A->ctx;
     hipStream_t st = ctx->stream;
-    CX_HIP(hipMemsetAsync(S->v_rows.p, 0, size_t(A->num_rows) * sizeof(double), st));
+    const bool sharded = ctx->nranks > 1 && A->is239;
+    if (CgnrPlain()) {  // round 3's form, for A/B runs and the bit-equality test
+      CX_HIP(hipMemsetAsync(S->v_rows.p, 0, size_t(A->num_rows) * sizeof(double), st));
+      CX_TRY(cxk_right_multiply(A, x, S->v_rows.p));
+      CX_HIP(hipMemsetAsync(y, 0, size_t(A->num_cols) * sizeof(double), st));
+      CX_TRY(cxk_left_multiply(A, S->v_rows.p, y));
+      if (sharded) CX_TRY(cx_allreduce_device(ctx, y + 3 * int64_t(A->P), 9 * int64_t(A->C)));
+      if (D) hipLaunchKernelGGL(k_add_d2x, dim3(grid_for(size(), 256)), dim3(256), 0, st, y, D, x, size());
+      CX_HIP(hipGetLastError());
+      return CX_OK;
+    }
     CX_TRY(S->ktimer.begin(2, st));
-    CX_TRY(cxk_right_multiply(A, x, S->v_rows.p));
+    CX_TRY(cxk_right_multiply(A, x, S->v_rows.p, false));
     CX_TRY(S->ktimer.end(2, st));
-    CX_HIP(hipMemsetAsync(y, 0, size_t(A->num_cols) * sizeof(double), st));
+    bool folded = false;
     CX_TRY(S->ktimer.begin(3, st));
-    CX_TRY(cxk_left_multiply(A, S->v_rows.p, y));
+    CX_TRY(cxk_left_multiply(A, S->v_rows.p, y, false, sharded ? nullptr : D, x, &folded));
     CX_TRY(S->ktimer.end(3, st));
-    if (ctx->nranks > 1 && A->is239) CX_TRY(cx_allreduce_device(ctx, y + 3 * int64_t(A->P), 9 * int64_t(A->C)));
-    if (D) hipLaunchKernelGGL(k_add_d2x, dim3(grid_for(size(), 256)), dim3(256), 0, st, y, D, x, size());
+    if (sharded) CX_TRY(cx_allreduce_device(ctx, y + 3 * int64_t(A->P), 9 * int64_t(A->C)));
+    if (D && !folded) hipLaunchKernelGGL(k_add_d2x, dim3(grid_for(size(), 256)), dim3(256), 0, st, y, D, x, size());
     CX_HIP(hipGetLastError());
     return CX_OK;
   }
@@ -1330,6 +1381,17 @@ struct CgnrJacobiOp : LinOp {
   cx_solver* S;
   cx_matrix* A;
   int64_t size() const override { return A->num_cols; }
+  // z = M r and r.z in one launch (k_cgnr_jacobi_dot: the sum of k_dot2_fused(r, z), term by term)
+  int apply_dot(const double* x, double* y, const DotTail& tail, bool* done) override {
+    const int64_t n = size();
+    *done = n > 0 && !CgnrPlain();
+    if (!*done) return CX_OK;
+    const int nb = int(std::min<int64_t>(kRedBlocks, std::max<int64_t>(1, (n + 1023) / 1024)));
+    hipLaunchKernelGGL(k_cgnr_jacobi_dot, dim3(nb), dim3(256), 0, A->ctx->stream, (const double*)S->pt_blocks.p, (const double*)S->cam_blocks.p,
+                       x, y, 3 * int64_t(A->P), n, tail);
+    CX_HIP(hipGetLastError());
+    return CX_OK;
+  }
   int apply(const double* x, double* y) override {
     hipStream_t st = A->ctx->stream;
     if (A->P) hipLaunchKernelGGL(k_blockdiag_multiply<3>, dim3(grid_for(3 * int64_t(A->P), 256)), dim3(256), 0, st, S->pt_blocks.p, x, y, int64_t(A->P));
@@ -1612,12 +1674,11 @@ int SolveCgnr239(cx_solver* S, cx_matrix* A, const double* b, const double* D, d
     return CX_ERR_UNSUPPORTED;
   }
   // rhs = J'b
-  CX_HIP(hipMemsetAsync(S->v_rhs.p, 0, n * sizeof(double), st));
-  CX_TRY(cxk_left_multiply(A, b, S->v_rhs.p));
+  CX_TRY(cxk_left_multiply(A, b, S->v_rhs.p, false));
   if (ctx->nranks > 1) CX_TRY(cx_allreduce_device(ctx, S->v_rhs.p + ne, n - ne));
   CX_TRY(sw.stop(&S->timing.eliminate_ms));
   CX_TRY(sw.start());
-  CX_HIP(hipMemsetAsync(x, 0, n * sizeof(double), st));
+  // (x arrives zeroed: cx_solver_solve and cxe_solve clear the whole solution vector before they come here)
   CgnrOp lhs;
   lhs.S = S; lhs.A = A; lhs.D = D;
   CgnrJacobiOp jac;
@@ -1945,8 +2006,10 @@ int cx_solver_solve(cx_solver* S, cx_matrix* A, const double* b, const cx_per_so
   }
   S->num_pending = 0;
   S->ktimer.enabled = S->diag;
+  S->timing.sampled = S->diag ? 1.0 : 0.0;
   if (S->diag) {
     S->timing = cx_solve_timing{};
+    S->timing.sampled = 1.0;
     S->ktimer.reset();
     static const int forced = std::getenv("CX_KTIMER_SAMPLES") ? std::atoi(std::getenv("CX_KTIMER_SAMPLES")) : -1;  // A/B switch
     // small problems are bound by their launches: one sampled launch per kernel reports its time

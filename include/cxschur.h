@@ -178,6 +178,8 @@ typedef struct {
   double allreduce_host_ms;   /* host time spent enqueueing them (or, with the callback transport, inside the callback) */
   double allreduce_calls;     /* collectives of the solve */
   double allreduce_bytes;     /* payload summed over them (8 bytes per double) */
+  double sampled;             /* 1: the phase times above (and cx_solver_kernel_stats) were taken during THIS solve; 0: they
+                                 are those of the last solve that took them (launch-bound solvers, see cx_solver_last_timing) */
 } cx_solve_timing;
 
 /* Device time of one kernel (or short kernel sequence) of the hot loop during the
@@ -374,7 +376,8 @@ int cx_solver_solve(cx_solver* s, cx_matrix* A, const double* b,
 /* Phase times of the last solve.  A launch-bound solver (one rank, at most 4096 reduced unknowns: some twenty enqueues of
  * 2-17 us kernels, where every timing event costs about as much as a kernel) takes phase times and kernel samples on its
  * first solve and on every 16th after it (CX_DIAG_PERIOD=n in the environment: every n-th, 1 = always); in between the
- * phases and kernel samples of the last sampled solve stay, and total_ms is host wall time around the solve. */
+ * phases and kernel samples of the last sampled solve stay (cx_solve_timing.sampled = 0 says so), and total_ms is host
+ * wall time around the solve. */
 int cx_solver_last_timing(const cx_solver* s, cx_solve_timing* out);
 /* per-kernel device times of the last (sampled, see above) solve (ExecutionSummary of the reference is host
  * wall time per phase, execution_summary.h:45-83; this is its device-side counterpart) */

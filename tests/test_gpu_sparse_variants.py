@@ -44,3 +44,17 @@ def test_single_workgroup_cg_tail_keeps_the_bits():
     assert run({"CX_NO_SMALL_SETUP": "1"}) == fused
     assert "(0, " in fused[0]      # SUCCESS somewhere, and more than one residual reset period was crossed
     assert any(int(t.split(")")[0]) > 20 for t in fused[0].split(", ")[1::2])
+
+
+def test_cgnr_operator_without_memsets_keeps_the_bits():
+    """CGNR's operator writes J x and J'(J x) + D^2 x outright (no zeroing, the LM diagonal inside the kernels that write y)
+    and its Jacobi preconditioner sums r.z in the launch that forms z: steps and iteration counts of tools/cgnr_bits.py
+    (fp64 and fp32 products, with and without D, JACOBI / IDENTITY) are those of round 3's separate launches."""
+    def run(env):
+        e = dict(os.environ)
+        e.update(env)
+        out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "cgnr_bits.py")], env=e, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                             text=True, timeout=600)
+        assert out.returncode == 0, out.stderr[-2000:]
+        return out.stdout.strip().splitlines()[-2:]
+    assert run({}) == run({"CX_CGNR_PLAIN": "1"})
