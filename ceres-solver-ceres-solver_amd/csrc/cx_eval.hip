@@ -884,22 +884,21 @@ int cx_evaluator_evaluate(cx_evaluator* e, const double* state, double* cost, do
   if (scaled_j && !A->ft_valid) CX_TRY(cx_matrix_ensure_ft(A));
   CX_HIP(hipEventRecord(ctx->ev[7], st));
   if (gradient) {
-    // g = J' r (program_evaluator.h:242-258)
-    CX_HIP(hipMemsetAsync(hg.dptr, 0, size_t(ncols) * sizeof(double), st));
+    // g = J' r (program_evaluator.h:242-258), written outright (the products' kernels cover every entry)
     if (scratch_j) {  // the product reads the scratch copies (pointers are taken at launch), the matrix keeps its own
       const bool ft_valid = A->ft_valid, use_f32 = A->use_f32;
       std::swap(A->d_values.p, e->d_scratch_values.p);
       std::swap(A->d_Ft.p, e->d_scratch_Ft.p);
       A->ft_valid = true;
       A->use_f32 = false;
-      const int rc = cxk_left_multiply(A, res_dev, hg.dptr);
+      const int rc = cxk_left_multiply(A, res_dev, hg.dptr, false);
       std::swap(A->d_values.p, e->d_scratch_values.p);
       std::swap(A->d_Ft.p, e->d_scratch_Ft.p);
       A->ft_valid = ft_valid;
       A->use_f32 = use_f32;
       CX_TRY(rc);
     } else {
-      CX_TRY(cxk_left_multiply(A, res_dev, hg.dptr));
+      CX_TRY(cxk_left_multiply(A, res_dev, hg.dptr, false));
     }
     if (ctx->nranks > 1) CX_TRY(cx_allreduce_device(ctx, hg.dptr + 3 * int64_t(e->P), 9 * int64_t(e->C)));
     // the stored J carries the column scales: (J S)'r = S J'r, and the gradient of the caller's (unscaled) problem is
