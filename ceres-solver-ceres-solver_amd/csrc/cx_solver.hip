@@ -338,7 +338,9 @@ struct SmallTail {
   CgState* st;
   CgState* ring;
   int ring_slots;
+  long long* dbg;  // CX_SMALL_TAIL_DEBUG: 8 timestamps (s_memtime) of thread 0 at the phase boundaries, else NULL
 };
+#define CX_TAIL_STAMP(slot) do { if (a.dbg && tid == 0) a.dbg[slot] = (long long)__builtin_readcyclecounter(); } while (0)
 __device__ __forceinline__ double small_total(const double* sc, int lane, int G) {
   const double v = lane < G ? ((sc[4 * lane] + sc[4 * lane + 1]) + sc[4 * lane + 2]) + sc[4 * lane + 3] : 0.0;
   return wave_sum(v);
@@ -361,6 +363,7 @@ __global__ __launch_bounds__(1024) void k_cg_small_tail(SmallTail a) {
     ran_q = 0;
   }
   const int n = a.n, G = (n + 255) / 256;
+  CX_TAIL_STAMP(0);
   constexpr bool kPrefetch = PASSES == 1;
   double pv[PASSES], qv[PASSES], dv[PASSES], xv0[PASSES], rv0[PASSES], rhsv[PASSES], mrow[kPrefetch ? 9 : 1];
   int sg0[PASSES], sg1[PASSES];
@@ -375,10 +378,10 @@ __global__ __launch_bounds__(1024) void k_cg_small_tail(SmallTail a) {
       sg1[k] = a.prod.cam_seg_start[c + 1];
       pv[k] = a.p[i];
       if (a.prod.d) dv[k] = a.prod.d[i];
+      xv0[k] = a.x[i];
+      rv0[k] = a.r[i];
+      rhsv[k] = a.rhs[i];
       if (kPrefetch) {
-        xv0[k] = a.x[i];
-        rv0[k] = a.r[i];
-        rhsv[k] = a.rhs[i];
         const double* m = a.blocks + int64_t(c) * 81 + (i - c * 9) * 9;
 #pragma unroll
         for (int kk = 0; kk < 9; ++kk) mrow[kk] = m[kk];
@@ -386,16 +389,49 @@ __global__ __launch_bounds__(1024) void k_cg_small_tail(SmallTail a) {
     }
   }
   __syncthreads();
+  CX_TAIL_STAMP(1);
   if (ls.flag) return;  // (an iteration enqueued ahead of the host's look at the ring: nothing to do, nothing to publish)
-  // (1) q = sum of the camera's segment partials + d^2 p ; p.q  (k_cam_reduce9_dot)
+  // (1) q = sum of the camera's segment partials + d^2 p ; p.q  (k_cam_reduce9_dot).  The segment sums of a thread's PASSES
+  // entries advance together: PASSES independent loads in flight per step instead of one (each sum keeps its own order).
+  double seg_sum[PASSES];
+  {
+    const double* sp[PASSES];
+    int len[PASSES], maxlen = 0;
+#pragma unroll
+    for (int k = 0; k < PASSES; ++k) {
+      const int i = k * 1024 + tid;
+      seg_sum[k] = 0.0;
+      len[k] = (i < n) ? sg1[k] - sg0[k] : 0;
+      sp[k] = a.prod.partial9 + int64_t(sg0[k]) * 9 + (i < n ? i - (i / 9) * 9 : 0);
+      maxlen = max(maxlen, len[k]);
+    }
+    if (PASSES == 1) {
+      for (int j = 0; j < len[0]; ++j) seg_sum[0] += sp[0][int64_t(j) * 9];
+    } else {
+      // kChunk segments of every pass are requested together (clamped addresses, the additions stay predicated and in
+      // order): a partial sum written by another XCD's workgroup is a trip to memory, 1-2 us, and a camera of a mid-size
+      // problem has a dozen of them
+      constexpr int kChunk = 6;
+      for (int j0 = 0; j0 < maxlen; j0 += kChunk) {
+        double v[PASSES][kChunk];
+#pragma unroll
+        for (int k = 0; k < PASSES; ++k)
+#pragma unroll
+          for (int u = 0; u < kChunk; ++u) v[k][u] = sp[k][int64_t(max(min(j0 + u, len[k] - 1), 0)) * 9];
+#pragma unroll
+        for (int k = 0; k < PASSES; ++k)
+#pragma unroll
+          for (int u = 0; u < kChunk; ++u)
+            if (j0 + u < len[k]) seg_sum[k] += v[k][u];
+      }
+    }
+  }
 #pragma unroll
   for (int k = 0; k < PASSES; ++k) {
     const int i = k * 1024 + tid;
     double s0 = 0.0;
     if (i < n) {
-      const int c = i / 9, kk = i - c * 9;
-      double s = 0.0;
-      for (int sg = sg0[k]; sg < sg1[k]; ++sg) s += a.prod.partial9[int64_t(sg) * 9 + kk];
+      double s = seg_sum[k];
       const double xv = pv[k];
       if (a.prod.d) s += dv[k] * dv[k] * xv;
       a.q[i] = s;
@@ -406,11 +442,13 @@ __global__ __launch_bounds__(1024) void k_cg_small_tail(SmallTail a) {
     if (lane == 0) sc0[k * 16 + wave] = ws;
   }
   __syncthreads();
+  CX_TAIL_STAMP(2);
   if (wave == 0) {
     const double tot = small_total(sc0, lane, G);
     if (lane == 0) cg_scalar_step(tot, 0.0, FIN_PQ, a.iter, 0, &ls, nullptr, 0);
   }
   __syncthreads();
+  CX_TAIL_STAMP(3);
   if (ls.flag == 0) {
     const double alpha = ls.alpha;
     // (2) x += alpha p ; r -= alpha q ; tmp = rhs + r ; x.tmp, r.r  (k_update_xr_dot)
@@ -419,9 +457,9 @@ __global__ __launch_bounds__(1024) void k_cg_small_tail(SmallTail a) {
       const int i = k * 1024 + tid;
       double s0 = 0.0, s1 = 0.0;
       if (i < n) {
-        const double xv = (kPrefetch ? xv0[k] : a.x[i]) + alpha * pv[k];
-        const double rv = (kPrefetch ? rv0[k] : a.r[i]) - alpha * qv[k];
-        const double tv = (kPrefetch ? rhsv[k] : a.rhs[i]) + rv;
+        const double xv = xv0[k] + alpha * pv[k];
+        const double rv = rv0[k] - alpha * qv[k];
+        const double tv = rhsv[k] + rv;
         a.x[i] = xv;
         a.r[i] = rv;
         a.tmp[i] = tv;
@@ -445,9 +483,22 @@ __global__ __launch_bounds__(1024) void k_cg_small_tail(SmallTail a) {
       }
     }
     __syncthreads();
+    CX_TAIL_STAMP(4);
     if (ls.flag == 0) {
-      // (3) head of iteration iter + 1: z = blockdiag(M) r ; r.z  (k_blockdiag9_dot)
+      // (3) head of iteration iter + 1: z = blockdiag(M) r ; r.z  (k_blockdiag9_dot).  All block rows of the thread's
+      // entries are requested before the first product (PASSES > 1; one pass had them from the top of the kernel).
       double zv[PASSES];
+      double mr[kPrefetch ? 1 : PASSES][9];
+      if (!kPrefetch) {
+#pragma unroll
+        for (int k = 0; k < PASSES; ++k) {
+          const int i = min(k * 1024 + tid, n - 1);
+          const int blk = i / 9, row = i - blk * 9;
+          const double* m = a.blocks + int64_t(blk) * 81 + row * 9;
+#pragma unroll
+          for (int kk = 0; kk < 9; ++kk) mr[k][kk] = m[kk];
+        }
+      }
 #pragma unroll
       for (int k = 0; k < PASSES; ++k) {
         const int i = k * 1024 + tid;
@@ -455,11 +506,10 @@ __global__ __launch_bounds__(1024) void k_cg_small_tail(SmallTail a) {
         zv[k] = 0.0;
         if (i < n) {
           const int blk = i / 9, row = i - blk * 9;
-          const double* m = a.blocks + int64_t(blk) * 81 + row * 9;
           const double* rv = rl + blk * 9;
           double s = 0.0;
 #pragma unroll
-          for (int kk = 0; kk < 9; ++kk) s += (kPrefetch ? mrow[kk] : m[kk]) * rv[kk];
+          for (int kk = 0; kk < 9; ++kk) s += (kPrefetch ? mrow[kk] : mr[k][kk]) * rv[kk];
           zv[k] = s;
           s0 += rv[row] * s;
         }
@@ -478,6 +528,7 @@ __global__ __launch_bounds__(1024) void k_cg_small_tail(SmallTail a) {
         }
       }
       __syncthreads();
+      CX_TAIL_STAMP(5);
       if (ls.flag == 0) {
         const double beta = ls.beta;
         // (4) p = z + beta p  (k_update_p, iteration >= 2)
@@ -492,6 +543,7 @@ __global__ __launch_bounds__(1024) void k_cg_small_tail(SmallTail a) {
   // state back to global memory (the next kernels on the stream read it), then the ring -- what the general path's
   // cg_scalar_step publishes, in its order: the state after the Q test (or, when the p.q step ended the run, that state) as
   // iteration iter, a failure of the r.z step as iteration iter + 1
+  CX_TAIL_STAMP(6);
   if (tid != 0) return;
   *a.st = ls;
   auto publish = [&](const CgState& v, int seq) {
@@ -503,6 +555,7 @@ __global__ __launch_bounds__(1024) void k_cg_small_tail(SmallTail a) {
   if (ran_q) publish(pub_q, a.iter);
   else if (ls.flag != 0) publish(ls, a.iter);
   if (publish_rho) publish(pub_rho, a.iter + 1);
+  CX_TAIL_STAMP(7);
 }
 
 // ---- small problems, the set-up: everything between the two passes over J of ImplicitSchurComplement::Init and the first
@@ -1030,7 +1083,18 @@ struct CgDriver {
           CX_TRY(rc);
         }
         if (!reset && small_ok) {
-          SmallTail a{probe, pre.block9_inverse(), x, r, p, z, rhs, tmp, int(n), iter, ds, S->ring_d, kRingSlots};
+          static long long* dbg = [] {
+            long long* p = nullptr;
+            if (std::getenv("CX_SMALL_TAIL_DEBUG")) (void)hipHostMalloc(reinterpret_cast<void**>(&p), 8 * sizeof(long long), hipHostMallocMapped);
+            return p;
+          }();
+          SmallTail a{probe, pre.block9_inverse(), x, r, p, z, rhs, tmp, int(n), iter, ds, S->ring_d, kRingSlots, dbg};
+          if (dbg && iter == 2) {  // (development aid: the stamps of iteration 1's kernel, printed while iteration 2 is enqueued)
+            (void)hipStreamSynchronize(st);
+            std::fprintf(stderr, "small tail stamps (cycles since kernel start):");
+            for (int q = 1; q < 8; ++q) std::fprintf(stderr, " %lld", dbg[q] - dbg[0]);
+            std::fprintf(stderr, "\n");
+          }
           if (n <= 1024) hipLaunchKernelGGL(k_cg_small_tail<1>, dim3(1), dim3(1024), 0, st, a);
           else hipLaunchKernelGGL(k_cg_small_tail<4>, dim3(1), dim3(1024), 0, st, a);
           CX_HIP(hipGetLastError());
