@@ -20,11 +20,12 @@ run final13682_sparse_schur_mixed --solver sparse_schur --mixed --steps 2 --warm
 run final13682_cluster_tridiagonal --eta 1e-2 --preconditioner cluster_tridiagonal --steps 2 --warmup 1
 run dubrovnik356_dense_schur --workload dubrovnik356 --solver dense_schur --steps 5 --warmup 2
 run ladybug49 --workload ladybug49 --steps 20 --warmup 3
+run ladybug49_cgnr --workload ladybug49 --solver cgnr --steps 20 --warmup 3
 for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $c --kernel-trace --output-format csv -d $OUT/pmc_$c -- python3 $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --no-sparse-schur --no-boundary --steps 2 --warmup 1 > /dev/null 2> $OUT/pmc_$c.err
   cp $(ls $OUT/pmc_$c/*/*counter_collection.csv | head -1) $OUT/pmc_$c.csv
   echo "pmc $c done"
 done
 # keep the merged output small: drop the raw traces
-rm -rf $OUT/final13682 $OUT/final13682_sparse_schur $OUT/final13682_sparse_schur_mixed $OUT/final13682_cluster_tridiagonal $OUT/dubrovnik356_dense_schur $OUT/ladybug49 $OUT/pmc_FETCH_SIZE $OUT/pmc_WRITE_SIZE
+rm -rf $OUT/final13682 $OUT/final13682_sparse_schur $OUT/final13682_sparse_schur_mixed $OUT/final13682_cluster_tridiagonal $OUT/dubrovnik356_dense_schur $OUT/ladybug49 $OUT/ladybug49_cgnr $OUT/pmc_FETCH_SIZE $OUT/pmc_WRITE_SIZE
 ls -la $OUT
