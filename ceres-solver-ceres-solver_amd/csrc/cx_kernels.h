@@ -402,6 +402,56 @@ __device__ __forceinline__ void block_sum_store(const double (&v)[N], double* sc
   __syncthreads();
 }
 
+// ---- many sums at once.  The butterfly above costs 6 shuffles per value; with N values per lane a wavefront can do with
+// about 2: at the step with partner lane ^ MASK a lane keeps the lower or the upper half of its values (by its bit MASK),
+// hands the other half over and adds what it receives -- 54 -> 27 -> 14 -> 7 -> 4 -> 2 -> 1.  After the six steps every lane holds
+// ONE finished 64-lane total, that of value wave_multi_index<N, 32>(lane) (-1: none).  A fixed tree, the same in every call:
+// deterministic (and a different association than wave_sum's, so a kernel uses one or the other for a given quantity).
+// k_cam_init / k_cam_diag: 45 (+ 9) sums per segment were 324 shuffles of 64-bit values per wavefront, the LDS crossbar's
+// busiest customer on mid-size problems (a Dubrovnik-356 segment is ONE pass of 256 rows); now 55.
+template <int N, int MASK>
+struct WaveMulti {
+  static_assert(N >= 1 && N <= 2 * MASK, "N values need log2 steps down to one per lane");
+  static constexpr int H = (N + 1) / 2;
+  __device__ __forceinline__ static double run(const double (&v)[N], int lane) {
+    double w[H];
+    const bool upper = (lane & MASK) != 0;
+#pragma unroll
+    for (int j = 0; j < H; ++j) {
+      const double a = v[j];
+      const double b = (j + H < N) ? v[j + H] : 0.0;
+      const double keep = upper ? b : a, give = upper ? a : b;
+      w[j] = keep + __shfl_xor(give, MASK, 64);
+    }
+    if constexpr (MASK == 1) return w[0];
+    else return WaveMulti<H, MASK / 2>::run(w, lane);
+  }
+  // which of the N values this lane's result is the total of (-1: of none)
+  __device__ __forceinline__ static int index(int lane) {
+    int pos = 0;
+    if constexpr (MASK > 1) {
+      pos = WaveMulti<H, MASK / 2>::index(lane);
+      if (pos < 0) return -1;
+    }
+    const int src = pos + ((lane & MASK) ? H : 0);
+    return src < N ? src : -1;
+  }
+};
+
+// block_sum_store with the wavefront stage above: out[0..N) = the N sums over the workgroup (4 wavefronts, added in wave
+// order).  scratch: N * 4 doubles of LDS.  N <= 64.
+template <int N>
+__device__ __forceinline__ void block_sum_store_multi(const double (&v)[N], double* scratch, double* __restrict__ out) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const double total = WaveMulti<N, 32>::run(v, lane);
+  const int idx = WaveMulti<N, 32>::index(lane);
+  if (idx >= 0) scratch[idx * 4 + wave] = total;
+  __syncthreads();
+  const int t = threadIdx.x;
+  if (t < N) out[t] = ((scratch[t * 4] + scratch[t * 4 + 1]) + scratch[t * 4 + 2]) + scratch[t * 4 + 3];
+  __syncthreads();
+}
+
 // Inverse of a symmetric positive definite 3x3 (row-major, upper triangle read)
 // through LLT, the arithmetic of selfadjointView<Upper>().llt().solve(I)
 // (implicit_schur_complement.cc:201-202).  ok = false if not PD.

@@ -558,8 +558,9 @@ __global__ __launch_bounds__(kBlock) void k_cam_init(const double* __restrict__ 
       }
     }
   }
-  block_sum_store<45>(acc, red, partial45 + int64_t(sgm) * 45);
-  if (tprime) block_sum_store<9>(acc9, red, partial9 + int64_t(sgm) * 9);
+  static_assert(kBlock == 256, "block_sum_store_multi adds four wavefronts");
+  block_sum_store_multi<45>(acc, red, partial45 + int64_t(sgm) * 45);
+  if (tprime) block_sum_store_multi<9>(acc9, red, partial9 + int64_t(sgm) * 9);
 }
 
 // ---------------------------------------------- camera-major 9x9 block diagonals
@@ -617,7 +618,7 @@ __global__ __launch_bounds__(kBlock) void k_cam_diag(const double* __restrict__ 
       }
     }
   }
-  block_sum_store<45>(acc, red, partial + int64_t(s) * 45);
+  block_sum_store_multi<45>(acc, red, partial + int64_t(s) * 45);
 }
 
 // out[9c + k] = sum of the camera's 9-wide segment partials, in segment order
