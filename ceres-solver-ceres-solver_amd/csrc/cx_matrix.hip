@@ -217,7 +217,9 @@ __global__ __launch_bounds__(kBlock) void k_cam_ft(const T* __restrict__ Ft,
       for (int k = 0; k < 9; ++k) acc[k] += f[k] * tv.x + f[9 + k] * tv.y;
     }
   }
-  block_sum_store<9>(acc, red, partial + int64_t(s) * 9);
+  // (13 shuffles per wavefront instead of 54: a segment of a mid-size problem is one pass, and then the reduction was half
+  // of the kernel's instructions)
+  block_sum_store_multi<9>(acc, red, partial + int64_t(s) * 9);
 }
 
 // y_f[9c + k] (+)= sum of the camera's segment partials, in segment order (deterministic),
