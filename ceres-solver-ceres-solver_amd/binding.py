@@ -37,7 +37,7 @@ EXPORTED_SYMBOLS = [
     "cx_matrix_left_multiply", "cx_matrix_right_multiply_e", "cx_matrix_right_multiply_f",
     "cx_matrix_left_multiply_e", "cx_matrix_left_multiply_f", "cx_matrix_squared_column_norm", "cx_matrix_scale_columns",
     "cx_matrix_last_kernel_ms", "cx_solver_create", "cx_solver_destroy", "cx_solver_default_options",
-    "cx_solver_solve", "cx_solver_last_timing", "cx_solver_kernel_stats", "cx_schur_eliminate_dense", "cx_schur_back_substitute",
+    "cx_solver_solve", "cx_solver_last_timing", "cx_solver_sample_next", "cx_solver_kernel_stats", "cx_schur_eliminate_dense", "cx_schur_back_substitute",
     "cx_implicit_schur_multiply", "cx_dense_cholesky_solve", "cx_evaluator_create_bal", "cx_evaluator_destroy",
     "cx_evaluator_jacobian", "cx_evaluator_row_of_observation", "cx_evaluator_evaluate", "cx_evaluator_set_loss", "cx_minimizer_default_options", "cx_minimize", "cx_schur_sparse_structure", "cx_visibility_structure", "cx_visibility_clusters_host",
     "cx_evaluator_set_camera_model", "cx_evaluator_num_parameters", "cx_evaluator_num_effective_parameters", "cx_evaluator_plus",
@@ -522,6 +522,10 @@ class Solver:
         _check(self.lib.cx_solver_kernel_stats(self._h, arr, 8, ctypes.byref(n)))
         return [dict(name=arr[i].name.decode(), sampled_ms=arr[i].sampled_ms,
                      sampled_launches=arr[i].sampled_launches, launches=arr[i].launches) for i in range(n.value)]
+
+    def sample_next(self):
+        """the next solve takes phase times and kernel samples (launch-bound solvers take them every 16th solve only)"""
+        _check(self.lib.cx_solver_sample_next(self._h))
 
     def timing(self):
         t = cx_solve_timing()

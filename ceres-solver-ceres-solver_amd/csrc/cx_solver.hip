@@ -2046,6 +2046,14 @@ int cx_solver_kernel_stats(const cx_solver* s, cx_kernel_stat* out, int32_t capa
   return CX_OK;
 }
 
+int cx_solver_sample_next(cx_solver* s) {
+  CX_CHECK_ARG(s);
+  s->diag_requested = true;
+  for (cx_solver* part : s->parts)
+    if (part) part->diag_requested = true;
+  return CX_OK;
+}
+
 int cx_solver_last_timing(const cx_solver* s, cx_solve_timing* out) {
   CX_CHECK_ARG(s && out);
   *out = s->timing;
@@ -2065,7 +2073,8 @@ int cx_solver_solve(cx_solver* S, cx_matrix* A, const double* b, const cx_per_so
   const bool launch_bound = ctx->nranks <= 1 && A->num_cols_f <= kSmallCgMax;
   {
     static const int period = std::getenv("CX_DIAG_PERIOD") ? std::max(1, std::atoi(std::getenv("CX_DIAG_PERIOD"))) : int(cx_solver::kDiagPeriod);
-    S->diag = !launch_bound || (S->num_solves % period) == 0;  // see cx_solver::diag
+    S->diag = !launch_bound || S->diag_requested || (S->num_solves % period) == 0;  // see cx_solver::diag
+    S->diag_requested = false;
     ++S->num_solves;
   }
   S->num_pending = 0;

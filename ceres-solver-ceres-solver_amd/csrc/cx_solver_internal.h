@@ -157,6 +157,7 @@ struct cx_solver {
   static constexpr int kDiagPeriod = 16;
   int64_t num_solves = 0;
   bool diag = true;
+  bool diag_requested = false;  // cx_solver_sample_next
   // front on a multi-shard context (cx_multi.hip): one solver per shard, created at the first solve of a matrix
   std::vector<cx_solver*> parts;
   const cx_matrix* parts_for = nullptr;

@@ -379,6 +379,9 @@ int cx_solver_solve(cx_solver* s, cx_matrix* A, const double* b,
  * phases and kernel samples of the last sampled solve stay (cx_solve_timing.sampled = 0 says so), and total_ms is host
  * wall time around the solve. */
 int cx_solver_last_timing(const cx_solver* s, cx_solve_timing* out);
+/* The next solve of s takes phase times and kernel samples whatever the period (a caller that wants them for a particular
+ * solve of a launch-bound solver). */
+int cx_solver_sample_next(cx_solver* s);
 /* per-kernel device times of the last (sampled, see above) solve (ExecutionSummary of the reference is host
  * wall time per phase, execution_summary.h:45-83; this is its device-side counterpart) */
 int cx_solver_kernel_stats(const cx_solver* s, cx_kernel_stat* out, int32_t capacity, int32_t* count);
