@@ -14,7 +14,8 @@ from .structure import BlockStructure, cx_block_structure
 # RCCL between processes: the host driver of this pool supports dmabuf IPC only (must be set before the runtime starts)
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libcxschur.so")
+# CXSCHUR_LIB: another build of the same library (A/B runs of compile-time switches on one box)
+LIB_PATH = os.environ.get("CXSCHUR_LIB") or os.path.join(_HERE, "csrc", "libcxschur.so")
 _lib = None
 
 HOST, DEVICE = 0, 1

@@ -174,8 +174,11 @@ __global__ void k_to_float(const double* __restrict__ src, float* __restrict__ d
 
 // Camera-major pass: one workgroup per segment (<= kSegRows rows of ONE camera),
 // partial[seg][0..8] = sum over the segment of Ft_r' t_row(r).
+#ifndef CX_CAM_FT_OCCUPANCY
+#define CX_CAM_FT_OCCUPANCY 4
+#endif
 template <typename T>
-__global__ __launch_bounds__(kBlock) void k_cam_ft(const T* __restrict__ Ft,
+__global__ __launch_bounds__(kBlock, CX_CAM_FT_OCCUPANCY) void k_cam_ft(const T* __restrict__ Ft,
                                                    const int32_t* __restrict__ cam_rows,
                                                    const int32_t* __restrict__ seg_begin,
                                                    const double* __restrict__ t,

@@ -161,8 +161,11 @@ __global__ __launch_bounds__(kBlock) void k_chunk_ete(const double* __restrict__
 // MODE 2 (BACKSUB): s = b - F z;  x_pt = (E'E)^-1 E' s                       (BackSubstitute)
 // MODE 3 (SPSE)   : t = F x_f ;  out = E (E'E)^-1 E' t                      (power series operator)
 // T = float reads the fp32 copies of the cells (mixed-precision CG, modes 0 and 3); arithmetic is fp64.
+#ifndef CX_CHUNK_PASS_OCCUPANCY
+#define CX_CHUNK_PASS_OCCUPANCY 6
+#endif
 template <int MODE, typename T>
-__global__ __launch_bounds__(kBlock) void k_chunk_pass(const T* __restrict__ E,
+__global__ __launch_bounds__(kBlock, CX_CHUNK_PASS_OCCUPANCY) void k_chunk_pass(const T* __restrict__ E,
                                                        const T* __restrict__ F,
                                                        const int32_t* __restrict__ tile_row,
                                                        const int32_t* __restrict__ tile_pt,
@@ -331,8 +334,11 @@ __global__ __launch_bounds__(kBlock) void k_chunk_pass(const T* __restrict__ E,
 // (gathering F inside k_cam_init, to save the separate k_permute_ft, was measured 1.6x slower: two
 // dependent loads per piece at 2 workgroups per CU do not hide their latency)
 // Same per-point / per-segment summation orders as the separate kernels.
+#ifndef CX_CHUNK_INIT_OCCUPANCY
+#define CX_CHUNK_INIT_OCCUPANCY 5
+#endif
 template <bool USE_LLT>
-__global__ __launch_bounds__(kBlock) void k_chunk_init(const double* __restrict__ E,
+__global__ __launch_bounds__(kBlock, CX_CHUNK_INIT_OCCUPANCY) void k_chunk_init(const double* __restrict__ E,
                                                        const int32_t* __restrict__ tile_row,
                                                        const int32_t* __restrict__ tile_pt,
                                                        const int32_t* __restrict__ pt_start,
@@ -468,8 +474,11 @@ __global__ __launch_bounds__(kBlock) void k_chunk_init(const double* __restrict_
 }
 
 // One workgroup per camera-major segment of Ft.
+#ifndef CX_CAM_INIT_OCCUPANCY
+#define CX_CAM_INIT_OCCUPANCY 2
+#endif
 template <bool WITH_SCHUR>
-__global__ __launch_bounds__(kBlock) void k_cam_init(const double* __restrict__ F, const double* __restrict__ E,
+__global__ __launch_bounds__(kBlock, CX_CAM_INIT_OCCUPANCY) void k_cam_init(const double* __restrict__ F, const double* __restrict__ E,
                                                      const int32_t* __restrict__ cam_rows,
                                                      const int32_t* __restrict__ row_pt,
                                                      const int32_t* __restrict__ seg_begin,
@@ -567,8 +576,11 @@ __global__ __launch_bounds__(kBlock) void k_cam_init(const double* __restrict__ 
 // WITH_SCHUR = false: partial[seg] = sum F_r' F_r                      (block diagonal of F'F)
 // WITH_SCHUR = true : partial[seg] = sum F_r'F_r - (E_r'F_r)'(E'E)^-1(E_r'F_r)   (block diagonal of S)
 // 45 upper-triangle entries per segment, packed row-major (a <= b).
+#ifndef CX_CAM_DIAG_OCCUPANCY
+#define CX_CAM_DIAG_OCCUPANCY 3
+#endif
 template <bool WITH_SCHUR>
-__global__ __launch_bounds__(kBlock) void k_cam_diag(const double* __restrict__ Ft,
+__global__ __launch_bounds__(kBlock, CX_CAM_DIAG_OCCUPANCY) void k_cam_diag(const double* __restrict__ Ft,
                                                      const double* __restrict__ E,
                                                      const int32_t* __restrict__ cam_rows,
                                                      const int32_t* __restrict__ row_pt,
@@ -1348,7 +1360,10 @@ __global__ __launch_bounds__(kBlock) void k_pair_items_staged(const int32_t* __r
 // Little's law fits what is seen: a CU holds ~280 pairs in flight (five workgroups x 28 staged + 28 requested, by registers and
 // LDS alike -- LDS-DMA would hold the same), 448 B each = 32 MB chip-wide, at ~3 us of loaded latency = the ~9.4 TB/s the
 // kernel pulls on the CU side (65 % L2 hits).
-__global__ __launch_bounds__(kBlock) void k_row_h(const double* __restrict__ E, const double* __restrict__ F,
+#ifndef CX_ROW_H_OCCUPANCY
+#define CX_ROW_H_OCCUPANCY 4
+#endif
+__global__ __launch_bounds__(kBlock, CX_ROW_H_OCCUPANCY) void k_row_h(const double* __restrict__ E, const double* __restrict__ F,
                                                   const int32_t* __restrict__ row_pt, const double* __restrict__ ete_inv,
                                                   int64_t O, double* __restrict__ h0, double* __restrict__ h1) {
   __shared__ double lds[kBlock * 18];
