@@ -178,7 +178,7 @@ __global__ void k_to_float(const double* __restrict__ src, float* __restrict__ d
 #define CX_CAM_FT_OCCUPANCY 4
 #endif
 template <typename T>
-__global__ __launch_bounds__(kBlock, CX_CAM_FT_OCCUPANCY) void k_cam_ft(const T* __restrict__ Ft,
+__global__ __launch_bounds__(kBlock, sizeof(T) == 4 ? CX_CAM_FT_OCCUPANCY + 1 : CX_CAM_FT_OCCUPANCY) void k_cam_ft(const T* __restrict__ Ft,
                                                    const int32_t* __restrict__ cam_rows,
                                                    const int32_t* __restrict__ seg_begin,
                                                    const double* __restrict__ t,
