@@ -162,7 +162,7 @@ __global__ __launch_bounds__(kBlock) void k_chunk_ete(const double* __restrict__
 // MODE 3 (SPSE)   : t = F x_f ;  out = E (E'E)^-1 E' t                      (power series operator)
 // T = float reads the fp32 copies of the cells (mixed-precision CG, modes 0 and 3); arithmetic is fp64.
 #ifndef CX_CHUNK_PASS_OCCUPANCY
-#define CX_CHUNK_PASS_OCCUPANCY 6
+#define CX_CHUNK_PASS_OCCUPANCY 5
 #endif
 template <int MODE, typename T>
 __global__ __launch_bounds__(kBlock, CX_CHUNK_PASS_OCCUPANCY) void k_chunk_pass(const T* __restrict__ E,
