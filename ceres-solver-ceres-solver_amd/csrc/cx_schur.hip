@@ -164,8 +164,11 @@ __global__ __launch_bounds__(kBlock) void k_chunk_ete(const double* __restrict__
 #ifndef CX_CHUNK_PASS_OCCUPANCY
 #define CX_CHUNK_PASS_OCCUPANCY 5
 #endif
+#ifndef CX_CHUNK_PASS_OCCUPANCY_F32
+#define CX_CHUNK_PASS_OCCUPANCY_F32 6
+#endif
 template <int MODE, typename T>
-__global__ __launch_bounds__(kBlock, CX_CHUNK_PASS_OCCUPANCY) void k_chunk_pass(const T* __restrict__ E,
+__global__ __launch_bounds__(kBlock, sizeof(T) == 4 ? CX_CHUNK_PASS_OCCUPANCY_F32 : CX_CHUNK_PASS_OCCUPANCY) void k_chunk_pass(const T* __restrict__ E,
                                                        const T* __restrict__ F,
                                                        const int32_t* __restrict__ tile_row,
                                                        const int32_t* __restrict__ tile_pt,
