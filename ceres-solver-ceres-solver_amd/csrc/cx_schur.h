@@ -16,6 +16,8 @@ int cxs_camera_block_diagonal(cx_matrix* A, double* blocks);
 int cxs_implicit_init(cx_matrix* A, const double* D, const double* b, bool want_blocks, bool with_schur,
                       double* ete_inv, double* rows_scratch, double* blocks, double* rhs_out, int* d_flag,
                       bool defer_reduce = false);
+// blocks[81C] = block diagonal of F'F, ftb[9C] = F't (t: one value per scalar row), one pass over the camera-major copy
+int cxs_camera_blocks_and_ft(cx_matrix* A, const double* t, double* blocks, double* ftb);
 int cxs_block9_add_diag_invert(cx_context* ctx, double* blocks, const double* Df, int C, int* d_flag);
 // dense lhs (9C x 9C row-major, upper block triangle) and rhs of the reduced system
 int cxs_eliminate_dense(cx_matrix* A, const double* b, const double* D, bool add_df, double* lhs, double* rhs);

@@ -1824,6 +1824,28 @@ int cxs_camera_block_diagonal(cx_matrix* A, double* blocks) {
   return CX_OK;
 }
 
+// blocks[81C] = block diagonal of F'F and ftb[9C] = F't in ONE pass over the camera-major copy (k_cam_init without the Schur
+// terms: the kernel of the implicit set-up, here for CGNR's Jacobi blocks and the camera part of J'b).
+int cxs_camera_blocks_and_ft(cx_matrix* A, const double* t, double* blocks, double* ftb) {
+  hipStream_t st = A->ctx->stream;
+  if (A->num_segs == 0) {
+    CX_HIP(hipMemsetAsync(blocks, 0, 81 * size_t(std::max(A->C, 1)) * sizeof(double), st));
+    if (A->C > 0) CX_HIP(hipMemsetAsync(ftb, 0, 9 * size_t(A->C) * sizeof(double), st));
+    return CX_OK;
+  }
+  CX_TRY(cx_matrix_ensure_ft(A));
+  CX_TRY(A->d_partials9.alloc(size_t(A->num_segs) * 9));
+  hipLaunchKernelGGL(k_cam_init<false>, dim3(xcd_grid(A->num_segs)), dim3(kBlock), 0, st, (const double*)nullptr, (const double*)nullptr,
+                     A->d_cam_rows.p, A->d_row_pt.p, A->d_seg_begin.p, (const double*)nullptr, t, (const double*)A->d_Ft.p,
+                     A->d_partials.p, A->d_partials9.p, A->num_segs);
+  hipLaunchKernelGGL(k_cam_diag_reduce, dim3(grid_for(int64_t(A->C) * 45, 256)), dim3(256), 0, st,
+                     (const double*)A->d_partials.p, A->d_cam_seg_start.p, blocks, A->C);
+  hipLaunchKernelGGL(k_sum_segments9, dim3(grid_for(int64_t(A->C) * 9, 256)), dim3(256), 0, st,
+                     (const double*)A->d_partials9.p, A->d_cam_seg_start.p, ftb, A->C);
+  CX_HIP(hipGetLastError());
+  return CX_OK;
+}
+
 int cxs_block9_add_diag_invert(cx_context* ctx, double* blocks, const double* Df, int C, int* d_flag) {
   if (C == 0) return CX_OK;
   hipLaunchKernelGGL(k_block9_add_diag_invert, dim3(grid_for(C, kInvertBlocks)), dim3(kInvertBlocks * 9), 0, ctx->stream, blocks, Df, C, d_flag);

@@ -774,6 +774,96 @@ __global__ void k_blockdiag_multiply(const double* __restrict__ blocks, const do
   z[i] = s;
 }
 
+// CGNR set-up, the point side in ONE pass over E (chunk-aligned tiles, the cells staged through LDS like k_left_e_239):
+// the 3x3 point blocks of J'J + D^2 inverted through LLT (k_point_jacobi) and the point part of J'b (k_left_e_239), both
+// summed over a point's rows in row order as those kernels do.
+__global__ __launch_bounds__(kBlock) void k_point_jacobi_etb(const double* __restrict__ E, const int32_t* __restrict__ tile_row,
+                                                             const int32_t* __restrict__ tile_pt, const int32_t* __restrict__ pt_start,
+                                                             const double* __restrict__ D, const double* __restrict__ b,
+                                                             double* __restrict__ blocks, double* __restrict__ ye,
+                                                             int* __restrict__ not_pd) {
+  __shared__ double lds[kBlock * 9];  // staging (6 per row), then 9 products per row
+  __shared__ double red[9 * 4];
+  const int t = blockIdx.x, tid = threadIdx.x;
+  const int r0 = tile_row[t], r1 = tile_row[t + 1];
+  const int p0 = tile_pt[t], p1 = tile_pt[t + 1];
+  double m[9], etb[3];
+  bool have = false;
+  int p = p0;
+  if (r1 - r0 <= kBlock) {
+    const int nvalid = r1 - r0;
+    double e[6];
+    stage_cells<6>(E + 6 * int64_t(r0), nvalid, lds, e);
+    __syncthreads();  // (the staging area is reused for the products)
+    if (tid < nvalid) {
+      const double2 bv = reinterpret_cast<const double2*>(b)[r0 + tid];
+      double* w = lds + tid * 9;
+      w[0] = e[0] * e[0] + e[3] * e[3];
+      w[1] = e[0] * e[1] + e[3] * e[4];
+      w[2] = e[0] * e[2] + e[3] * e[5];
+      w[3] = e[1] * e[1] + e[4] * e[4];
+      w[4] = e[1] * e[2] + e[4] * e[5];
+      w[5] = e[2] * e[2] + e[5] * e[5];
+      w[6] = e[0] * bv.x + e[3] * bv.y;
+      w[7] = e[1] * bv.x + e[4] * bv.y;
+      w[8] = e[2] * bv.x + e[5] * bv.y;
+    }
+    __syncthreads();
+    if (tid < p1 - p0) {
+      p = p0 + tid;
+      have = true;
+      double s[9];
+#pragma unroll
+      for (int k = 0; k < 9; ++k) s[k] = 0.0;
+      for (int j = pt_start[p] - r0; j < pt_start[p + 1] - r0; ++j) {
+#pragma unroll
+        for (int k = 0; k < 9; ++k) s[k] += lds[j * 9 + k];
+      }
+      m[0] = s[0]; m[1] = s[1]; m[2] = s[2]; m[4] = s[3]; m[5] = s[4]; m[8] = s[5];
+      etb[0] = s[6]; etb[1] = s[7]; etb[2] = s[8];
+    }
+  } else {
+    // one point whose chunk is longer than a tile: strided loop + block reduction
+    double s[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) s[k] = 0.0;
+    for (int r = r0 + tid; r < r1; r += kBlock) {
+      const double* e = E + 6 * int64_t(r);
+      const double2 bv = reinterpret_cast<const double2*>(b)[r];
+      s[0] += e[0] * e[0] + e[3] * e[3];
+      s[1] += e[0] * e[1] + e[3] * e[4];
+      s[2] += e[0] * e[2] + e[3] * e[5];
+      s[3] += e[1] * e[1] + e[4] * e[4];
+      s[4] += e[1] * e[2] + e[4] * e[5];
+      s[5] += e[2] * e[2] + e[5] * e[5];
+      s[6] += e[0] * bv.x + e[3] * bv.y;
+      s[7] += e[1] * bv.x + e[4] * bv.y;
+      s[8] += e[2] * bv.x + e[5] * bv.y;
+    }
+    block_sum<9>(s, red);
+    if (tid == 0) {
+      have = true;
+      m[0] = s[0]; m[1] = s[1]; m[2] = s[2]; m[4] = s[3]; m[5] = s[4]; m[8] = s[5];
+      etb[0] = s[6]; etb[1] = s[7]; etb[2] = s[8];
+    }
+  }
+  if (!have) return;
+  if (D) {
+    const double* d = D + 3 * int64_t(p);
+    m[0] += d[0] * d[0]; m[4] += d[1] * d[1]; m[8] += d[2] * d[2];
+  }
+  m[3] = m[1]; m[6] = m[2]; m[7] = m[5];
+  double inv[9];
+  bool ok;
+  inv3_llt(m, inv, ok);
+  if (!ok) *not_pd = 1;
+#pragma unroll
+  for (int k = 0; k < 9; ++k) blocks[9 * int64_t(p) + k] = inv[k];
+  ye[3 * int64_t(p)] = etb[0];
+  ye[3 * int64_t(p) + 1] = etb[1];
+  ye[3 * int64_t(p) + 2] = etb[2];
+}
+
 // CGNR Jacobi: 3x3 point blocks of J'J + D^2, inverted through LLT
 __global__ __launch_bounds__(kBlock) void k_point_jacobi(const double* __restrict__ E,
                                                          const int32_t* __restrict__ pt_start,
@@ -1725,20 +1815,27 @@ int SolveCgnr239(cx_solver* S, cx_matrix* A, const double* b, const double* D, d
   CX_HIP(hipMemsetAsync(S->flag.p, 0, sizeof(int), st));
   CX_TRY(sw.start());
   CX_TRY(cx_matrix_ensure_ft(A));
-  if (o.preconditioner_type == CX_JACOBI) {
+  const bool jacobi = o.preconditioner_type == CX_JACOBI;
+  if (jacobi) {
     // BlockSparseJacobiPreconditioner::UpdateImpl (block_jacobi_preconditioner.cc:59-115)
     CX_TRY(S->pt_blocks.alloc(9 * size_t(A->P)));
     CX_TRY(S->cam_blocks.alloc(81 * size_t(A->C)));
-    if (A->P) hipLaunchKernelGGL(k_point_jacobi, dim3(grid_for(A->P, kBlock)), dim3(kBlock), 0, st, A->d_values.p, A->d_pt_start.p, D, S->pt_blocks.p, A->P, S->flag.p);
-    CX_TRY(cxs_camera_block_diagonal(A, S->cam_blocks.p));
+    // the points' blocks of J'J and the point part of the right-hand side J'b in one pass over E (round 3: k_point_jacobi, one
+    // thread walking a point's rows, then k_left_e_239)
+    if (A->P) hipLaunchKernelGGL(k_point_jacobi_etb, dim3(A->num_tiles), dim3(kBlock), 0, st, (const double*)A->d_values.p, A->d_tile_row.p,
+                                 A->d_tile_pt.p, A->d_pt_start.p, D, b, S->pt_blocks.p, S->v_rhs.p, S->flag.p);
+    // the cameras' blocks of J'J and the camera part of the right-hand side J'b from the SAME pass over the camera-major
+    // copy (k_cam_init, the kernel of the implicit Schur set-up; round 3: k_cam_diag, then k_cam_ft)
+    CX_TRY(cxs_camera_blocks_and_ft(A, b, S->cam_blocks.p, S->v_rhs.p + ne));
     if (ctx->nranks > 1) CX_TRY(cx_allreduce_device(ctx, S->cam_blocks.p, 81 * int64_t(A->C)));
     CX_TRY(cxs_block9_add_diag_invert(ctx, S->cam_blocks.p, D ? D + ne : nullptr, A->C, S->flag.p));
   } else if (o.preconditioner_type != CX_IDENTITY) {
     cx_set_error("CGNR supports JACOBI and IDENTITY preconditioners (cgnr_solver.cc:125-133)");
     return CX_ERR_UNSUPPORTED;
+  } else {
+    // rhs = J'b
+    CX_TRY(cxk_left_multiply(A, b, S->v_rhs.p, false));
   }
-  // rhs = J'b
-  CX_TRY(cxk_left_multiply(A, b, S->v_rhs.p, false));
   if (ctx->nranks > 1) CX_TRY(cx_allreduce_device(ctx, S->v_rhs.p + ne, n - ne));
   CX_TRY(sw.stop(&S->timing.eliminate_ms));
   CX_TRY(sw.start());
