@@ -30,8 +30,9 @@ int cxs_eliminate_sparse(cx_matrix* A, const double* b, const double* D, double*
 // item_ids (device, optional): only these work items are summed (the cells a visibility preconditioner keeps)
 // f32_operands (use_mixed_precision_solves: the cells feed a single precision factor): the per-row operand H = K'B is kept
 // in float, one 128-byte line per row, products and sums in double
+// rhs (optional): the reduced right-hand side F'(b - E (E'E)^-1 E'b) out of the same passes (b may be NULL: zeros)
 int cxs_assemble_pair_items(cx_matrix* A, const double* D, const int32_t* item_ids = nullptr, int64_t num_selected = 0,
-                            bool f32_operands = false);
+                            bool f32_operands = false, const double* b = nullptr, double* rhs = nullptr);
 int cxs_eliminate_rhs(cx_matrix* A, const double* b, double* rhs);
 // tile-sparse Cholesky (cx_sparse_chol.hip).  For the explicit S of a matrix: plan into A->sp, then assemble + factor
 // + solve in one call.

@@ -1855,13 +1855,33 @@ int cxs_block9_add_diag_invert(cx_context* ctx, double* blocks, const double* Df
 
 // Gather assembly shared by the dense and the block-sparse explicit S: (E'E + D_e^2)^-1 (closed-form inverse
 // of InvertPSDMatrix<3>), B / G of every row, F'F diagonal blocks, per-item pair sums.
-int cxs_assemble_pair_items(cx_matrix* A, const double* D, const int32_t* item_ids, int64_t num_selected, bool f32_operands) {
+// rhs != nullptr: the reduced right-hand side F'(b - E (E'E)^-1 E'b) is delivered too, and from the SAME two passes that
+// produce (E'E + D^2)^-1 and the F'F diagonal blocks -- k_chunk_init<cofactor> writes t' = b - E (E'E)^-1 E'b next to the
+// inverses, k_cam_init sums F't' next to the blocks (the set-up kernels of the implicit Schur complement; round 3 ran
+// k_chunk_ete, k_cam_diag and then k_chunk_pass<1>, k_cam_ft: two passes over J more).
+int cxs_assemble_pair_items(cx_matrix* A, const double* D, const int32_t* item_ids, int64_t num_selected, bool f32_operands,
+                            const double* b, double* rhs) {
   hipStream_t st = A->ctx->stream;
   CX_TRY(A->d_elim_ete.alloc(size_t(std::max<int64_t>(9 * int64_t(A->P), 1))));
   CX_TRY(A->d_elim_diag.alloc(size_t(std::max<int64_t>(81 * int64_t(A->C), 1))));
+  static const bool fuse_allowed = std::getenv("CX_ELIMINATE_RHS_SEPARATE") == nullptr;  // A/B switch: round 3's four passes
+  const bool fused_rhs = fuse_allowed && rhs != nullptr && b != nullptr && A->num_tiles > 0 && A->num_segs > 0;
   // the cofactor inverse reports nothing, exactly as InvertPSDMatrix<3> (invert_psd_matrix.h:60-63): a singular
   // E'E + D^2 shows as Inf/NaN in S and ends the solve in the Cholesky factorisation, as in the reference
-  CX_TRY(cxs_compute_ete_inverse(A, D, nullptr, A->d_elim_ete.p, nullptr, false, nullptr));
+  if (fused_rhs) {
+    CX_TRY(A->d_elim_rows.alloc(size_t(std::max<int64_t>(A->num_rows, 1))));
+    hipLaunchKernelGGL(k_chunk_init<false>, dim3(A->num_tiles), dim3(kBlock), 0, st, (const double*)A->d_values.p, A->d_tile_row.p,
+                       A->d_tile_pt.p, A->d_pt_start.p, A->d_row_pt.p, D, b, A->d_elim_ete.p, A->d_elim_rows.p, (int*)nullptr);
+    CX_HIP(hipGetLastError());
+  } else {
+    CX_TRY(cxs_compute_ete_inverse(A, D, nullptr, A->d_elim_ete.p, nullptr, false, nullptr));
+  }
+  // the F'F diagonal blocks (and, fused, the right-hand side) -- called where the variants below had the block diagonal
+  auto camera_pass = [&]() -> int {
+    if (fused_rhs) return cxs_camera_blocks_and_ft(A, A->d_elim_rows.p, A->d_elim_diag.p, rhs);
+    CX_TRY(cxs_camera_block_diagonal(A, A->d_elim_diag.p));
+    return rhs ? cxs_eliminate_rhs(A, b, rhs) : CX_OK;
+  };
   static const bool one_table = std::getenv("CX_PAIR_BG") == nullptr && std::getenv("CX_PAIR_ITEMS_DIRECT") == nullptr;  // A/B switch
   static const bool allow_f32 = std::getenv("CX_PAIR_H64") == nullptr;  // A/B switch: fp64 operands under a float factor
   if (one_table && f32_operands && allow_f32) {  // round 4: the same on a float table, one 128-byte line per row
@@ -1870,7 +1890,7 @@ int cxs_assemble_pair_items(cx_matrix* A, const double* D, const int32_t* item_i
       hipLaunchKernelGGL(k_row_h32, dim3(grid_for(A->O, kBlock)), dim3(kBlock), 0, st, (const double*)A->d_values.p,
                          (const double*)(A->d_values.p + 6 * A->O), (const int32_t*)A->d_row_pt.p, (const double*)A->d_elim_ete.p,
                          A->O, A->d_elim_h32.p);
-    CX_TRY(cxs_camera_block_diagonal(A, A->d_elim_diag.p));
+    CX_TRY(camera_pass());
     const int32_t* ids = item_ids ? item_ids : (A->d_item_order.n > 0 && A->d_item_order.p ? (const int32_t*)A->d_item_order.p : nullptr);
     const int64_t n_items = item_ids ? num_selected : A->num_items;
     static const bool xcd = std::getenv("CX_NO_XCD_ITEMS") == nullptr;
@@ -1896,7 +1916,7 @@ int cxs_assemble_pair_items(cx_matrix* A, const double* D, const int32_t* item_i
       hipLaunchKernelGGL(k_row_h, dim3(grid_for(A->O, kBlock)), dim3(kBlock), 0, st, (const double*)A->d_values.p,
                          (const double*)(A->d_values.p + 6 * A->O), (const int32_t*)A->d_row_pt.p, (const double*)A->d_elim_ete.p,
                          A->O, A->d_elim_bg0.p, A->d_elim_bg1.p);
-    CX_TRY(cxs_camera_block_diagonal(A, A->d_elim_diag.p));
+    CX_TRY(camera_pass());
     // all items: in the launch order of the pair-list builder (groups of block rows interleaved by block column, so that the
     // right operands of neighbouring block rows meet in one XCD's L2)
     const int32_t* ids = item_ids ? item_ids : (A->d_item_order.n > 0 && A->d_item_order.p ? (const int32_t*)A->d_item_order.p : nullptr);
@@ -1917,7 +1937,7 @@ int cxs_assemble_pair_items(cx_matrix* A, const double* D, const int32_t* item_i
     hipLaunchKernelGGL(k_row_bg, dim3(grid_for(A->O, kBlock)), dim3(kBlock), 0, st, (const double*)A->d_values.p,
                        (const double*)(A->d_values.p + 6 * A->O), (const int32_t*)A->d_row_pt.p,
                        (const double*)A->d_elim_ete.p, A->O, A->d_elim_bg0.p, A->d_elim_bg1.p, A->d_elim_bg2.p);
-  CX_TRY(cxs_camera_block_diagonal(A, A->d_elim_diag.p));
+  CX_TRY(camera_pass());
   const int64_t launch_items = item_ids ? num_selected : A->num_items;
   static const bool xcd_items = std::getenv("CX_NO_XCD_ITEMS") == nullptr;  // A/B switch
   static const bool staged = std::getenv("CX_PAIR_ITEMS_DIRECT") == nullptr;  // A/B switch: round 1's k_pair_items
@@ -1949,13 +1969,15 @@ int cxs_eliminate_dense(cx_matrix* A, const double* b, const double* D, bool add
   const double* Df = (D && add_df) ? D + 3 * int64_t(A->P) : nullptr;
   CX_TRY(cxs_build_pair_lists(A));
   if (A->pairs_state == 1) {
-    CX_TRY(cxs_assemble_pair_items(A, D));
+    CX_TRY(cxs_assemble_pair_items(A, D, nullptr, 0, false, b, rhs));
     if (n > 0) CX_HIP(hipMemsetAsync(lhs, 0, size_t(n) * n * sizeof(double), st));
     if (A->num_cells > 0)
       hipLaunchKernelGGL(k_pair_cells, dim3(unsigned((A->num_cells + 2) / 3)), dim3(3 * 81), 0, st,
                          (const int32_t*)A->d_cell_c1.p, (const int32_t*)A->d_cell_c2.p, (const int32_t*)A->d_cell_item_start.p,
                          (const double*)A->d_item_partial.p, (const double*)A->d_elim_diag.p, Df, lhs, (double*)nullptr, C,
                          A->num_cells);
+    CX_HIP(hipGetLastError());
+    return CX_OK;  // (the right-hand side came out of the assembly's own passes)
   } else {
     // scatter path: fp64 atomics into a block-major copy of S
     CX_TRY(A->d_elim_ete.alloc(size_t(std::max<int64_t>(9 * int64_t(A->P), 1))));
@@ -1988,14 +2010,14 @@ int cxs_eliminate_sparse(cx_matrix* A, const double* b, const double* D, double*
     return CX_ERR_UNSUPPORTED;
   }
   CX_TRY(A->d_S.alloc(size_t(std::max<int64_t>(A->num_cells, 1)) * 81));
-  CX_TRY(cxs_assemble_pair_items(A, D, nullptr, 0, f32_operands));
+  CX_TRY(cxs_assemble_pair_items(A, D, nullptr, 0, f32_operands, b, rhs));
   if (A->num_cells > 0)
     hipLaunchKernelGGL(k_pair_cells, dim3(unsigned((A->num_cells + 2) / 3)), dim3(3 * 81), 0, A->ctx->stream,
                        (const int32_t*)A->d_cell_c1.p, (const int32_t*)A->d_cell_c2.p, (const int32_t*)A->d_cell_item_start.p,
                        (const double*)A->d_item_partial.p, (const double*)A->d_elim_diag.p, (const double*)nullptr,
                        (double*)nullptr, A->d_S.p, A->C, A->num_cells);
   CX_HIP(hipGetLastError());
-  return cxs_eliminate_rhs(A, b, rhs);
+  return CX_OK;
 }
 
 int cxs_sparse_multiply(cx_matrix* A, const double* x, double* y) {

@@ -1915,8 +1915,7 @@ int SolveSparseSchur239(cx_solver* S, cx_matrix* A, const double* b, const doubl
     CX_TRY(cxs_eliminate_sparse(A, b, D, S->v_rhs.p, f32_operands));
     CX_TRY(cx_allreduce_device(ctx, S->v_rhs.p, nf));
   } else {
-    CX_TRY(cxs_assemble_pair_items(A, D, nullptr, 0, f32_operands));
-    CX_TRY(cxs_eliminate_rhs(A, b, S->v_rhs.p));
+    CX_TRY(cxs_assemble_pair_items(A, D, nullptr, 0, f32_operands, b, S->v_rhs.p));
   }
   CX_TRY(sw.stop(&S->timing.eliminate_ms));
   CX_TRY(sw.start());
