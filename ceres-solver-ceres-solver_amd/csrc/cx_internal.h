@@ -245,6 +245,9 @@ struct cx_matrix {
   int32_t num_segs = 0;
   DevBuf<double> d_Ft;                   // camera-major copy of the F cells [O][18]
   bool ft_valid = false;
+  // d_partials holds the per-segment partial sums of the F'F diagonal blocks of the CURRENT values (k_cam_init<false> has just
+  // run and nothing has used the buffer since): the explicit assembly then only adds them up (set and cleared by the caller)
+  bool ftf_partials_current = false;
   DevBuf<float> d_vals32, d_Ft32;        // fp32 copies for mixed-precision CGNR (cx_matrix_ensure_f32)
   bool f32_valid = false;
   bool use_f32 = false;                  // products read the fp32 copies (fp64 accumulation)

@@ -1879,7 +1879,13 @@ int cxs_assemble_pair_items(cx_matrix* A, const double* D, const int32_t* item_i
   // the F'F diagonal blocks (and, fused, the right-hand side) -- called where the variants below had the block diagonal
   auto camera_pass = [&]() -> int {
     if (fused_rhs) return cxs_camera_blocks_and_ft(A, A->d_elim_rows.p, A->d_elim_diag.p, rhs);
-    CX_TRY(cxs_camera_block_diagonal(A, A->d_elim_diag.p));
+    if (A->ftf_partials_current && A->num_segs > 0) {  // (the implicit set-up of this solve has summed them already)
+      hipLaunchKernelGGL(k_cam_diag_reduce, dim3(grid_for(int64_t(A->C) * 45, 256)), dim3(256), 0, st,
+                         (const double*)A->d_partials.p, A->d_cam_seg_start.p, A->d_elim_diag.p, A->C);
+      CX_HIP(hipGetLastError());
+    } else {
+      CX_TRY(cxs_camera_block_diagonal(A, A->d_elim_diag.p));
+    }
     return rhs ? cxs_eliminate_rhs(A, b, rhs) : CX_OK;
   };
   static const bool one_table = std::getenv("CX_PAIR_BG") == nullptr && std::getenv("CX_PAIR_ITEMS_DIRECT") == nullptr;  // A/B switch

@@ -1672,6 +1672,12 @@ int SolveIterativeSchur239(cx_solver* S, cx_matrix* A, const double* b, const do
   if (want_blocks && !small_setup) CX_TRY(cxs_block9_add_diag_invert(ctx, S->cam_blocks.p, D ? D + ne : nullptr, A->C, S->flag.p));
   if (visibility) {
     // VisibilityBasedPreconditioner::UpdateImpl (visibility_based_preconditioner.cc:321-364)
+    // (the set-up above ran k_cam_init<false>: the F'F block partial sums the preconditioner's assembly needs are in place)
+    struct PartialsInPlace {  // cleared however this block is left
+      cx_matrix* A;
+      ~PartialsInPlace() { A->ftf_partials_current = false; }
+    } in_place{A};
+    A->ftf_partials_current = o.preconditioner_type != CX_SCHUR_JACOBI && !small_setup && A->num_tiles > 0 && A->num_segs > 0;
     CX_TRY(cxv_factor(A, vis_plan, D, false, vis_flag));
     if (o.preconditioner_type == CX_CLUSTER_TRIDIAGONAL) {
       // "If it works, great, otherwise we scale all the cells in the preconditioner corresponding to the edges
