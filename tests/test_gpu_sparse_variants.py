@@ -58,3 +58,56 @@ def test_cgnr_operator_without_memsets_keeps_the_bits():
         assert out.returncode == 0, out.stderr[-2000:]
         return out.stdout.strip().splitlines()[-2:]
     assert run({}) == run({"CX_CGNR_PLAIN": "1"})
+
+
+def test_assembly_that_also_delivers_the_right_hand_side(tmp_path):
+    """The explicit Schur assembly takes the reduced right-hand side out of its own two set-up passes (k_chunk_init<cofactor>
+    writes t' next to the inverses, k_cam_init sums F't' next to the F'F blocks): DENSE_SCHUR, SPARSE_SCHUR (fp64 and float
+    factor, tile-sparse forced) and explicit-S ITERATIVE_SCHUR steps of tools/schur_bits.py against the four separate passes
+    of round 3 -- same termination and iteration counts, steps equal to rounding (1e-11 of |x| through a double precision
+    factor; 1e-7 where a single precision factor or a truncated CG run amplifies the last bits of the right-hand side)."""
+    import numpy as np
+
+    def run(env, name):
+        e = dict(os.environ)
+        e.update(env)
+        e["CX_SPARSE_CHOLESKY"] = "1"
+        path = str(tmp_path / name)
+        out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "schur_bits.py"), "--dump", path], env=e, stdout=subprocess.PIPE,
+                             stderr=subprocess.PIPE, text=True, timeout=600)
+        assert out.returncode == 0, out.stderr[-2000:]
+        z = np.load(path)
+        return out.stdout.strip().splitlines()[-2], [z[k] for k in z.files]
+    counts_a, xa = run({}, "fused.npz")
+    counts_b, xb = run({"CX_ELIMINATE_RHS_SEPARATE": "1"}, "separate.npz")
+    assert counts_a == counts_b
+    assert len(xa) == len(xb) == 16
+    for k, (a, b) in enumerate(zip(xa, xb)):
+        exact = (k % 8) in (0, 1, 2, 3)            # DENSE_SCHUR and fp64 SPARSE_SCHUR, with and without D
+        tol = 1e-11 if exact else 1e-7
+        assert np.linalg.norm(a - b) <= tol * np.linalg.norm(b), (k, np.linalg.norm(a - b) / np.linalg.norm(b))
+
+
+def test_launch_bound_solver_samples_its_timings_on_request(cxschur):
+    """A launch-bound solver takes phase times and kernel samples on its first solve and every 16th after it; in between
+    cx_solve_timing.sampled is 0 and cx_solver_sample_next() asks for the next one."""
+    cx = cxschur
+    if os.environ.get("CX_DIAG_PERIOD"):
+        pytest.skip("CX_DIAG_PERIOD overrides the period this test states")
+    ctx = cx.Context(0)
+    prob = cx.bal.make_preset("ladybug49")
+    ev = cx.Evaluator(ctx, prob)
+    _, res, _ = ev.evaluate(prob.state())
+    A = ev.jacobian()
+    S = cx.Solver(ctx, type=cx.ITERATIVE_SCHUR, preconditioner_type=cx.JACOBI, num_eliminate_blocks=prob.num_points)
+    flags = []
+    for i in range(4):
+        S.solve(A, res, None, r_tolerance=-1.0, q_tolerance=0.1)
+        flags.append(S.timing()["sampled"])
+    assert flags[0] == 1.0 and flags[1:] == [0.0, 0.0, 0.0]
+    assert S.timing()["total_ms"] > 0.0 and S.timing()["reduced_solve_ms"] > 0.0    # the phases of solve 0 stay
+    S.sample_next()
+    S.solve(A, res, None, r_tolerance=-1.0, q_tolerance=0.1)
+    assert S.timing()["sampled"] == 1.0 and len(S.kernel_stats()) > 0
+    S.close()
+    ev.close()
