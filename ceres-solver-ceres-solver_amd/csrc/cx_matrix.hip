@@ -1109,8 +1109,9 @@ int cx_matrix_right_multiply_overwrite(cx_matrix* A, const double* x, double* y,
   HostOrDevice hx(A->ctx), hy(A->ctx);
   CX_TRY(hx.in(x, size_t(A->num_cols), memspace));
   CX_TRY(hy.inout(y, size_t(A->num_rows), memspace, false));  // nothing of y crosses PCIe on the way in
-  CX_HIP(hipMemsetAsync(hy.dptr, 0, size_t(A->num_rows) * sizeof(double), A->ctx->stream));
-  CX_TRY(Timed(A, [&] { return A->embed ? cxe_matrix_op(A, 0, hx.dptr, hy.dptr) : cxk_right_multiply(A, hx.dptr, hy.dptr); }));
+  // the static kernel writes every row itself (no zeroing, no read of the old value); an embedding accumulates into zeros
+  if (A->embed) CX_HIP(hipMemsetAsync(hy.dptr, 0, size_t(A->num_rows) * sizeof(double), A->ctx->stream));
+  CX_TRY(Timed(A, [&] { return A->embed ? cxe_matrix_op(A, 0, hx.dptr, hy.dptr) : cxk_right_multiply(A, hx.dptr, hy.dptr, false); }));
   return hy.out();
 }
 

@@ -387,8 +387,7 @@ struct Minimizer {
     it.linear_solver_ms = MsSince(t0);
     // model_cost_change = -(J step)' (f + J step / 2); a non-finite step makes it NaN, hence invalid,
     // which is what IsArrayValid -> FAILURE leads to in the reference
-    CX_HIP(hipMemsetAsync(model_residuals.p, 0, size_t(m) * sizeof(double), st));
-    CX_TRY(cx_matrix_right_multiply(J, step.p, model_residuals.p, CX_DEVICE));
+    CX_TRY(cx_matrix_right_multiply_overwrite(J, step.p, model_residuals.p, CX_DEVICE));  // (written outright: no zeroing, no read of the old value)
     double dot = 0.0, unused = 0.0;
     CX_TRY(Reduce<RED_MODEL_COST>(model_residuals.p, residuals.p, m, m, dot, unused));
     model_cost_change = -dot;
