@@ -1829,8 +1829,10 @@ int cxs_camera_block_diagonal(cx_matrix* A, double* blocks) {
 int cxs_camera_blocks_and_ft(cx_matrix* A, const double* t, double* blocks, double* ftb) {
   hipStream_t st = A->ctx->stream;
   if (A->num_segs == 0) {
-    CX_HIP(hipMemsetAsync(blocks, 0, 81 * size_t(std::max(A->C, 1)) * sizeof(double), st));
-    if (A->C > 0) CX_HIP(hipMemsetAsync(ftb, 0, 9 * size_t(A->C) * sizeof(double), st));
+    if (A->C > 0) {
+      CX_HIP(hipMemsetAsync(blocks, 0, 81 * size_t(A->C) * sizeof(double), st));
+      CX_HIP(hipMemsetAsync(ftb, 0, 9 * size_t(A->C) * sizeof(double), st));
+    }
     return CX_OK;
   }
   CX_TRY(cx_matrix_ensure_ft(A));
