@@ -387,7 +387,6 @@ int cxk_squared_column_norm(cx_matrix* A, double* x);
 int cxk_scale_columns(cx_matrix* A, const double* scale);
 
 // y_f (+)= F' t  for the static path; t is row-sized
-int cxk_left_multiply_e(cx_matrix* A, const double* x, double* ye, bool accumulate);
 int cxk_ft_multiply(cx_matrix* A, const double* t, double* y_f, bool accumulate, const double* d_f = nullptr,
                     const double* x_f = nullptr);
 // first half of it: the per-segment partial sums only (A->d_partials, 9 per segment)

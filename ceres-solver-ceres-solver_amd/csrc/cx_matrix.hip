@@ -691,18 +691,6 @@ int cxk_right_multiply(cx_matrix* A, const double* x, double* y, bool accumulate
   return CX_OK;
 }
 
-// the point part of A'x only (static layout): y_e (+)= E'x
-int cxk_left_multiply_e(cx_matrix* A, const double* x, double* ye, bool accumulate) {
-  if (!A->is239) {
-    cx_set_error("cxk_left_multiply_e needs the static <2,3,9> layout");
-    return CX_ERR_UNSUPPORTED;
-  }
-  hipLaunchKernelGGL(k_left_e_239<double>, dim3(A->num_tiles), dim3(kBlock), 0, A->ctx->stream, (const double*)A->d_values.p,
-                     A->d_tile_row.p, A->d_tile_pt.p, A->d_pt_start.p, x, ye, accumulate ? 1 : 0, A->stop);
-  CX_HIP(hipGetLastError());
-  return CX_OK;
-}
-
 // accumulate = false: y = A'x (the static kernels write every entry themselves: their tiles cover all points, empty ones
 // included, and the camera reduction writes every camera; the dynamic-size path zeroes y first).
 // d != nullptr: y (+)= A'x + diag(d)^2 dx in the same launches (static layout; *folded says whether it happened).

@@ -775,8 +775,9 @@ __global__ void k_blockdiag_multiply(const double* __restrict__ blocks, const do
 }
 
 // CGNR set-up, the point side in ONE pass over E (chunk-aligned tiles, the cells staged through LDS like k_left_e_239):
-// the 3x3 point blocks of J'J + D^2 inverted through LLT (k_point_jacobi) and the point part of J'b (k_left_e_239), both
-// summed over a point's rows in row order as those kernels do.
+// the 3x3 point blocks of J'J + D^2 inverted through LLT (BlockSparseJacobiPreconditioner, block_jacobi_preconditioner.cc:59-115;
+// round 3's k_point_jacobi: one thread walking a point's rows) and the point part of J'b (k_left_e_239), both summed over a
+// point's rows in row order as those kernels do.
 __global__ __launch_bounds__(kBlock) void k_point_jacobi_etb(const double* __restrict__ E, const int32_t* __restrict__ tile_row,
                                                              const int32_t* __restrict__ tile_pt, const int32_t* __restrict__ pt_start,
                                                              const double* __restrict__ D, const double* __restrict__ b,
@@ -862,38 +863,6 @@ __global__ __launch_bounds__(kBlock) void k_point_jacobi_etb(const double* __res
   ye[3 * int64_t(p)] = etb[0];
   ye[3 * int64_t(p) + 1] = etb[1];
   ye[3 * int64_t(p) + 2] = etb[2];
-}
-
-// CGNR Jacobi: 3x3 point blocks of J'J + D^2, inverted through LLT
-__global__ __launch_bounds__(kBlock) void k_point_jacobi(const double* __restrict__ E,
-                                                         const int32_t* __restrict__ pt_start,
-                                                         const double* __restrict__ D, double* __restrict__ blocks,
-                                                         int P, int* __restrict__ not_pd) {
-  const int p = blockIdx.x * blockDim.x + threadIdx.x;
-  if (p >= P) return;
-  double m[9];
-#pragma unroll
-  for (int k = 0; k < 9; ++k) m[k] = 0.0;
-  for (int r = pt_start[p]; r < pt_start[p + 1]; ++r) {
-    const double* e = E + 6 * int64_t(r);
-    m[0] += e[0] * e[0] + e[3] * e[3];
-    m[1] += e[0] * e[1] + e[3] * e[4];
-    m[2] += e[0] * e[2] + e[3] * e[5];
-    m[4] += e[1] * e[1] + e[4] * e[4];
-    m[5] += e[1] * e[2] + e[4] * e[5];
-    m[8] += e[2] * e[2] + e[5] * e[5];
-  }
-  if (D) {
-    const double* d = D + 3 * int64_t(p);
-    m[0] += d[0] * d[0]; m[4] += d[1] * d[1]; m[8] += d[2] * d[2];
-  }
-  m[3] = m[1]; m[6] = m[2]; m[7] = m[5];
-  double inv[9];
-  bool ok;
-  inv3_llt(m, inv, ok);
-  if (!ok) *not_pd = 1;
-#pragma unroll
-  for (int k = 0; k < 9; ++k) blocks[9 * int64_t(p) + k] = inv[k];
 }
 
 // ------------------------------------------------------------------ operators
