@@ -938,3 +938,47 @@ def test_preconditioner_failure_is_reported(ctx, oracle, explicit):
     S.close()
     A.close()
 
+
+
+@pytest.mark.parametrize("stype,pre", SOLVERS + [("SPARSE_SCHUR", "IDENTITY")])
+def test_points_and_a_camera_without_observations(ctx, oracle, stype, pre):
+    """A structure whose column blocks are not all observed: two points in the middle, the LAST point and one camera have no
+    residual block.  The static kernels write such entries themselves (the chunk-aligned tiles cover every point, the camera
+    reduction every camera): J x, J'y and diag(J'J) against the oracle, and the LM-style solve of every solver type -- with
+    D > 0 the unobserved blocks are still positive definite -- with the oracle's iteration count.  (Round 4 made the products of
+    CGNR and of the evaluator's gradient write their results outright instead of accumulating into zeros.)"""
+    base = cx.bal.make_bal_like(16, 700, 2800, 2)
+    P, C = base.num_points, base.num_cameras
+    drop_points = np.array([5, 6, P - 1])
+    drop_camera = 7
+    keep = ~np.isin(base.point_index, drop_points) & (base.camera_index != drop_camera)
+    prob = cx.bal.BalProblem(C, P, base.camera_index[keep], base.point_index[keep], base.observations[keep], base.cameras, base.points)
+    O = prob.num_observations
+    bs, order = cx.bal.build_structure(prob)
+    vals = cx.bal.random_jacobian_values(O, 11)
+    rng = np.random.default_rng(12)
+    b = rng.standard_normal(2 * O)
+    D = rng.uniform(0.5, 2.0, bs.num_cols)
+    nelim = 0 if stype == "CGNR" else P
+    A = cx.Matrix(ctx, bs, nelim)
+    assert A.is_static_239
+    A.set_values(vals)
+    x, y0 = rng.standard_normal(A.num_cols), rng.standard_normal(A.num_rows)
+    assert relerr(A.right_multiply(x, y0), oracle.right_multiply(bs, vals, x, y0)) < REL
+    z, c0 = rng.standard_normal(A.num_rows), rng.standard_normal(A.num_cols)
+    assert relerr(A.left_multiply(z, c0), oracle.left_multiply(bs, vals, z, c0)) < REL
+    sq = A.squared_column_norm()
+    assert relerr(sq, oracle.squared_column_norm(bs, vals)) < REL
+    assert np.all(sq[3 * 5:3 * 7] == 0.0) and np.all(sq[3 * (P - 1):3 * P] == 0.0) and np.all(sq[3 * P + 9 * drop_camera:3 * P + 9 * drop_camera + 9] == 0.0)
+    kw = dict(type=getattr(cx, stype), preconditioner_type=getattr(cx, pre), num_eliminate_blocks=nelim, max_num_iterations=200)
+    S = cx.Solver(ctx, **kw)
+    xs, s = S.solve(A, b, D, r_tolerance=-1.0, q_tolerance=0.1)
+    oo = oracle.make_options(type=getattr(oracle, stype), preconditioner_type=getattr(oracle, pre), num_eliminate_blocks=P, max_num_iterations=200)
+    xr, sr = oracle.solve(bs, vals, b, D, oo, r_tolerance=-1.0, q_tolerance=0.1)
+    assert s.termination_type == sr.termination_type, (s.message, sr.message)
+    assert s.num_iterations == sr.num_iterations, (s.message, sr.message)
+    assert np.all(np.isfinite(xs)) and relerr(xs, xr) < 1e-8
+    # the unobserved blocks: (D^2) x = 0
+    assert np.all(xs[3 * 5:3 * 7] == 0.0) and np.all(xs[3 * P + 9 * drop_camera:3 * P + 9 * drop_camera + 9] == 0.0)
+    S.close()
+    A.close()
