@@ -982,3 +982,22 @@ def test_points_and_a_camera_without_observations(ctx, oracle, stype, pre):
     assert np.all(xs[3 * 5:3 * 7] == 0.0) and np.all(xs[3 * P + 9 * drop_camera:3 * P + 9 * drop_camera + 9] == 0.0)
     S.close()
     A.close()
+
+
+def test_evaluator_gradient_with_unobserved_blocks(ctx, oracle):
+    """The evaluator's gradient J'r is written outright (no zeroing first): parameter blocks without residual blocks get
+    their zeros from the product kernels themselves -- also when the buffer held something else before."""
+    base = cx.bal.make_bal_like(16, 700, 2800, 2)
+    P, C = base.num_points, base.num_cameras
+    keep = ~np.isin(base.point_index, [5, 6, P - 1]) & (base.camera_index != 7)
+    prob = cx.bal.BalProblem(C, P, base.camera_index[keep], base.point_index[keep], base.observations[keep], base.cameras, base.points)
+    bs, order = cx.bal.build_structure(prob)
+    ev = cx.Evaluator(ctx, prob)
+    state = prob.state()
+    for trial in range(2):   # (the second evaluation finds the first one's gradient in the library's scratch)
+        st = state + trial * 1e-3 * np.random.default_rng(3).standard_normal(state.size)
+        cost, res, grad = ev.evaluate(st)
+        cost_r, res_r, grad_r, _ = oracle.bal_evaluate(bs, C, P, prob.camera_index, prob.point_index, prob.observations, order, st)
+        assert relerr(grad, grad_r) < 1e-10 and abs(cost - cost_r) <= 1e-11 * cost_r
+        assert np.all(grad[3 * 5:3 * 7] == 0.0) and np.all(grad[3 * (P - 1):3 * P] == 0.0) and np.all(grad[3 * P + 9 * 7:3 * P + 9 * 8] == 0.0)
+    ev.close()
