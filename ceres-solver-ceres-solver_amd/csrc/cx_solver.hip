@@ -1735,7 +1735,6 @@ int SolveExplicitSchur239(cx_solver* S, cx_matrix* A, const double* b, const dou
   hipStream_t st = ctx->stream;
   const int64_t nf = 9 * int64_t(A->C), ne = 3 * int64_t(A->P);
   Stopwatch sw{S, st};
-  CX_TRY(S->ete_inv.alloc(9 * size_t(A->P)));
   CX_TRY(S->v_rhs.alloc(nf));
   CX_TRY(S->v_x.alloc(nf));
   CX_TRY(S->cam_blocks.alloc(81 * size_t(std::max(A->C, 1))));
@@ -1978,7 +1977,6 @@ int SolveDenseSchur239(cx_solver* S, cx_matrix* A, const double* b, const double
   Stopwatch sw{S, st};
   CX_TRY(S->lhs.alloc(size_t(nf) * nf));
   CX_TRY(S->v_rhs.alloc(nf));
-  CX_TRY(S->ete_inv.alloc(9 * size_t(A->P)));
   CX_TRY(S->flag.alloc(1));
   CX_HIP(hipMemsetAsync(S->flag.p, 0, sizeof(int), st));
   CX_TRY(sw.start());
@@ -2009,9 +2007,9 @@ int SolveDenseSchur239(cx_solver* S, cx_matrix* A, const double* b, const double
   CX_TRY(sw.stop(&S->timing.reduced_solve_ms));
   CX_TRY(sw.start());
   if (summary->termination_type == CX_SUCCESS) {
-    // SchurEliminator::BackSubstitute (schur_eliminator_impl.h:307-373): cofactor inverse of E'E + D^2
-    CX_TRY(cxs_compute_ete_inverse(A, D, nullptr, S->ete_inv.p, nullptr, false, S->flag.p));
-    CX_TRY(cxs_chunk_pass(A, 2, S->ete_inv.p, z, b, x));
+    // SchurEliminator::BackSubstitute (schur_eliminator_impl.h:307-373): the cofactor inverses of E'E + D^2 are the
+    // eliminator's own (A->d_elim_ete, filled by cxs_eliminate_dense above on either of its paths)
+    CX_TRY(cxs_chunk_pass(A, 2, A->d_elim_ete.p, z, b, x));
   }
   CX_TRY(sw.stop(&S->timing.back_substitute_ms));
   // (reached with use_mixed_precision_solves / refinement only when no tile plan could be built for this structure)
