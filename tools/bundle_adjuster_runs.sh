@@ -24,4 +24,8 @@ if [ "$R" != "02" ]; then
   run --preset final13682 --num_iterations 8 --preconditioner jacobi --devices 0,0,0,0
   run --preset final13682 --num_iterations 8 --linear_solver sparse_schur --devices 0,0,0,0
 fi
+if [ "$R" != "02" ] && [ "$R" != "03" ]; then
+  # round 4: CGNR (operator without memsets, set-up in two passes over J)
+  run --preset synthetic10M --num_iterations 8 --linear_solver cgnr
+fi
 grep -n "^###\|^Time\|Minimizer iterations" $OUT
